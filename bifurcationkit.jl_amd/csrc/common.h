@@ -1,0 +1,151 @@
+// Internal header of libbkhip: context, error handling, kernel-launcher prototypes.
+// gfx950 (MI355X / CDNA4) only.  See include/bkhip.h for the public C ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/bkhip.h"
+
+namespace bk {
+
+constexpr int kMaxBasis = 64;      // largest Krylov dimension + 1 the fused kernels are built for
+constexpr int kRedSlots = 256;     // doubles in the reduction result buffers
+constexpr int kRedBlocks = 1024;   // blocks of a reduction kernel (stage 1); stage 2 is one block
+
+struct Coefs {                     // by-value kernel argument: coefficients of a fused multi-axpy
+    double c[kMaxBasis];
+};
+
+struct ProfEntry {
+    double ms = 0.0;
+    long long calls = 0;
+    double bytes = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+enum CommKind { COMM_NONE = 0, COMM_RCCL = 1, COMM_HOST = 2 };
+
+}  // namespace bk
+
+struct bk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // communicator
+    int rank = 0, nranks = 1;
+    bk::CommKind comm = bk::COMM_NONE;
+    ncclComm_t nccl = nullptr;
+    bk_allreduce_fn h_allreduce = nullptr;
+    bk_sendrecv_fn h_sendrecv = nullptr;
+    void* h_user = nullptr;
+    // reduction scratch
+    double* d_partials = nullptr;   // [kRedBlocks * kMaxBasis+2]
+    double* d_red = nullptr;        // [kRedSlots]
+    double* h_red = nullptr;        // pinned [kRedSlots]
+    // workspace pool (device buffers keyed by size in doubles)
+    std::multimap<size_t, double*> pool_free;
+    std::map<double*, size_t> pool_all;
+    std::vector<double*> host_pinned;
+    // options + profiling
+    std::map<std::string, double> opts;
+    bool prof = false;
+    std::map<std::string, bk::ProfEntry> prof_entries;
+    std::vector<hipEvent_t> event_pool;
+    std::string err;
+
+    double opt(const char* key, double dflt) const {
+        auto it = opts.find(key);
+        return it == opts.end() ? dflt : it->second;
+    }
+};
+
+namespace bk {
+
+int set_error(bk_ctx* ctx, const char* fmt, ...);
+
+#define BK_HIP(ctx, call)                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return bk::set_error((ctx), "%s:%d: %s failed: %s", __FILE__, __LINE__, #call,    \
+                                 hipGetErrorString(e_));                                      \
+    } while (0)
+
+#define BK_NCCL(ctx, call)                                                                    \
+    do {                                                                                      \
+        ncclResult_t e_ = (call);                                                             \
+        if (e_ != ncclSuccess)                                                                \
+            return bk::set_error((ctx), "%s:%d: %s failed: %s", __FILE__, __LINE__, #call,    \
+                                 ncclGetErrorString(e_));                                     \
+    } while (0)
+
+#define BK_TRY(call)             \
+    do {                         \
+        int s_ = (call);         \
+        if (s_ != 0) return s_;  \
+    } while (0)
+
+// ---- workspace pool ---------------------------------------------------------------------
+int ws_get(bk_ctx* ctx, size_t n, double** out);
+void ws_put(bk_ctx* ctx, double* p);
+
+struct WsGuard {    // RAII return-to-pool
+    bk_ctx* ctx;
+    std::vector<double*> ptrs;
+    explicit WsGuard(bk_ctx* c) : ctx(c) {}
+    ~WsGuard() { for (double* p : ptrs) ws_put(ctx, p); }
+    int get(size_t n, double** out) {
+        int s = ws_get(ctx, n, out);
+        if (s == 0) ptrs.push_back(*out);
+        return s;
+    }
+};
+
+// ---- profiling --------------------------------------------------------------------------
+struct ProfScope {  // records a start/stop event pair on the ctx stream around a launch sequence
+    bk_ctx* ctx;
+    ProfEntry* e = nullptr;
+    hipEvent_t start = nullptr, stop = nullptr;
+    ProfScope(bk_ctx* c, const char* name, double alg_bytes);
+    ~ProfScope();
+};
+
+// ---- reductions (deterministic two-stage; global over the communicator) -----------------
+// After a stage-1 kernel wrote d_partials[nblocks][nvals], reduce -> all-reduce -> host.
+// op: 0 = sum, 1 = max.  On return ctx->h_red[0..nvals) holds the results (stream synchronised).
+int reduce_finish(bk_ctx* ctx, int nblocks, int nvals, int op);
+int comm_allreduce_host(bk_ctx* ctx, double* buf, int n, int op);   // small host-side all-reduce
+
+// ---- BLAS-1 launchers (vecops.hip) ---------------------------------------------------------
+int v_copy(bk_ctx* ctx, size_t n, const double* x, double* y);
+int v_zero(bk_ctx* ctx, size_t n, double* x);
+int v_scale(bk_ctx* ctx, size_t n, double a, double* x);
+int v_axpby(bk_ctx* ctx, size_t n, double a, const double* x, double b, double* y);
+// z = a x + b y (z may alias x or y)
+int v_axpbyz(bk_ctx* ctx, size_t n, double a, const double* x, double b, const double* y, double* z);
+int v_dot(bk_ctx* ctx, size_t n, const double* x, const double* y, double* out);
+int v_dot2(bk_ctx* ctx, size_t n, const double* x, const double* y1, const double* y2, double* out2);
+int v_nrm2(bk_ctx* ctx, size_t n, const double* x, double* out);
+int v_nrminf(bk_ctx* ctx, size_t n, const double* x, double* out);
+// out[i] = <V_i, w> for i < k, out[k] = <w, w>;  V_i = V + i*ldv
+int v_multidot(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const double* w, double* out);
+// dst = scale * (src + sum_i c[i] V_i); src may be NULL (treated as 0); if nrm2sq != NULL the
+// squared 2-norm of dst is returned (global).  dst may alias src.
+int v_multiaxpy(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const double* c,
+                const double* src, double scale, double* dst, double* nrm2sq);
+// dst_j = sum_{i<m} Q(i,j) V_i for j < kout (Q host, column-major m x kout); dst may alias V
+int v_basis_combine(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int m, const double* Qhost, int kout,
+                    double* dst, size_t lddst);
+// uniform [0,1) pseudo-random fill, deterministic in (seed, global index)
+int v_fill_random(bk_ctx* ctx, size_t n, size_t global_offset, unsigned long long seed, double* x);
+
+}  // namespace bk

@@ -1,0 +1,377 @@
+// Context, workspace pool, profiling scopes, deterministic reduction finish, communicator glue.
+#include "common.h"
+#include "ops.h"
+
+namespace bk {
+
+int set_error(bk_ctx* ctx, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else fprintf(stderr, "bkhip: %s\n", buf);
+    return -1;
+}
+
+// ------------------------------------------------------------------ workspace pool
+int ws_get(bk_ctx* ctx, size_t n, double** out) {
+    if (n == 0) n = 1;
+    auto it = ctx->pool_free.find(n);
+    if (it != ctx->pool_free.end()) {
+        *out = it->second;
+        ctx->pool_free.erase(it);
+        return 0;
+    }
+    double* p = nullptr;
+    hipError_t e = hipMalloc(&p, n * sizeof(double));
+    if (e != hipSuccess) {
+        // release cached buffers and retry once
+        for (auto& kv : ctx->pool_free) { (void)hipFree(kv.second); ctx->pool_all.erase(kv.second); }
+        ctx->pool_free.clear();
+        e = hipMalloc(&p, n * sizeof(double));
+        if (e != hipSuccess)
+            return set_error(ctx, "hipMalloc of %zu doubles failed: %s", n, hipGetErrorString(e));
+    }
+    ctx->pool_all[p] = n;
+    *out = p;
+    return 0;
+}
+
+void ws_put(bk_ctx* ctx, double* p) {
+    if (!p) return;
+    auto it = ctx->pool_all.find(p);
+    if (it == ctx->pool_all.end()) return;
+    ctx->pool_free.insert({it->second, p});
+}
+
+// ------------------------------------------------------------------ profiling
+static hipEvent_t get_event(bk_ctx* ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+ProfScope::ProfScope(bk_ctx* c, const char* name, double alg_bytes) : ctx(c) {
+    if (!ctx->prof) return;
+    e = &ctx->prof_entries[name];
+    e->calls += 1;
+    e->bytes += alg_bytes;
+    start = get_event(ctx);
+    stop = get_event(ctx);
+    (void)hipEventRecord(start, ctx->stream);
+}
+
+ProfScope::~ProfScope() {
+    if (!e) return;
+    (void)hipEventRecord(stop, ctx->stream);
+    e->pending.push_back({start, stop});
+}
+
+static void prof_resolve(bk_ctx* ctx) {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->prof_entries) {
+        for (auto& pr : kv.second.pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) kv.second.ms += ms;
+            ctx->event_pool.push_back(pr.first);
+            ctx->event_pool.push_back(pr.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+// ------------------------------------------------------------------ reductions
+__global__ void __launch_bounds__(256) reduce_stage2_kernel(const double* __restrict__ partials, int nblocks,
+                                                            int nvals, int op, double* __restrict__ out) {
+    const int v = blockIdx.x;
+    double acc = (op == 0) ? 0.0 : -1.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) {
+        const double x = partials[(size_t)b * nvals + v];
+        acc = (op == 0) ? acc + x : fmax(acc, x);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_down(acc, off, 64);
+        acc = (op == 0) ? acc + o : fmax(acc, o);
+    }
+    __shared__ double sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = sm[0];
+        for (int w = 1; w < 4; ++w) r = (op == 0) ? r + sm[w] : fmax(r, sm[w]);
+        out[v] = r;
+    }
+}
+
+int comm_allreduce_host(bk_ctx* ctx, double* buf, int n, int op) {
+    if (ctx->comm == COMM_NONE || ctx->nranks == 1) return 0;
+    if (ctx->comm == COMM_HOST) {
+        if (ctx->h_allreduce(ctx->h_user, buf, n, op) != 0) return set_error(ctx, "host allreduce callback failed");
+        return 0;
+    }
+    // RCCL: stage through the device result buffer
+    if (n > kRedSlots) return set_error(ctx, "comm_allreduce_host: n too large");
+    BK_HIP(ctx, hipMemcpyAsync(ctx->d_red, buf, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    BK_NCCL(ctx, ncclAllReduce(ctx->d_red, ctx->d_red, n, ncclDouble, op == 0 ? ncclSum : ncclMax, ctx->nccl,
+                               ctx->stream));
+    BK_HIP(ctx, hipMemcpyAsync(buf, ctx->d_red, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int reduce_finish(bk_ctx* ctx, int nblocks, int nvals, int op) {
+    if (nvals > kRedSlots) return set_error(ctx, "reduce_finish: too many values");
+    hipLaunchKernelGGL(reduce_stage2_kernel, dim3(nvals), dim3(256), 0, ctx->stream, ctx->d_partials, nblocks,
+                       nvals, op, ctx->d_red);
+    BK_HIP(ctx, hipGetLastError());
+    if (ctx->comm == COMM_RCCL && ctx->nranks > 1) {
+        BK_NCCL(ctx, ncclAllReduce(ctx->d_red, ctx->d_red, nvals, ncclDouble, op == 0 ? ncclSum : ncclMax,
+                                   ctx->nccl, ctx->stream));
+    }
+    BK_HIP(ctx, hipMemcpyAsync(ctx->h_red, ctx->d_red, nvals * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->comm == COMM_HOST && ctx->nranks > 1) {
+        if (ctx->h_allreduce(ctx->h_user, ctx->h_red, nvals, op) != 0)
+            return set_error(ctx, "host allreduce callback failed");
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------ halo exchange
+// Exchange `width` boundary planes (plane = `plane` doubles) of the local slab `v` (nplanes planes)
+// with the neighbour ranks: halo_lo <- last planes of rank-1, halo_hi <- first planes of rank+1.
+int halo_exchange(bk_ctx* ctx, const double* v, size_t plane, int nplanes, int width, double* halo_lo,
+                  double* halo_hi) {
+    if (ctx->nranks == 1) return 0;
+    const int lo = ctx->rank - 1, hi = ctx->rank + 1;
+    const bool has_lo = lo >= 0, has_hi = hi < ctx->nranks;
+    const size_t cnt = plane * (size_t)width;
+    if (nplanes < width) return set_error(ctx, "halo_exchange: slab thinner than the halo width");
+    const double* send_lo = v;                                        // my first planes -> rank-1
+    const double* send_hi = v + plane * (size_t)(nplanes - width);    // my last planes  -> rank+1
+    if (ctx->comm == COMM_RCCL) {
+        BK_NCCL(ctx, ncclGroupStart());
+        if (has_lo) {
+            BK_NCCL(ctx, ncclSend(send_lo, cnt, ncclDouble, lo, ctx->nccl, ctx->stream));
+            BK_NCCL(ctx, ncclRecv(halo_lo, cnt, ncclDouble, lo, ctx->nccl, ctx->stream));
+        }
+        if (has_hi) {
+            BK_NCCL(ctx, ncclSend(send_hi, cnt, ncclDouble, hi, ctx->nccl, ctx->stream));
+            BK_NCCL(ctx, ncclRecv(halo_hi, cnt, ncclDouble, hi, ctx->nccl, ctx->stream));
+        }
+        BK_NCCL(ctx, ncclGroupEnd());
+        return 0;
+    }
+    // host-staged (test communicator)
+    std::vector<double> s_lo(has_lo ? cnt : 0), s_hi(has_hi ? cnt : 0), r_lo(has_lo ? cnt : 0), r_hi(has_hi ? cnt : 0);
+    if (has_lo) BK_HIP(ctx, hipMemcpyAsync(s_lo.data(), send_lo, cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (has_hi) BK_HIP(ctx, hipMemcpyAsync(s_hi.data(), send_hi, cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // even ranks talk to the upper neighbour first, odd ranks to the lower one (deadlock-free pairing)
+    for (int phase = 0; phase < 2; ++phase) {
+        const bool up = ((ctx->rank & 1) == 0) ? (phase == 0) : (phase == 1);
+        if (up && has_hi) {
+            if (ctx->h_sendrecv(ctx->h_user, s_hi.data(), cnt, hi, r_hi.data(), cnt, hi) != 0)
+                return set_error(ctx, "host sendrecv callback failed");
+        } else if (!up && has_lo) {
+            if (ctx->h_sendrecv(ctx->h_user, s_lo.data(), cnt, lo, r_lo.data(), cnt, lo) != 0)
+                return set_error(ctx, "host sendrecv callback failed");
+        }
+    }
+    if (has_lo) BK_HIP(ctx, hipMemcpyAsync(halo_lo, r_lo.data(), cnt * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (has_hi) BK_HIP(ctx, hipMemcpyAsync(halo_hi, r_hi.data(), cnt * 8, hipMemcpyHostToDevice, ctx->stream));
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+static int ctx_init_common(bk_ctx* ctx, int device, void* stream) {
+    ctx->device = device;
+    BK_HIP(ctx, hipSetDevice(device));
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        BK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    BK_HIP(ctx, hipMalloc(&ctx->d_partials, sizeof(double) * kRedBlocks * (kMaxBasis + 2)));
+    BK_HIP(ctx, hipMalloc(&ctx->d_red, sizeof(double) * kRedSlots));
+    BK_HIP(ctx, hipHostMalloc(&ctx->h_red, sizeof(double) * kRedSlots, hipHostMallocDefault));
+    return 0;
+}
+
+}  // namespace bk
+
+using namespace bk;
+
+extern "C" {
+
+int bk_version(void) { return 100; }
+
+int bk_ctx_create(bk_ctx** out, int device, void* stream) {
+    if (!out) return -1;
+    bk_ctx* ctx = new bk_ctx();
+    int s = ctx_init_common(ctx, device, stream);
+    if (s != 0) {
+        fprintf(stderr, "bkhip: bk_ctx_create failed: %s\n", ctx->err.c_str());
+        delete ctx;
+        *out = nullptr;
+        return s;
+    }
+    *out = ctx;
+    return 0;
+}
+
+int bk_comm_unique_id(void* id128) {
+    static_assert(sizeof(ncclUniqueId) <= BK_UNIQUE_ID_BYTES, "unique id does not fit");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return -1;
+    memset(id128, 0, BK_UNIQUE_ID_BYTES);
+    memcpy(id128, &id, sizeof(id));
+    return 0;
+}
+
+int bk_ctx_create_dist(bk_ctx** out, int device, void* stream, int rank, int nranks, const void* id128) {
+    if (!out || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return -1;
+    bk_ctx* ctx = new bk_ctx();
+    int s = ctx_init_common(ctx, device, stream);
+    if (s == 0) {
+        ncclUniqueId id;
+        memcpy(&id, id128, sizeof(id));
+        ncclResult_t r = ncclCommInitRank(&ctx->nccl, nranks, id, rank);
+        if (r != ncclSuccess) s = set_error(ctx, "ncclCommInitRank failed: %s", ncclGetErrorString(r));
+    }
+    if (s != 0) {
+        fprintf(stderr, "bkhip: bk_ctx_create_dist failed: %s\n", ctx->err.c_str());
+        delete ctx;
+        *out = nullptr;
+        return s;
+    }
+    ctx->rank = rank;
+    ctx->nranks = nranks;
+    ctx->comm = COMM_RCCL;
+    *out = ctx;
+    return 0;
+}
+
+int bk_ctx_create_hostcomm(bk_ctx** out, int device, void* stream, int rank, int nranks, bk_allreduce_fn allreduce,
+                           bk_sendrecv_fn sendrecv, void* user) {
+    if (!out || !allreduce || !sendrecv || nranks < 1 || rank < 0 || rank >= nranks) return -1;
+    bk_ctx* ctx = new bk_ctx();
+    int s = ctx_init_common(ctx, device, stream);
+    if (s != 0) {
+        fprintf(stderr, "bkhip: bk_ctx_create_hostcomm failed: %s\n", ctx->err.c_str());
+        delete ctx;
+        *out = nullptr;
+        return s;
+    }
+    ctx->rank = rank;
+    ctx->nranks = nranks;
+    ctx->comm = COMM_HOST;
+    ctx->h_allreduce = allreduce;
+    ctx->h_sendrecv = sendrecv;
+    ctx->h_user = user;
+    *out = ctx;
+    return 0;
+}
+
+int bk_ctx_destroy(bk_ctx* ctx) {
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->pool_all) (void)hipFree(kv.first);
+    for (auto& kv : ctx->prof_entries)
+        for (auto& pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->d_partials) (void)hipFree(ctx->d_partials);
+    if (ctx->d_red) (void)hipFree(ctx->d_red);
+    if (ctx->h_red) (void)hipHostFree(ctx->h_red);
+    if (ctx->nccl) (void)ncclCommDestroy(ctx->nccl);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+const char* bk_last_error(bk_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int bk_ctx_sync(bk_ctx* ctx) {
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int bk_ctx_set_option(bk_ctx* ctx, const char* key, double value) {
+    if (!ctx || !key) return -1;
+    ctx->opts[key] = value;
+    return 0;
+}
+
+int bk_ctx_get_option(bk_ctx* ctx, const char* key, double* value) {
+    if (!ctx || !key || !value) return -1;
+    auto it = ctx->opts.find(key);
+    if (it == ctx->opts.end()) return set_error(ctx, "unknown option %s", key);
+    *value = it->second;
+    return 0;
+}
+
+int bk_prof_enable(bk_ctx* ctx, int on) {
+    if (!ctx) return -1;
+    if (!on) prof_resolve(ctx);
+    ctx->prof = on != 0;
+    return 0;
+}
+
+int bk_prof_reset(bk_ctx* ctx) {
+    if (!ctx) return -1;
+    prof_resolve(ctx);
+    ctx->prof_entries.clear();
+    return 0;
+}
+
+int bk_prof_get(bk_ctx* ctx, const char* name, double* total_ms, long long* calls, double* alg_bytes) {
+    if (!ctx || !name) return -1;
+    prof_resolve(ctx);
+    auto it = ctx->prof_entries.find(name);
+    if (it == ctx->prof_entries.end()) {
+        if (total_ms) *total_ms = 0.0;
+        if (calls) *calls = 0;
+        if (alg_bytes) *alg_bytes = 0.0;
+        return 0;
+    }
+    if (total_ms) *total_ms = it->second.ms;
+    if (calls) *calls = it->second.calls;
+    if (alg_bytes) *alg_bytes = it->second.bytes;
+    return 0;
+}
+
+int bk_malloc(bk_ctx* ctx, size_t n, double** out) {
+    if (!ctx || !out) return -1;
+    BK_HIP(ctx, hipSetDevice(ctx->device));
+    BK_HIP(ctx, hipMalloc(out, (n ? n : 1) * sizeof(double)));
+    return 0;
+}
+
+int bk_free(bk_ctx* ctx, double* p) {
+    if (!ctx) return -1;
+    if (p) BK_HIP(ctx, hipFree(p));
+    return 0;
+}
+
+int bk_upload(bk_ctx* ctx, double* dst, const double* src, size_t n) {
+    BK_HIP(ctx, hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int bk_download(bk_ctx* ctx, double* dst, const double* src, size_t n) {
+    BK_HIP(ctx, hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+}  // extern "C"

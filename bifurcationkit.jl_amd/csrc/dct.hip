@@ -1,0 +1,233 @@
+// Exact inverse of L1 + shift = (I + Lap)^2 + shift*I through the DCT-II diagonalisation of the
+// Neumann-ghost Laplacian.
+//
+// Reference role: the left preconditioner `Pl = cholesky(Symmetric(L1))` of examples/SH3d.jl:88-93
+// (shift = 0) and `lu(L1 + I)` of examples/SH2d-fronts.jl:121 (shift = 1): sparse direct factors of the
+// assembled matrix, applied once per GMRES iteration.  The 1-D operator D (tridiag(1,-2,1)/h^2 with
+// corner entries -1/h^2, examples/SH3d.jl:21-32) has eigenpairs
+//     lambda_k = -(4/h^2) sin^2(pi k / 2N),   phi_k[n] = s_k cos(pi (2n+1) k / 2N),  k = 0..N-1
+// (s_0 = sqrt(1/N), s_k = sqrt(2/N)), so with Phi = Phi_z (x) Phi_y (x) Phi_x
+//     (L1 + shift)^-1 v = Phi diag( 1 / ((1 + lam_x + lam_y + lam_z)^2 + shift) ) Phi' v .
+//
+// Kernels:
+//   dct_axis_direct   any N: one thread per output element, O(N) dot with a row of the (N x N)
+//                     orthonormal DCT matrix.  Correctness baseline and the path for N that are not
+//                     powers of two (the reference example runs 22^3).
+//   dct_axis_fft      N = 2^q, 8 <= N <= 1024: one workgroup owns a tile of lines staged in LDS and runs a
+//                     radix-2 Stockham FFT of the Makhoul-permuted line there; HBM traffic is one read and
+//                     one write of the array per axis.  (dct_fast.hip)
+//   spectral_scale    multiply by the inverse symbol.
+#include <cmath>
+#include <vector>
+
+#include "ops.h"
+
+namespace bk {
+
+int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, const double* twid, const double* in,
+                 double* out, const double* symx, const double* symy, const double* symz, double shift, int fuse_scale);
+bool dct_axis_fft_supported(int n);
+
+struct DctPlan {
+    int ndim = 0;
+    int n[3] = {1, 1, 1};
+    double shift = 0.0;
+    double* T[3] = {nullptr, nullptr, nullptr};    // T[k*N + n]  = s_k cos(pi (2n+1) k / 2N)   (forward rows)
+    double* TT[3] = {nullptr, nullptr, nullptr};   // TT[n*N + k] = same, transposed
+    double* lam[3] = {nullptr, nullptr, nullptr};  // eigenvalues lambda_k per axis
+    double* twid[3] = {nullptr, nullptr, nullptr}; // fast path: twiddle tables
+    double* t1 = nullptr;
+    double* t2 = nullptr;
+    size_t total = 0;
+};
+
+namespace {
+
+// forward: out[k, r] = sum_n T[k][n] in[n, r];  inverse: out[n, r] = sum_k T[k][n] in[k, r]
+// Array viewed as [n2][n1][n0] (n0 fastest); `axis` selects the transformed index.
+__global__ void __launch_bounds__(256) dct_axis_direct(int n0, int n1, int n2, int axis, const double* __restrict__ M,
+                                                       const double* __restrict__ in, double* __restrict__ out) {
+    // M is laid out so that M[q*N + o] multiplies input index q for output index o
+    const size_t total = (size_t)n0 * n1 * n2;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int i0 = (int)(idx % n0);
+    const int i1 = (int)((idx / n0) % n1);
+    const int i2 = (int)(idx / ((size_t)n0 * n1));
+    int N, o;
+    size_t stride, base;
+    if (axis == 0) { N = n0; o = i0; stride = 1; base = (size_t)n0 * (i1 + (size_t)n1 * i2); }
+    else if (axis == 1) { N = n1; o = i1; stride = n0; base = i0 + (size_t)n0 * n1 * i2; }
+    else { N = n2; o = i2; stride = (size_t)n0 * n1; base = i0 + (size_t)n0 * i1; }
+    double acc = 0.0;
+    for (int q = 0; q < N; ++q) acc = fma(M[(size_t)q * N + o], in[base + (size_t)q * stride], acc);
+    out[idx] = acc;
+}
+
+__global__ void __launch_bounds__(256) spectral_scale_kernel(int n0, int n1, int n2, const double* __restrict__ lx,
+                                                             const double* __restrict__ ly,
+                                                             const double* __restrict__ lz, double shift,
+                                                             double* __restrict__ a) {
+    const size_t total = (size_t)n0 * n1 * n2;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int i0 = (int)(idx % n0);
+    const int i1 = (int)((idx / n0) % n1);
+    const int i2 = (int)(idx / ((size_t)n0 * n1));
+    const double s = 1.0 + lx[i0] + ly[i1] + (lz ? lz[i2] : 0.0);
+    a[idx] = a[idx] / (s * s + shift);
+}
+
+}  // namespace
+
+int dct_plan_create(bk_ctx* ctx, int ndim, const int n[3], const double ainv[3], double shift, DctPlan** out) {
+    DctPlan* p = new DctPlan();
+    p->ndim = ndim;
+    p->shift = shift;
+    p->total = 1;
+    for (int a = 0; a < 3; ++a) { p->n[a] = a < ndim ? n[a] : 1; p->total *= (size_t)p->n[a]; }
+    for (int a = 0; a < ndim; ++a) {
+        const int N = p->n[a];
+        std::vector<double> T((size_t)N * N), TT((size_t)N * N), lam(N);
+        for (int k = 0; k < N; ++k) {
+            const double sk = k == 0 ? std::sqrt(1.0 / N) : std::sqrt(2.0 / N);
+            for (int q = 0; q < N; ++q) {
+                // reduce the argument mod 4N exactly before calling cos: (2q+1)k can be large
+                const long long arg = ((long long)(2 * q + 1) * k) % (4LL * N);
+                const double c = sk * std::cos(M_PI * (double)arg / (2.0 * N));
+                T[(size_t)k * N + q] = c;
+                TT[(size_t)q * N + k] = c;
+            }
+            const double sn = std::sin(M_PI * k / (2.0 * N));
+            lam[k] = -4.0 * ainv[a] * sn * sn;
+        }
+        if (hipMalloc(&p->T[a], sizeof(double) * N * N) != hipSuccess ||
+            hipMalloc(&p->TT[a], sizeof(double) * N * N) != hipSuccess ||
+            hipMalloc(&p->lam[a], sizeof(double) * N) != hipSuccess) {
+            dct_plan_destroy(p);
+            return set_error(ctx, "dct plan: allocation failed");
+        }
+        (void)hipMemcpy(p->T[a], T.data(), sizeof(double) * N * N, hipMemcpyHostToDevice);
+        (void)hipMemcpy(p->TT[a], TT.data(), sizeof(double) * N * N, hipMemcpyHostToDevice);
+        (void)hipMemcpy(p->lam[a], lam.data(), sizeof(double) * N, hipMemcpyHostToDevice);
+        if (dct_axis_fft_supported(N)) {
+            // twiddles: w[j] = exp(-2 pi i j / N) for j < N/2 (FFT) followed by the Makhoul post-twiddle
+            // e[k] = exp(-i pi k / 2N), k < N
+            std::vector<double> tw(2 * (size_t)(N / 2) + 2 * (size_t)N);
+            for (int j = 0; j < N / 2; ++j) {
+                tw[2 * j] = std::cos(2.0 * M_PI * j / N);
+                tw[2 * j + 1] = -std::sin(2.0 * M_PI * j / N);
+            }
+            for (int k = 0; k < N; ++k) {
+                tw[N + 2 * k] = std::cos(M_PI * k / (2.0 * N));
+                tw[N + 2 * k + 1] = -std::sin(M_PI * k / (2.0 * N));
+            }
+            if (hipMalloc(&p->twid[a], sizeof(double) * tw.size()) != hipSuccess) {
+                dct_plan_destroy(p);
+                return set_error(ctx, "dct plan: allocation failed");
+            }
+            (void)hipMemcpy(p->twid[a], tw.data(), sizeof(double) * tw.size(), hipMemcpyHostToDevice);
+        }
+    }
+    if (hipMalloc(&p->t1, sizeof(double) * p->total) != hipSuccess ||
+        hipMalloc(&p->t2, sizeof(double) * p->total) != hipSuccess) {
+        dct_plan_destroy(p);
+        return set_error(ctx, "dct plan: scratch allocation failed");
+    }
+    *out = p;
+    return 0;
+}
+
+void dct_plan_destroy(DctPlan* p) {
+    if (!p) return;
+    for (int a = 0; a < 3; ++a) {
+        if (p->T[a]) (void)hipFree(p->T[a]);
+        if (p->TT[a]) (void)hipFree(p->TT[a]);
+        if (p->lam[a]) (void)hipFree(p->lam[a]);
+        if (p->twid[a]) (void)hipFree(p->twid[a]);
+    }
+    if (p->t1) (void)hipFree(p->t1);
+    if (p->t2) (void)hipFree(p->t2);
+    delete p;
+}
+
+int dct_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out) {
+    const int n0 = p->n[0], n1 = p->n[1], n2 = p->n[2];
+    const unsigned grid = (unsigned)((p->total + 255) / 256);
+    const bool use_fft = ctx->opt("dct_fft", 1.0) != 0.0;
+    ProfScope ps(ctx, "precond", 16.0 * p->total);
+    // forward along each axis: v -> t1 -> t2 -> ... ; then scale; then inverse in reverse order
+    const double* src = v;
+    double* bufs[2] = {p->t1, p->t2};
+    int cur = 0;
+    auto axis_pass = [&](int a, int inverse, const double* in, double* o) -> int {
+        const int N = p->n[a];
+        if (use_fft && p->twid[a]) {
+            return dct_axis_fft(ctx, n0, n1, n2, a, inverse, p->twid[a], in, o, nullptr, nullptr, nullptr, 0.0, 0);
+        }
+        (void)N;
+        // forward: out[k] = sum_n T[k][n] in[n]  -> M[q=n][o=k] = TT ; inverse: out[n] = sum_k T[k][n] in[k] -> M = T
+        hipLaunchKernelGGL(dct_axis_direct, dim3(grid), dim3(256), 0, ctx->stream, n0, n1, n2, a,
+                           inverse ? p->T[a] : p->TT[a], in, o);
+        BK_HIP(ctx, hipGetLastError());
+        return 0;
+    };
+    for (int a = 0; a < p->ndim; ++a) {
+        BK_TRY(axis_pass(a, 0, src, bufs[cur]));
+        src = bufs[cur];
+        cur ^= 1;
+    }
+    // src now holds the spectrum (in bufs[cur^1])
+    double* spec = bufs[cur ^ 1];
+    hipLaunchKernelGGL(spectral_scale_kernel, dim3(grid), dim3(256), 0, ctx->stream, n0, n1, n2, p->lam[0], p->lam[1],
+                       p->ndim == 3 ? p->lam[2] : nullptr, p->shift, spec);
+    BK_HIP(ctx, hipGetLastError());
+    src = spec;
+    for (int a = p->ndim - 1; a >= 0; --a) {
+        double* dst = (a == 0) ? out : bufs[cur];
+        BK_TRY(axis_pass(a, 1, src, dst));
+        src = dst;
+        cur ^= 1;
+    }
+    return 0;
+}
+
+namespace {
+struct ShDctPrecond : bk_precond {
+    DctPlan* plan = nullptr;
+    ~ShDctPrecond() override { dct_plan_destroy(plan); }
+    int apply(const double* v, double* out) override { return dct_apply(ctx, plan, v, out); }
+};
+}  // namespace
+
+}  // namespace bk
+
+using namespace bk;
+
+extern "C" {
+
+int bk_precond_sh_create(bk_problem* prob, double shift, bk_precond** out) {
+    if (!prob || !out) return -1;
+    bk_ctx* ctx = prob->ctx;
+    if (prob->desc.pde != BK_PDE_SH) return set_error(ctx, "bk_precond_sh_create: Swift-Hohenberg 2-D/3-D only");
+    if (ctx->nranks > 1) return set_error(ctx, "bk_precond_sh_create: multi-GPU DCT transpose not implemented yet");
+    ShDctPrecond* P = new ShDctPrecond();
+    P->ctx = ctx;
+    P->n = prob->nloc;
+    int s = dct_plan_create(ctx, prob->desc.ndim, prob->desc.n, prob->ainv, shift, &P->plan);
+    if (s != 0) { delete P; return s; }
+    *out = P;
+    return 0;
+}
+
+int bk_precond_destroy(bk_precond* pc) {
+    delete pc;
+    return 0;
+}
+
+int bk_precond_apply(bk_precond* pc, const double* v, double* out) {
+    if (!pc || !v || !out) return -1;
+    return pc->apply(v, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,205 @@
+// Shift-invert Krylov-Schur eigensolver: (eig::ShiftInvert)(J, nev), src/EigSolver.jl:246-266, with the
+// outer iteration of KrylovKit.eigsolve (Arnoldi / Lanczos + Krylov-Schur thick restart) as used by
+// examples/SH3d.jl:96-113 (SH3dEig: sigma = 0.1, :LM, tol 1e-12, krylovdim max(30, nev+30), maxiter 20).
+// Every operator application is one device-resident GMRES solve of (J - sigma I) x = v.
+// The Krylov basis lives in HBM; the (<= 63 x 63) Rayleigh quotient is decomposed on the host (dense.h).
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <vector>
+
+#include "dense.h"
+#include "ops.h"
+
+namespace bk {
+
+// exposed by solver.hip (same translation unit would be nicer; keep one definition)
+int arnoldi_step_public(bk_ctx* ctx, bk_op* A, double* V, size_t ld, std::vector<double>& tails, int j, double* w,
+                        double* h, double* beta);
+
+namespace {
+
+struct ShiftInvertOp : bk_op {      // rhs -> (J - sigma I)^-1 rhs = ls(J, rhs; a0 = -sigma, a1 = 1)[1]  (:259-261)
+    bk_op* J;
+    double sigma;
+    bk_gmres_opts ls;
+    bk_precond* pl;
+    int solves = 0, failed = 0, inner_ops = 0;
+    int apply(const double* x, double, double b0, double b1, double* out, double*) override {
+        if (b0 != 0.0 || b1 != 1.0) return set_error(ctx, "ShiftInvertOp: only plain application is supported");
+        GmresResult r;
+        BK_TRY(linsolve(ctx, J, x, out, -sigma, 1.0, ls, pl, &r));
+        solves += 1;
+        inner_ops += r.niter;
+        if (!r.converged) failed += 1;
+        return 0;
+    }
+};
+
+}  // namespace
+}  // namespace bk
+
+using namespace bk;
+using dense::cplx;
+
+extern "C" int bk_eig_shiftinvert(bk_ctx* ctx, bk_op* J, int nev, const bk_eig_opts* eo, const bk_gmres_opts* lsopts,
+                                  bk_precond* pl, double* vals_re, double* vals_im, double* vecs, double* vecs_im,
+                                  size_t ldvecs, int* nconv_out, int* numops_out) {
+    if (!ctx || !J || !eo || !lsopts || !vals_re || !vals_im || nev < 1) return -1;
+    if (J->ntail != 0) return set_error(ctx, "bk_eig_shiftinvert: operator must be unbordered");
+    const size_t n = J->n;
+    int m = eo->krylovdim;
+    if (m > kMaxBasis - 1) m = kMaxBasis - 1;
+    if (nev > m) return set_error(ctx, "bk_eig_shiftinvert: nev=%d exceeds the Krylov dimension %d", nev, m);
+    ShiftInvertOp A;
+    A.ctx = ctx; A.n = n; A.ntail = 0; A.J = J; A.sigma = eo->sigma; A.ls = *lsopts; A.pl = pl;
+
+    WsGuard ws(ctx);
+    const size_t ld = (n + 31) / 32 * 32;
+    double *V = nullptr, *w = nullptr;
+    BK_TRY(ws.get(ld * (size_t)(m + 1), &V));
+    BK_TRY(ws.get(ld, &w));
+    std::vector<double> tails(m + 1, 0.0);
+
+    // x0 = rand(N) (examples/SH3d.jl:109): deterministic in (seed, global index) so that the start vector
+    // does not depend on the slab decomposition
+    size_t goff = 0;
+    {
+        // global offset of this rank's slab = sum of lower ranks' lengths; slabs are contiguous
+        double offs[1] = {0.0};
+        if (ctx->nranks > 1) {
+            std::vector<double> lens(ctx->nranks, 0.0);
+            lens[ctx->rank] = (double)n;
+            BK_TRY(comm_allreduce_host(ctx, lens.data(), ctx->nranks, 0));
+            for (int r = 0; r < ctx->rank; ++r) offs[0] += lens[r];
+        }
+        goff = (size_t)offs[0];
+    }
+    BK_TRY(v_fill_random(ctx, n, goff, eo->seed, V));
+    double nrm;
+    BK_TRY(v_nrm2(ctx, n, V, &nrm));
+    BK_TRY(v_scale(ctx, n, 1.0 / nrm, V));
+
+    dense::Mat H(m + 1, m);
+    int k = 0, numiter = 0, nconv = 0;
+    std::vector<cplx> mu;
+    dense::CMat Y;
+    std::vector<int> order;
+    std::vector<double> resid;
+    bool breakdown = false;
+    int meff = m;
+    std::vector<double> h(m + 2, 0.0);
+    while (true) {
+        numiter += 1;
+        while (k < meff) {
+            double beta = 0.0;
+            BK_TRY(arnoldi_step_public(ctx, &A, V, ld, tails, k, w, h.data(), &beta));
+            for (int i = 0; i <= k; ++i) H(i, k) = h[i];
+            H(k + 1, k) = beta;
+            k += 1;
+            if (beta == 0.0) { breakdown = true; meff = k; break; }
+        }
+        // Rayleigh quotient B = H[:meff,:meff], border b = H[meff,:meff]
+        dense::Mat B(meff, meff);
+        std::vector<double> b(meff, 0.0);
+        for (int j = 0; j < meff; ++j) {
+            for (int i = 0; i < meff; ++i) B(i, j) = H(i, j);
+            b[j] = breakdown ? 0.0 : H(meff, j);
+        }
+        mu.assign(meff, cplx(0.0, 0.0));
+        Y = dense::CMat(meff, meff);
+        if (eo->hermitian) {
+            std::vector<double> wv;
+            dense::Mat Z;
+            if (dense::jacobi_eigh(B, wv, Z) < 0) return set_error(ctx, "eig: Jacobi sweep did not converge");
+            for (int j = 0; j < meff; ++j) {
+                mu[j] = cplx(wv[j], 0.0);
+                for (int i = 0; i < meff; ++i) Y(i, j) = cplx(Z(i, j), 0.0);
+            }
+        } else {
+            if (dense::eig_general(B, mu, Y) != 0) return set_error(ctx, "eig: QR iteration did not converge");
+        }
+        order.resize(meff);
+        for (int i = 0; i < meff; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return std::abs(mu[x]) > std::abs(mu[y]); });  // :LM
+        resid.assign(meff, 0.0);
+        for (int jj = 0; jj < meff; ++jj) {
+            const int j = order[jj];
+            cplx s = 0.0;
+            for (int i = 0; i < meff; ++i) s += b[i] * Y(i, j);
+            resid[jj] = std::abs(s);
+        }
+        nconv = 0;
+        while (nconv < meff && resid[nconv] < eo->tol) nconv += 1;
+        if (nconv >= nev || numiter >= eo->maxiter || breakdown) break;
+        // ---- Krylov-Schur thick restart: keep the leading Ritz directions
+        int keep = (3 * meff + 2 * nconv) / 5;
+        if (keep < nev) keep = std::min(nev, meff - 1);
+        if (keep >= meff) keep = meff - 1;
+        if (!eo->hermitian && keep < meff && std::fabs(mu[order[keep - 1]].imag()) > 0.0 &&
+            std::abs(mu[order[keep - 1]] - std::conj(mu[order[keep]])) <=
+                1e-8 * std::abs(mu[order[keep - 1]]))
+            keep += 1;                       // never split a complex-conjugate pair
+        dense::Mat C(meff, eo->hermitian ? keep : 2 * keep);
+        for (int jj = 0; jj < keep; ++jj) {
+            const int j = order[jj];
+            for (int i = 0; i < meff; ++i) {
+                C(i, eo->hermitian ? jj : 2 * jj) = Y(i, j).real();
+                if (!eo->hermitian) C(i, 2 * jj + 1) = Y(i, j).imag();
+            }
+        }
+        dense::Mat Q;
+        const int kq = dense::orthonormalize_columns(C, 1e-8, Q);
+        if (kq < 1 || kq >= meff) return set_error(ctx, "eig: restart basis has rank %d of %d", kq, meff);
+        // V[0..kq) <- V[0..meff) Q  (in place), V[kq] <- V[meff]
+        BK_TRY(v_basis_combine(ctx, n, V, ld, meff, Q.a.data(), kq, V, ld));
+        BK_TRY(v_copy(ctx, n, V + (size_t)meff * ld, V + (size_t)kq * ld));
+        dense::Mat Hn(m + 1, m);
+        for (int c = 0; c < kq; ++c) {
+            for (int r = 0; r < kq; ++r) {
+                double s = 0.0;
+                for (int i = 0; i < meff; ++i) {
+                    double t = 0.0;
+                    for (int l = 0; l < meff; ++l) t += B(i, l) * Q(l, c);
+                    s += Q(i, r) * t;
+                }
+                Hn(r, c) = s;
+            }
+            double s = 0.0;
+            for (int i = 0; i < meff; ++i) s += b[i] * Q(i, c);
+            Hn(kq, c) = s;
+        }
+        H = Hn;
+        k = kq;
+    }
+    // ---- back-transform 1/mu + sigma, sort by decreasing real part (__sort_spectrum, src/EigSolver.jl:16-19)
+    const int nout = std::min(nev, meff);
+    std::vector<cplx> lam(nout);
+    std::vector<int> sel(nout);
+    for (int jj = 0; jj < nout; ++jj) {
+        sel[jj] = order[jj];
+        lam[jj] = cplx(1.0, 0.0) / mu[order[jj]] + eo->sigma;
+    }
+    std::vector<int> perm(nout);
+    for (int i = 0; i < nout; ++i) perm[i] = i;
+    std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) { return lam[x].real() > lam[y].real(); });
+    for (int i = 0; i < nout; ++i) {
+        vals_re[i] = lam[perm[i]].real();
+        vals_im[i] = lam[perm[i]].imag();
+    }
+    for (int i = nout; i < nev; ++i) { vals_re[i] = NAN; vals_im[i] = NAN; }
+    if (vecs) {
+        if (ldvecs < n) return set_error(ctx, "bk_eig_shiftinvert: ldvecs < local length");
+        std::vector<double> Qr((size_t)meff * nout), Qi((size_t)meff * nout);
+        for (int c = 0; c < nout; ++c)
+            for (int i = 0; i < meff; ++i) {
+                Qr[(size_t)i + (size_t)c * meff] = Y(i, sel[perm[c]]).real();
+                Qi[(size_t)i + (size_t)c * meff] = Y(i, sel[perm[c]]).imag();
+            }
+        BK_TRY(v_basis_combine(ctx, n, V, ld, meff, Qr.data(), nout, vecs, ldvecs));
+        if (vecs_im) BK_TRY(v_basis_combine(ctx, n, V, ld, meff, Qi.data(), nout, vecs_im, ldvecs));
+    }
+    if (nconv_out) *nconv_out = std::min(nconv, nout);
+    if (numops_out) *numops_out = A.solves;
+    return 0;
+}

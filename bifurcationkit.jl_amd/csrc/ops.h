@@ -1,0 +1,111 @@
+// Internal: operator / problem / preconditioner objects behind the opaque C handles, and the
+// stencil launchers.
+#pragma once
+
+#include "common.h"
+
+namespace bk {
+
+int halo_exchange(bk_ctx* ctx, const double* v, size_t plane, int nplanes, int width, double* halo_lo,
+                  double* halo_hi);
+
+// ---- stencil launchers (stencil.hip) --------------------------------------------------------
+struct ShArgs {             // Swift-Hohenberg 2-D/3-D, Neumann-ghost (mirror) boundaries
+    int nx, ny, nz;         // local extents (nz = planes owned by this rank; 1 in 2-D)
+    int nzg, zoff;          // global plane count, global index of local plane 0
+    double ax, ay, az;      // 1/hx^2, 1/hy^2, 1/hz^2 (az = 0 in 2-D)
+    double l, nu;           // parameters
+    double a0, a1;          // out = a0*v + a1*( -L1 v + g(u) v )
+    int mode;               // 0: JVP, g = l + 2 nu u - 3 u^2 ; 1: residual (v == u), g = l + nu u - u^2
+    const double* v;
+    const double* u;        // JVP only
+    double* out;
+    const double* halo_lo;  // 2 planes below local plane 0 (multi-GPU interior boundary) or NULL
+    const double* halo_hi;  // 2 planes above local plane nz-1 or NULL
+};
+int sh_apply(bk_ctx* ctx, const ShArgs& a);
+
+struct CglArgs {            // 2-D cubic-quintic complex Ginzburg-Landau, Dirichlet, SoA [u1; u2]
+    int nx, ny;
+    double ax, ay;
+    double r, mu, nu, c3, c5, gamma;
+    double a0, a1;
+    int mode;               // 0: JVP, 1: residual (v == u)
+    const double* v;
+    const double* u;
+    double* out;
+};
+int cgl_apply(bk_ctx* ctx, const CglArgs& a);
+
+struct Sh1dArgs {           // 1-D cubic-quintic SH, Dirichlet, L1 = -(I + D)^2
+    int nx;
+    double ax;
+    double lam, nu;
+    double a0, a1;
+    int mode;               // 0: JVP g = lam + 3 nu u^2 - 5 u^4 ; 1: residual g = lam + nu u^2 - u^4
+    const double* v;
+    const double* u;
+    double* out;
+};
+int sh1d_apply(bk_ctx* ctx, const Sh1dArgs& a);
+
+// ---- DCT preconditioner launchers (dct.hip) -------------------------------------------------
+struct DctPlan;
+int dct_plan_create(bk_ctx* ctx, int ndim, const int n[3], const double ainv[3], double shift, DctPlan** out);
+void dct_plan_destroy(DctPlan* p);
+int dct_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out);
+
+}  // namespace bk
+
+// ---- objects behind the opaque handles ---------------------------------------------------------
+struct bk_problem {
+    bk_ctx* ctx = nullptr;
+    bk_problem_desc desc{};
+    size_t nloc = 0;        // local vector length
+    size_t plane = 0;       // doubles per slab plane
+    int lo = 0, hi = 0;     // slab [lo, hi) of the slowest index
+    double ainv[3] = {0, 0, 0};
+    double* halo_lo = nullptr;
+    double* halo_hi = nullptr;
+    int apply(int mode, const double* v, const double* u, const double* params, double a0, double a1, double* out);
+};
+
+struct bk_op {              // a linear operator on (device vector [+ one host tail scalar])
+    bk_ctx* ctx = nullptr;
+    size_t n = 0;           // local device length
+    int ntail = 0;          // 0, or 1 for bordered (N+1) operators
+    virtual ~bk_op() {}
+    // out = a0*x + a1*A(x)
+    virtual int apply(const double* x, double xt, double a0, double a1, double* out, double* outt) = 0;
+};
+
+struct bk_precond {
+    bk_ctx* ctx = nullptr;
+    size_t n = 0;
+    virtual ~bk_precond() {}
+    virtual int apply(const double* v, double* out) = 0;     // out = Pl \ v ; out may alias v
+};
+
+namespace bk {
+
+struct PdeJacobian : bk_op {          // J(u, params) of a bk_problem; references u
+    bk_problem* prob;
+    const double* u;
+    double params[BK_MAX_PARAMS];
+    int apply(const double* x, double xt, double a0, double a1, double* out, double* outt) override;
+};
+
+// GMRES core on an operator (solver.hip)
+struct GmresResult {
+    int converged = 0;
+    int niter = 0;
+    double resnorm = 0.0;
+};
+// Solve (alpha0 + alpha1 A) x = b, x0 = 0.  Tails (bt in, *xt out) only when A->ntail == 1.
+int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, double bt, double* x, double* xt, double alpha0,
+               double alpha1, const bk_gmres_opts& o, GmresResult* res);
+// The public linear solve with optional left preconditioner (reference branch semantics)
+int linsolve(bk_ctx* ctx, bk_op* J, const double* rhs, double* x, double a0, double a1, const bk_gmres_opts& o,
+             bk_precond* pl, GmresResult* res);
+
+}  // namespace bk

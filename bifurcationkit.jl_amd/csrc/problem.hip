@@ -1,0 +1,150 @@
+// bk_problem: grid description + slab decomposition + residual / Jacobian-operator entry points.
+#include "ops.h"
+
+using namespace bk;
+
+int bk_problem::apply(int mode, const double* v, const double* u, const double* params, double a0, double a1,
+                      double* out) {
+    const bk_problem_desc& d = desc;
+    if (d.pde == BK_PDE_SH) {
+        ShArgs a;
+        a.nx = d.n[0];
+        a.ny = d.n[1];
+        a.nz = d.ndim == 3 ? (hi - lo) : 1;
+        a.nzg = d.ndim == 3 ? d.n[2] : 1;
+        a.zoff = d.ndim == 3 ? lo : 0;
+        a.ax = ainv[0]; a.ay = ainv[1]; a.az = d.ndim == 3 ? ainv[2] : 0.0;
+        a.l = params[0]; a.nu = params[1];
+        a.a0 = a0; a.a1 = a1; a.mode = mode;
+        a.v = v; a.u = u; a.out = out;
+        a.halo_lo = halo_lo; a.halo_hi = halo_hi;
+        if (ctx->nranks > 1) BK_TRY(halo_exchange(ctx, v, plane, a.nz, 2, halo_lo, halo_hi));
+        return sh_apply(ctx, a);
+    }
+    if (d.pde == BK_PDE_CGL2D) {
+        CglArgs a;
+        a.nx = d.n[0]; a.ny = d.n[1];
+        a.ax = ainv[0]; a.ay = ainv[1];
+        a.r = params[0]; a.mu = params[1]; a.nu = params[2]; a.c3 = params[3]; a.c5 = params[4]; a.gamma = params[5];
+        a.a0 = a0; a.a1 = a1; a.mode = mode;
+        a.v = v; a.u = u; a.out = out;
+        return cgl_apply(ctx, a);
+    }
+    if (d.pde == BK_PDE_SH1D) {
+        Sh1dArgs a;
+        a.nx = d.n[0];
+        a.ax = ainv[0];
+        a.lam = params[0]; a.nu = params[1];
+        a.a0 = a0; a.a1 = a1; a.mode = mode;
+        a.v = v; a.u = u; a.out = out;
+        return sh1d_apply(ctx, a);
+    }
+    return set_error(ctx, "unknown pde kind %d", d.pde);
+}
+
+int PdeJacobian::apply(const double* x, double, double a0, double a1, double* out, double*) {
+    return prob->apply(0, x, u, params, a0, a1, out);
+}
+
+static int nparams_of(int pde) { return pde == BK_PDE_CGL2D ? 6 : 2; }
+
+extern "C" {
+
+int bk_problem_create(bk_ctx* ctx, const bk_problem_desc* desc, bk_problem** out) {
+    if (!ctx || !desc || !out) return -1;
+    const bk_problem_desc& d = *desc;
+    if (d.pde == BK_PDE_SH && d.ndim != 2 && d.ndim != 3) return set_error(ctx, "BK_PDE_SH needs ndim 2 or 3");
+    if (d.pde == BK_PDE_SH1D && d.ndim != 1) return set_error(ctx, "BK_PDE_SH1D needs ndim 1");
+    if (d.pde == BK_PDE_CGL2D && d.ndim != 2) return set_error(ctx, "BK_PDE_CGL2D needs ndim 2");
+    if (d.pde != BK_PDE_SH && d.pde != BK_PDE_SH1D && d.pde != BK_PDE_CGL2D) return set_error(ctx, "unknown pde kind");
+    for (int a = 0; a < d.ndim; ++a)
+        if (d.n[a] < 2 || !(d.l[a] > 0.0)) return set_error(ctx, "bad grid extent on axis %d", a);
+    bk_problem* p = new bk_problem();
+    p->ctx = ctx;
+    p->desc = d;
+    for (int a = d.ndim; a < 3; ++a) { p->desc.n[a] = 1; p->desc.l[a] = 1.0; }
+    for (int a = 0; a < d.ndim; ++a) {
+        const double h = 2.0 * d.l[a] / d.n[a];     // hx = 2lx/Nx, examples/SH3d.jl:18
+        p->ainv[a] = 1.0 / (h * h);
+    }
+    if (ctx->nranks > 1) {
+        if (!(d.pde == BK_PDE_SH && d.ndim == 3)) {
+            delete p;
+            return set_error(ctx, "multi-GPU decomposition is implemented for the 3-D Swift-Hohenberg problem only");
+        }
+        const int nz = d.n[2], R = ctx->nranks, r = ctx->rank;
+        const int base = nz / R, rem = nz % R;
+        p->lo = r * base + (r < rem ? r : rem);
+        p->hi = p->lo + base + (r < rem ? 1 : 0);
+        if (p->hi - p->lo < 2) { delete p; return set_error(ctx, "z-slab thinner than 2 planes"); }
+        p->plane = (size_t)d.n[0] * d.n[1];
+        p->nloc = p->plane * (size_t)(p->hi - p->lo);
+        if (hipMalloc(&p->halo_lo, 2 * p->plane * sizeof(double)) != hipSuccess ||
+            hipMalloc(&p->halo_hi, 2 * p->plane * sizeof(double)) != hipSuccess) {
+            delete p;
+            return set_error(ctx, "halo allocation failed");
+        }
+    } else {
+        const int slow = d.ndim - 1;
+        p->lo = 0;
+        p->hi = d.n[slow];
+        size_t n = 1;
+        for (int a = 0; a < d.ndim; ++a) n *= (size_t)d.n[a];
+        p->plane = n / (size_t)d.n[slow];
+        p->nloc = n * (d.pde == BK_PDE_CGL2D ? 2 : 1);
+    }
+    *out = p;
+    return 0;
+}
+
+int bk_problem_destroy(bk_problem* p) {
+    if (!p) return 0;
+    if (p->halo_lo) (void)hipFree(p->halo_lo);
+    if (p->halo_hi) (void)hipFree(p->halo_hi);
+    delete p;
+    return 0;
+}
+
+int bk_problem_nlocal(bk_problem* p, size_t* nlocal, int* slab_lo, int* slab_hi) {
+    if (!p) return -1;
+    if (nlocal) *nlocal = p->nloc;
+    if (slab_lo) *slab_lo = p->lo;
+    if (slab_hi) *slab_hi = p->hi;
+    return 0;
+}
+
+int bk_residual(bk_problem* p, const double* u, const double* params, int nparams, double* out) {
+    if (!p || !u || !params || !out) return -1;
+    if (nparams < nparams_of(p->desc.pde)) return set_error(p->ctx, "bk_residual: expected %d parameters", nparams_of(p->desc.pde));
+    if (u == out) return set_error(p->ctx, "bk_residual: out must not alias u");
+    return p->apply(1, u, u, params, 0.0, 1.0, out);
+}
+
+int bk_jacobian(bk_problem* p, const double* u, const double* params, int nparams, bk_op** out) {
+    if (!p || !u || !params || !out) return -1;
+    if (nparams < nparams_of(p->desc.pde) || nparams > BK_MAX_PARAMS)
+        return set_error(p->ctx, "bk_jacobian: expected %d parameters", nparams_of(p->desc.pde));
+    PdeJacobian* J = new PdeJacobian();
+    J->ctx = p->ctx;
+    J->n = p->nloc;
+    J->ntail = 0;
+    J->prob = p;
+    J->u = u;
+    for (int i = 0; i < BK_MAX_PARAMS; ++i) J->params[i] = i < nparams ? params[i] : 0.0;
+    *out = J;
+    return 0;
+}
+
+int bk_op_destroy(bk_op* op) {
+    delete op;
+    return 0;
+}
+
+int bk_op_apply(bk_op* op, const double* v, double a0, double a1, double* out) {
+    if (!op || !v || !out) return -1;
+    if (op->ntail != 0) return set_error(op->ctx, "bk_op_apply: bordered operators are internal");
+    if (v == out) return set_error(op->ctx, "bk_op_apply: out must not alias v");
+    return op->apply(v, 0.0, a0, a1, out, nullptr);
+}
+
+}  // extern "C"

@@ -1,0 +1,614 @@
+// Device-resident Krylov solvers behind the reference's plugin surface:
+//   gmres_core / linsolve   GMRESKrylovKit + GMRESIterativeSolvers      src/LinearSolver.jl:149-291
+//   bk_bls_bordering        BorderingBLS (BEC + k refinements)           src/LinearBorderSolver.jl:88-166
+//   bk_bls_matrixfree       MatrixFreeBLS on BorderedArray(u, p)         src/LinearBorderSolver.jl:326-335,424-437
+//   bk_eig_shiftinvert      ShiftInvert + Krylov-Schur outer iteration   src/EigSolver.jl:246-266, examples/SH3d.jl:96-113
+//   bk_newton               _newton                                      src/Newton.jl:66-114
+//   bk_newton_palc          newton_palc                                  src/continuation/Palc.jl:187-305
+//
+// MI355X design.  The Krylov basis never leaves HBM; the host only sees (k+2) doubles per Arnoldi step.
+// Orthogonalisation is classical Gram-Schmidt with DGKS selective re-orthogonalisation, done as TWO
+// streaming passes per step instead of the reference packages' 2k..4k BLAS-1 passes:
+//   pass A  multidot : h = V'w and ||w||^2        reads (k+1) vectors
+//   pass B  multiaxpy: v_{k+1} = (w - V h)/beta   reads (k+1), writes 1; beta^2 = ||w||^2 - ||h||^2
+// (re-orthogonalise with a second A/B pair only when beta < eta ||w||).  The Hessenberg matrix, Givens
+// rotations, the (a0, a1) shift and the restart logic stay on the host, as in the packages.
+#include <cmath>
+#include <vector>
+
+#include "dense.h"
+#include "ops.h"
+
+namespace bk {
+
+namespace {
+
+inline size_t round_up(size_t n, size_t m) { return (n + m - 1) / m * m; }
+
+struct Basis {                 // (m+1) device vectors + host tails
+    double* V = nullptr;
+    size_t ld = 0;
+    std::vector<double> t;     // tails
+    double* vec(int i) { return V + (size_t)i * ld; }
+};
+
+// ---------------------------------------------------------------- bordered-vector helpers
+struct VecOps {
+    bk_ctx* ctx;
+    size_t n;
+    int ntail;
+    int dot(const double* x, double xt, const double* y, double yt, double* out) {
+        BK_TRY(v_dot(ctx, n, x, y, out));
+        if (ntail) *out += xt * yt;
+        return 0;
+    }
+    int nrm2(const double* x, double xt, double* out) {
+        double s;
+        BK_TRY(v_dot(ctx, n, x, x, &s));
+        if (ntail) s += xt * xt;
+        *out = std::sqrt(s);
+        return 0;
+    }
+};
+
+// One Arnoldi step: w = A V[j]; orthogonalise against V[0..j]; write V[j+1] = w / beta.
+// h[0..j] receives the projections, *beta the norm of the remainder (0 => breakdown, V[j+1] not written).
+int arnoldi_step(bk_ctx* ctx, bk_op* A, Basis& B, int j, double* w, double* h, double* beta, double op_a0,
+                 double op_a1) {
+    const size_t n = A->n;
+    const int nt = A->ntail;
+    double wt = 0.0;
+    BK_TRY(A->apply(B.vec(j), nt ? B.t[j] : 0.0, op_a0, op_a1, w, &wt));
+    const int k = j + 1;
+    double hh[kMaxBasis + 1];
+    BK_TRY(v_multidot(ctx, n, B.V, B.ld, k, w, hh));
+    double ww = hh[k];
+    if (nt) {
+        for (int i = 0; i < k; ++i) hh[i] += B.t[i] * wt;
+        ww += wt * wt;
+    }
+    double hsq = 0.0;
+    for (int i = 0; i < k; ++i) { h[i] = hh[i]; hsq += hh[i] * hh[i]; }
+    double b2 = ww - hsq;
+    const double eta = ctx->opt("dgks_eta", 0.7071067811865476);
+    const double tiny = 1e-28 * ww;
+    if (!(b2 > tiny) || ww == 0.0) {
+        // w lies (numerically) in span(V): verify with an explicit pass before declaring breakdown
+        double c[kMaxBasis];
+        for (int i = 0; i < k; ++i) c[i] = -h[i];
+        double nn = 0.0;
+        BK_TRY(v_multiaxpy(ctx, n, B.V, B.ld, k, c, w, 1.0, w, &nn));
+        if (nt) {
+            for (int i = 0; i < k; ++i) wt -= h[i] * B.t[i];
+            nn += wt * wt;
+        }
+        if (!(nn > 1e-30 * ww) || ww == 0.0) { *beta = 0.0; return 0; }
+        // not a breakdown after all: normalise and fall through to a re-orthogonalisation
+        const double bn = std::sqrt(nn);
+        BK_TRY(v_axpbyz(ctx, n, 1.0 / bn, w, 0.0, nullptr, B.vec(k)));
+        if (nt) B.t[k] = wt / bn;
+        b2 = nn;
+        *beta = bn;
+    } else {
+        const double be = std::sqrt(b2);
+        double c[kMaxBasis];
+        for (int i = 0; i < k; ++i) c[i] = -h[i];
+        BK_TRY(v_multiaxpy(ctx, n, B.V, B.ld, k, c, w, 1.0 / be, B.vec(k), nullptr));
+        if (nt) {
+            double t = wt;
+            for (int i = 0; i < k; ++i) t -= h[i] * B.t[i];
+            B.t[k] = t / be;
+        }
+        *beta = be;
+        if (b2 >= eta * eta * ww) return 0;          // DGKS: no cancellation, one pass is enough
+    }
+    // re-orthogonalise v = V[k] (unit norm up to the cancellation error): s = V'v; v = (v - V s)/||.||
+    double ss[kMaxBasis + 1];
+    BK_TRY(v_multidot(ctx, n, B.V, B.ld, k, B.vec(k), ss));
+    double vv = ss[k];
+    if (nt) {
+        for (int i = 0; i < k; ++i) ss[i] += B.t[i] * B.t[k];
+        vv += B.t[k] * B.t[k];
+    }
+    double ssq = 0.0;
+    for (int i = 0; i < k; ++i) ssq += ss[i] * ss[i];
+    double c2 = vv - ssq;
+    if (!(c2 > 1e-28 * vv)) { *beta = 0.0; return 0; }
+    const double cn = std::sqrt(c2);
+    double c[kMaxBasis];
+    for (int i = 0; i < k; ++i) { c[i] = -ss[i]; h[i] += (*beta) * ss[i]; }
+    BK_TRY(v_multiaxpy(ctx, n, B.V, B.ld, k, c, B.vec(k), 1.0 / cn, B.vec(k), nullptr));
+    if (nt) {
+        double t = B.t[k];
+        for (int i = 0; i < k; ++i) t -= ss[i] * B.t[i];
+        B.t[k] = t / cn;
+    }
+    *beta = (*beta) * cn;
+    return 0;
+}
+
+}  // namespace
+
+// Arnoldi step on a caller-owned basis (eig.hip)
+int arnoldi_step_public(bk_ctx* ctx, bk_op* A, double* V, size_t ld, std::vector<double>& tails, int j, double* w,
+                        double* h, double* beta) {
+    Basis B;
+    B.V = V;
+    B.ld = ld;
+    B.t.swap(tails);
+    const int s = arnoldi_step(ctx, A, B, j, w, h, beta, 0.0, 1.0);
+    B.t.swap(tails);
+    return s;
+}
+
+// ================================================================== GMRES
+int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, double bt, double* x, double* xt, double alpha0,
+               double alpha1, const bk_gmres_opts& o, GmresResult* res) {
+    const size_t n = A->n;
+    const int nt = A->ntail;
+    const int m = o.dim;
+    if (m < 1 || m > kMaxBasis - 1) return set_error(ctx, "gmres: Krylov dimension %d outside [1, %d]", m, kMaxBasis - 1);
+    const bool kk = (o.flavor == BK_GMRES_KRYLOVKIT);
+    // KrylovKit builds the Krylov space on A and applies (alpha0, alpha1) to the Hessenberg matrix;
+    // IterativeSolvers iterates on the shifted operator itself.
+    const double op_a0 = kk ? 0.0 : alpha0, op_a1 = kk ? 1.0 : alpha1;
+    const double s0 = kk ? alpha0 : 0.0, s1 = kk ? alpha1 : 1.0;
+    VecOps vo{ctx, n, nt};
+    WsGuard ws(ctx);
+    Basis B;
+    B.ld = round_up(n, 32);
+    BK_TRY(ws.get(B.ld * (size_t)(m + 1), &B.V));
+    B.t.assign(m + 1, 0.0);
+    double *w = nullptr, *r = nullptr;
+    BK_TRY(ws.get(B.ld, &w));
+    BK_TRY(ws.get(B.ld, &r));
+
+    BK_TRY(v_zero(ctx, n, x));
+    double xtail = 0.0;
+    double bnorm = 0.0;
+    BK_TRY(vo.nrm2(b, bt, &bnorm));
+    double beta = bnorm;                       // x0 = 0  =>  r0 = b
+    const double tol = kk ? std::max(o.atol, o.rtol * bnorm) : std::max(o.rtol * bnorm, o.atol);
+    int numops = kk ? 1 : 0;                   // KrylovKit applies A once to x0 to fix the scalar type
+    int iters = 0;                             // IterativeSolvers counts inner iterations
+    res->converged = 0;
+    if (kk ? (beta < tol) : (beta <= tol)) {
+        res->converged = 1; res->niter = kk ? numops : 0; res->resnorm = beta;
+        if (xt) *xt = 0.0;
+        return 0;
+    }
+    BK_TRY(v_copy(ctx, n, b, r));
+    double rt = bt;
+
+    std::vector<double> R((size_t)m * m, 0.0), y(m + 1, 0.0), cs(m, 0.0), sn(m, 0.0), h(m + 1, 0.0), col(m + 1, 0.0);
+    auto Rat = [&](int i, int j) -> double& { return R[(size_t)i + (size_t)j * m]; };
+    int numiter = 0;
+    double hnext = 0.0;
+    bool have_first = false;
+
+    auto start_cycle = [&]() -> int {        // V[0] = r / beta ; first Arnoldi column
+        BK_TRY(v_axpbyz(ctx, n, 1.0 / beta, r, 0.0, nullptr, B.vec(0)));
+        if (nt) B.t[0] = rt / beta;
+        BK_TRY(arnoldi_step(ctx, A, B, 0, w, h.data(), &hnext, op_a0, op_a1));
+        numops += 1;
+        have_first = true;
+        return 0;
+    };
+
+    const int max_cycles = kk ? o.maxiter : 1 << 30;
+    BK_TRY(start_cycle());
+    while (numiter < max_cycles) {
+        numiter += 1;
+        std::fill(y.begin(), y.end(), 0.0);
+        y[0] = beta;
+        int k = 0;
+        bool stop = false;
+        while (true) {
+            // column k of the (shifted) Hessenberg is in h[0..k], hnext
+            k += 1;
+            iters += 1;
+            for (int i = 0; i < k; ++i) col[i] = s1 * h[i];
+            col[k - 1] += s0;
+            for (int i = 0; i < k - 1; ++i) {
+                const double t = cs[i] * col[i] + sn[i] * col[i + 1];
+                col[i + 1] = -sn[i] * col[i] + cs[i] * col[i + 1];
+                col[i] = t;
+            }
+            double rr;
+            dense::givens(col[k - 1], s1 * hnext, cs[k - 1], sn[k - 1], rr);
+            col[k - 1] = rr;
+            for (int i = 0; i < k; ++i) Rat(i, k - 1) = col[i];
+            y[k] = -sn[k - 1] * y[k - 1];
+            y[k - 1] = cs[k - 1] * y[k - 1];
+            beta = std::fabs(y[k]);
+            const bool conv = kk ? !(beta > tol) : (beta <= tol);
+            if (conv || k >= m || hnext == 0.0) break;
+            if (!kk && iters >= o.maxiter) { stop = true; break; }
+            BK_TRY(arnoldi_step(ctx, A, B, k, w, h.data(), &hnext, op_a0, op_a1));
+            numops += 1;
+        }
+        // solve R yk = y[0..k) and update x += V[0..k) yk
+        std::vector<double> yk(k);
+        for (int i = k - 1; i >= 0; --i) {
+            double s = y[i];
+            for (int j = i + 1; j < k; ++j) s -= Rat(i, j) * yk[j];
+            yk[i] = s / Rat(i, i);
+        }
+        BK_TRY(v_multiaxpy(ctx, n, B.V, B.ld, k, yk.data(), x, 1.0, x, nullptr));
+        if (nt) for (int i = 0; i < k; ++i) xtail += yk[i] * B.t[i];
+
+        if (kk) {
+            if (beta > tol && hnext != 0.0) {
+                // residual from the Krylov data: r = y[k] * V[0..k] * (G_1' ... G_k' e_{k+1})
+                std::vector<double> z(k + 1, 0.0);
+                z[k] = 1.0;
+                for (int i = k - 1; i >= 0; --i) {
+                    const double t = cs[i] * z[i] - sn[i] * z[i + 1];
+                    z[i + 1] = sn[i] * z[i] + cs[i] * z[i + 1];
+                    z[i] = t;
+                }
+                for (int i = 0; i <= k; ++i) z[i] *= y[k];
+                BK_TRY(v_multiaxpy(ctx, n, B.V, B.ld, k + 1, z.data(), nullptr, 1.0, r, nullptr));
+                if (nt) { rt = 0.0; for (int i = 0; i <= k; ++i) rt += z[i] * B.t[i]; }
+            } else {
+                // explicit residual r = b - (a0 + a1 A) x, "to ensure that no numerical errors have accumulated"
+                double wt = 0.0;
+                BK_TRY(A->apply(x, xtail, alpha0, alpha1, w, &wt));
+                numops += 1;
+                BK_TRY(v_axpbyz(ctx, n, 1.0, b, -1.0, w, r));
+                if (nt) rt = bt - wt;
+                BK_TRY(vo.nrm2(r, rt, &beta));
+                if (beta < tol) { res->converged = 1; break; }
+            }
+            if (numiter < max_cycles) {
+                BK_TRY(vo.nrm2(r, rt, &beta));
+                if (beta == 0.0) { res->converged = 1; break; }
+                BK_TRY(start_cycle());
+            }
+        } else {
+            if (beta <= tol) { res->converged = 1; break; }
+            if (stop || iters >= o.maxiter) break;
+            double wt = 0.0;
+            BK_TRY(A->apply(x, xtail, alpha0, alpha1, w, &wt));
+            BK_TRY(v_axpbyz(ctx, n, 1.0, b, -1.0, w, r));
+            if (nt) rt = bt - wt;
+            BK_TRY(vo.nrm2(r, rt, &beta));
+            if (beta <= tol) { res->converged = 1; break; }
+            BK_TRY(start_cycle());
+        }
+    }
+    (void)have_first;
+    res->niter = kk ? numops : iters;
+    res->resnorm = beta;
+    if (xt) *xt = xtail;
+    return 0;
+}
+
+namespace {
+
+// v -> a0 v + a1 Pl^-1 (J v)   (order 0: KrylovKit branch, src/LinearSolver.jl:270-277)
+// v -> Pl^-1 (a0 v + a1 J v)   (order 1: IterativeSolvers `Pl`, :198-201)
+// v -> a0 v + a1 J v           (no preconditioner; used by the IterativeSolvers flavor)
+struct ShiftPrecOp : bk_op {
+    bk_op* J;
+    bk_precond* P;
+    double a0, a1;
+    int order;
+    double* tmp;
+    int apply(const double* x, double, double b0, double b1, double* out, double*) override {
+        // out = b0 x + b1 * W(x)
+        if (!P) return J->apply(x, 0.0, b0 + b1 * a0, b1 * a1, out, nullptr);
+        if (order == 0) {
+            BK_TRY(J->apply(x, 0.0, 0.0, 1.0, tmp, nullptr));
+            BK_TRY(P->apply(tmp, tmp));
+            return v_axpbyz(ctx, n, b0 + b1 * a0, x, b1 * a1, tmp, out);
+        }
+        BK_TRY(J->apply(x, 0.0, a0, a1, tmp, nullptr));
+        BK_TRY(P->apply(tmp, tmp));
+        return v_axpbyz(ctx, n, b0, x, b1, tmp, out);
+    }
+};
+
+}  // namespace
+
+int linsolve(bk_ctx* ctx, bk_op* J, const double* rhs, double* x, double a0, double a1, const bk_gmres_opts& o,
+             bk_precond* pl, GmresResult* res) {
+    if (J->ntail != 0) return set_error(ctx, "linsolve: operator must be unbordered");
+    if (x == rhs) return set_error(ctx, "linsolve: x must not alias rhs");
+    const bool kk = (o.flavor == BK_GMRES_KRYLOVKIT);
+    if (!pl && kk) return gmres_core(ctx, J, rhs, 0.0, x, nullptr, a0, a1, o, res);
+    WsGuard ws(ctx);
+    ShiftPrecOp W;
+    W.ctx = ctx; W.n = J->n; W.ntail = 0;
+    W.J = J; W.P = pl; W.a0 = a0; W.a1 = a1; W.order = kk ? 0 : 1; W.tmp = nullptr;
+    const double* b = rhs;
+    if (pl) {
+        double* prhs = nullptr;
+        BK_TRY(ws.get(J->n, &W.tmp));
+        BK_TRY(ws.get(J->n, &prhs));
+        BK_TRY(pl->apply(rhs, prhs));            // ldiv!(similar(rhs), Pl, copy(rhs)) :278
+        b = prhs;
+    }
+    return gmres_core(ctx, &W, b, 0.0, x, nullptr, 0.0, 1.0, o, res);
+}
+
+}  // namespace bk
+
+using namespace bk;
+
+// ================================================================== C ABI: linear solves
+extern "C" {
+
+void bk_gmres_default_opts(bk_gmres_opts* o, int flavor) {
+    if (!o) return;
+    o->flavor = flavor;
+    if (flavor == BK_GMRES_ITERATIVESOLVERS) {      // src/LinearSolver.jl:151-160
+        o->dim = 200 > kMaxBasis - 1 ? kMaxBasis - 1 : 200;
+        o->maxiter = 100; o->atol = 0.0; o->rtol = 1e-8;
+    } else {                                        // KrylovDefaults, src/LinearSolver.jl:225-234
+        o->dim = 30; o->maxiter = 100; o->atol = 1e-12; o->rtol = 1e-12;
+    }
+}
+
+int bk_gmres(bk_ctx* ctx, bk_op* J, const double* rhs, double* x, double a0, double a1, const bk_gmres_opts* opts,
+             bk_precond* pl, int* converged, int* niter, double* resnorm) {
+    if (!ctx || !J || !rhs || !x || !opts) return -1;
+    GmresResult r;
+    BK_TRY(linsolve(ctx, J, rhs, x, a0, a1, *opts, pl, &r));
+    if (converged) *converged = r.converged;
+    if (niter) *niter = r.niter;
+    if (resnorm) *resnorm = r.resnorm;
+    return 0;
+}
+
+int bk_gmres2(bk_ctx* ctx, bk_op* J, const double* rhs1, const double* rhs2, double* x1, double* x2, double a0,
+              double a1, const bk_gmres_opts* opts, bk_precond* pl, int* converged, int niter[2]) {
+    if (!ctx || !J || !rhs1 || !rhs2 || !x1 || !x2 || !opts) return -1;
+    if (x1 == x2) return set_error(ctx, "bk_gmres2: x1 and x2 must be distinct buffers");
+    GmresResult r1, r2;
+    BK_TRY(linsolve(ctx, J, rhs1, x1, a0, a1, *opts, pl, &r1));
+    BK_TRY(linsolve(ctx, J, rhs2, x2, a0, a1, *opts, pl, &r2));
+    if (converged) *converged = r1.converged & r2.converged;
+    if (niter) { niter[0] = r1.niter; niter[1] = r2.niter; }
+    return 0;
+}
+
+}  // extern "C"
+
+// ================================================================== bordered solvers
+namespace bk {
+
+struct BorderingState {          // caches dx = (shift + J)^-1 dR between BEC passes
+    double* dx = nullptr;
+    bool have_dx = false;
+    int it_dx = 0;
+    int cv_dx = 1;
+};
+
+// BEC, src/LinearBorderSolver.jl:125-144.  x1 <- (shift+J)^-1 R - dl * dx.
+static int bec(bk_ctx* ctx, bk_op* J, const double* dR, const double* dzu, double dzp, const double* R, double nn,
+               double xiu, double xip, bool has_shift, double shift, double dotscale, const bk_gmres_opts& ls,
+               bk_precond* pl, BorderingState& st, double* x1, double* dl, int* cv, int it[2]) {
+    const size_t n = J->n;
+    GmresResult r1;
+    const double a0 = has_shift ? shift : 0.0;
+    BK_TRY(linsolve(ctx, J, R, x1, a0, 1.0, ls, pl, &r1));
+    if (!st.have_dx) {
+        GmresResult r2;
+        BK_TRY(linsolve(ctx, J, dR, st.dx, a0, 1.0, ls, pl, &r2));
+        st.have_dx = true; st.it_dx = r2.niter; st.cv_dx = r2.converged;
+    }
+    double d[2];
+    BK_TRY(v_dot2(ctx, n, dzu, x1, st.dx, d));
+    d[0] *= dotscale; d[1] *= dotscale;
+    *dl = (nn - d[0] * xiu) / (dzp * xip - d[1] * xiu);
+    BK_TRY(v_axpby(ctx, n, -(*dl), st.dx, 1.0, x1));
+    *cv = r1.converged & st.cv_dx;
+    it[0] = r1.niter; it[1] = st.it_dx;
+    return 0;
+}
+
+int bls_bordering(bk_ctx* ctx, bk_op* J, const double* dR, const double* dzu, double dzp, const double* R, double nn,
+                  double xiu, double xip, bool has_shift, double shift, double dotscale, const bk_bordering_opts& bo,
+                  const bk_gmres_opts& ls, bk_precond* pl, double* dX, double* dl, int* converged, int itlinear[2]) {
+    const size_t n = J->n;
+    WsGuard ws(ctx);
+    BorderingState st;
+    BK_TRY(ws.get(n, &st.dx));
+    int cv = 0, it[2] = {0, 0};
+    BK_TRY(bec(ctx, J, dR, dzu, dzp, R, nn, xiu, xip, has_shift, shift, dotscale, ls, pl, st, dX, dl, &cv, it));
+    int k = 0;
+    bool fail = true;
+    double *dXr = nullptr, *dX1 = nullptr;
+    while (bo.check_precision && k < bo.k && fail) {
+        // residualBEC, :146-166: dXr = R - (shift + J) dX - dl dR ; dlr = n - xip dzp dl - xiu dotp(dzu, dX)
+        if (!dXr) { BK_TRY(ws.get(n, &dXr)); BK_TRY(ws.get(n, &dX1)); }
+        BK_TRY(J->apply(dX, 0.0, has_shift ? shift : 0.0, 1.0, dXr, nullptr));
+        BK_TRY(v_axpby(ctx, n, *dl, dR, 1.0, dXr));
+        BK_TRY(v_axpby(ctx, n, 1.0, R, -1.0, dXr));
+        double dd, nr;
+        BK_TRY(v_dot(ctx, n, dzu, dX, &dd));
+        const double dlr = nn - xip * dzp * (*dl) - xiu * dotscale * dd;
+        BK_TRY(v_nrm2(ctx, n, dXr, &nr));
+        fail = nr > bo.tol || std::fabs(dlr) > bo.tol;
+        if (fail) {
+            double dl1 = 0.0;
+            BK_TRY(bec(ctx, J, dR, dzu, dzp, dXr, dlr, xiu, xip, has_shift, shift, dotscale, ls, pl, st, dX1, &dl1, &cv, it));
+            BK_TRY(v_axpby(ctx, n, 1.0, dX1, 1.0, dX));
+            *dl += dl1;
+            k += 1;
+        }
+    }
+    if (converged) *converged = cv;
+    if (itlinear) { itlinear[0] = it[0]; itlinear[1] = it[1]; }
+    return 0;
+}
+
+// MatrixFreeBLSmap on BorderedArray, src/LinearBorderSolver.jl:326-335
+struct BorderedMapOp : bk_op {
+    bk_op* J;
+    const double* a;      // dR
+    const double* bvec;   // dzu (scaled by xiu * dotscale through `bscale`)
+    double bscale, c;
+    bool has_shift;
+    double shift;
+    int apply(const double* x, double xt, double b0, double b1, double* out, double* outt) override {
+        // out.u = b0 x + b1 (J x + shift x + xt a) ; out.p = b0 xt + b1 (bscale <b, x> + c xt)
+        BK_TRY(J->apply(x, 0.0, b0 + b1 * (has_shift ? shift : 0.0), b1, out, nullptr));
+        if (xt != 0.0 && b1 != 0.0) BK_TRY(v_axpby(ctx, n, b1 * xt, a, 1.0, out));
+        double d;
+        BK_TRY(v_dot(ctx, n, bvec, x, &d));
+        *outt = b0 * xt + b1 * (bscale * d + c * xt);
+        return 0;
+    }
+};
+
+}  // namespace bk
+
+extern "C" {
+
+int bk_bls_bordering(bk_ctx* ctx, bk_op* J, const double* dR, const double* dzu, double dzp, const double* R,
+                     double n, double xiu, double xip, int has_shift, double shift, double dotscale,
+                     const bk_bordering_opts* bopts, const bk_gmres_opts* lsopts, bk_precond* pl, double* dX,
+                     double* dl, int* converged, int itlinear[2]) {
+    if (!ctx || !J || !dR || !dzu || !R || !bopts || !lsopts || !dX || !dl) return -1;
+    if (dX == R || dX == dR || dX == dzu) return set_error(ctx, "bk_bls_bordering: dX must be a fresh buffer");
+    if (bopts->k < 1) return set_error(ctx, "BorderingBLS: number of recursions must be positive");
+    return bls_bordering(ctx, J, dR, dzu, dzp, R, n, xiu, xip, has_shift != 0, shift, dotscale, *bopts, *lsopts, pl, dX,
+                         dl, converged, itlinear);
+}
+
+int bk_bls_matrixfree(bk_ctx* ctx, bk_op* J, const double* dR, const double* dzu, double dzp, const double* R,
+                      double n, double xiu, double xip, int has_shift, double shift, double dotscale,
+                      const bk_gmres_opts* lsopts, double* dX, double* dl, int* converged, int* itlinear) {
+    if (!ctx || !J || !dR || !dzu || !R || !lsopts || !dX || !dl) return -1;
+    if (dX == R || dX == dR || dX == dzu) return set_error(ctx, "bk_bls_matrixfree: dX must be a fresh buffer");
+    BorderedMapOp M;
+    M.ctx = ctx; M.n = J->n; M.ntail = 1;
+    M.J = J; M.a = dR; M.bvec = dzu; M.bscale = xiu * dotscale; M.c = dzp * xip;
+    M.has_shift = has_shift != 0; M.shift = shift;
+    GmresResult r;
+    BK_TRY(gmres_core(ctx, &M, R, n, dX, dl, 0.0, 1.0, *lsopts, &r));
+    if (converged) *converged = r.converged;
+    if (itlinear) *itlinear = r.niter;
+    return 0;
+}
+
+}  // extern "C"
+
+// ================================================================== Newton correctors
+namespace bk {
+
+static int norm_of(bk_ctx* ctx, size_t n, const double* x, bool inf, double* out) {
+    return inf ? v_nrminf(ctx, n, x, out) : v_nrm2(ctx, n, x, out);
+}
+
+}  // namespace bk
+
+extern "C" {
+
+int bk_newton(bk_ctx* ctx, bk_problem* prob, double* x, const double* params, int nparams, const bk_newton_opts* no,
+              const bk_gmres_opts* lsopts, bk_precond* pl, bk_newton_result* res) {
+    if (!ctx || !prob || !x || !params || !no || !lsopts || !res) return -1;
+    if (no->max_iterations > BK_MAX_NEWTON_ITER) return set_error(ctx, "max_iterations > %d", BK_MAX_NEWTON_ITER);
+    const size_t n = prob->nloc;
+    WsGuard ws(ctx);
+    double *fx = nullptr, *u = nullptr;
+    BK_TRY(ws.get(n, &fx));
+    BK_TRY(ws.get(n, &u));
+    BK_TRY(bk_residual(prob, x, params, nparams, fx));
+    double r;
+    BK_TRY(norm_of(ctx, n, fx, no->norm_inf != 0, &r));
+    int step = 0, itlin = 0;
+    res->residuals[0] = r;
+    while (step < no->max_iterations && r > no->tol) {
+        bk_op* J = nullptr;
+        BK_TRY(bk_jacobian(prob, x, params, nparams, &J));
+        GmresResult g;
+        int s = linsolve(ctx, J, fx, u, 0.0, 1.0, *lsopts, pl, &g);
+        bk_op_destroy(J);
+        if (s != 0) return s;
+        itlin += g.niter;
+        BK_TRY(v_axpby(ctx, n, -1.0, u, 1.0, x));            // minus!!(x, u), src/Newton.jl:97
+        BK_TRY(bk_residual(prob, x, params, nparams, fx));
+        BK_TRY(norm_of(ctx, n, fx, no->norm_inf != 0, &r));
+        step += 1;
+        res->residuals[step] = r;
+    }
+    res->converged = res->residuals[step] < no->tol;
+    res->itnewton = step;
+    res->itlinear = itlin;
+    return 0;
+}
+
+int bk_newton_palc(bk_ctx* ctx, bk_problem* prob, double* x, double* p, const double* z0u, double z0p,
+                   const double* tauu, double taup, double ds, double theta, const double* params, int nparams,
+                   int ipar, double p_min, double p_max, const bk_newton_opts* no, const bk_bordering_opts* bo,
+                   const bk_gmres_opts* lsopts, bk_precond* pl, bk_newton_result* res) {
+    if (!ctx || !prob || !x || !p || !z0u || !tauu || !params || !no || !bo || !lsopts || !res) return -1;
+    if (ipar < 0 || ipar >= nparams || nparams > BK_MAX_PARAMS) return set_error(ctx, "bad parameter index");
+    if (no->max_iterations > BK_MAX_NEWTON_ITER) return set_error(ctx, "max_iterations > %d", BK_MAX_NEWTON_ITER);
+    const size_t n = prob->nloc;
+    // length(x) of the reference's NormalisedDot (Palc.jl:1-6) = GLOBAL number of unknowns
+    double Nglob = 1.0;
+    for (int a = 0; a < prob->desc.ndim; ++a) Nglob *= prob->desc.n[a];
+    if (prob->desc.pde == BK_PDE_CGL2D) Nglob *= 2.0;
+    const double dotscale = 1.0 / Nglob;
+    const double eps = 1.4901161193847656e-08;             // sqrt(eps(Float64)): src/Problems.jl:69-70
+    WsGuard ws(ctx);
+    double *res_f = nullptr, *dFdp = nullptr, *u = nullptr;
+    BK_TRY(ws.get(n, &res_f));
+    BK_TRY(ws.get(n, &dFdp));
+    BK_TRY(ws.get(n, &u));
+    double par[BK_MAX_PARAMS];
+    for (int i = 0; i < nparams; ++i) par[i] = params[i];
+    const bool inf = no->norm_inf != 0;
+    double dz0;                                            // <z0.u, tau.u>: second term of arc_length_eq, Palc.jl:51-55
+    BK_TRY(v_dot(ctx, n, z0u, tauu, &dz0));
+    auto Nfun = [&](double pp, double* out) -> int {       // Palc.jl:212
+        double d;
+        BK_TRY(v_dot(ctx, n, x, tauu, &d));
+        *out = (d * dotscale * theta + (pp - z0p) * taup * (1.0 - theta) - ds) - (dz0 * dotscale * theta);
+        return 0;
+    };
+    double pc = *p;
+    par[ipar] = pc;
+    BK_TRY(bk_residual(prob, x, par, nparams, res_f));
+    double res_n, rf;
+    BK_TRY(Nfun(pc, &res_n));
+    BK_TRY(norm_of(ctx, n, res_f, inf, &rf));
+    double r = std::max(rf, std::fabs(res_n));
+    int step = 0, itlin = 0;
+    res->residuals[0] = r;
+    while (step < no->max_iterations && r > no->tol) {
+        par[ipar] = pc + eps;                              // dFdp = (F(x, p + eps) - res_f)/eps, Palc.jl:239-240
+        BK_TRY(bk_residual(prob, x, par, nparams, dFdp));
+        BK_TRY(v_axpby(ctx, n, -1.0 / eps, res_f, 1.0 / eps, dFdp));
+        par[ipar] = pc;
+        bk_op* J = nullptr;
+        BK_TRY(bk_jacobian(prob, x, par, nparams, &J));
+        double up = 0.0;
+        int cv = 0, it[2] = {0, 0};
+        int s = bls_bordering(ctx, J, dFdp, tauu, taup, res_f, res_n, theta, 1.0 - theta, false, 0.0, dotscale, *bo,
+                              *lsopts, pl, u, &up, &cv, it);
+        bk_op_destroy(J);
+        if (s != 0) return s;
+        itlin += it[0] + it[1];
+        BK_TRY(v_axpby(ctx, n, -1.0, u, 1.0, x));            // x = minus!!(x, u), Palc.jl:282
+        pc = std::min(std::max(pc - up, p_min), p_max);      // clamp, :283
+        par[ipar] = pc;
+        BK_TRY(bk_residual(prob, x, par, nparams, res_f));
+        BK_TRY(Nfun(pc, &res_n));
+        BK_TRY(norm_of(ctx, n, res_f, inf, &rf));
+        r = std::max(rf, std::fabs(res_n));
+        step += 1;
+        res->residuals[step] = r;
+    }
+    *p = pc;
+    res->converged = res->residuals[step] < no->tol;
+    res->itnewton = step;
+    res->itlinear = itlin;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,464 @@
+// BLAS-1 and the fused Krylov-basis kernels (multi-dot V'w, multi-axpy w - V h with fused scale + norm).
+// All HBM-bound streaming kernels: 16-byte loads per lane, grid-stride over <= kRedBlocks*2 blocks of
+// 256 threads (4 wavefronts of 64), wave64 shuffle reductions -> LDS -> per-block partial -> a
+// second tiny kernel (fixed order => bitwise reproducible run to run).
+//
+// They replace the VectorInterface calls of the reference's Krylov loops (src/BorderedArrays.jl:86-217
+// and the orthogonalisation inside KrylovKit / IterativeSolvers).
+#include "common.h"
+
+namespace bk {
+
+namespace {
+
+constexpr int kThreads = 256;
+
+inline int grid_for(size_t n, int per_thread, int max_blocks) {
+    size_t b = (n + (size_t)kThreads * per_thread - 1) / ((size_t)kThreads * per_thread);
+    if (b < 1) b = 1;
+    if (b > (size_t)max_blocks) b = max_blocks;
+    return (int)b;
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    return v;
+}
+
+// ------------------------------------------------------------------ elementwise
+template <int VEC>
+__global__ void __launch_bounds__(kThreads) axpbyz_kernel(size_t n, double a, const double* __restrict__ x, double b,
+                                                          const double* y, double* z, int has_x, int has_y) {
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    if (VEC == 2) {
+        const size_t n2 = n >> 1;
+        for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += stride) {
+            double2 r = make_double2(0.0, 0.0);
+            if (has_x) { const double2 xv = reinterpret_cast<const double2*>(x)[i]; r.x = a * xv.x; r.y = a * xv.y; }
+            if (has_y) { const double2 yv = reinterpret_cast<const double2*>(y)[i]; r.x += b * yv.x; r.y += b * yv.y; }
+            reinterpret_cast<double2*>(z)[i] = r;
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+            const size_t i = n - 1;
+            double r = 0.0;
+            if (has_x) r = a * x[i];
+            if (has_y) r += b * y[i];
+            z[i] = r;
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+            double r = 0.0;
+            if (has_x) r = a * x[i];
+            if (has_y) r += b * y[i];
+            z[i] = r;
+        }
+    }
+}
+
+// splitmix64-based uniform [0,1): deterministic in (seed, global index)
+__global__ void __launch_bounds__(kThreads) fill_random_kernel(size_t n, size_t goff, unsigned long long seed,
+                                                               double* __restrict__ x) {
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(goff + i + 1);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z = z ^ (z >> 31);
+        x[i] = (double)(z >> 11) * (1.0 / 9007199254740992.0);
+    }
+}
+
+// ------------------------------------------------------------------ reductions, stage 1
+// NV outputs per block: out[block*NV + j].
+template <int VEC, int NY>   // dot of x with NY vectors y[0..NY) ; if y==x it is a squared norm
+__global__ void __launch_bounds__(kThreads) dot_kernel(size_t n, const double* __restrict__ x,
+                                                       const double* __restrict__ y0, const double* __restrict__ y1,
+                                                       double* __restrict__ partials) {
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    double s0 = 0.0, s1 = 0.0;
+    if (VEC == 2) {
+        const size_t n2 = n >> 1;
+        for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += stride) {
+            const double2 xv = reinterpret_cast<const double2*>(x)[i];
+            const double2 a = reinterpret_cast<const double2*>(y0)[i];
+            s0 = fma(xv.x, a.x, s0); s0 = fma(xv.y, a.y, s0);
+            if (NY == 2) {
+                const double2 b = reinterpret_cast<const double2*>(y1)[i];
+                s1 = fma(xv.x, b.x, s1); s1 = fma(xv.y, b.y, s1);
+            }
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+            s0 = fma(x[n - 1], y0[n - 1], s0);
+            if (NY == 2) s1 = fma(x[n - 1], y1[n - 1], s1);
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+            s0 = fma(x[i], y0[i], s0);
+            if (NY == 2) s1 = fma(x[i], y1[i], s1);
+        }
+    }
+    __shared__ double sm[2][4];
+    s0 = wave_sum(s0);
+    if (NY == 2) s1 = wave_sum(s1);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { sm[0][w] = s0; sm[1][w] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partials[(size_t)blockIdx.x * NY + 0] = (sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3]);
+        if (NY == 2) partials[(size_t)blockIdx.x * NY + 1] = (sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3]);
+    }
+}
+
+__global__ void __launch_bounds__(kThreads) absmax_kernel(size_t n, const double* __restrict__ x,
+                                                          double* __restrict__ partials) {
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    double m = 0.0;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) m = fmax(m, fabs(x[i]));
+    __shared__ double sm[4];
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+}
+
+// ------------------------------------------------------------------ fused multi-dot
+// partials[block][j] = sum_chunk V_j . w  (j < k), partials[block][k] = sum_chunk w . w.
+// KB = compile-time bucket >= k: accumulators stay in registers, loads of absent vectors are skipped
+// by a wave-uniform predicate.  Every thread keeps KB+1 independent load streams in flight.
+template <int KB, int VEC>
+__global__ void __launch_bounds__(kThreads) multidot_kernel(size_t n, const double* __restrict__ V, size_t ldv, int k,
+                                                            const double* __restrict__ w,
+                                                            double* __restrict__ partials) {
+    double acc[KB];
+#pragma unroll
+    for (int j = 0; j < KB; ++j) acc[j] = 0.0;
+    double ww = 0.0;
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    if (VEC == 2) {
+        const size_t n2 = n >> 1;
+        for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += stride) {
+            const double2 wv = reinterpret_cast<const double2*>(w)[i];
+            ww = fma(wv.x, wv.x, ww); ww = fma(wv.y, wv.y, ww);
+#pragma unroll
+            for (int j = 0; j < KB; ++j) {
+                if (j < k) {
+                    const double2 vv = reinterpret_cast<const double2*>(V + (size_t)j * ldv)[i];
+                    acc[j] = fma(vv.x, wv.x, acc[j]);
+                    acc[j] = fma(vv.y, wv.y, acc[j]);
+                }
+            }
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+            const double wv = w[n - 1];
+            ww = fma(wv, wv, ww);
+#pragma unroll
+            for (int j = 0; j < KB; ++j)
+                if (j < k) acc[j] = fma(V[(size_t)j * ldv + n - 1], wv, acc[j]);
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+            const double wv = w[i];
+            ww = fma(wv, wv, ww);
+#pragma unroll
+            for (int j = 0; j < KB; ++j)
+                if (j < k) acc[j] = fma(V[(size_t)j * ldv + i], wv, acc[j]);
+        }
+    }
+    __shared__ double sm[4][KB + 1];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+        const double s = wave_sum(acc[j]);
+        if (lane == 0) sm[wid][j] = s;
+    }
+    {
+        const double s = wave_sum(ww);
+        if (lane == 0) sm[wid][KB] = s;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j <= k; j += kThreads) {
+        const int src = (j == k) ? KB : j;
+        partials[(size_t)blockIdx.x * (k + 1) + j] = (sm[0][src] + sm[1][src]) + (sm[2][src] + sm[3][src]);
+    }
+}
+
+// ------------------------------------------------------------------ fused multi-axpy (+scale, +norm)
+// dst = scale * (src + sum_{j<k} c[j] V_j);  partials[block] = sum_chunk dst^2 (if want_norm).
+template <int KB, int VEC>
+__global__ void __launch_bounds__(kThreads) multiaxpy_kernel(size_t n, const double* __restrict__ V, size_t ldv, int k,
+                                                             Coefs cf, const double* src, double scale, double* dst,
+                                                             int want_norm, double* __restrict__ partials) {
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    double nn = 0.0;
+    if (VEC == 2) {
+        const size_t n2 = n >> 1;
+        for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += stride) {
+            double2 r = src ? reinterpret_cast<const double2*>(src)[i] : make_double2(0.0, 0.0);
+#pragma unroll
+            for (int j = 0; j < KB; ++j) {
+                if (j < k) {
+                    const double2 vv = reinterpret_cast<const double2*>(V + (size_t)j * ldv)[i];
+                    r.x = fma(cf.c[j], vv.x, r.x);
+                    r.y = fma(cf.c[j], vv.y, r.y);
+                }
+            }
+            r.x *= scale; r.y *= scale;
+            reinterpret_cast<double2*>(dst)[i] = r;
+            nn = fma(r.x, r.x, nn); nn = fma(r.y, r.y, nn);
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+            const size_t i = n - 1;
+            double r = src ? src[i] : 0.0;
+#pragma unroll
+            for (int j = 0; j < KB; ++j)
+                if (j < k) r = fma(cf.c[j], V[(size_t)j * ldv + i], r);
+            r *= scale;
+            dst[i] = r;
+            nn = fma(r, r, nn);
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+            double r = src ? src[i] : 0.0;
+#pragma unroll
+            for (int j = 0; j < KB; ++j)
+                if (j < k) r = fma(cf.c[j], V[(size_t)j * ldv + i], r);
+            r *= scale;
+            dst[i] = r;
+            nn = fma(r, r, nn);
+        }
+    }
+    if (want_norm) {
+        __shared__ double sm[4];
+        nn = wave_sum(nn);
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = nn;
+        __syncthreads();
+        if (threadIdx.x == 0) partials[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    }
+}
+
+// ------------------------------------------------------------------ basis rotation  dst_j = sum_i Q(i,j) V_i
+// One thread owns element(s) e: it loads V_i[e] for all i < m into registers, then forms the kout outputs
+// one at a time -- so dst may alias V (Krylov-Schur restart rotates the basis in place).  Q (m x kout,
+// column-major) is wave-uniform and comes through the scalar cache.
+template <int KB>
+__global__ void __launch_bounds__(kThreads) combine_kernel(size_t n, const double* V, size_t ldv, int m,
+                                                           const double* __restrict__ Q, int kout, double* dst,
+                                                           size_t lddst) {
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t e = (size_t)blockIdx.x * kThreads + threadIdx.x; e < n; e += stride) {
+        double in[KB];
+#pragma unroll
+        for (int i = 0; i < KB; ++i) in[i] = (i < m) ? V[(size_t)i * ldv + e] : 0.0;
+        for (int j = 0; j < kout; ++j) {
+            const double* q = Q + (size_t)j * m;
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < KB; ++i)
+                if (i < m) acc = fma(q[i], in[i], acc);
+            dst[(size_t)j * lddst + e] = acc;
+        }
+    }
+}
+
+}  // namespace
+
+// ================================================================== launchers
+int v_copy(bk_ctx* ctx, size_t n, const double* x, double* y) {
+    if (n == 0 || x == y) return 0;
+    ProfScope ps(ctx, "blas1", 16.0 * n);
+    BK_HIP(ctx, hipMemcpyAsync(y, x, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+
+int v_zero(bk_ctx* ctx, size_t n, double* x) {
+    if (n == 0) return 0;
+    ProfScope ps(ctx, "blas1", 8.0 * n);
+    BK_HIP(ctx, hipMemsetAsync(x, 0, n * sizeof(double), ctx->stream));
+    return 0;
+}
+
+int v_axpbyz(bk_ctx* ctx, size_t n, double a, const double* x, double b, const double* y, double* z) {
+    if (n == 0) return 0;
+    const int has_y = (y != nullptr && b != 0.0) ? 1 : 0;
+    const int hx = (x != nullptr && a != 0.0) ? 1 : 0;
+    ProfScope ps(ctx, "blas1", 8.0 * n * (1 + hx + has_y));
+    const bool vec = aligned16(z) && (!hx || aligned16(x)) && (!has_y || aligned16(y));
+    const int grid = grid_for(n, vec ? 2 : 1, 4096);
+    if (vec)
+        hipLaunchKernelGGL((axpbyz_kernel<2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, a, x, b, y, z, hx, has_y);
+    else
+        hipLaunchKernelGGL((axpbyz_kernel<1>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, a, x, b, y, z, hx, has_y);
+    BK_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int v_axpby(bk_ctx* ctx, size_t n, double a, const double* x, double b, double* y) {
+    return v_axpbyz(ctx, n, a, x, b, y, y);
+}
+
+int v_scale(bk_ctx* ctx, size_t n, double a, double* x) { return v_axpbyz(ctx, n, a, x, 0.0, nullptr, x); }
+
+int v_fill_random(bk_ctx* ctx, size_t n, size_t goff, unsigned long long seed, double* x) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(fill_random_kernel, dim3(grid_for(n, 1, 4096)), dim3(kThreads), 0, ctx->stream, n, goff, seed, x);
+    BK_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+static int dot_launch(bk_ctx* ctx, size_t n, const double* x, const double* y0, const double* y1, int ny, double* out) {
+    const bool vec = aligned16(x) && aligned16(y0) && (ny == 1 || aligned16(y1));
+    const int grid = grid_for(n, vec ? 2 : 1, kRedBlocks);
+    {
+        ProfScope ps(ctx, "blas1", 8.0 * n * ((x == y0 ? 1 : 2) + (ny - 1)));
+        if (ny == 1) {
+            if (vec) hipLaunchKernelGGL((dot_kernel<2, 1>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, x, y0, y1, ctx->d_partials);
+            else hipLaunchKernelGGL((dot_kernel<1, 1>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, x, y0, y1, ctx->d_partials);
+        } else {
+            if (vec) hipLaunchKernelGGL((dot_kernel<2, 2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, x, y0, y1, ctx->d_partials);
+            else hipLaunchKernelGGL((dot_kernel<1, 2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, x, y0, y1, ctx->d_partials);
+        }
+        BK_HIP(ctx, hipGetLastError());
+    }
+    BK_TRY(reduce_finish(ctx, grid, ny, 0));
+    for (int j = 0; j < ny; ++j) out[j] = ctx->h_red[j];
+    return 0;
+}
+
+int v_dot(bk_ctx* ctx, size_t n, const double* x, const double* y, double* out) {
+    return dot_launch(ctx, n, x, y, nullptr, 1, out);
+}
+
+int v_dot2(bk_ctx* ctx, size_t n, const double* x, const double* y1, const double* y2, double* out2) {
+    return dot_launch(ctx, n, x, y1, y2, 2, out2);
+}
+
+int v_nrm2(bk_ctx* ctx, size_t n, const double* x, double* out) {
+    double s = 0.0;
+    BK_TRY(dot_launch(ctx, n, x, x, nullptr, 1, &s));
+    *out = sqrt(s);
+    return 0;
+}
+
+int v_nrminf(bk_ctx* ctx, size_t n, const double* x, double* out) {
+    const int grid = grid_for(n, 1, kRedBlocks);
+    {
+        ProfScope ps(ctx, "blas1", 8.0 * n);
+        hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(kThreads), 0, ctx->stream, n, x, ctx->d_partials);
+        BK_HIP(ctx, hipGetLastError());
+    }
+    BK_TRY(reduce_finish(ctx, grid, 1, 1));
+    *out = ctx->h_red[0];
+    return 0;
+}
+
+template <int KB>
+static void launch_multidot(bk_ctx* ctx, bool vec, int grid, size_t n, const double* V, size_t ldv, int k, const double* w) {
+    if (vec) hipLaunchKernelGGL((multidot_kernel<KB, 2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, w, ctx->d_partials);
+    else hipLaunchKernelGGL((multidot_kernel<KB, 1>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, w, ctx->d_partials);
+}
+
+int v_multidot(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const double* w, double* out) {
+    if (k < 0 || k > kMaxBasis) return set_error(ctx, "v_multidot: k=%d out of range", k);
+    const bool vec = aligned16(V) && aligned16(w) && (ldv % 2 == 0);
+    const int grid = grid_for(n, vec ? 2 : 1, kRedBlocks);
+    {
+        ProfScope ps(ctx, "multidot", 8.0 * n * (k + 1));
+        if (k <= 4) launch_multidot<4>(ctx, vec, grid, n, V, ldv, k, w);
+        else if (k <= 8) launch_multidot<8>(ctx, vec, grid, n, V, ldv, k, w);
+        else if (k <= 16) launch_multidot<16>(ctx, vec, grid, n, V, ldv, k, w);
+        else if (k <= 24) launch_multidot<24>(ctx, vec, grid, n, V, ldv, k, w);
+        else if (k <= 32) launch_multidot<32>(ctx, vec, grid, n, V, ldv, k, w);
+        else if (k <= 48) launch_multidot<48>(ctx, vec, grid, n, V, ldv, k, w);
+        else launch_multidot<64>(ctx, vec, grid, n, V, ldv, k, w);
+        BK_HIP(ctx, hipGetLastError());
+    }
+    BK_TRY(reduce_finish(ctx, grid, k + 1, 0));
+    for (int j = 0; j <= k; ++j) out[j] = ctx->h_red[j];
+    return 0;
+}
+
+template <int KB>
+static void launch_multiaxpy(bk_ctx* ctx, bool vec, int grid, size_t n, const double* V, size_t ldv, int k, const Coefs& cf,
+                             const double* src, double scale, double* dst, int want_norm) {
+    if (vec) hipLaunchKernelGGL((multiaxpy_kernel<KB, 2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials);
+    else hipLaunchKernelGGL((multiaxpy_kernel<KB, 1>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials);
+}
+
+int v_multiaxpy(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const double* c, const double* src,
+                double scale, double* dst, double* nrm2sq) {
+    if (k < 0 || k > kMaxBasis) return set_error(ctx, "v_multiaxpy: k=%d out of range", k);
+    Coefs cf;
+    for (int j = 0; j < kMaxBasis; ++j) cf.c[j] = (j < k) ? c[j] : 0.0;
+    const bool vec = aligned16(V) && aligned16(dst) && (!src || aligned16(src)) && (ldv % 2 == 0);
+    const int want = nrm2sq ? 1 : 0;
+    const int grid = grid_for(n, vec ? 2 : 1, want ? kRedBlocks : 4096);
+    {
+        ProfScope ps(ctx, "multiaxpy", 8.0 * n * (k + 1 + (src ? 1 : 0)));
+        if (k <= 4) launch_multiaxpy<4>(ctx, vec, grid, n, V, ldv, k, cf, src, scale, dst, want);
+        else if (k <= 8) launch_multiaxpy<8>(ctx, vec, grid, n, V, ldv, k, cf, src, scale, dst, want);
+        else if (k <= 16) launch_multiaxpy<16>(ctx, vec, grid, n, V, ldv, k, cf, src, scale, dst, want);
+        else if (k <= 24) launch_multiaxpy<24>(ctx, vec, grid, n, V, ldv, k, cf, src, scale, dst, want);
+        else if (k <= 32) launch_multiaxpy<32>(ctx, vec, grid, n, V, ldv, k, cf, src, scale, dst, want);
+        else if (k <= 48) launch_multiaxpy<48>(ctx, vec, grid, n, V, ldv, k, cf, src, scale, dst, want);
+        else launch_multiaxpy<64>(ctx, vec, grid, n, V, ldv, k, cf, src, scale, dst, want);
+        BK_HIP(ctx, hipGetLastError());
+    }
+    if (want) {
+        BK_TRY(reduce_finish(ctx, grid, 1, 0));
+        *nrm2sq = ctx->h_red[0];
+    }
+    return 0;
+}
+
+
+int v_basis_combine(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int m, const double* Qhost, int kout,
+                    double* dst, size_t lddst) {
+    if (m < 1 || m > kMaxBasis || kout < 1 || kout > kMaxBasis) return set_error(ctx, "v_basis_combine: bad sizes");
+    double* Qd = nullptr;
+    BK_TRY(ws_get(ctx, (size_t)kMaxBasis * kMaxBasis, &Qd));
+    // pageable host -> device copy of a few KB; synchronous w.r.t. the host buffer
+    hipError_t e = hipMemcpyAsync(Qd, Qhost, sizeof(double) * (size_t)m * kout, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { ws_put(ctx, Qd); return set_error(ctx, "v_basis_combine: upload failed: %s", hipGetErrorString(e)); }
+    const int grid = grid_for(n, 1, 4096);
+    {
+        ProfScope ps(ctx, "combine", 8.0 * n * (m + kout));
+        if (m <= 16) hipLaunchKernelGGL((combine_kernel<16>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, m, Qd, kout, dst, lddst);
+        else if (m <= 32) hipLaunchKernelGGL((combine_kernel<32>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, m, Qd, kout, dst, lddst);
+        else if (m <= 48) hipLaunchKernelGGL((combine_kernel<48>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, m, Qd, kout, dst, lddst);
+        else hipLaunchKernelGGL((combine_kernel<64>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, m, Qd, kout, dst, lddst);
+    }
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // Qd is recycled through the pool
+    ws_put(ctx, Qd);
+    if (e != hipSuccess) return set_error(ctx, "v_basis_combine: %s", hipGetErrorString(e));
+    return 0;
+}
+
+}  // namespace bk
+
+using namespace bk;
+
+extern "C" {
+
+int bk_vec_copy(bk_ctx* ctx, size_t n, const double* x, double* y) { return v_copy(ctx, n, x, y); }
+int bk_vec_zero(bk_ctx* ctx, size_t n, double* x) { return v_zero(ctx, n, x); }
+int bk_vec_scale(bk_ctx* ctx, size_t n, double a, double* x) { return v_scale(ctx, n, a, x); }
+int bk_vec_axpby(bk_ctx* ctx, size_t n, double a, const double* x, double b, double* y) {
+    return v_axpby(ctx, n, a, x, b, y);
+}
+int bk_vec_dot(bk_ctx* ctx, size_t n, const double* x, const double* y, double* out) {
+    return v_dot(ctx, n, x, y, out);
+}
+int bk_vec_nrm2(bk_ctx* ctx, size_t n, const double* x, double* out) { return v_nrm2(ctx, n, x, out); }
+int bk_vec_nrminf(bk_ctx* ctx, size_t n, const double* x, double* out) { return v_nrminf(ctx, n, x, out); }
+
+}  // extern "C"

@@ -1,0 +1,230 @@
+/*
+ * bkhip.h -- C ABI of the MI355X-native Newton-Krylov corrector for BifurcationKit.jl's
+ * pseudo-arclength continuation (PALC).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch / C++ types.  Each entry
+ * point cites the reference interface (paths relative to the BifurcationKit.jl checkout) it
+ * replaces.  Julia reaches it with `ccall` (julia/BifurcationKitHIP.jl); the
+ * parity tests reach it with Python `ctypes` using the same call sequence.
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = ok, <0 = error (bk_last_error() has the text).
+ *     Non-convergence of an iterative solver is NOT an error: it is reported through the
+ *     `converged` out-parameter, like the reference which only `@debug`s it
+ *     (src/Newton.jl:93, src/LinearSolver.jl:289).
+ *   - `double*` vector arguments are DEVICE pointers (HIP) to fp64 data of the problem's LOCAL
+ *     length (bk_problem_nlocal); scalars travel by value / host pointers.
+ *   - all work is enqueued on the context's HIP stream; functions that return host scalars
+ *     synchronise that stream before returning, the others are asynchronous.
+ *   - state layout: flat index = i + Nx*(j + Ny*k), x fastest -- the order the reference's
+ *     `kron` assembly and `vec` of an [x,y,z] comprehension produce (examples/SH3d.jl:38-39,77).
+ *     Multi-GPU: z-slabs (3-D) / y-slabs (2-D) of contiguous planes, one slab per rank.
+ */
+#ifndef BKHIP_H
+#define BKHIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bk_ctx bk_ctx;         /* device, stream, scratch, (optional) communicator        */
+typedef struct bk_problem bk_problem; /* a stencil PDE on a grid: residual F(u,p) and J(u,p)      */
+typedef struct bk_op bk_op;           /* a linear operator handle = what `jacobian(prob,x,p)` returns */
+typedef struct bk_precond bk_precond; /* a left preconditioner Pl (GMRESKrylovKit.Pl)              */
+
+/* ------------------------------------------------------------------ context ---------------- */
+
+#define BK_UNIQUE_ID_BYTES 128
+
+int bk_version(void);
+/* Create a single-GPU context on `device`; `stream` is a hipStream_t (NULL = create one).       */
+int bk_ctx_create(bk_ctx** ctx, int device, void* stream);
+/* Multi-GPU context: one process per GPU, RCCL communicator built from a unique id that rank 0
+ * obtained with bk_comm_unique_id() and broadcast out-of-band (torch.distributed / MPI).
+ * No reference counterpart: the reference is single-process.             */
+int bk_comm_unique_id(void* id128);
+int bk_ctx_create_dist(bk_ctx** ctx, int device, void* stream, int rank, int nranks,
+                       const void* id128);
+/* Test-only communicator: collectives staged through host buffers and user callbacks (lets two
+ * ranks share one GPU, or run over gloo).  allreduce(user, buf, n, op) with op 0=sum 1=max acts
+ * in place on a host buffer; sendrecv(user, sendbuf, nsend, dst, recvbuf, nrecv, src) exchanges
+ * host buffers with neighbour ranks (dst/src = -1: no peer).                                     */
+typedef int (*bk_allreduce_fn)(void* user, double* buf, int n, int op);
+typedef int (*bk_sendrecv_fn)(void* user, const double* sendbuf, size_t nsend, int dst,
+                              double* recvbuf, size_t nrecv, int src);
+int bk_ctx_create_hostcomm(bk_ctx** ctx, int device, void* stream, int rank, int nranks,
+                           bk_allreduce_fn allreduce, bk_sendrecv_fn sendrecv, void* user);
+int bk_ctx_destroy(bk_ctx* ctx);
+const char* bk_last_error(bk_ctx* ctx);
+int bk_ctx_sync(bk_ctx* ctx);
+/* Tuning knobs ("sh_kernel": 0 gather / 1 streaming; "sh_zchunk"; "dgks_eta_ppm"; ...).         */
+int bk_ctx_set_option(bk_ctx* ctx, const char* key, double value);
+int bk_ctx_get_option(bk_ctx* ctx, const char* key, double* value);
+/* Per-kernel timing with HIP events on the context's stream (bench.py's roofline leg):
+ * names: "jvp", "residual", "multidot", "multiaxpy", "precond", "blas1".                        */
+int bk_prof_enable(bk_ctx* ctx, int on);
+int bk_prof_reset(bk_ctx* ctx);
+int bk_prof_get(bk_ctx* ctx, const char* name, double* total_ms, long long* calls,
+                double* alg_bytes);
+
+/* ------------------------------------------------------------------ memory ----------------- */
+
+int bk_malloc(bk_ctx* ctx, size_t n, double** out);
+int bk_free(bk_ctx* ctx, double* p);
+int bk_upload(bk_ctx* ctx, double* dst_dev, const double* src_host, size_t n);
+int bk_download(bk_ctx* ctx, double* dst_host, const double* src_dev, size_t n);
+
+/* ---------------------------------------- BLAS-1: the VectorInterface methods ---------------
+ * of src/BorderedArrays.jl:86-217 on the `.u` part (the scalar `.p` part stays on the host).
+ * Dots / norms are global (all-reduced over the communicator) and deterministic run-to-run.     */
+int bk_vec_copy(bk_ctx* ctx, size_t n, const double* x, double* y);              /* _copyto!    :34 */
+int bk_vec_zero(bk_ctx* ctx, size_t n, double* x);                               /* zerovector! :97 */
+int bk_vec_scale(bk_ctx* ctx, size_t n, double a, double* x);                    /* scale!     :118 */
+int bk_vec_axpby(bk_ctx* ctx, size_t n, double a, const double* x, double b, double* y);
+                                                     /* y = a x + b y : VI.add!(y,x,a,b) :180-196 */
+int bk_vec_dot(bk_ctx* ctx, size_t n, const double* x, const double* y, double* out); /* inner :213 */
+int bk_vec_nrm2(bk_ctx* ctx, size_t n, const double* x, double* out);            /* norm     :55-70 */
+int bk_vec_nrminf(bk_ctx* ctx, size_t n, const double* x, double* out);  /* norminf LinearSolver.jl:4 */
+
+/* ------------------------------------------------------------------ problems --------------- */
+
+enum {
+    BK_PDE_SH = 1,    /* Swift-Hohenberg 2-D/3-D, Neumann-ghost: examples/SH3d.jl:16-53,
+                         examples/SH2d-fronts.jl:13-34.  params = {l, nu}                           */
+    BK_PDE_SH1D = 2,  /* 1-D cubic-quintic SH, Dirichlet: examples/SHpde_snaking.jl:16-25.
+                         params = {lambda, nu}                                                      */
+    BK_PDE_CGL2D = 3  /* 2-D complex Ginzburg-Landau, 2 stacked real fields, Dirichlet:
+                         examples/cGL2d.jl:6-54,281-318.  params = {r, mu, nu, c3, c5, gamma}       */
+};
+#define BK_MAX_PARAMS 8
+
+typedef struct {
+    int pde;            /* BK_PDE_*                                                              */
+    int ndim;           /* 1, 2 or 3                                                             */
+    int n[3];           /* GLOBAL Nx, Ny, Nz (unused dims = 1)                                   */
+    double l[3];        /* half-widths lx, ly, lz: h = 2 l / N (examples/SH3d.jl:18-20)           */
+} bk_problem_desc;
+
+int bk_problem_create(bk_ctx* ctx, const bk_problem_desc* desc, bk_problem** out);
+int bk_problem_destroy(bk_problem* prob);
+/* local (this rank's) vector length and the slab [lo, hi) of the slowest grid index it owns     */
+int bk_problem_nlocal(bk_problem* prob, size_t* nlocal, int* slab_lo, int* slab_hi);
+/* out = F(u, params): F_sh examples/SH3d.jl:44-47, R_SH SHpde_snaking.jl:19-23,
+ * Fcgl! examples/cGL2d.jl:44-47                                                                  */
+int bk_residual(bk_problem* prob, const double* u, const double* params, int nparams, double* out);
+/* J(u, params) as an operator handle: the closure `dx -> dF_sh(x, p, dx)` of
+ * examples/SH3d.jl:119 / the opaque Jacobian object of src/Problems.jl:98-101.  Like the Julia
+ * closure it REFERENCES u (no copy): u must stay alive and unchanged while the handle is used. */
+int bk_jacobian(bk_problem* prob, const double* u, const double* params, int nparams, bk_op** out);
+int bk_op_destroy(bk_op* op);
+/* out = a0*v + a1*J*v : _axpy_op, src/LinearSolver.jl:46-64 (a0=0,a1=1: apply, src/Utils.jl:191) */
+int bk_op_apply(bk_op* op, const double* v, double a0, double a1, double* out);
+
+/* ------------------------------------------------------------------ preconditioner ---------
+ * Pl^-1 = ((I + Lap)^2 + shift I)^-1 applied exactly through the DCT-II diagonalisation of the
+ * Neumann-ghost Laplacian.  shift = 0 is `Pl = cholesky(Symmetric(L1))` of examples/SH3d.jl:88;
+ * shift = 1 is `lu(L1 + I)` of examples/SH2d-fronts.jl:121.                                      */
+int bk_precond_sh_create(bk_problem* prob, double shift, bk_precond** out);
+int bk_precond_destroy(bk_precond* pc);
+int bk_precond_apply(bk_precond* pc, const double* v, double* out);   /* out = Pl \ v             */
+
+/* ------------------------------------------------------------------ linear solver ----------
+ * (ls::AbstractLinearSolver)(J, rhs; a0, a1) -> (x, success, niter): src/LinearSolver.jl:12.   */
+enum {
+    BK_GMRES_KRYLOVKIT = 0,        /* GMRESKrylovKit semantics, src/LinearSolver.jl:223-291:
+                                      maxiter = restart cycles, tol = max(atol, rtol*||b||),
+                                      niter = numops (operator applications)                       */
+    BK_GMRES_ITERATIVESOLVERS = 1  /* GMRESIterativeSolvers semantics, :149-206: maxiter = inner
+                                      iterations, tol = max(rtol*||r0||, atol), niter = iterations */
+};
+typedef struct {
+    int flavor;      /* BK_GMRES_*                                                               */
+    int dim;         /* Krylov dimension / restart (GMRESKrylovKit.dim, GMRESIterativeSolvers.restart) */
+    int maxiter;
+    double atol;
+    double rtol;
+} bk_gmres_opts;
+void bk_gmres_default_opts(bk_gmres_opts* o, int flavor);   /* the reference's defaults           */
+/* Solve (a0 I + a1 J) x = rhs, x0 = 0.  `pl` may be NULL.  With `pl` the KrylovKit flavor solves
+ * (a0 I + a1 Pl^-1 J) x = Pl^-1 rhs -- shift applied after the preconditioner, exactly the
+ * reference's branch src/LinearSolver.jl:268-288.  x must not alias rhs; rhs is not modified.   */
+int bk_gmres(bk_ctx* ctx, bk_op* J, const double* rhs, double* x, double a0, double a1,
+             const bk_gmres_opts* opts, bk_precond* pl, int* converged, int* niter,
+             double* resnorm);
+/* (ls)(J, rhs1, rhs2): two sequential solves, flags ANDed, src/LinearSolver.jl:15-19.           */
+int bk_gmres2(bk_ctx* ctx, bk_op* J, const double* rhs1, const double* rhs2, double* x1,
+              double* x2, double a0, double a1, const bk_gmres_opts* opts, bk_precond* pl,
+              int* converged, int niter[2]);
+
+/* ------------------------------------------------------------------ bordered solvers -------
+ * (lbs)(J, dR, dzu, dzp, R, n, xi_u, xi_p; shift, dotp) -> (dX, dl, success, itlinear):
+ * src/LinearBorderSolver.jl:3-6.  Solves
+ *     [ shift I + J      dR     ] [dX]   [R]
+ *     [ xi_u dzu' S   xi_p dzp  ] [dl] = [n]       with dotp(x,y) = dotscale * <x,y>
+ * (PALC passes dotscale = 1/N, xi_u = theta, xi_p = 1-theta: solve_bls_palc :16-36).            */
+typedef struct {
+    double tol;            /* BorderingBLS.tol             (:63)                                  */
+    int check_precision;   /* BorderingBLS.check_precision (:66)                                  */
+    int k;                 /* BorderingBLS.k               (:69)                                  */
+} bk_bordering_opts;
+int bk_bls_bordering(bk_ctx* ctx, bk_op* J, const double* dR, const double* dzu, double dzp,
+                     const double* R, double n, double xiu, double xip, int has_shift,
+                     double shift, double dotscale, const bk_bordering_opts* bopts,
+                     const bk_gmres_opts* lsopts, bk_precond* pl, double* dX, double* dl,
+                     int* converged, int itlinear[2]);                   /* BorderingBLS :88-166 */
+int bk_bls_matrixfree(bk_ctx* ctx, bk_op* J, const double* dR, const double* dzu, double dzp,
+                      const double* R, double n, double xiu, double xip, int has_shift,
+                      double shift, double dotscale, const bk_gmres_opts* lsopts, double* dX,
+                      double* dl, int* converged, int* itlinear);        /* MatrixFreeBLS :424-437 */
+
+/* ------------------------------------------------------------------ eigensolver ------------
+ * (eig::ShiftInvert)(J, nev) -> (vals, vecs, converged, niter): src/EigSolver.jl:246-266 with a
+ * Krylov-Schur (KrylovKit.eigsolve-style) outer iteration; the SH3dEig of examples/SH3d.jl:96-113.
+ * Eigenvalues come back sorted by decreasing real part (__sort_spectrum, src/EigSolver.jl:16-19).
+ * vecs (may be NULL) receives nev device vectors of local length, stride ldvecs, real parts of
+ * the eigenvectors (imaginary parts in vecs_im when not NULL; symmetric problems: zero).        */
+typedef struct {
+    double sigma;      /* shift                                                                    */
+    int krylovdim;     /* examples/SH3d.jl:109: max(30, nev+30)                                   */
+    int maxiter;       /* restarts                                                                 */
+    double tol;        /* Ritz residual tolerance                                                  */
+    int hermitian;     /* ishermitian = true -> Lanczos-like symmetric Rayleigh quotient          */
+    unsigned long long seed;   /* start vector: rand(N) in the reference (SH3d.jl:109)            */
+} bk_eig_opts;
+int bk_eig_shiftinvert(bk_ctx* ctx, bk_op* J, int nev, const bk_eig_opts* eopts,
+                       const bk_gmres_opts* lsopts, bk_precond* pl, double* vals_re,
+                       double* vals_im, double* vecs, double* vecs_im, size_t ldvecs, int* nconv,
+                       int* numops);
+
+/* ------------------------------------------------------------------ Newton correctors ------ */
+typedef struct {
+    double tol;           /* NewtonPar.tol            src/Newton.jl:19                            */
+    int max_iterations;   /* NewtonPar.max_iterations :21                                         */
+    int norm_inf;         /* normN: 1 = norminf (examples/SH3d.jl:166), 0 = 2-norm                */
+} bk_newton_opts;
+#define BK_MAX_NEWTON_ITER 64
+typedef struct {
+    int converged;
+    int itnewton;
+    int itlinear;                                /* itlineartot, src/Newton.jl:60                 */
+    double residuals[BK_MAX_NEWTON_ITER + 1];    /* NonLinearSolution.residuals                   */
+} bk_newton_result;
+/* _newton, src/Newton.jl:66-114: x is the initial guess on entry, the solution on exit.         */
+int bk_newton(bk_ctx* ctx, bk_problem* prob, double* x, const double* params, int nparams,
+              const bk_newton_opts* nopts, const bk_gmres_opts* lsopts, bk_precond* pl,
+              bk_newton_result* res);
+/* newton_palc, src/continuation/Palc.jl:187-305 (linesearch = false) with BorderingBLS:
+ * (x, *p) = predictor on entry, corrected point on exit; (z0u, z0p) last point, (tauu, taup)
+ * tangent; the continuation parameter is params[ipar].                                          */
+int bk_newton_palc(bk_ctx* ctx, bk_problem* prob, double* x, double* p, const double* z0u,
+                   double z0p, const double* tauu, double taup, double ds, double theta,
+                   const double* params, int nparams, int ipar, double p_min, double p_max,
+                   const bk_newton_opts* nopts, const bk_bordering_opts* bopts,
+                   const bk_gmres_opts* lsopts, bk_precond* pl, bk_newton_result* res);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BKHIP_H */

@@ -1,0 +1,305 @@
+"""ORACLE (test infrastructure) -- host Krylov loops the reference delegates to third-party
+Julia packages, restated from their published algorithms.
+
+The packages are NOT under /root/reference (Project.toml:53,56 compat ranges only, no
+Manifest) and Julia is not installed here, so these restatements are "parity unpinned"
+against real package output; they are anchored on the reference's call sites
+(src/LinearSolver.jl:198,256-291; src/EigSolver.jl:157-160,257-266; examples/SH3d.jl:96-113)
+and on its test identities (test/linear_solvers/test_linear.jl:106-169, :666-677).
+
+  gmres_krylovkit      KrylovKit.linsolve (GMRES) ^0.7-0.10: restarted GMRES(krylovdim) on
+                       (a0 + a1 A), Krylov space built on A itself, shift applied to the
+                       Hessenberg; ModifiedGramSchmidt2 (KrylovDefaults.orth); maxiter = number
+                       of restart cycles; stop on |y[k+1]| <= max(atol, rtol*||b||) then verify
+                       with an explicit residual; returns numops (operator applications), which
+                       BK reports as "iterations" (src/LinearSolver.jl:291).
+  gmres_iterativesolvers  IterativeSolvers.gmres 0.8.4-0.9: restarted GMRES, single-pass MGS,
+                       progressive Givens, maxiter = total inner iterations, stop on
+                       ||r|| <= max(reltol*||r0||, abstol)  (src/LinearSolver.jl:186-206).
+  eigsolve_krylovschur KrylovKit.eigsolve: Arnoldi/Lanczos + Krylov-Schur thick restart
+                       (src/EigSolver.jl:149-160, examples/SH3d.jl:109).
+  shift_invert         src/EigSolver.jl:257-266.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.linalg as sla
+
+
+def apply(J, x):
+    """src/Utils.jl:191-195: ``A*x`` for matrices, ``f(x)`` for anything callable."""
+    if callable(J):
+        return J(x)
+    return J @ x
+
+
+def axpy_op(J, v, a0, a1):
+    """_axpy_op, src/LinearSolver.jl:46-64: (a0 I + a1 J) v."""
+    return a0 * v + a1 * apply(J, v)
+
+
+def _mgs2(w, V, k):
+    """ModifiedGramSchmidt2: one MGS sweep then one re-orthogonalisation sweep against V[0..k-1]."""
+    h = np.zeros(k)
+    for i in range(k):
+        h[i] = V[i] @ w
+        w = w - h[i] * V[i]
+    for i in range(k):
+        s = V[i] @ w
+        w = w - s * V[i]
+        h[i] += s
+    return w, h
+
+
+def _givens(f, g):
+    """Real Givens (c, s, r) with [c s; -s c] [f; g] = [r; 0]."""
+    if g == 0.0:
+        return 1.0, 0.0, f
+    if f == 0.0:
+        return 0.0, 1.0, g
+    r = np.hypot(f, g)
+    return f / r, g / r, r
+
+
+def gmres_krylovkit(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, rtol=1e-12,
+                    Pl=None, history=None):
+    """Solve (a0 + a1 A) x = b from x0 = 0.  Returns (x, converged, numops, normres).
+
+    ``Pl`` (callable applying Pl^-1) selects the preconditioned branch of GMRESKrylovKit,
+    src/LinearSolver.jl:268-288: the operator becomes ``dx -> a0 dx + a1 Pl^-1 (A dx)`` (shift applied
+    AFTER the preconditioner -- the reference's quirk, kept) and the right-hand side ``Pl^-1 b``;
+    tolerances then act on the preconditioned residual."""
+    if Pl is not None:
+        A_, a0_, a1_ = A, a0, a1
+        lin = lambda dx: a1_ * Pl(apply(A_, dx)) + a0_ * dx
+        return gmres_krylovkit(lin, Pl(np.asarray(b, dtype=float)), 0.0, 1.0, krylovdim=krylovdim,
+                               maxiter=maxiter, atol=atol, rtol=rtol, history=history)
+    b = np.asarray(b, dtype=float)
+    n = b.shape[0]
+    x = np.zeros(n)
+    r = b.copy()                       # y0 = A*0 = 0 (the package still applies A once)
+    numops = 1
+    beta = np.linalg.norm(r)
+    tol = max(atol, rtol * np.linalg.norm(b))
+    if beta < tol:
+        return x, True, numops, beta
+    m = krylovdim
+    V = np.zeros((m + 1, n))
+    R = np.zeros((m, m))
+    y = np.zeros(m + 1)
+    cs = np.zeros(m)
+    sn = np.zeros(m)
+    numiter = 0
+
+    def start(r, beta):
+        # ArnoldiIterator initialize: v1 = r/||r||, w = A v1, h11, residual
+        V[0] = r / beta
+        w = apply(A, V[0])
+        w, h = _mgs2(w, V, 1)
+        return w, h, np.linalg.norm(w)
+
+    w, h, nrm = start(r, beta)
+    numops += 1
+    while numiter < maxiter:
+        numiter += 1
+        y[:] = 0.0
+        y[0] = beta
+        k = 1
+        R[0, 0] = a0 + a1 * h[0]
+        cs[0], sn[0], R[0, 0] = _givens(R[0, 0], a1 * nrm)
+        y[1] = -sn[0] * y[0]
+        y[0] = cs[0] * y[0]
+        beta = abs(y[1])
+        if history is not None:
+            history.append(beta)
+        while beta > tol and k < m:
+            V[k] = w / nrm
+            w = apply(A, V[k])
+            numops += 1
+            w, h = _mgs2(w, V, k + 1)
+            nrm = np.linalg.norm(w)
+            k += 1
+            col = a1 * h
+            col[k - 1] += a0
+            for i in range(k - 1):
+                t = cs[i] * col[i] + sn[i] * col[i + 1]
+                col[i + 1] = -sn[i] * col[i] + cs[i] * col[i + 1]
+                col[i] = t
+            cs[k - 1], sn[k - 1], col[k - 1] = _givens(col[k - 1], a1 * nrm)
+            R[:k, k - 1] = col
+            y[k] = -sn[k - 1] * y[k - 1]
+            y[k - 1] = cs[k - 1] * y[k - 1]
+            beta = abs(y[k])
+            if history is not None:
+                history.append(beta)
+        yk = sla.solve_triangular(R[:k, :k], y[:k])
+        x = x + V[:k].T @ yk
+        if beta > tol:
+            # residual from the Krylov data: r = y[k+1] * (V_{k+1} G_1' ... G_k') e_{k+1}
+            V[k] = w / nrm
+            z = np.zeros(k + 1)
+            z[k] = 1.0
+            for i in range(k - 1, -1, -1):
+                t = cs[i] * z[i] - sn[i] * z[i + 1]
+                z[i + 1] = sn[i] * z[i] + cs[i] * z[i + 1]
+                z[i] = t
+            r = y[k] * (V[: k + 1].T @ z)
+        else:
+            r = b - a0 * x - a1 * apply(A, x)
+            numops += 1
+            beta = np.linalg.norm(r)
+            if beta < tol:
+                return x, True, numops, beta
+        if numiter < maxiter:
+            beta = np.linalg.norm(r)
+            w, h, nrm = start(r, beta)
+            numops += 1
+    return x, False, numops, beta
+
+
+def gmres_iterativesolvers(A, b, a0=0.0, a1=1.0, *, restart=200, maxiter=100, reltol=1e-8, abstol=0.0,
+                           Pl=None):
+    """IterativeSolvers.gmres on v -> a0 v + a1 A v (src/LinearSolver.jl:195-201), x0 = 0.
+    ``Pl`` (optional) is a callable applying Pl^-1.  Returns (x, isconverged, iters)."""
+    b = np.asarray(b, dtype=float)
+    n = b.shape[0]
+    op = lambda v: axpy_op(A, v, a0, a1)
+    prec = (lambda v: v) if Pl is None else Pl
+    x = np.zeros(n)
+    restart = min(restart, n)
+    r = prec(b.copy())
+    beta = np.linalg.norm(r)
+    tol = max(reltol * beta, abstol)
+    iters = 0
+    if beta <= tol:
+        return x, True, 0
+    V = np.zeros((restart + 1, n))
+    while iters < maxiter:
+        H = np.zeros((restart + 1, restart))
+        cs = np.zeros(restart)
+        sn = np.zeros(restart)
+        g = np.zeros(restart + 1)
+        g[0] = beta
+        V[0] = r / beta
+        k = 0
+        while k < restart and iters < maxiter:
+            w = prec(op(V[k]))
+            for i in range(k + 1):
+                H[i, k] = V[i] @ w
+                w = w - H[i, k] * V[i]
+            H[k + 1, k] = np.linalg.norm(w)
+            if H[k + 1, k] != 0.0:
+                V[k + 1] = w / H[k + 1, k]
+            for i in range(k):
+                t = cs[i] * H[i, k] + sn[i] * H[i + 1, k]
+                H[i + 1, k] = -sn[i] * H[i, k] + cs[i] * H[i + 1, k]
+                H[i, k] = t
+            cs[k], sn[k], H[k, k] = _givens(H[k, k], H[k + 1, k])
+            H[k + 1, k] = 0.0
+            g[k + 1] = -sn[k] * g[k]
+            g[k] = cs[k] * g[k]
+            k += 1
+            iters += 1
+            beta = abs(g[k])
+            if beta <= tol:
+                break
+        yk = sla.solve_triangular(H[:k, :k], g[:k])
+        x = x + V[:k].T @ yk
+        if beta <= tol:
+            return x, True, iters
+        r = prec(b - op(x))
+        beta = np.linalg.norm(r)
+    return x, beta <= tol, iters
+
+
+def _which_key(which):
+    if which == "LM":
+        return lambda lam: -np.abs(lam)
+    if which == "LR":
+        return lambda lam: -np.real(lam)
+    if which == "SR":
+        return lambda lam: np.real(lam)
+    raise ValueError(which)
+
+
+def eigsolve_krylovschur(A, x0, howmany, which="LM", *, tol=1e-12, krylovdim=30, maxiter=100,
+                         hermitian=False):
+    """Arnoldi (Lanczos when ``hermitian``) with Krylov-Schur thick restart.
+    Returns (vals[complex], vecs[list of ndarray], nconverged, numops)."""
+    x0 = np.asarray(x0, dtype=float)
+    n = x0.shape[0]
+    m = min(krylovdim, n)
+    key = _which_key(which)
+    V = np.zeros((m + 1, n))
+    H = np.zeros((m + 1, m))
+    V[0] = x0 / np.linalg.norm(x0)
+    k = 0
+    numops = 0
+    numiter = 0
+    while True:
+        numiter += 1
+        while k < m:
+            w = apply(A, V[k])
+            numops += 1
+            w, h = _mgs2(w, V, k + 1)
+            beta = np.linalg.norm(w)
+            H[: k + 1, k] = h
+            H[k + 1, k] = beta
+            V[k + 1] = w / beta if beta > 0 else 0.0
+            k += 1
+        B = H[:m, :m].copy()
+        bvec = H[m, :m].copy()
+        if hermitian:
+            B = 0.5 * (B + B.T)
+            lam, Y = np.linalg.eigh(B)
+            lam = lam.astype(complex)
+            Y = Y.astype(complex)
+        else:
+            lam, Y = np.linalg.eig(B)
+            Y = Y / np.linalg.norm(Y, axis=0)
+        order = np.argsort([key(l) for l in lam], kind="stable")
+        lam, Y = lam[order], Y[:, order]
+        res = np.abs(bvec @ Y)
+        nconv = 0
+        while nconv < m and res[nconv] < tol:
+            nconv += 1
+        if nconv >= howmany or numiter >= maxiter or m == n:
+            break
+        keep = (3 * m + 2 * nconv) // 5
+        # never split a complex-conjugate pair
+        if (not hermitian) and keep < m and abs(lam[keep - 1].imag) > 0 and \
+                np.isclose(lam[keep - 1], np.conj(lam[keep])):
+            keep += 1
+        # real orthonormal basis Q of the invariant subspace spanned by the kept Ritz vectors
+        Z = np.concatenate([Y[:, :keep].real, Y[:, :keep].imag], axis=1)
+        Uz, sv, _ = np.linalg.svd(Z, full_matrices=False)
+        Q = Uz[:, :keep]
+        Vnew = Q.T @ V[:m]
+        Bk = Q.T @ B @ Q
+        bk = bvec @ Q
+        V[:keep] = Vnew
+        V[keep] = V[m]
+        H[:] = 0.0
+        H[:keep, :keep] = Bk
+        H[keep, :keep] = bk
+        k = keep
+    nout = max(howmany, min(nconv, m)) if nconv > howmany else howmany
+    nout = min(nout, m)
+    vals = lam[:nout]
+    vecs = []
+    for i in range(nout):
+        v = (Y[:, i] @ V[:m].astype(complex)) if np.iscomplexobj(Y) else Y[:, i] @ V[:m]
+        if np.abs(v.imag).max() < 1e-14 * max(1.0, np.abs(v.real).max()):
+            v = v.real
+        vecs.append(v)
+    return vals, vecs, min(nconv, nout), numops
+
+
+def shift_invert(J, nev, sigma, ls, eig):
+    """ShiftInvert, src/EigSolver.jl:257-266.  ``ls(J, rhs, a0, a1) -> (x, ok, it)``;
+    ``eig(Jmap, nev) -> (vals, vecs, cv, n)``.  Back-transform 1/mu + sigma, sort by real part desc."""
+    Jmap = lambda rhs: ls(J, rhs, -sigma, 1.0)[0]
+    vals, vecs, cv, nops = eig(Jmap, nev)
+    lam = 1.0 / np.asarray(vals) + sigma
+    ind = sorted(range(len(lam)), key=lambda i: -lam[i].real)      # __sort_spectrum :16-19
+    return np.asarray([complex(lam[i]) for i in ind]), [vecs[i] for i in ind], cv, nops
