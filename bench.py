@@ -1,0 +1,277 @@
+#!/usr/bin/env python
+"""bench.py -- Newton-Krylov PALC corrector steps/s on the 3-D Swift-Hohenberg grid (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[4]/[3]): SH3d on an n^3 grid (default 512^3, fp64, 1 GiB per
+vector), l = 0.1, nu = 1.2 (examples/SH3d.jl:86), GMRES(30) rtol 1e-9 (SH3d.jl:93) with the exact spectral
+preconditioner Pl = (L1 + I)^-1 (`lu(L1 + I)`, examples/SH2d-fronts.jl:121; the `+ 1` of the reference's own
+512^2 GPU example, examples/SH2d-fronts-cuda.jl:63), PALC with theta = 0.5, ds = -0.001,
+BorderingBLS(check_precision = false) (SH3d.jl:160-163).
+
+Synthetic state with a checkable answer.  The branch point is built from the reference's own example cell:
+Newton-converge sol0 (SH3d.jl:77-80) on a `cell`^3 grid over [-pi, pi)^3, then tile it by even reflections to
+n^3 = (n/cell)^3 cells (h = 2 pi / cell; with cell = 32 that is h = 0.196 and 16 wavelengths per axis -- the
+grid spacing and domain of examples/SH2d-fronts-cuda.jl:66-69).  Because the Neumann-ghost boundary rule IS an
+even reflection, the tiled field is an exact discrete solution on the big grid, and every quantity of the big
+corrector (residual history, p, GMRES operator counts) must reproduce the single-cell run -- a size-independent
+parity check against the CPU oracle at full size (tests/test_gpu_fullsize.py).  The kernels do not know about
+the symmetry: every byte of every 1 GiB vector is streamed.
+
+One "step" = one pass through the corrector loop src/continuation/Palc.jl:237-295 from the PALC predictor:
+finite-difference dF/dp (1 residual), Jacobian handle, bordered solve (2 preconditioned GMRES solves to
+rtol 1e-9), update, residual, norms.  Every timed step repeats that first corrector iteration from the same
+predictor, so the work per step is identical and nothing is cached between steps.  Inputs are resident in HBM
+before the timed region; synthetic data (the reference's own initial guess, Newton-converged on the device).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the kernel with the largest share of the timed region,
+measured with HIP events on the library's stream (bk_prof_*); `cpu_baseline` times the NumPy/SciPy oracle
+(reference formulation: assembled sparse L1, MGS2 GMRES) on a bounded sample on this host.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=512, help="grid points per axis (BASELINE metric: 512)")
+    ap.add_argument("--cell", type=int, default=32, help="points per 2*pi cell (h = 2 pi / cell)")
+    ap.add_argument("--shift", type=float, default=1.0, help="preconditioner (L1 + shift I)^-1")
+    ap.add_argument("--cpu-sample", type=int, default=96, help="grid size of the CPU-baseline sample (0: skip)")
+    ap.add_argument("--no-precond", action="store_true")
+    ap.add_argument("--sh-kernel", type=int, default=1)
+    ap.add_argument("--dgks-eta", type=float, default=None)
+    return ap.parse_args()
+
+
+def tile_cell(cell_vec, nc, n, slab, device):
+    """Even-reflection tiling of a cell field (flat, x fastest, nc^3) to this rank's z-slab of the n^3 grid."""
+    import torch
+    T = n // nc
+    idx = torch.cat([torch.arange(nc) if c % 2 == 0 else torch.arange(nc - 1, -1, -1) for c in range(T)]).to(device)
+    c = cell_vec.reshape(nc, nc, nc)                      # [z, y, x]
+    lo, hi = slab
+    out = c[idx[lo:hi]][:, idx][:, :, idx]
+    return out.contiguous().reshape(-1)
+
+
+def cell_branch_points(ctx_cell, hip, nc, shift, ds, eta=150.0):
+    """Two Newton-converged points of the reference example on the nc^3 cell over [-pi, pi)^3 (device)."""
+    import torch
+    prob = hip.SwiftHohenberg(ctx_cell, (nc,) * 3, (math.pi,) * 3, l=0.1, nu=1.2)
+    P = hip.DCTPreconditioner(prob, shift)
+    ls = hip.GMRESKrylovKit(dim=30, rtol=1e-9, atol=1e-12, maxiter=150, Pl=P)
+    x = -math.pi + (2.0 * math.pi / nc) * torch.arange(nc, dtype=torch.float64, device=ctx_cell.torch_device)
+    s = torch.cos(x)[None, :] * torch.cos(x)[:, None]           # sol0, SH3d.jl:77-80 ([y, x]; constant in z)
+    s = s - s.min()
+    s = s / s.max()
+    s = s * 1.2
+    u0 = hip.HipVec(ctx_cell, s.reshape(1, nc, nc).expand(nc, nc, nc).contiguous().reshape(-1))
+    s0 = hip.newton_native(prob, u0, 0.1, ls, tol=1e-10, max_iterations=40, norm_inf=True)
+    s1 = hip.newton_native(prob, s0["u"], 0.1 + ds / eta, ls, tol=1e-10, max_iterations=20, norm_inf=True)
+    return prob, ls, s0, s1
+
+
+def cpu_baseline(ns, nc, shift, steps=1):
+    """Time the oracle's corrector step (reference formulation: assembled sparse L1, MGS2 GMRES) on an ns^3 tiling
+    of the nc^3 cell, single thread."""
+    import numpy as np
+    from oracle import bordered, krylov, operators, palc
+    ds = -0.001
+    cdims, cls_ = (nc,) * 3, (math.pi,) * 3
+    shc = operators.SwiftHohenberg(cdims, cls_)
+    pc = palc.Problem(lambda x, p: shc.F(x, p, 1.2), lambda x, p: (lambda dx: shc.dF(x, p, 1.2, dx)))
+    Plc = operators.dct_preconditioner(cdims, cls_, shift)
+    cls_s = lambda J, r, a0=0.0, a1=1.0: krylov.gmres_krylovkit(J, r, a0, a1, krylovdim=30, maxiter=150, rtol=1e-9,
+                                                                 atol=1e-12, Pl=Plc)[:3]
+    c0 = palc.newton(pc, shc.guess(), 0.1, cls_s, tol=1e-10, max_iterations=40, normN=palc.norminf)
+    c1 = palc.newton(pc, c0["u"], 0.1 + ds / 150.0, cls_s, tol=1e-10, max_iterations=20, normN=palc.norminf)
+    T = ns // nc
+    idx = np.concatenate([np.arange(nc) if c % 2 == 0 else np.arange(nc)[::-1] for c in range(T)])
+    tile = lambda v: np.ascontiguousarray(v.reshape(nc, nc, nc)[np.ix_(idx, idx, idx)]).reshape(-1)
+    dims, ls = (ns,) * 3, (math.pi * T,) * 3
+    sh = operators.SwiftHohenberg(dims, ls)
+    Pl = operators.dct_preconditioner(dims, ls, shift)
+    ols = lambda J, r, a0=0.0, a1=1.0: krylov.gmres_krylovkit(J, r, a0, a1, krylovdim=30, maxiter=150, rtol=1e-9,
+                                                               atol=1e-12, Pl=Pl)[:3]
+    prob = palc.Problem(lambda x, p: sh.F(x, p, 1.2), lambda x, p: (lambda dx: sh.dF(x, p, 1.2, dx)))
+    z0, z1 = (tile(c0["u"]), 0.1), (tile(c1["u"]), 0.1 + ds / 150.0)
+    tau = palc.secant_tangent(z1, z0, ds, 0.5)
+    zp = palc.add_tangent(z0, tau, ds)
+    bls = lambda *a, **k: bordered.bordering_bls(ols, *a, check_precision=False, **k)
+    t0 = time.perf_counter()
+    itl = 0
+    for _ in range(steps):
+        so = palc.newton_palc(prob, z0, tau, zp, ds, 0.5, bls, tol=0.0, max_iterations=1, normN=palc.norminf)
+        itl = so["itlineartot"]
+    dt = (time.perf_counter() - t0) / steps
+    return dict(seconds_per_step=dt, n=sh.N, itlinear=itl, residuals=so["residuals"])
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local)
+    from bk_amd import hip
+
+    comm = None
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            idt = torch.tensor(list(hip.Context.unique_id()), dtype=torch.uint8, device="cuda")
+        dist.broadcast(idt, 0)
+        comm = ("rccl", rank, world, bytes(idt.cpu().tolist()))
+    ctx = hip.Context(local, comm)
+    ctx.set_option("sh_kernel", args.sh_kernel)
+    if args.dgks_eta is not None:
+        ctx.set_option("dgks_eta", args.dgks_eta)
+
+    n, nc = args.size, args.cell
+    if n % nc != 0:
+        raise SystemExit("--size must be a multiple of --cell")
+    T = n // nc
+    lx = math.pi * T
+    ds, theta = -0.001, 0.5
+    # ---- setup (untimed)
+    t_setup = time.perf_counter()
+    ctx_cell = ctx if world == 1 else hip.Context(local)
+    cprob, cls_, c0, c1 = cell_branch_points(ctx_cell, hip, nc, args.shift, ds)
+    prob = hip.SwiftHohenberg(ctx, (n, n, n), (lx,) * 3, l=0.1, nu=1.2)
+    P = None if args.no_precond else hip.DCTPreconditioner(prob, args.shift)
+    ls = hip.GMRESKrylovKit(dim=30, rtol=1e-9, atol=1e-12, maxiter=150, Pl=P)       # SH3d.jl:93
+    bls = hip.BorderingBLS(ls, check_precision=False)                               # SH3d.jl:163
+    B = hip.BorderedArray
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    p0, p1 = 0.1, 0.1 + ds / 150.0
+    u0 = hip.HipVec(ctx, tile_cell(c0["u"].t, nc, n, prob.slab, ctx.torch_device), prob.nglobal)
+    u1 = hip.HipVec(ctx, tile_cell(c1["u"].t, nc, n, prob.slab, ctx.torch_device), prob.nglobal)
+    res0 = prob.residual(u0, p0).norminf()           # the tiled field is an exact discrete solution
+    res1 = prob.residual(u1, p1).norminf()
+    z0, z1 = B(u0, p0), B(u1, p1)
+    tau = z1.copy().add_(z0, -1.0)
+    nrm = math.sqrt(tau.u.inner(tau.u) / prob.nglobal * theta + tau.p * tau.p * (1 - theta))
+    tau.scale_(math.copysign(1.0, ds) / nrm)                                        # Secant tangent, Tangents.jl:28-42
+    z_pred = z0.copy().add_(tau, ds)
+    full = hip.newton_palc_native(prob, z0, tau, z_pred, ds, theta, bls, tol=1e-9, max_iterations=15,
+                                  p_min=-0.1, p_max=0.15, norm_inf=True)
+    # the same corrector on the single cell: must give the same trajectory
+    cb_ = hip.BorderedArray
+    cz0, cz1 = cb_(c0["u"], p0), cb_(c1["u"], p1)
+    ctau = cz1.copy().add_(cz0, -1.0)
+    cn = math.sqrt(ctau.u.inner(ctau.u) / cprob.nglobal * theta + ctau.p * ctau.p * (1 - theta))
+    ctau.scale_(math.copysign(1.0, ds) / cn)
+    cfull = hip.newton_palc_native(cprob, cz0, ctau, cz0.copy().add_(ctau, ds), ds, theta,
+                                   hip.BorderingBLS(cls_, check_precision=False), tol=1e-9, max_iterations=15,
+                                   p_min=-0.1, p_max=0.15, norm_inf=True)
+    barrier()
+    t_setup = time.perf_counter() - t_setup
+
+    def one_step():
+        return hip.newton_palc_native(prob, z0, tau, z_pred, ds, theta, bls, tol=0.0, max_iterations=1,
+                                      p_min=-0.1, p_max=0.15, norm_inf=True)
+
+    for _ in range(args.warmup):
+        last = one_step()
+    barrier()
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ctx.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    kernels = {}
+    for name in ("jvp", "residual", "multidot", "multiaxpy", "precond", "blas1", "combine"):
+        e = ctx.prof_get(name)
+        if e["calls"]:
+            kernels[name] = dict(ms_total=e["ms"], calls=e["calls"], avg_ms=e["ms"] / e["calls"],
+                                 alg_gb_per_call=e["bytes"] / e["calls"] / 1e9,
+                                 gbs=e["bytes"] / max(e["ms"], 1e-9) / 1e6)
+    dom = max(kernels, key=lambda k: kernels[k]["ms_total"]) if kernels else None
+    roofline = None
+    if dom:
+        k = kernels[dom]
+        roofline = dict(kernel=dom, bound="hbm", achieved=k["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=k["gbs"] / HBM_PEAK_GBS, traffic=None, avg_ms=k["avg_ms"], calls=k["calls"],
+                        alg_bytes_per_launch=k["alg_gb_per_call"] * 1e9)
+
+    if rank == 0:
+        ms = dt / max(args.steps, 1) * 1e3
+        out = {
+            "metric": "newton_krylov_corrector_steps_per_s", "value": args.steps / dt, "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"SH3d {n}^3 PALC corrector (Palc.jl:237-295 pass), GMRES(30) rtol 1e-9, "
+                                   f"Pl = (L1+shift)^-1 (DCT), BorderingBLS",
+                       "grid": [n, n, n], "unknowns": prob.nglobal, "parallelism": f"z-slabs x{world}",
+                       "itlinear_per_step": last["itlineartot"], "residual_after_step": last["residuals"][-1],
+                       "cell": nc, "h": 2 * math.pi / nc, "precond_shift": args.shift,
+                       "cell_newton": {"converged": c0["converged"], "itnewton": c0["itnewton"],
+                                       "residual": c0["residuals"][-1]},
+                       "tiled_state_residual_inf": [res0, res1],
+                       "full_corrector": {"converged": full["converged"], "itnewton": full["itnewton"],
+                                          "itlinear": full["itlineartot"], "residuals": full["residuals"],
+                                          "p": full["u"].p},
+                       "cell_corrector": {"converged": cfull["converged"], "itnewton": cfull["itnewton"],
+                                          "itlinear": cfull["itlineartot"], "residuals": cfull["residuals"],
+                                          "p": cfull["u"].p},
+                       "setup_seconds": t_setup, "sh_kernel": args.sh_kernel,
+                       "preconditioner": "none" if P is None else "dct"},
+            "roofline": roofline, "kernels": kernels,
+        }
+        cb = None
+        if world == 1 and args.cpu_sample > 0:
+            try:
+                c = cpu_baseline(args.cpu_sample, nc, args.shift)
+                scaled = (1.0 / c["seconds_per_step"]) * (c["n"] / prob.nglobal)
+                cb = {"value": scaled, "unit": "steps/s", "cores": 1, "kind": "port",
+                      "sample": f"1 corrector step on SH3d {args.cpu_sample}^3 ({c['n']} unknowns, same cell tiling, h and "
+                                f"solver settings, {c['itlinear']} GMRES operator applications) took "
+                                f"{c['seconds_per_step']:.2f} s with the NumPy/SciPy oracle (assembled sparse L1, "
+                                f"MGS2 GMRES, DCT preconditioner), scaled by unknowns ratio to {n}^3; "
+                                f"CPU restatement of the reference path, not Julia"}
+            except Exception as e:  # the baseline must not take the bench line down
+                cb = {"value": None, "unit": "steps/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
+        out["cpu_baseline"] = cb
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

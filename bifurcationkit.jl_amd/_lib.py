@@ -1,0 +1,153 @@
+"""ctypes binding of ``lib/libbkhip.so`` (C ABI: ``include/bkhip.h``).
+
+The binding is the Python twin of the Julia ``ccall`` shim (``julia/BifurcationKitHIP.jl``): same entry
+points, same argument order.  There is NO fallback: if the shared library is missing the import of any
+product module raises, and every compute call needs a visible MI355X.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbkhip.so")
+
+BK_UNIQUE_ID_BYTES = 128
+BK_MAX_PARAMS = 8
+BK_MAX_NEWTON_ITER = 64
+
+BK_PDE_SH, BK_PDE_SH1D, BK_PDE_CGL2D = 1, 2, 3
+BK_GMRES_KRYLOVKIT, BK_GMRES_ITERATIVESOLVERS = 0, 1
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+
+
+class ProblemDesc(C.Structure):
+    _fields_ = [("pde", C.c_int), ("ndim", C.c_int), ("n", C.c_int * 3), ("l", C.c_double * 3)]
+
+
+class GmresOpts(C.Structure):
+    _fields_ = [("flavor", C.c_int), ("dim", C.c_int), ("maxiter", C.c_int), ("atol", C.c_double),
+                ("rtol", C.c_double)]
+
+
+class BorderingOpts(C.Structure):
+    _fields_ = [("tol", C.c_double), ("check_precision", C.c_int), ("k", C.c_int)]
+
+
+class EigOpts(C.Structure):
+    _fields_ = [("sigma", C.c_double), ("krylovdim", C.c_int), ("maxiter", C.c_int), ("tol", C.c_double),
+                ("hermitian", C.c_int), ("seed", C.c_ulonglong)]
+
+
+class NewtonOpts(C.Structure):
+    _fields_ = [("tol", C.c_double), ("max_iterations", C.c_int), ("norm_inf", C.c_int)]
+
+
+class NewtonResult(C.Structure):
+    _fields_ = [("converged", C.c_int), ("itnewton", C.c_int), ("itlinear", C.c_int),
+                ("residuals", C.c_double * (BK_MAX_NEWTON_ITER + 1))]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, c_double_p, C.c_int, C.c_int)
+SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, c_double_p, C.c_size_t, C.c_int, c_double_p, C.c_size_t, C.c_int)
+
+VP = C.c_void_p     # opaque handles and device pointers travel as void*
+D = C.c_double
+I = C.c_int
+SZ = C.c_size_t
+
+# name -> (restype, argtypes): every symbol include/bkhip.h declares
+SIGNATURES = {
+    "bk_version": (I, []),
+    "bk_ctx_create": (I, [C.POINTER(VP), I, VP]),
+    "bk_comm_unique_id": (I, [VP]),
+    "bk_ctx_create_dist": (I, [C.POINTER(VP), I, VP, I, I, VP]),
+    "bk_ctx_create_hostcomm": (I, [C.POINTER(VP), I, VP, I, I, ALLREDUCE_FN, SENDRECV_FN, VP]),
+    "bk_ctx_destroy": (I, [VP]),
+    "bk_last_error": (C.c_char_p, [VP]),
+    "bk_ctx_sync": (I, [VP]),
+    "bk_ctx_set_option": (I, [VP, C.c_char_p, D]),
+    "bk_ctx_get_option": (I, [VP, C.c_char_p, c_double_p]),
+    "bk_prof_enable": (I, [VP, I]),
+    "bk_prof_reset": (I, [VP]),
+    "bk_prof_get": (I, [VP, C.c_char_p, c_double_p, C.POINTER(C.c_longlong), c_double_p]),
+    "bk_malloc": (I, [VP, SZ, C.POINTER(VP)]),
+    "bk_free": (I, [VP, VP]),
+    "bk_upload": (I, [VP, VP, c_double_p, SZ]),
+    "bk_download": (I, [VP, c_double_p, VP, SZ]),
+    "bk_vec_copy": (I, [VP, SZ, VP, VP]),
+    "bk_vec_zero": (I, [VP, SZ, VP]),
+    "bk_vec_scale": (I, [VP, SZ, D, VP]),
+    "bk_vec_axpby": (I, [VP, SZ, D, VP, D, VP]),
+    "bk_vec_dot": (I, [VP, SZ, VP, VP, c_double_p]),
+    "bk_vec_nrm2": (I, [VP, SZ, VP, c_double_p]),
+    "bk_vec_nrminf": (I, [VP, SZ, VP, c_double_p]),
+    "bk_krylov_multidot": (I, [VP, SZ, VP, SZ, I, VP, c_double_p]),
+    "bk_krylov_multiaxpy": (I, [VP, SZ, VP, SZ, I, c_double_p, VP, D, VP, c_double_p]),
+    "bk_problem_create": (I, [VP, C.POINTER(ProblemDesc), C.POINTER(VP)]),
+    "bk_problem_destroy": (I, [VP]),
+    "bk_problem_nlocal": (I, [VP, C.POINTER(SZ), c_int_p, c_int_p]),
+    "bk_residual": (I, [VP, VP, c_double_p, I, VP]),
+    "bk_jacobian": (I, [VP, VP, c_double_p, I, C.POINTER(VP)]),
+    "bk_op_destroy": (I, [VP]),
+    "bk_op_apply": (I, [VP, VP, D, D, VP]),
+    "bk_precond_sh_create": (I, [VP, D, C.POINTER(VP)]),
+    "bk_precond_destroy": (I, [VP]),
+    "bk_precond_apply": (I, [VP, VP, VP]),
+    "bk_gmres_default_opts": (None, [C.POINTER(GmresOpts), I]),
+    "bk_gmres": (I, [VP, VP, VP, VP, D, D, C.POINTER(GmresOpts), VP, c_int_p, c_int_p, c_double_p]),
+    "bk_gmres2": (I, [VP, VP, VP, VP, VP, VP, D, D, C.POINTER(GmresOpts), VP, c_int_p, c_int_p]),
+    "bk_bls_bordering": (I, [VP, VP, VP, VP, D, VP, D, D, D, I, D, D, C.POINTER(BorderingOpts),
+                             C.POINTER(GmresOpts), VP, VP, c_double_p, c_int_p, c_int_p]),
+    "bk_bls_matrixfree": (I, [VP, VP, VP, VP, D, VP, D, D, D, I, D, D, C.POINTER(GmresOpts), VP, c_double_p,
+                              c_int_p, c_int_p]),
+    "bk_eig_shiftinvert": (I, [VP, VP, I, C.POINTER(EigOpts), C.POINTER(GmresOpts), VP, c_double_p, c_double_p,
+                               VP, VP, SZ, c_int_p, c_int_p]),
+    "bk_newton": (I, [VP, VP, VP, c_double_p, I, C.POINTER(NewtonOpts), C.POINTER(GmresOpts), VP,
+                      C.POINTER(NewtonResult)]),
+    "bk_newton_palc": (I, [VP, VP, VP, c_double_p, VP, D, VP, D, D, D, c_double_p, I, I, D, D,
+                           C.POINTER(NewtonOpts), C.POINTER(BorderingOpts), C.POINTER(GmresOpts), VP,
+                           C.POINTER(NewtonResult)]),
+}
+
+_lib = None
+
+
+class BkHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libbkhip.so (once) and attach prototypes.  Raises if the library is missing: the product has
+    no CPU fallback by design."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C bifurcationkit.jl_amd/csrc).  There is no CPU fallback.")
+    # one HIP runtime per process: if torch is in use it must be imported first so that its bundled
+    # libamdhip64.so.7 / librccl.so.1 are the ones this library binds to (same SONAMEs as /opt/rocm's).
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the C ABI itself
+        pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(ctx_handle, status, what=""):
+    if status != 0:
+        msg = ""
+        if _lib is not None and ctx_handle:
+            raw = _lib.bk_last_error(ctx_handle)
+            msg = raw.decode() if raw else ""
+        raise BkHipError(f"{what} failed with status {status}: {msg}")

@@ -1,0 +1,282 @@
+"""Host-side continuation engine restated minimally around the plugin surface: the CALLER of the hot path.
+
+In a Julia deployment this file is not needed -- BifurcationKit's own ``continuation`` / ``newton`` call the
+HIP plugins through ``julia/BifurcationKitHIP.jl``.  It exists so that the same call sequence can be driven
+(and parity-tested) from Python.  It is written against duck-typed vectors (``HipVec`` / ``BorderedArray``
+or any type with copy/zerovector/scale_/add_/inner/norm/norminf/copyto_/__len__) and plugin callables:
+
+  ls(J, rhs, a0=0, a1=1) -> (x, ok, it)                   AbstractLinearSolver   src/LinearSolver.jl:12
+  bls(J, dR, dzu, dzp, R, n, xiu, xip, shift=, dotp=)      AbstractBorderedLinearSolver  src/LinearBorderSolver.jl:3-6
+  eig(J, nev) -> (vals, vecs, ok, it)                      AbstractEigenSolver    src/EigSolver.jl:4-12
+
+Restated pieces (reference file:line):
+  newton                _newton                              src/Newton.jl:66-114
+  DotTheta / arc_length_eq / newton_palc                     src/continuation/Palc.jl:23-56, 187-305
+  solve_bls_palc                                             src/LinearBorderSolver.jl:16-36
+  Secant / Bordered tangents, addtangent!                    src/continuation/Tangents.jl:8-104
+  _step_size_control!                                        src/continuation/Contbase.jl:77-102
+  compute_eigenvalues / is_stable / detect_bifurcation       src/Utils.jl:67-104, src/Bifurcations.jl:5-28
+  iterate (first two points, one step)                       src/Continuation.jl:349-456, 458-504
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field, replace
+
+import numpy as np
+
+from .hip import BorderedArray
+
+
+def norminf(x):
+    return x.norminf()
+
+
+def norm2(x):
+    return x.norm()
+
+
+@dataclass
+class NewtonPar:
+    """src/Newton.jl:17-33."""
+    tol: float = 1e-12
+    max_iterations: int = 25
+    verbose: bool = False
+    linsolver: object = None
+    eigsolver: object = None
+
+
+@dataclass
+class ContinuationPar:
+    """src/ContParameters.jl:44-100 (the fields the PALC path reads)."""
+    dsmin: float = 1e-4
+    dsmax: float = 1e-1
+    ds: float = 1e-2
+    a: float = 0.5
+    p_min: float = -1.0
+    p_max: float = 1.0
+    max_steps: int = 400
+    eta: float = 150.0
+    nev: int = 3
+    tol_stability: float = 1e-10
+    detect_bifurcation: int = 3
+    newton_options: NewtonPar = field(default_factory=NewtonPar)
+
+
+@dataclass
+class PALC:
+    """src/continuation/Palc.jl:70-84."""
+    tangent: str = "secant"          # Secant() | Bordered()
+    theta: float = 0.5
+    bls: object = None
+
+    def update(self, contparams):    # Palc.jl:100-110: a bls without solver inherits the Newton linsolver
+        if self.bls is not None and getattr(self.bls, "solver", None) is None:
+            return replace(self, bls=self.bls.update_bls(contparams.newton_options.linsolver))
+        return self
+
+
+@dataclass
+class NonLinearSolution:
+    """src/Newton.jl:49-63."""
+    u: object
+    residuals: list
+    converged: bool
+    itnewton: int
+    itlineartot: int
+
+
+def newton(prob, x0, p, options: NewtonPar, normN=norm2) -> NonLinearSolution:
+    """_newton, src/Newton.jl:66-114."""
+    x = x0.copy()
+    fx = prob.residual(x, p)
+    res = normN(fx)
+    residuals = [res]
+    step, itlin = 0, 0
+    while step < options.max_iterations and res > options.tol:
+        J = prob.jacobian(x, p)
+        u, cv, it = options.linsolver(J, fx)
+        itlin += int(np.sum(it))
+        x.add_(u, -1.0)                       # minus!!(x, u)
+        fx = prob.residual(x, p)
+        res = normN(fx)
+        residuals.append(res)
+        step += 1
+        if options.verbose:
+            print(f"  newton {step:3d}  res = {res:.4e}  itlinear = {it}")
+    return NonLinearSolution(x, residuals, residuals[-1] < options.tol, step, itlin)
+
+
+def dot_theta(u1, u2, p1, p2, theta):
+    """DotTheta with NormalisedDot, Palc.jl:1-6, 35."""
+    return u1.inner(u2) / len(u1) * theta + p1 * p2 * (1.0 - theta)
+
+
+def solve_bls_palc(bls, theta, tau, J, dR, R, n, shift=None):
+    """src/LinearBorderSolver.jl:16-36: xi_u = theta, xi_p = 1 - theta, dotp = dot/length."""
+    N = len(R)
+    return bls(J, dR, tau.u, tau.p, R, n, theta, 1.0 - theta, shift=shift,
+               dotp=lambda x, y: x.inner(y) / N, dotscale=1.0 / N)
+
+
+def newton_palc(prob, z0, tau0, z_pred, ds, theta, bls, options: NewtonPar, p_min=-math.inf, p_max=math.inf,
+                normN=norm2) -> NonLinearSolution:
+    """newton_palc, Palc.jl:187-305 (linesearch = false)."""
+    eps = prob.delta
+
+    def Nfun(u, p):                            # arc_length_eq, Palc.jl:44-56 (two dots, as written)
+        return (dot_theta(u, tau0.u, p - z0.p, tau0.p, theta) - ds) - (dot_theta(z0.u, tau0.u, p - z0.p, 0.0, theta))
+
+    x = z_pred.u.copy()
+    p = float(z_pred.p)
+    res_f = prob.residual(x, p)
+    res_n = Nfun(x, p)
+    res = max(normN(res_f), abs(res_n))
+    residuals = [res]
+    step, itlin = 0, 0
+    while step < options.max_iterations and res > options.tol:
+        dFdp = prob.residual(x, p + eps)
+        dFdp.add_(res_f, -1.0)
+        dFdp.scale_(1.0 / eps)
+        J = prob.jacobian(x, p)
+        u, up, flag, it = solve_bls_palc(bls, theta, tau0, J, dFdp, res_f, res_n)
+        itlin += int(np.sum(it))
+        x.add_(u, -1.0)
+        p = min(max(p - up, p_min), p_max)
+        res_f = prob.residual(x, p)
+        res_n = Nfun(x, p)
+        res = max(normN(res_f), abs(res_n))
+        residuals.append(res)
+        step += 1
+        if options.verbose:
+            print(f"  newton_palc {step:3d}  res = {res:.4e}  itlinear = {it}")
+    return NonLinearSolution(BorderedArray(x, p), residuals, residuals[-1] < options.tol, step, itlin)
+
+
+def secant_tangent(z1, z0, ds, theta):
+    """_secant_tangent!, Tangents.jl:28-42."""
+    tau = z1.copy()
+    tau.add_(z0, -1.0)
+    a = math.copysign(1.0, ds) / math.sqrt(dot_theta(tau.u, tau.u, tau.p, tau.p, theta))
+    return tau.scale_(a)
+
+
+def bordered_tangent(prob, z, tau, theta, bls):
+    """gettangent!(::Bordered), Tangents.jl:71-104."""
+    eps = prob.delta
+    dFdl = prob.residual(z.u, z.p + eps)
+    dFdl.add_(prob.residual(z.u, z.p), -1.0)
+    dFdl.scale_(1.0 / eps)
+    J = prob.jacobian(z.u, z.p)
+    tu, tp, flag, _ = solve_bls_palc(bls, theta, tau, J, dFdl, z.u.zerovector(), 1.0)
+    a = 1.0 / math.sqrt(dot_theta(tu, tu, tp, tp, theta))
+    a *= math.copysign(1.0, dot_theta(tau.u, tu, tau.p, tp, theta))
+    return BorderedArray(tu, tp).scale_(a), flag
+
+
+def step_size_control(ds, converged, itnewton, cp: ContinuationPar):
+    """_step_size_control!, Contbase.jl:77-102 -> (dsnew, stop)."""
+    if not converged:
+        if abs(ds) <= cp.dsmin:
+            return ds, True
+        dsnew = math.copysign(max(abs(ds) / 2.0, cp.dsmin), ds)
+    else:
+        Nmax = cp.newton_options.max_iterations
+        factor = (Nmax - itnewton) / Nmax
+        dsnew = ds * (1.0 + cp.a * factor ** 2)
+    dsnew = math.copysign(min(max(abs(dsnew), cp.dsmin), cp.dsmax), dsnew)     # clamp_ds
+    return dsnew, False
+
+
+def is_stable(eigvalues, tol_stability):
+    """Bifurcations.jl:5-19 -> (n_unstable, n_imag)."""
+    ev = np.asarray(eigvalues)
+    return (int(np.sum(ev.real > tol_stability)),
+            int(np.sum((np.abs(ev.imag) > tol_stability) & (ev.real > tol_stability))))
+
+
+@dataclass
+class ContResult:
+    """The per-step record of src/Continuation.jl:259-272 plus detected stability changes."""
+    param: list = field(default_factory=list)
+    itnewton: list = field(default_factory=list)
+    itlinear: list = field(default_factory=list)
+    ds: list = field(default_factory=list)
+    n_unstable: list = field(default_factory=list)
+    n_imag: list = field(default_factory=list)
+    eig: list = field(default_factory=list)
+    residuals: list = field(default_factory=list)
+    specialpoint: list = field(default_factory=list)
+    sol: list = field(default_factory=list)
+
+
+def continuation(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm2, verbosity=0, save_sol=False,
+                 corrector=newton_palc) -> ContResult:
+    """PALC branch.  Continuation.jl:349-456 (two Newton solves + secant tangent), :458-504 (one step:
+    corrector!, compute_eigenvalues!, step_size_control!, getpredictor!)."""
+    alg = alg.update(cp)
+    nopt = cp.newton_options
+    eig = nopt.eigsolver if cp.detect_bifurcation > 0 else None
+    sol0 = newton(prob, x0, p0, nopt, normC)
+    if not sol0.converged:
+        raise RuntimeError("Newton failed to converge for the initial guess on the branch")
+    p1 = p0 + cp.ds / cp.eta
+    sol1 = newton(prob, sol0.u, p1, nopt, normC)
+    if not sol1.converged:
+        raise RuntimeError("Newton failed to converge. Required for the computation of the initial tangent")
+    z0 = BorderedArray(sol0.u, p0)
+    z1 = BorderedArray(sol1.u, p1)
+    br = ContResult()
+    n_unst, n_imag = -1, -1
+
+    def eigen(z, n_prev):
+        nev_ = max(max(n_prev, 0) + 5, cp.nev)                          # Utils.jl:78-79
+        vals, _, cv, it = eig(prob.jacobian(z.u, z.p), nev_)
+        nu, ni = is_stable(vals, cp.tol_stability)
+        return vals, nu, ni
+
+    def record(z, sol, ds, vals):
+        br.param.append(z.p); br.itnewton.append(sol.itnewton); br.itlinear.append(sol.itlineartot)
+        br.ds.append(ds); br.n_unstable.append(n_unst); br.n_imag.append(n_imag)
+        br.residuals.append(list(sol.residuals)); br.eig.append(vals)
+        if save_sol:
+            br.sol.append(z.u.copy())
+
+    vals = None
+    if eig is not None:
+        vals, n_unst, n_imag = eigen(z0, -1)
+    ds = cp.ds
+    tau = secant_tangent(z1, z0, ds, alg.theta)                         # initialize!, Palc.jl:112-123
+    z = z0.copy()
+    z_old = z0.copy()
+    z_pred = z.copy().add_(tau, ds)                                     # addtangent!
+    record(z, sol0, ds, vals)
+    step = 0
+    while step < cp.max_steps:
+        if z_pred.p <= cp.p_min or z_pred.p >= cp.p_max:
+            break              # the reference switches to a Natural corrector at the clamped p (Palc.jl:157-160)
+        sol = corrector(prob, z, tau, z_pred, ds, alg.theta, alg.bls, nopt, cp.p_min, cp.p_max, normC)
+        conv = sol.converged
+        if verbosity:
+            print(f"step {step:3d} ds={ds:+.3e} p={z.p:+.6f} -> {sol.u.p:+.6f} conv={conv} "
+                  f"itnewton={sol.itnewton} itlinear={sol.itlineartot}")
+        if conv:
+            z_old.copyto_(z)
+            z.copyto_(sol.u)
+            prev_unst = n_unst
+            if eig is not None:
+                vals, n_unst, n_imag = eigen(z, n_unst)
+                if prev_unst != -1 and n_unst != prev_unst:             # detect_bifurcation, Bifurcations.jl:22-28
+                    br.specialpoint.append(dict(step=step + 1, param=z.p, n_unstable=(prev_unst, n_unst)))
+            step += 1
+            record(z, sol, ds, vals)
+        ds, stop = step_size_control(ds, conv, sol.itnewton, cp)
+        if stop:
+            break
+        if conv:                                                         # Palc.jl:140-143
+            if alg.tangent == "secant":
+                tau = secant_tangent(z, z_old, ds, alg.theta)
+            else:
+                tau, _ = bordered_tangent(prob, z, tau, alg.theta, alg.bls)
+        z_pred = z.copy().add_(tau, ds)
+    return br

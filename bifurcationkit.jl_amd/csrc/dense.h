@@ -50,7 +50,7 @@ inline int jacobi_eigh(const Mat& Ain, std::vector<double>& w, Mat& Z) {
             diag += A(i, i) * A(i, i);
             for (int j = 0; j < i; ++j) off += 2.0 * A(i, j) * A(i, j);
         }
-        if (off <= 1e-32 * (diag + off) || off == 0.0) break;
+        if (off <= 1e-30 * (diag + off) || off == 0.0) break;   // ||offdiag||_F <= 1e-15 ||A||_F
         for (int p = 0; p < n - 1; ++p)
             for (int q = p + 1; q < n; ++q) {
                 const double apq = A(p, q);

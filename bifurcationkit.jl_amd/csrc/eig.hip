@@ -19,16 +19,28 @@ int arnoldi_step_public(bk_ctx* ctx, bk_op* A, double* V, size_t ld, std::vector
 
 namespace {
 
-struct ShiftInvertOp : bk_op {      // rhs -> (J - sigma I)^-1 rhs = ls(J, rhs; a0 = -sigma, a1 = 1)[1]  (:259-261)
+// Jshift = du -> J(du) .- sigma .* du   (examples/SH3d.jl:106)
+struct ShiftedOp : bk_op {
     bk_op* J;
     double sigma;
+    int apply(const double* x, double, double b0, double b1, double* out, double*) override {
+        return J->apply(x, 0.0, b0 - b1 * sigma, b1, out, nullptr);
+    }
+};
+
+// A = du -> ls(Jshift, du)[1]   (examples/SH3d.jl:107).  The shift is folded into the operator BEFORE the
+// (optionally preconditioned) solve, exactly as SH3dEig does; this sidesteps the reference's Pl+shift quirk
+// (src/LinearSolver.jl:268-277 solves (a0 I + a1 Pl^-1 J), which is not a shift-invert of J).  Without a
+// preconditioner it is identical to ShiftInvert's ls(J, rhs; a0 = -sigma, a1 = 1) (src/EigSolver.jl:259-261).
+struct ShiftInvertOp : bk_op {
+    ShiftedOp Js;
     bk_gmres_opts ls;
     bk_precond* pl;
     int solves = 0, failed = 0, inner_ops = 0;
     int apply(const double* x, double, double b0, double b1, double* out, double*) override {
         if (b0 != 0.0 || b1 != 1.0) return set_error(ctx, "ShiftInvertOp: only plain application is supported");
         GmresResult r;
-        BK_TRY(linsolve(ctx, J, x, out, -sigma, 1.0, ls, pl, &r));
+        BK_TRY(linsolve(ctx, &Js, x, out, 0.0, 1.0, ls, pl, &r));
         solves += 1;
         inner_ops += r.niter;
         if (!r.converged) failed += 1;
@@ -52,7 +64,8 @@ extern "C" int bk_eig_shiftinvert(bk_ctx* ctx, bk_op* J, int nev, const bk_eig_o
     if (m > kMaxBasis - 1) m = kMaxBasis - 1;
     if (nev > m) return set_error(ctx, "bk_eig_shiftinvert: nev=%d exceeds the Krylov dimension %d", nev, m);
     ShiftInvertOp A;
-    A.ctx = ctx; A.n = n; A.ntail = 0; A.J = J; A.sigma = eo->sigma; A.ls = *lsopts; A.pl = pl;
+    A.ctx = ctx; A.n = n; A.ntail = 0; A.ls = *lsopts; A.pl = pl;
+    A.Js.ctx = ctx; A.Js.n = n; A.Js.ntail = 0; A.Js.J = J; A.Js.sigma = eo->sigma;
 
     WsGuard ws(ctx);
     const size_t ld = (n + 31) / 32 * 32;

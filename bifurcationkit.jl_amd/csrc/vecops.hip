@@ -460,5 +460,14 @@ int bk_vec_dot(bk_ctx* ctx, size_t n, const double* x, const double* y, double* 
 }
 int bk_vec_nrm2(bk_ctx* ctx, size_t n, const double* x, double* out) { return v_nrm2(ctx, n, x, out); }
 int bk_vec_nrminf(bk_ctx* ctx, size_t n, const double* x, double* out) { return v_nrminf(ctx, n, x, out); }
+int bk_krylov_multidot(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const double* w, double* out) {
+    if (!ctx || !V || !w || !out) return -1;
+    return v_multidot(ctx, n, V, ldv, k, w, out);
+}
+int bk_krylov_multiaxpy(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const double* c, const double* src,
+                        double scale, double* dst, double* nrm2sq) {
+    if (!ctx || !V || !c || !dst) return -1;
+    return v_multiaxpy(ctx, n, V, ldv, k, c, src, scale, dst, nrm2sq);
+}
 
 }  // extern "C"

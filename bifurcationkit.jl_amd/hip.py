@@ -1,0 +1,596 @@
+"""Host-side mirror of BifurcationKit's plugin surface, backed by ``libbkhip.so``.
+
+Same names, argument meaning and error behaviour as the reference types they stand in for
+(paths relative to the BifurcationKit.jl checkout):
+
+  HipVec              state vector with the VectorInterface subset the PALC path uses
+                      (src/BorderedArrays.jl:86-217; checklist in SURVEY.md section 8b)
+  GMRESKrylovKit      src/LinearSolver.jl:223-291      ``ls(J, rhs; a0, a1) -> (x, success, numops)``
+  GMRESIterativeSolvers  src/LinearSolver.jl:149-206
+  BorderingBLS        src/LinearBorderSolver.jl:59-166  ``bls(J, dR, dzu, dzp, R, n, xi_u, xi_p; shift, dotp)``
+  MatrixFreeBLS       src/LinearBorderSolver.jl:404-437
+  ShiftInvert         src/EigSolver.jl:246-266 (+ the SH3dEig of examples/SH3d.jl:96-113)
+  SwiftHohenberg / SwiftHohenberg1D / CGL2d   the operator definitions of examples/SH3d.jl,
+                      SH2d-fronts.jl, SHpde_snaking.jl, cGL2d.jl as ``BifurcationProblem``-like objects
+                      whose ``jacobian`` returns an opaque device handle (src/Problems.jl:98-101)
+
+PyTorch is used for device memory and the HIP stream only; all arithmetic runs in the HIP library.
+Non-convergence is never an exception (flags, like the reference); misuse and device errors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """``bk_ctx``: one per process / GPU.  ``comm`` = None | ("rccl", rank, nranks, id_bytes) |
+    ("host", rank, nranks, allreduce, sendrecv)."""
+
+    def __init__(self, device: int = 0, comm=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("bifurcationkit.jl_amd needs a visible MI355X (no CPU fallback)")
+        self.lib = L.load()
+        self.device = device
+        torch.cuda.set_device(device)
+        self.torch_device = torch.device("cuda", device)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        h = C.c_void_p()
+        self.rank, self.nranks = 0, 1
+        self._keep = []
+        if comm is None:
+            st = self.lib.bk_ctx_create(C.byref(h), device, C.c_void_p(stream))
+        elif comm[0] == "rccl":
+            _, rank, nranks, idb = comm
+            buf = C.create_string_buffer(bytes(idb), L.BK_UNIQUE_ID_BYTES)
+            st = self.lib.bk_ctx_create_dist(C.byref(h), device, C.c_void_p(stream), rank, nranks, buf)
+            self.rank, self.nranks = rank, nranks
+        elif comm[0] == "host":
+            _, rank, nranks, allreduce, sendrecv = comm
+            ar = L.ALLREDUCE_FN(allreduce)
+            sr = L.SENDRECV_FN(sendrecv)
+            self._keep += [ar, sr]
+            st = self.lib.bk_ctx_create_hostcomm(C.byref(h), device, C.c_void_p(stream), rank, nranks, ar, sr, None)
+            self.rank, self.nranks = rank, nranks
+        else:
+            raise ValueError(comm)
+        if st != 0 or not h.value:
+            raise L.BkHipError(f"bk_ctx_create failed ({st})")
+        self.h = h
+
+    @staticmethod
+    def unique_id() -> bytes:
+        lib = L.load()
+        buf = C.create_string_buffer(L.BK_UNIQUE_ID_BYTES)
+        if lib.bk_comm_unique_id(buf) != 0:
+            raise L.BkHipError("bk_comm_unique_id failed")
+        return buf.raw
+
+    def check(self, st, what=""):
+        L.check(self.h, st, what)
+
+    def set_option(self, key: str, value: float):
+        self.check(self.lib.bk_ctx_set_option(self.h, key.encode(), float(value)), "bk_ctx_set_option")
+
+    def sync(self):
+        self.check(self.lib.bk_ctx_sync(self.h), "bk_ctx_sync")
+
+    def prof_enable(self, on=True):
+        self.check(self.lib.bk_prof_enable(self.h, 1 if on else 0))
+
+    def prof_reset(self):
+        self.check(self.lib.bk_prof_reset(self.h))
+
+    def prof_get(self, name: str):
+        ms, calls, nbytes = C.c_double(), C.c_longlong(), C.c_double()
+        self.check(self.lib.bk_prof_get(self.h, name.encode(), C.byref(ms), C.byref(calls), C.byref(nbytes)))
+        return dict(ms=ms.value, calls=calls.value, bytes=nbytes.value)
+
+    def empty(self, n: int) -> torch.Tensor:
+        return torch.empty(int(n), dtype=torch.float64, device=self.torch_device)
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.lib.bk_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipVec:
+    """Device state vector (local slab) with the VectorInterface subset of SURVEY.md section 8b.
+    ``nglobal`` is what Julia's ``length(x)`` would return for the undistributed vector."""
+
+    __slots__ = ("ctx", "t", "nglobal")
+
+    def __init__(self, ctx: Context, t: torch.Tensor, nglobal: int | None = None):
+        assert t.dtype == torch.float64 and t.is_cuda and t.is_contiguous()
+        self.ctx, self.t = ctx, t
+        self.nglobal = int(nglobal if nglobal is not None else t.numel())
+
+    # --- construction / transfer
+    @classmethod
+    def from_numpy(cls, ctx, a, nglobal=None):
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(ctx.torch_device)
+        return cls(ctx, t, nglobal)
+
+    def numpy(self):
+        self.ctx.sync()
+        return self.t.cpu().numpy()
+
+    @property
+    def n(self):
+        return self.t.numel()
+
+    def __len__(self):           # Base.length: used by NormalisedDot, src/continuation/Palc.jl:4
+        return self.nglobal
+
+    def similar(self):
+        return HipVec(self.ctx, self.ctx.empty(self.n), self.nglobal)
+
+    # --- VectorInterface
+    def zerovector(self):        # VI.zerovector
+        z = self.similar()
+        self.ctx.check(self.ctx.lib.bk_vec_zero(self.ctx.h, self.n, _ptr(z.t)))
+        return z
+
+    def copy(self):              # _copy, src/BorderedArrays.jl:30
+        z = self.similar()
+        self.ctx.check(self.ctx.lib.bk_vec_copy(self.ctx.h, self.n, _ptr(self.t), _ptr(z.t)))
+        return z
+
+    def copyto_(self, src):      # _copyto!, src/BorderedArrays.jl:34
+        self.ctx.check(self.ctx.lib.bk_vec_copy(self.ctx.h, self.n, _ptr(src.t), _ptr(self.t)))
+        return self
+
+    def scale_(self, a):         # VI.scale!
+        self.ctx.check(self.ctx.lib.bk_vec_scale(self.ctx.h, self.n, float(a), _ptr(self.t)))
+        return self
+
+    def add_(self, x, a=1.0, b=1.0):   # VI.add!(y, x, a, b): y = b*y + a*x
+        self.ctx.check(self.ctx.lib.bk_vec_axpby(self.ctx.h, self.n, float(a), _ptr(x.t), float(b), _ptr(self.t)))
+        return self
+
+    def inner(self, y):          # VI.inner
+        out = C.c_double()
+        self.ctx.check(self.ctx.lib.bk_vec_dot(self.ctx.h, self.n, _ptr(self.t), _ptr(y.t), C.byref(out)))
+        return out.value
+
+    def norm(self):              # VI.norm / LinearAlgebra.norm
+        out = C.c_double()
+        self.ctx.check(self.ctx.lib.bk_vec_nrm2(self.ctx.h, self.n, _ptr(self.t), C.byref(out)))
+        return out.value
+
+    def norminf(self):           # norm(x, Inf) = norminf, src/LinearSolver.jl:4
+        out = C.c_double()
+        self.ctx.check(self.ctx.lib.bk_vec_nrminf(self.ctx.h, self.n, _ptr(self.t), C.byref(out)))
+        return out.value
+
+
+# ------------------------------------------------------------------------------------------ problems
+class HipJacobian:
+    """What ``jacobian(prob, x, p)`` returns: an opaque operator handle (``bk_op``).  Keeps ``x`` alive, like
+    the Julia closure ``dx -> dF_sh(x, p, dx)`` (examples/SH3d.jl:119) captures it."""
+
+    def __init__(self, prob, x: HipVec, params):
+        self.prob, self.ctx, self.x = prob, prob.ctx, x
+        arr = (C.c_double * len(params))(*params)
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.bk_jacobian(prob.h, _ptr(x.t), arr, len(params), C.byref(h)), "bk_jacobian")
+        self.h = h
+
+    def __call__(self, dx: HipVec, a0=0.0, a1=1.0) -> HipVec:      # apply(J, dx), src/Utils.jl:191-195
+        out = dx.similar()
+        self.ctx.check(self.ctx.lib.bk_op_apply(self.h, _ptr(dx.t), float(a0), float(a1), _ptr(out.t)), "bk_op_apply")
+        return out
+
+    def __del__(self):
+        try:
+            if self.h.value:
+                self.ctx.lib.bk_op_destroy(self.h)
+        except Exception:
+            pass
+
+
+class _PdeProblem:
+    """BifurcationProblem-like: ``residual(x, p)``, ``jacobian(x, p)``, parameter 'lens' = index into params
+    (src/Problems.jl:89-149)."""
+    pde = None
+    param_names = ()
+    nfields = 1
+
+    def __init__(self, ctx: Context, dims, ls, params: dict, lens: str):
+        self.ctx = ctx
+        self.dims = tuple(int(d) for d in dims)
+        self.ls = tuple(float(x) for x in ls)
+        self.params = dict(params)
+        self.lens = lens
+        self.ipar = self.param_names.index(lens)
+        self.delta = math.sqrt(np.finfo(float).eps)         # getdelta: src/Problems.jl:69-70
+        d = L.ProblemDesc()
+        d.pde = self.pde
+        d.ndim = len(self.dims)
+        for i in range(3):
+            d.n[i] = self.dims[i] if i < len(self.dims) else 1
+            d.l[i] = self.ls[i] if i < len(self.ls) else 1.0
+        h = C.c_void_p()
+        ctx.check(ctx.lib.bk_problem_create(ctx.h, C.byref(d), C.byref(h)), "bk_problem_create")
+        self.h = h
+        nl, lo, hi = C.c_size_t(), C.c_int(), C.c_int()
+        ctx.check(ctx.lib.bk_problem_nlocal(h, C.byref(nl), C.byref(lo), C.byref(hi)))
+        self.nlocal, self.slab = nl.value, (lo.value, hi.value)
+        self.nglobal = int(np.prod(self.dims)) * self.nfields
+
+    def _pvec(self, p):
+        vals = dict(self.params)
+        vals[self.lens] = float(p)
+        return [float(vals[k]) for k in self.param_names]
+
+    def residual(self, x: HipVec, p: float) -> HipVec:
+        out = x.similar()
+        pv = self._pvec(p)
+        arr = (C.c_double * len(pv))(*pv)
+        self.ctx.check(self.ctx.lib.bk_residual(self.h, _ptr(x.t), arr, len(pv), _ptr(out.t)), "bk_residual")
+        return out
+
+    def jacobian(self, x: HipVec, p: float) -> HipJacobian:
+        return HipJacobian(self, x, self._pvec(p))
+
+    def vec(self, a_global: np.ndarray) -> HipVec:
+        """Scatter a global NumPy state (x fastest) to this rank's slab."""
+        a = np.asarray(a_global, dtype=np.float64).reshape(-1)
+        if self.ctx.nranks == 1:
+            return HipVec.from_numpy(self.ctx, a, self.nglobal)
+        plane = int(np.prod(self.dims[:-1]))
+        lo, hi = self.slab
+        return HipVec.from_numpy(self.ctx, a[lo * plane:hi * plane], self.nglobal)
+
+    def __del__(self):
+        try:
+            if self.h.value:
+                self.ctx.lib.bk_problem_destroy(self.h)
+        except Exception:
+            pass
+
+
+class SwiftHohenberg(_PdeProblem):
+    """2-D/3-D quadratic-cubic SH, Neumann-ghost: examples/SH3d.jl:16-53, examples/SH2d-fronts.jl:13-34."""
+    pde = L.BK_PDE_SH
+    param_names = ("l", "nu")
+
+    def __init__(self, ctx, dims, ls, l=0.1, nu=1.2, lens="l"):
+        super().__init__(ctx, dims, ls, dict(l=l, nu=nu), lens)
+
+
+class SwiftHohenberg1D(_PdeProblem):
+    """1-D cubic-quintic SH, Dirichlet: examples/SHpde_snaking.jl:8-31."""
+    pde = L.BK_PDE_SH1D
+    param_names = ("lam", "nu")
+
+    def __init__(self, ctx, N, l, lam=-0.1, nu=2.0, lens="lam"):
+        super().__init__(ctx, (N,), (l,), dict(lam=lam, nu=nu), lens)
+
+
+class CGL2d(_PdeProblem):
+    """2-D cubic-quintic complex Ginzburg-Landau, SoA [u1; u2], Dirichlet: examples/cGL2d.jl:6-91."""
+    pde = L.BK_PDE_CGL2D
+    param_names = ("r", "mu", "nu", "c3", "c5", "gamma")
+    nfields = 2
+
+    def __init__(self, ctx, dims, ls, r=0.5, mu=0.1, nu=1.0, c3=-1.0, c5=1.0, gamma=0.0, lens="r"):
+        super().__init__(ctx, dims, ls, dict(r=r, mu=mu, nu=nu, c3=c3, c5=c5, gamma=gamma), lens)
+
+
+class DCTPreconditioner:
+    """``Pl``: exact ((I+Lap)^2 + shift)^-1 -- ``cholesky(Symmetric(L1))`` of examples/SH3d.jl:88 (shift=0),
+    ``lu(L1 + I)`` of examples/SH2d-fronts.jl:121 (shift=1)."""
+
+    def __init__(self, prob: SwiftHohenberg, shift: float = 0.0):
+        self.ctx, self.prob = prob.ctx, prob
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.bk_precond_sh_create(prob.h, float(shift), C.byref(h)), "bk_precond_sh_create")
+        self.h = h
+
+    def ldiv(self, v: HipVec) -> HipVec:        # Pl \ v
+        out = v.similar()
+        self.ctx.check(self.ctx.lib.bk_precond_apply(self.h, _ptr(v.t), _ptr(out.t)), "bk_precond_apply")
+        return out
+
+    def __del__(self):
+        try:
+            if self.h.value:
+                self.ctx.lib.bk_precond_destroy(self.h)
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------------ linear solvers
+class _GMRES:
+    flavor = L.BK_GMRES_KRYLOVKIT
+
+    def _opts(self):
+        o = L.GmresOpts()
+        o.flavor, o.dim, o.maxiter, o.atol, o.rtol = self.flavor, self.dim, self.maxiter, self.atol, self.rtol
+        return o
+
+    def _pl(self):
+        return self.Pl.h if self.Pl is not None else None
+
+    def __call__(self, J: HipJacobian, rhs: HipVec, a0=0.0, a1=1.0):
+        """(ls)(J, rhs; a0, a1) -> (x, success, niter): src/LinearSolver.jl:12."""
+        ctx = rhs.ctx
+        x = rhs.similar()
+        cv, it, rn = C.c_int(), C.c_int(), C.c_double()
+        o = self._opts()
+        ctx.check(ctx.lib.bk_gmres(ctx.h, J.h, _ptr(rhs.t), _ptr(x.t), float(a0), float(a1), C.byref(o), self._pl(),
+                                   C.byref(cv), C.byref(it), C.byref(rn)), "bk_gmres")
+        self.last_resnorm = rn.value
+        return x, bool(cv.value), it.value
+
+    def solve2(self, J, rhs1, rhs2, a0=0.0, a1=1.0):
+        """(ls)(J, rhs1, rhs2): src/LinearSolver.jl:15-19."""
+        x1, f1, it1 = self(J, rhs1, a0, a1)
+        x2, f2, it2 = self(J, rhs2, a0, a1)
+        return x1, x2, f1 and f2, (it1, it2)
+
+
+@dataclass
+class GMRESKrylovKit(_GMRES):
+    """Fields of src/LinearSolver.jl:223-250 (defaults = KrylovDefaults, :225-234)."""
+    dim: int = 30
+    atol: float = 1e-12
+    rtol: float = 1e-12
+    maxiter: int = 100
+    Pl: DCTPreconditioner | None = None
+    flavor = L.BK_GMRES_KRYLOVKIT
+
+
+@dataclass
+class GMRESIterativeSolvers(_GMRES):
+    """Fields of src/LinearSolver.jl:149-180: reltol, abstol, restart, maxiter, Pl."""
+    reltol: float = 1e-8
+    abstol: float = 0.0
+    restart: int = 63          # the reference default (200) allocates a 201-vector basis; capped
+    maxiter: int = 100
+    Pl: DCTPreconditioner | None = None
+    flavor = L.BK_GMRES_ITERATIVESOLVERS
+
+    @property
+    def dim(self):
+        return self.restart
+
+    @property
+    def atol(self):
+        return self.abstol
+
+    @property
+    def rtol(self):
+        return self.reltol
+
+
+# ------------------------------------------------------------------------------------------ bordered solvers
+@dataclass
+class BorderedArray:
+    """(u, p) pair, src/BorderedArrays.jl:23-26; VectorInterface methods :86-217."""
+    u: object
+    p: float
+
+    def copy(self):
+        return BorderedArray(self.u.copy(), self.p)
+
+    def zerovector(self):
+        return BorderedArray(self.u.zerovector(), 0.0)
+
+    def copyto_(self, src):
+        self.u.copyto_(src.u)
+        self.p = src.p
+        return self
+
+    def scale_(self, a):
+        self.u.scale_(a)
+        self.p *= a
+        return self
+
+    def add_(self, x, a=1.0, b=1.0):
+        self.u.add_(x.u, a, b)
+        self.p = b * self.p + a * x.p
+        return self
+
+    def inner(self, y):
+        return self.u.inner(y.u) + self.p * y.p
+
+    def norm(self):
+        return math.sqrt(self.u.norm() ** 2 + self.p ** 2)
+
+    def __len__(self):
+        return len(self.u) + 1
+
+
+@dataclass
+class BorderingBLS:
+    """src/LinearBorderSolver.jl:59-79.  With a native GMRES ``solver`` and HipVec arguments the whole bordered
+    solve is ONE library call (bk_bls_bordering); any other solver / vector type takes the generic path, which
+    is the reference's algorithm line by line (:88-166)."""
+    solver: object = None
+    tol: float = 1e-12
+    check_precision: bool = True
+    k: int = 1
+
+    def __post_init__(self):
+        assert self.k > 0, "Number of recursions must be positive"
+
+    def update_bls(self, ls):                      # update_bls, :490-493
+        return BorderingBLS(ls, self.tol, self.check_precision, self.k)
+
+    def __call__(self, J, dR, dzu, dzp, R, n, xiu=1.0, xip=1.0, *, shift=None, dotp=None, dotscale=None):
+        native = isinstance(self.solver, _GMRES) and isinstance(R, HipVec) and (dotp is None or dotscale is not None)
+        if native:
+            ctx = R.ctx
+            dX = R.similar()
+            dl, cv = C.c_double(), C.c_int()
+            it = (C.c_int * 2)()
+            bo = L.BorderingOpts(self.tol, 1 if self.check_precision else 0, self.k)
+            lo = self.solver._opts()
+            ctx.check(ctx.lib.bk_bls_bordering(
+                ctx.h, J.h, _ptr(dR.t), _ptr(dzu.t), float(dzp), _ptr(R.t), float(n), float(xiu), float(xip),
+                0 if shift is None else 1, 0.0 if shift is None else float(shift),
+                1.0 if dotscale is None else float(dotscale), C.byref(bo), C.byref(lo), self.solver._pl(),
+                _ptr(dX.t), C.byref(dl), C.byref(cv), it), "bk_bls_bordering")
+            return dX, dl.value, bool(cv.value), (it[0], it[1])
+        return self._generic(J, dR, dzu, dzp, R, n, xiu, xip, shift, dotp or (lambda x, y: x.inner(y)))
+
+    # generic path: BEC / residualBEC exactly as written in the reference
+    def _bec(self, J, dR, dzu, dzp, R, n, xiu, xip, shift, dotp):
+        kw = {} if shift is None else dict(a0=shift)
+        if hasattr(self.solver, "solve2"):
+            x1, dx, ok, it = self.solver.solve2(J, R, dR, **kw)
+        else:
+            x1, f1, i1 = self.solver(J, R, **kw)
+            dx, f2, i2 = self.solver(J, dR, **kw)
+            ok, it = f1 and f2, (i1, i2)
+        dl = (n - dotp(dzu, x1) * xiu) / (dzp * xip - dotp(dzu, dx) * xiu)
+        x1.add_(dx, -dl)
+        return x1, dl, ok, it
+
+    def _generic(self, J, dR, dzu, dzp, R, n, xiu, xip, shift, dotp):
+        dX, dl, cv, it = self._bec(J, dR, dzu, dzp, R, n, xiu, xip, shift, dotp)
+        k, fail = 0, True
+        while self.check_precision and k < self.k and fail:
+            dXr = J(dX)
+            if shift is not None:
+                dXr.add_(dX, shift)
+            dXr.add_(dR, dl)
+            dXr.add_(R, 1.0, -1.0)
+            dlr = n - xip * dzp * dl - xiu * dotp(dzu, dX)
+            fail = dXr.norm() > self.tol or abs(dlr) > self.tol
+            if fail:
+                dX1, dl1, cv, it = self._bec(J, dR, dzu, dzp, dXr, dlr, xiu, xip, shift, dotp)
+                dX.add_(dX1, 1.0)
+                dl += dl1
+                k += 1
+        return dX, dl, cv, it
+
+
+@dataclass
+class MatrixFreeBLS:
+    """src/LinearBorderSolver.jl:404-437 on BorderedArray(u, p): one GMRES on the (N+1) operator
+    MatrixFreeBLSmap (:326-335), device-resident with the scalar border on the host."""
+    solver: _GMRES = None
+
+    def update_bls(self, ls):
+        return MatrixFreeBLS(ls)
+
+    def __call__(self, J, dR, dzu, dzp, R, n, xiu=1.0, xip=1.0, *, shift=None, dotp=None, dotscale=None):
+        if not isinstance(self.solver, _GMRES) or not isinstance(R, HipVec):
+            raise TypeError("MatrixFreeBLS (HIP) needs a native GMRES solver and HipVec arguments")
+        if dotp is not None and dotscale is None:
+            raise TypeError("pass dotscale (dotp(x,y) = dotscale*<x,y>) for the native MatrixFreeBLS")
+        ctx = R.ctx
+        dX = R.similar()
+        dl, cv, it = C.c_double(), C.c_int(), C.c_int()
+        lo = self.solver._opts()
+        ctx.check(ctx.lib.bk_bls_matrixfree(
+            ctx.h, J.h, _ptr(dR.t), _ptr(dzu.t), float(dzp), _ptr(R.t), float(n), float(xiu), float(xip),
+            0 if shift is None else 1, 0.0 if shift is None else float(shift),
+            1.0 if dotscale is None else float(dotscale), C.byref(lo), _ptr(dX.t), C.byref(dl), C.byref(cv),
+            C.byref(it)), "bk_bls_matrixfree")
+        return dX, dl.value, bool(cv.value), it.value
+
+
+# ------------------------------------------------------------------------------------------ eigensolver
+@dataclass
+class ShiftInvert:
+    """ShiftInvert(sigma, ls, eig) of src/EigSolver.jl:246-266 with a KrylovKit.eigsolve-style outer
+    iteration -- the SH3dEig of examples/SH3d.jl:96-113: ``(eig)(J, nev) -> (vals, vecs, converged, numops)``,
+    eigenvalues Complex, sorted by decreasing real part; ``geteigenvector(eig, vecs, n) = vecs[n]``."""
+    sigma: float
+    ls: _GMRES
+    tol: float = 1e-12
+    maxiter: int = 20
+    krylovdim: int | None = None         # None -> max(30, nev + 30), examples/SH3d.jl:109
+    hermitian: bool = False
+    seed: int = 1234
+    save_vectors: bool = True
+
+    def __call__(self, J: HipJacobian, nev: int, **kwargs):
+        ctx = J.ctx
+        kd = self.krylovdim if self.krylovdim is not None else max(30, nev + 30)
+        kd = min(kd, 63, J.prob.nglobal - 1)
+        nev = min(nev, kd)
+        eo = L.EigOpts(float(self.sigma), int(kd), int(self.maxiter), float(self.tol), 1 if self.hermitian else 0,
+                       int(self.seed))
+        lo = self.ls._opts()
+        re = (C.c_double * nev)()
+        im = (C.c_double * nev)()
+        n = J.prob.nlocal
+        ld = (n + 31) // 32 * 32
+        vr = ctx.empty(ld * nev) if self.save_vectors else None
+        vi = ctx.empty(ld * nev) if (self.save_vectors and not self.hermitian) else None
+        nconv, nops = C.c_int(), C.c_int()
+        ctx.check(ctx.lib.bk_eig_shiftinvert(
+            ctx.h, J.h, nev, C.byref(eo), C.byref(lo), self.ls._pl(), re, im,
+            _ptr(vr) if vr is not None else None, _ptr(vi) if vi is not None else None, ld,
+            C.byref(nconv), C.byref(nops)), "bk_eig_shiftinvert")
+        vals = np.array([complex(re[i], im[i]) for i in range(nev)])
+        vecs = None
+        if vr is not None:
+            vecs = [(HipVec(ctx, vr[i * ld:i * ld + n], J.prob.nglobal),
+                     HipVec(ctx, vi[i * ld:i * ld + n], J.prob.nglobal) if vi is not None else None)
+                    for i in range(nev)]
+        return vals, vecs, nconv.value >= nev, nops.value
+
+    @staticmethod
+    def geteigenvector(vecs, n):
+        return vecs[n]
+
+
+# ------------------------------------------------------------------------------------------ native correctors
+def newton_native(prob: _PdeProblem, x0: HipVec, p: float, ls: _GMRES, tol=1e-12, max_iterations=25, norm_inf=False):
+    """_newton (src/Newton.jl:66-114) as one library call."""
+    ctx = prob.ctx
+    x = x0.copy()
+    pv = prob._pvec(p)
+    arr = (C.c_double * len(pv))(*pv)
+    no = L.NewtonOpts(float(tol), int(max_iterations), 1 if norm_inf else 0)
+    lo = ls._opts()
+    res = L.NewtonResult()
+    ctx.check(ctx.lib.bk_newton(ctx.h, prob.h, _ptr(x.t), arr, len(pv), C.byref(no), C.byref(lo), ls._pl(),
+                                C.byref(res)), "bk_newton")
+    return dict(u=x, converged=bool(res.converged), itnewton=res.itnewton, itlineartot=res.itlinear,
+                residuals=[res.residuals[i] for i in range(res.itnewton + 1)])
+
+
+def newton_palc_native(prob: _PdeProblem, z0: BorderedArray, tau: BorderedArray, z_pred: BorderedArray, ds, theta,
+                       bls: BorderingBLS, tol=1e-12, max_iterations=25, p_min=-math.inf, p_max=math.inf,
+                       norm_inf=False):
+    """newton_palc (src/continuation/Palc.jl:187-305, linesearch=false) with BorderingBLS as one library call."""
+    ctx = prob.ctx
+    x = z_pred.u.copy()
+    p = C.c_double(z_pred.p)
+    pv = prob._pvec(z_pred.p)
+    arr = (C.c_double * len(pv))(*pv)
+    no = L.NewtonOpts(float(tol), int(max_iterations), 1 if norm_inf else 0)
+    bo = L.BorderingOpts(bls.tol, 1 if bls.check_precision else 0, bls.k)
+    lo = bls.solver._opts()
+    res = L.NewtonResult()
+    big = 1.7e308
+    ctx.check(ctx.lib.bk_newton_palc(
+        ctx.h, prob.h, _ptr(x.t), C.byref(p), _ptr(z0.u.t), float(z0.p), _ptr(tau.u.t), float(tau.p), float(ds),
+        float(theta), arr, len(pv), prob.ipar, max(float(p_min), -big), min(float(p_max), big), C.byref(no),
+        C.byref(bo), C.byref(lo), bls.solver._pl(), C.byref(res)), "bk_newton_palc")
+    return dict(u=BorderedArray(x, p.value), converged=bool(res.converged), itnewton=res.itnewton,
+                itlineartot=res.itlinear, residuals=[res.residuals[i] for i in range(res.itnewton + 1)])

@@ -87,6 +87,14 @@ int bk_vec_axpby(bk_ctx* ctx, size_t n, double a, const double* x, double b, dou
 int bk_vec_dot(bk_ctx* ctx, size_t n, const double* x, const double* y, double* out); /* inner :213 */
 int bk_vec_nrm2(bk_ctx* ctx, size_t n, const double* x, double* out);            /* norm     :55-70 */
 int bk_vec_nrminf(bk_ctx* ctx, size_t n, const double* x, double* out);  /* norminf LinearSolver.jl:4 */
+/* Fused Krylov-basis primitives (what the Gram-Schmidt loops inside KrylovKit / IterativeSolvers do with
+ * k separate VI.inner / VI.add! passes).  V holds k vectors, V_i = V + i*ldv, k <= 64.
+ *   multidot : out[i] = <V_i, w> (i < k), out[k] = <w, w>           -- one pass over V and w
+ *   multiaxpy: dst = scale * (src + sum_i c[i] V_i); src may be NULL; *nrm2sq (may be NULL) = ||dst||^2 */
+int bk_krylov_multidot(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const double* w,
+                       double* out_host);
+int bk_krylov_multiaxpy(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const double* c_host,
+                        const double* src, double scale, double* dst, double* nrm2sq);
 
 /* ------------------------------------------------------------------ problems --------------- */
 

@@ -303,3 +303,16 @@ def shift_invert(J, nev, sigma, ls, eig):
     lam = 1.0 / np.asarray(vals) + sigma
     ind = sorted(range(len(lam)), key=lambda i: -lam[i].real)      # __sort_spectrum :16-19
     return np.asarray([complex(lam[i]) for i in ind]), [vecs[i] for i in ind], cv, nops
+
+
+def default_eig(J, nev):
+    """DefaultEig, src/EigSolver.jl:42-49: ``LA.eigen(Array(J); sortby = real)`` then the last ``nev``
+    entries in reverse order (decreasing real part).  Eigenvectors as LAPACK *geev returns them (unit
+    2-norm, largest component real) -- NumPy calls the same routine."""
+    A = J.toarray() if hasattr(J, "toarray") else np.asarray(J, dtype=float)
+    w, V = np.linalg.eig(A)
+    order = np.argsort(w.real, kind="stable")
+    w, V = w[order], V[:, order]
+    nev2 = min(nev, len(w))
+    sel = list(range(len(w) - 1, len(w) - 1 - nev2, -1))
+    return w[sel].astype(complex), V[:, sel].astype(complex), True, 1

@@ -168,3 +168,28 @@ class CGL2d:
 
     def dF(self, u, du, **p):
         return self.J(u, **p) @ du
+
+
+def dct_preconditioner(dims, ls, shift=0.0, workers=1):
+    """Exact ``(L1 + shift I)^-1`` for the Neumann-ghost ``L1 = (I + Lap)^2`` through the orthonormal DCT-II
+    (the 1-D operator of SH3d.jl:21-32 has eigenvectors cos(pi k (j+1/2)/N), eigenvalues -(4/h^2) sin^2(pi k/2N)).
+    CPU stand-in for ``Pl = cholesky(Symmetric(L1))`` (examples/SH3d.jl:88) at sizes where a sparse factorisation
+    no longer fits; mathematically the same operator.  Returns a callable v -> Pl \\ v on flat x-fastest vectors."""
+    import scipy.fft as sfft
+    dims = tuple(int(d) for d in dims)
+    lam = []
+    for n, l in zip(dims, ls):
+        h = 2.0 * l / n
+        lam.append(-(4.0 / h**2) * np.sin(np.pi * np.arange(n) / (2.0 * n)) ** 2)
+    # array axes are (z, y, x) for a C-ordered reshape of an x-fastest vector
+    shape = dims[::-1]
+    grids = np.meshgrid(*lam[::-1], indexing="ij")
+    sym = (1.0 + sum(grids)) ** 2 + shift
+
+    def apply(v):
+        a = np.asarray(v, dtype=float).reshape(shape)
+        s = sfft.dctn(a, type=2, norm="ortho", workers=workers)
+        s /= sym
+        return sfft.idctn(s, type=2, norm="ortho", workers=workers).reshape(-1)
+
+    return apply

@@ -1,0 +1,86 @@
+"""Kernel micro-benchmarks on the GPU box: HBM GB/s of the hot kernels at full size (512^3 = 1 GiB vectors).
+Prints one JSON line per measurement.  Usage: python scripts/kernel_sweep.py [size]"""
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from bk_amd import hip  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+what = sys.argv[2].split(",") if len(sys.argv) > 2 else ["jvp", "krylov", "blas", "precond"]
+ctx = hip.Context(0)
+N = n ** 3
+prob = hip.SwiftHohenberg(ctx, (n, n, n), (math.pi * n / 32,) * 3)
+g = torch.Generator(device="cuda").manual_seed(0)
+u = hip.HipVec(ctx, torch.rand(N, dtype=torch.float64, device="cuda", generator=g))
+v = hip.HipVec(ctx, torch.rand(N, dtype=torch.float64, device="cuda", generator=g))
+out = v.similar()
+
+
+def timeit(fn, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def report(name, secs, nbytes, **kw):
+    print(json.dumps(dict(kernel=name, n=n, ms=secs * 1e3, gbs=nbytes / secs / 1e9, frac_of_8TBs=nbytes / secs / 8e12, **kw)),
+          flush=True)
+
+
+if "jvp" in what:
+    J = prob.jacobian(u, 0.1)
+    lib = ctx.lib
+    pv = (C.c_double * 2)(0.1, 1.2)
+    for variant, zchunks in ((0, [0]), (1, [0, 8, 16, 32, 64, 128, 512])):
+        ctx.set_option("sh_kernel", variant)
+        for zc in zchunks:
+            ctx.set_option("sh_zchunk", zc)
+            f = lambda: ctx.check(lib.bk_op_apply(J.h, C.c_void_p(v.t.data_ptr()), 0.0, 1.0, C.c_void_p(out.t.data_ptr())))
+            report("sh3d_jvp", timeit(f), 24.0 * N, variant=variant, zchunk=zc)
+            f = lambda: ctx.check(lib.bk_residual(prob.h, C.c_void_p(u.t.data_ptr()), pv, 2, C.c_void_p(out.t.data_ptr())))
+            report("sh3d_residual", timeit(f), 16.0 * N, variant=variant, zchunk=zc)
+    ctx.set_option("sh_kernel", 1)
+    ctx.set_option("sh_zchunk", 0)
+
+if "blas" in what:
+    report("copy(torch)", timeit(lambda: out.t.copy_(v.t)), 16.0 * N)
+    report("axpby", timeit(lambda: out.add_(v, 0.5, 2.0)), 24.0 * N)
+    report("dot", timeit(lambda: u.inner(v)), 16.0 * N)
+    report("nrm2", timeit(lambda: u.norm()), 8.0 * N)
+    report("nrminf", timeit(lambda: u.norminf()), 8.0 * N)
+
+if "krylov" in what:
+    ld = (N + 31) // 32 * 32
+    kmax = 30 if n >= 512 else 45
+    V = torch.rand(ld * kmax, dtype=torch.float64, device="cuda", generator=g)
+    hbuf = (C.c_double * 65)()
+    for k in (1, 4, 8, 16, 24, 30, 45):
+        if k > kmax:
+            continue
+        f = lambda: ctx.check(ctx.lib.bk_krylov_multidot(ctx.h, N, C.c_void_p(V.data_ptr()), ld, k, C.c_void_p(v.t.data_ptr()), hbuf))
+        report("multidot", timeit(f, reps=3, warm=1), 8.0 * N * (k + 1), k=k)
+        cc = (C.c_double * k)(*([0.01] * k))
+        f = lambda: ctx.check(ctx.lib.bk_krylov_multiaxpy(ctx.h, N, C.c_void_p(V.data_ptr()), ld, k, cc, C.c_void_p(v.t.data_ptr()),
+                                                          1.0, C.c_void_p(out.t.data_ptr()), None))
+        report("multiaxpy", timeit(f, reps=3, warm=1), 8.0 * N * (k + 2), k=k)
+    del V
+
+if "precond" in what:
+    P = hip.DCTPreconditioner(prob, 1.0)
+    for fft in (0, 1):
+        ctx.set_option("dct_fft", fft)
+        f = lambda: ctx.check(ctx.lib.bk_precond_apply(P.h, C.c_void_p(v.t.data_ptr()), C.c_void_p(out.t.data_ptr())))
+        report("dct_precond", timeit(f, reps=2, warm=1), 16.0 * N, fft=fft)

@@ -1,0 +1,451 @@
+"""GPU parity tests (run on the MI355X box: ``pytest -m gpu``).  Every test calls the HIP path through the C ABI
+(ctypes, same call sequence as the Julia shim) and checks it against the CPU oracle on identical seeded
+inputs.  Tolerances are stated where they are used; fp64 throughout.
+
+Reference tests these mirror: test/linear_solvers/test_linear.jl:71-85,106-169,172-244,666-677;
+test/newton/test_newton.jl:23-52; test/continuation/simple_continuation.jl:74-103.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+pytestmark = pytest.mark.gpu
+
+from oracle import bordered, krylov, operators, palc  # noqa: E402  (checker only)
+
+EPS = np.finfo(float).eps
+
+
+def _hip():
+    from bk_amd import hip
+    return hip
+
+
+def _stencil_tol(L1, v):
+    """|fl(L1 v) - L1 v| <= c * eps * (|L1| |v|): bound by row-sum norm * max|v| * small constant."""
+    return 64 * EPS * abs(L1).sum(axis=1).max() * np.abs(v).max()
+
+
+# --------------------------------------------------------------------------------------------- BLAS-1
+@pytest.mark.parametrize("n", [1, 2, 63, 1000, 4097, 1 << 20])
+def test_blas1(ctx, n):
+    hip = _hip()
+    rng = np.random.default_rng(n)
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    X, Y = hip.HipVec.from_numpy(ctx, x), hip.HipVec.from_numpy(ctx, y)
+    assert np.isclose(X.inner(Y), x @ y, rtol=1e-12, atol=1e-12 * np.sqrt(n))
+    assert np.isclose(X.norm(), np.linalg.norm(x), rtol=1e-13)
+    assert X.norminf() == np.abs(x).max()
+    Z = Y.copy().add_(X, 0.3, -1.7)                      # y = -1.7 y + 0.3 x
+    assert np.allclose(Z.numpy(), -1.7 * y + 0.3 * x, rtol=1e-15, atol=1e-15)
+    assert np.allclose(X.copy().scale_(2.5).numpy(), 2.5 * x, rtol=0, atol=0)
+    assert np.all(X.zerovector().numpy() == 0.0)
+    # determinism: bitwise identical reductions run to run
+    assert X.inner(Y) == X.inner(Y)
+
+
+def test_blas1_unaligned_views(ctx):
+    hip = _hip()
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal(1001)
+    A = hip.HipVec.from_numpy(ctx, a)
+    V = hip.HipVec(ctx, A.t[1:])                         # 8-byte aligned only: scalar path
+    W = hip.HipVec(ctx, A.t[:-1])
+    assert np.isclose(V.inner(W), a[1:] @ a[:-1], rtol=1e-12)
+    assert np.isclose(V.norm(), np.linalg.norm(a[1:]), rtol=1e-13)
+
+
+@pytest.mark.parametrize("k", [1, 3, 8, 17, 30, 45, 64])
+@pytest.mark.parametrize("n", [777, 65536 + 3])
+def test_krylov_multidot_multiaxpy(ctx, k, n):
+    hip = _hip()
+    rng = np.random.default_rng(k * 1000 + n)
+    ld = (n + 31) // 32 * 32
+    V = np.zeros((k, ld))
+    V[:, :n] = rng.standard_normal((k, n))
+    w = rng.standard_normal(n)
+    Vd = hip.HipVec.from_numpy(ctx, V.reshape(-1))
+    wd = hip.HipVec.from_numpy(ctx, w)
+    out = (C.c_double * (k + 1))()
+    ctx.check(ctx.lib.bk_krylov_multidot(ctx.h, n, C.c_void_p(Vd.t.data_ptr()), ld, k, C.c_void_p(wd.t.data_ptr()), out))
+    ref = np.concatenate([V[:, :n] @ w, [w @ w]])
+    assert np.allclose(np.array(out[:]), ref, rtol=1e-12, atol=1e-11 * np.sqrt(n))
+    c = rng.standard_normal(k)
+    cc = (C.c_double * k)(*c)
+    dst = hip.HipVec.from_numpy(ctx, np.zeros(n))
+    nn = C.c_double()
+    ctx.check(ctx.lib.bk_krylov_multiaxpy(ctx.h, n, C.c_void_p(Vd.t.data_ptr()), ld, k, cc, C.c_void_p(wd.t.data_ptr()),
+                                          0.37, C.c_void_p(dst.t.data_ptr()), C.byref(nn)))
+    refv = 0.37 * (w + c @ V[:, :n])
+    assert np.allclose(dst.numpy(), refv, rtol=1e-13, atol=1e-13 * np.abs(refv).max())
+    assert np.isclose(nn.value, refv @ refv, rtol=1e-12)
+
+
+# --------------------------------------------------------------------------------------------- stencils
+SH_GRIDS = [((22, 22, 22), (np.pi,) * 3), ((20, 17, 13), (np.pi, 2.0, 1.3)), ((64, 48, 40), (5.0, 4.0, 3.0)),
+            ((130, 37, 21), (9.0, 3.0, 2.0)), ((66, 18, 5), (3.0, 2.0, 1.0)), ((5, 4, 3), (1.0, 1.0, 1.0)),
+            ((151, 100), (8 * np.pi, 4 * np.pi / np.sqrt(3))), ((64, 64), (6.0, 6.0)), ((7, 5), (1.0, 2.0))]
+
+
+@pytest.mark.parametrize("grid", SH_GRIDS)
+@pytest.mark.parametrize("variant", [0, 1])
+def test_sh_residual_and_jvp(ctx, grid, variant):
+    hip = _hip()
+    dims, ls = grid
+    sh = operators.SwiftHohenberg(dims, ls)
+    prob = hip.SwiftHohenberg(ctx, dims, ls, l=0.1, nu=1.2)
+    ctx.set_option("sh_kernel", variant)
+    try:
+        rng = np.random.default_rng(len(dims) * 100 + dims[0])
+        u = sh.guess() + 0.1 * rng.standard_normal(sh.N)
+        du = rng.standard_normal(sh.N)
+        U, DU = prob.vec(u), prob.vec(du)
+        F = prob.residual(U, 0.1).numpy()
+        Fref = sh.F(u, 0.1, 1.2)
+        tol = _stencil_tol(sh.L1, u) + 64 * EPS * np.abs(u).max() ** 3
+        assert np.abs(F - Fref).max() <= tol, (np.abs(F - Fref).max(), tol)
+        J = prob.jacobian(U, 0.1)
+        Jv = J(DU).numpy()
+        Jref = sh.dF(u, 0.1, 1.2, du)
+        tol = _stencil_tol(sh.L1, du)
+        assert np.abs(Jv - Jref).max() <= tol, (np.abs(Jv - Jref).max(), tol)
+        # _axpy_op: a0 v + a1 J v  (src/LinearSolver.jl:46-64), test_linear.jl:51-68
+        Jv2 = J(DU, 0.1, 0.9).numpy()
+        assert np.abs(Jv2 - (0.1 * du + 0.9 * Jref)).max() <= tol
+    finally:
+        ctx.set_option("sh_kernel", 1)
+
+
+@pytest.mark.parametrize("zchunk", [1, 3, 16])
+def test_sh_stream_zchunks(ctx, zchunk):
+    hip = _hip()
+    dims, ls = (40, 33, 19), (4.0, 3.0, 2.0)
+    sh = operators.SwiftHohenberg(dims, ls)
+    prob = hip.SwiftHohenberg(ctx, dims, ls)
+    rng = np.random.default_rng(zchunk)
+    u, du = rng.standard_normal(sh.N), rng.standard_normal(sh.N)
+    ctx.set_option("sh_zchunk", zchunk)
+    try:
+        Jv = prob.jacobian(prob.vec(u), 0.1)(prob.vec(du)).numpy()
+    finally:
+        ctx.set_option("sh_zchunk", 0)
+    assert np.abs(Jv - sh.dF(u, 0.1, 1.2, du)).max() <= _stencil_tol(sh.L1, du)
+
+
+def test_sh_jacobian_is_symmetric_and_linear(ctx):
+    """Size-independent properties (also used at full size in test_gpu_fullsize.py)."""
+    hip = _hip()
+    dims, ls = (48, 40, 36), (5.0, 4.0, 3.5)
+    prob = hip.SwiftHohenberg(ctx, dims, ls)
+    rng = np.random.default_rng(0)
+    N = int(np.prod(dims))
+    u, v, w = (prob.vec(rng.standard_normal(N)) for _ in range(3))
+    J = prob.jacobian(u, 0.1)
+    Jv, Jw = J(v), J(w)
+    assert np.isclose(Jv.inner(w), v.inner(Jw), rtol=1e-11)           # issymmetric = true, SH3d.jl:123
+    comb = v.copy().add_(w, -0.7, 2.0)                                 # 2 v - 0.7 w
+    lhs = J(comb)
+    rhs = Jv.copy().add_(Jw, -0.7, 2.0)
+    assert lhs.add_(rhs, -1.0).norminf() <= 1e-9 * rhs.norminf()
+
+
+def test_cgl_residual_and_jvp(ctx):
+    hip = _hip()
+    dims, ls = (41, 21), (np.pi, np.pi / 2)
+    c = operators.CGL2d(dims, ls)
+    prob = hip.CGL2d(ctx, dims, ls)
+    rng = np.random.default_rng(3)
+    u = 0.4 * rng.standard_normal(2 * c.n)
+    du = rng.standard_normal(2 * c.n)
+    p = c.default_params()
+    p["r"] = 1.2
+    p["gamma"] = 0.0
+    F = prob.residual(prob.vec(u), 1.2).numpy()
+    tol = 64 * EPS * abs(c.Delta).sum(axis=1).max() * max(np.abs(u).max(), np.abs(du).max())
+    assert np.abs(F - c.F(u, **p)).max() <= tol
+    Jv = prob.jacobian(prob.vec(u), 1.2)(prob.vec(du)).numpy()
+    assert np.abs(Jv - c.dF(u, du, **p)).max() <= tol
+
+
+def test_sh1d_residual_and_jvp(ctx):
+    hip = _hip()
+    s1 = operators.SwiftHohenberg1D(200, 6.0)
+    prob = hip.SwiftHohenberg1D(ctx, 200, 6.0)
+    rng = np.random.default_rng(8)
+    u = s1.guess() + 0.05 * rng.standard_normal(200)
+    du = rng.standard_normal(200)
+    tol = 64 * EPS * abs(s1.L1).sum(axis=1).max() * max(np.abs(u).max(), np.abs(du).max())
+    assert np.abs(prob.residual(prob.vec(u), -0.1).numpy() - s1.F(u, -0.1, 2.0)).max() <= tol
+    assert np.abs(prob.jacobian(prob.vec(u), -0.1)(prob.vec(du)).numpy() - s1.dF(u, -0.1, 2.0, du)).max() <= tol
+
+
+# --------------------------------------------------------------------------------------------- preconditioner
+@pytest.mark.parametrize("grid", [((22, 22, 22), (np.pi,) * 3), ((16, 8, 32), (2.0, 1.0, 3.0)),
+                                  ((12, 10, 9), (2.0, 2.0, 2.0)), ((24, 18), (3.0, 2.0)), ((64, 32), (6.0, 3.0))])
+@pytest.mark.parametrize("shift", [0.0, 1.0])
+def test_dct_preconditioner_is_exact_inverse(ctx, grid, shift):
+    hip = _hip()
+    dims, ls = grid
+    sh = operators.SwiftHohenberg(dims, ls)
+    prob = hip.SwiftHohenberg(ctx, dims, ls)
+    P = hip.DCTPreconditioner(prob, shift)
+    rng = np.random.default_rng(1)
+    v = rng.standard_normal(sh.N)
+    M = (sh.L1 + shift * sp.identity(sh.N)).tocsc()
+    ref = spla.splu(M).solve(v)
+    got = P.ldiv(prob.vec(v)).numpy()
+    # relative to cond(M): compare through the residual M got - v
+    assert np.abs(M @ got - v).max() <= 1e-9 * np.abs(v).max()
+    assert np.abs(got - ref).max() <= 1e-8 * np.abs(ref).max()
+
+
+# --------------------------------------------------------------------------------------------- linear solvers
+def _sh_setup(ctx, dims, ls, seed=0):
+    hip = _hip()
+    sh = operators.SwiftHohenberg(dims, ls)
+    prob = hip.SwiftHohenberg(ctx, dims, ls)
+    rng = np.random.default_rng(seed)
+    u = sh.guess()
+    return sh, prob, rng, u
+
+
+@pytest.mark.parametrize("shift", [(0.0, 1.0), (0.1, 0.9)])
+def test_gmres_krylovkit_preconditioned(ctx, shift):
+    """test_linear.jl:106-169 (each ls == J0\\rhs, with and without shift) on the SH3d Jacobian with
+    Pl = L1^-1 as in examples/SH3d.jl:88-93; the shifted preconditioned system is the reference's
+    (a0 I + a1 Pl^-1 J) x = Pl^-1 rhs (src/LinearSolver.jl:268-288)."""
+    hip = _hip()
+    a0, a1 = shift
+    sh, prob, rng, u = _sh_setup(ctx, (14, 12, 10), (np.pi,) * 3)
+    rhs = rng.standard_normal(sh.N)
+    P = hip.DCTPreconditioner(prob, 0.0)
+    ls = hip.GMRESKrylovKit(dim=30, rtol=1e-10, atol=1e-12, maxiter=150, Pl=P)
+    J = prob.jacobian(prob.vec(u), 0.1)
+    x, ok, nops = ls(J, prob.vec(rhs), a0, a1)
+    Jm = sh.J(u, 0.1, 1.2).toarray()
+    L1inv = np.linalg.inv(sh.L1.toarray())
+    ref = np.linalg.solve(a0 * np.eye(sh.N) + a1 * L1inv @ Jm, L1inv @ rhs)
+    assert ok
+    assert np.abs(x.numpy() - ref).max() <= 1e-7 * np.abs(ref).max()
+    lu = spla.splu(sh.L1.tocsc())
+    xo, oko, nopso, _ = krylov.gmres_krylovkit(sh.J(u, 0.1, 1.2), rhs, a0, a1, krylovdim=30, rtol=1e-10, atol=1e-12,
+                                               maxiter=150, Pl=lu.solve)
+    assert oko and abs(nops - nopso) <= 2, (nops, nopso)           # same Krylov space => same iteration count
+    assert np.abs(x.numpy() - xo).max() <= 1e-7 * np.abs(xo).max()
+
+
+def test_gmres_unpreconditioned_shift_and_restart(ctx):
+    hip = _hip()
+    sh, prob, rng, u = _sh_setup(ctx, (10, 9, 8), (1.0, 1.0, 1.0))
+    rhs = rng.standard_normal(sh.N)
+    J = prob.jacobian(prob.vec(u), 0.1)
+    Jm = sh.J(u, 0.1, 1.2)
+    a0 = 2.0 * abs(Jm).sum(axis=1).max()                              # diagonally dominant shifted system
+    for ls in (hip.GMRESKrylovKit(dim=10, rtol=1e-11, atol=0.0, maxiter=100),
+               hip.GMRESIterativeSolvers(reltol=1e-11, restart=10, maxiter=500)):
+        x, ok, it = ls(J, prob.vec(rhs), a0, 1.0)
+        ref = spla.spsolve((a0 * sp.identity(sh.N) + Jm).tocsc(), rhs)
+        assert ok and it > 10                                         # restarted at least once
+        assert np.abs(x.numpy() - ref).max() <= 1e-9 * np.abs(ref).max()
+    xo, oko, nopso, _ = krylov.gmres_krylovkit(Jm, rhs, a0, 1.0, krylovdim=10, rtol=1e-11, atol=0.0, maxiter=100)
+    x, ok, nops = hip.GMRESKrylovKit(dim=10, rtol=1e-11, atol=0.0, maxiter=100)(J, prob.vec(rhs), a0, 1.0)
+    assert abs(nops - nopso) <= 2, (nops, nopso)
+    xi, oki, iti = krylov.gmres_iterativesolvers(Jm, rhs, a0, 1.0, restart=10, reltol=1e-11, maxiter=500)
+    x, ok, it = hip.GMRESIterativeSolvers(reltol=1e-11, restart=10, maxiter=500)(J, prob.vec(rhs), a0, 1.0)
+    assert abs(it - iti) <= 2, (it, iti)
+
+
+def test_gmres_nonconvergence_is_a_flag_not_an_error(ctx):
+    hip = _hip()
+    sh, prob, rng, u = _sh_setup(ctx, (12, 12, 12), (np.pi,) * 3)
+    J = prob.jacobian(prob.vec(u), 0.1)
+    x, ok, it = hip.GMRESKrylovKit(dim=5, rtol=1e-12, maxiter=2)(J, prob.vec(rng.standard_normal(sh.N)))
+    assert ok is False and it > 0
+
+
+# --------------------------------------------------------------------------------------------- bordered solvers
+@pytest.mark.parametrize("shift", [None, 0.3])
+@pytest.mark.parametrize("xi", [(1.0, 1.0), (0.4, 0.6)])
+def test_bordered_solvers_vs_explicit(ctx, shift, xi):
+    """test_linear.jl:172-244: each BLS == explicit (N+1) solve, incl. shift and xi_u/xi_p."""
+    hip = _hip()
+    sh, prob, rng, u = _sh_setup(ctx, (10, 8, 6), (np.pi, 2.5, 2.0), seed=4)
+    n = sh.N
+    Jm = sh.J(u, 0.1, 1.2).toarray()
+    dR, dzu, R = rng.standard_normal(n), rng.standard_normal(n), rng.standard_normal(n)
+    dzp, nn = 0.37, -0.8
+    xiu, xip = xi
+    dotscale = 1.0 / n
+    A = np.block([[Jm + (0.0 if shift is None else shift) * np.eye(n), dR[:, None]],
+                  [xiu * dotscale * dzu[None, :], np.array([[xip * dzp]])]])
+    ref = np.linalg.solve(A, np.concatenate([R, [nn]]))
+    J = prob.jacobian(prob.vec(u), 0.1)
+    args = (J, prob.vec(dR), prob.vec(dzu), dzp, prob.vec(R), nn, xiu, xip)
+    P = hip.DCTPreconditioner(prob, 0.0)
+    if shift is None:
+        ls = hip.GMRESKrylovKit(dim=40, rtol=1e-12, atol=1e-13, maxiter=100, Pl=P)
+    else:
+        # with Pl AND a shift GMRESKrylovKit solves (a0 I + Pl^-1 J), not Pl^-1 (a0 I + J) (the reference's quirk,
+        # src/LinearSolver.jl:268-277); the IterativeSolvers flavor preconditions the shifted operator itself
+        ls = hip.GMRESIterativeSolvers(reltol=1e-13, restart=40, maxiter=2000, Pl=P)   # Pl^-1 (a0 I + J): proper
+    for bls in (hip.BorderingBLS(ls, check_precision=True, k=2), hip.BorderingBLS(ls, check_precision=False)):
+        dX, dl, ok, it = bls(*args, shift=shift, dotscale=dotscale)
+        assert ok, it
+        assert np.abs(dX.numpy() - ref[:-1]).max() <= 1e-7 * np.abs(ref).max()
+        assert np.isclose(dl, ref[-1], rtol=1e-7, atol=1e-9)
+    # the generic (reference line-by-line) path gives the same answer as the native one
+    generic = hip.BorderingBLS(lambda J_, r, a0=0.0, a1=1.0: ls(J_, r, a0, a1), check_precision=False)
+    dXg, dlg, okg, _ = generic(*args, shift=shift, dotp=lambda x, y: x.inner(y) * dotscale)
+    assert np.abs(dXg.numpy() - ref[:-1]).max() <= 1e-7 * np.abs(ref).max() and np.isclose(dlg, ref[-1], rtol=1e-7, atol=1e-9)
+    # MatrixFreeBLS: one GMRES on the (N+1) operator
+    mf = hip.MatrixFreeBLS(hip.GMRESKrylovKit(dim=63, rtol=1e-12, atol=1e-13, maxiter=600))
+    dXm, dlm, okm, itm = mf(*args, shift=shift, dotscale=dotscale)
+    if okm:
+        assert np.abs(dXm.numpy() - ref[:-1]).max() <= 1e-6 * np.abs(ref).max()
+        assert np.isclose(dlm, ref[-1], rtol=1e-6, atol=1e-8)           # p-component rtol 1e-6, test_linear.jl:~230
+
+
+# --------------------------------------------------------------------------------------------- eigensolver
+def test_shift_invert_vs_dense(ctx):
+    """test_linear.jl:666-677 (ShiftInvert vs eigvals < 1e-9) with the SH3dEig settings of
+    examples/SH3d.jl:96-113: sigma = 0.1, Pl = L1^-1, inner GMRES rtol 1e-9, tol 1e-12, hermitian."""
+    hip = _hip()
+    sh, prob, rng, u = _sh_setup(ctx, (12, 12, 12), (np.pi,) * 3)
+    s = palc.newton(palc.Problem(lambda x, p: sh.F(x, p, 1.2), lambda x, p: sh.J(x, p, 1.2)), u, 0.1,
+                    bordered.default_ls, tol=1e-10, max_iterations=40, normN=palc.norminf)
+    assert s["converged"]
+    us = s["u"]
+    Jm = sh.J(us, 0.1, 1.2)
+    ev = np.linalg.eigvalsh(Jm.toarray())
+    P = hip.DCTPreconditioner(prob, 0.0)
+    ls = hip.GMRESKrylovKit(dim=30, rtol=1e-9, atol=1e-12, maxiter=150, Pl=P)
+    eig = hip.ShiftInvert(0.1, ls, tol=1e-12, maxiter=20, hermitian=True)
+    J = prob.jacobian(prob.vec(us), 0.1)
+    vals, vecs, cv, nops = eig(J, 10)
+    assert np.all(np.diff(vals.real) <= 1e-12)                        # sorted by decreasing real part
+    assert np.all(np.abs(vals.imag) < 1e-12)
+    want = np.sort(sorted(ev, key=lambda l: -abs(1.0 / (l - 0.1)))[:10])[::-1]     # :LM of (J - sigma)^-1
+    assert np.abs(vals.real - want).max() < 1e-7, (vals.real, want)   # inner solves are 1e-9 accurate
+    for lam, (vr, vi) in zip(vals[:5], vecs[:5]):
+        v = vr.numpy()
+        assert np.linalg.norm(Jm @ v - lam.real * v) <= 1e-6 * np.abs(ev).max() * np.linalg.norm(v)
+    # oracle run of the same algorithm (KrylovKit-style Lanczos/Krylov-Schur + preconditioned GMRES)
+    lu = spla.splu(sh.L1.tocsc())
+    ols = lambda J_, r, a0=0.0, a1=1.0: krylov.gmres_krylovkit(lambda x: J_ @ x + a0 * x, r, 0.0, 1.0, krylovdim=30,
+                                                                maxiter=150, rtol=1e-9, atol=1e-12, Pl=lu.solve)[:3]
+    oeig = lambda Jmap, nev: krylov.eigsolve_krylovschur(Jmap, rng.random(sh.N), nev, "LM", tol=1e-12,
+                                                         krylovdim=max(30, nev + 30), maxiter=20, hermitian=True)
+    ovals, _, _, _ = krylov.shift_invert(Jm, 10, 0.1, ols, oeig)
+    assert np.abs(vals.real - ovals.real).max() < 1e-7
+
+
+def test_shift_invert_plain_operator(ctx):
+    """ShiftInvert on J itself (no Pl): eigenvalues of the symmetric SH Jacobian nearest sigma, vs eigvalsh."""
+    hip = _hip()
+    sh, prob, rng, u = _sh_setup(ctx, (8, 7, 6), (1.2, 1.1, 1.0))
+    Jm = sh.J(u, 0.1, 1.2).toarray()
+    ev = np.linalg.eigvalsh(Jm)
+    sigma = ev.max() + 5.0                                            # (J - sigma) is definite: plain GMRES converges
+    ls = hip.GMRESKrylovKit(dim=63, rtol=1e-12, atol=1e-14, maxiter=300)
+    eig = hip.ShiftInvert(sigma, ls, tol=1e-10, maxiter=30, hermitian=True)
+    vals, vecs, cv, nops = eig(prob.jacobian(prob.vec(u), 0.1), 6)
+    want = np.sort(ev)[::-1][:6]
+    assert cv and np.abs(vals.real - want).max() < 1e-8 * max(1.0, np.abs(want).max())
+    for lam, (vr, _) in zip(vals, vecs):
+        v = vr.numpy()
+        assert np.linalg.norm(Jm @ v - lam.real * v) <= 1e-6 * np.abs(ev).max() * np.linalg.norm(v)
+
+
+def test_shift_invert_nonsymmetric_cgl(ctx):
+    """cGL2d Jacobian (non-symmetric, complex pairs): examples/cGL2d.jl:96 uses EigArpack(1.0, :LM) = ARPACK
+    shift-invert; compare with dense eigvals."""
+    hip = _hip()
+    dims, ls_ = (12, 8), (np.pi, np.pi / 2)
+    c = operators.CGL2d(dims, ls_)
+    prob = hip.CGL2d(ctx, dims, ls_)
+    u = np.zeros(2 * c.n)
+    p = c.default_params()
+    p["r"] = 1.2
+    Jm = c.J(u, **p).toarray()
+    ev = np.linalg.eigvals(Jm)
+    sigma = 3.0
+    want = sorted(ev, key=lambda l: -abs(1.0 / (l - sigma)))[:6]
+    ls = hip.GMRESKrylovKit(dim=63, rtol=1e-12, atol=1e-14, maxiter=300)
+    eig = hip.ShiftInvert(sigma, ls, tol=1e-10, maxiter=40, hermitian=False)
+    vals, vecs, cv, nops = eig(prob.jacobian(prob.vec(u), 1.2), 6)
+    assert np.all(np.diff(vals.real) <= 1e-10)
+    d = np.abs(np.array(want)[:, None] - vals[None, :])
+    assert d.min(axis=1).max() < 1e-7, (sorted(want, key=lambda z: -z.real), vals)
+    for lam, (vr, vi) in zip(vals, vecs):
+        v = vr.numpy() + 1j * vi.numpy()
+        assert np.linalg.norm(Jm @ v - lam * v) <= 1e-6 * np.abs(ev).max() * np.linalg.norm(v)
+
+
+# --------------------------------------------------------------------------------------------- Newton / PALC
+def _oracle_ls(sh):
+    lu = spla.splu(sh.L1.tocsc())
+    return lambda J, r, a0=0.0, a1=1.0: krylov.gmres_krylovkit(J, r, a0, a1, krylovdim=30, maxiter=150, rtol=1e-9,
+                                                                atol=1e-12, Pl=lu.solve)[:3]
+
+
+def test_newton_matches_oracle(ctx):
+    """examples/SH3d.jl:125-127: Newton from sol0 with GMRES + Pl; residual history vs the CPU oracle."""
+    hip = _hip()
+    from bk_amd import continuation as Cn
+    dims, ls_ = (16, 16, 16), (np.pi,) * 3
+    sh, prob, rng, u = _sh_setup(ctx, dims, ls_)
+    oprob = palc.Problem(lambda x, p: sh.F(x, p, 1.2), lambda x, p: (lambda dx: sh.dF(x, p, 1.2, dx)))
+    so = palc.newton(oprob, u, 0.1, _oracle_ls(sh), tol=1e-8, max_iterations=20, normN=palc.norminf)
+    P = hip.DCTPreconditioner(prob, 0.0)
+    ls = hip.GMRESKrylovKit(dim=30, rtol=1e-9, atol=1e-12, maxiter=150, Pl=P)
+    sg = Cn.newton(prob, prob.vec(u), 0.1, Cn.NewtonPar(tol=1e-8, max_iterations=20, linsolver=ls), Cn.norminf)
+    sn = hip.newton_native(prob, prob.vec(u), 0.1, ls, tol=1e-8, max_iterations=20, norm_inf=True)
+    assert so["converged"] and sg.converged and sn["converged"]
+    assert sg.itnewton == so["itnewton"] == sn["itnewton"]
+    # corrector residuals match the CPU reference to 1e-10 relative (to the initial residual) -- BASELINE.json
+    r0 = so["residuals"][0]
+    for a, b, c in zip(sg.residuals, so["residuals"], sn["residuals"]):
+        assert abs(a - b) <= 1e-10 * r0 + 1e-6 * b, (sg.residuals, so["residuals"])
+        assert abs(c - b) <= 1e-10 * r0 + 1e-6 * b
+    assert np.abs(sg.u.numpy() - so["u"]).max() <= 1e-7
+    assert np.abs(sn["u"].numpy() - so["u"]).max() <= 1e-7
+
+
+def test_palc_branch_matches_oracle(ctx):
+    """examples/SH3d.jl:160-166: PALC(tangent = Bordered(), bls = BorderingBLS(solver = ls, check_precision =
+    false)), ds = -0.001, dsmax = 0.005, newton tol 1e-9, normC = norminf, eigensolve each step."""
+    hip = _hip()
+    from bk_amd import continuation as Cn
+    dims, ls_ = (12, 12, 12), (np.pi,) * 3
+    sh, prob, rng, u = _sh_setup(ctx, dims, ls_)
+    oprob = palc.Problem(lambda x, p: sh.F(x, p, 1.2), lambda x, p: (lambda dx: sh.dF(x, p, 1.2, dx)))
+    ols = _oracle_ls(sh)
+    s0 = palc.newton(oprob, u, 0.1, ols, tol=1e-9, max_iterations=30, normN=palc.norminf)
+    assert s0["converged"]
+    obls = lambda *a, **k: bordered.bordering_bls(ols, *a, check_precision=False, **k)
+    kw = dict(ds=-0.001, dsmin=1e-4, dsmax=0.005, p_min=-0.1, p_max=0.15, max_steps=4, tol=1e-9, max_iterations=15)
+    bo = palc.continuation(oprob, s0["u"], 0.1, ls=ols, bls=obls, tangent="bordered", normC=palc.norminf, **kw)
+    P = hip.DCTPreconditioner(prob, 0.0)
+    ls = hip.GMRESKrylovKit(dim=30, rtol=1e-9, atol=1e-12, maxiter=150, Pl=P)
+    nopt = Cn.NewtonPar(tol=1e-9, max_iterations=15, linsolver=ls)
+    cp = Cn.ContinuationPar(ds=-0.001, dsmin=1e-4, dsmax=0.005, p_min=-0.1, p_max=0.15, max_steps=4,
+                            detect_bifurcation=0, newton_options=nopt)
+    alg = Cn.PALC(tangent="bordered", theta=0.5, bls=hip.BorderingBLS(None, check_precision=False))
+    for corrector in (Cn.newton_palc,
+                      lambda prob_, z, tau, zp, ds, th, bls, no, pmin, pmax, nrm: _native_corrector(hip, Cn, prob_, z, tau, zp, ds, th, bls, no, pmin, pmax)):
+        bg = Cn.continuation(prob, prob.vec(s0["u"]), 0.1, alg, cp, normC=Cn.norminf, corrector=corrector)
+        assert len(bg.param) == len(bo.param)
+        assert np.allclose(bg.param, bo.param, rtol=0, atol=1e-8), (bg.param, bo.param)
+        assert bg.itnewton == bo.itnewton
+        for a, b in zip(bg.residuals[1:], bo.residuals[1:]):
+            assert abs(a[0] - b[0]) <= 1e-10 * max(b[0], 1e-3) + 1e-12      # same predictor residual
+            assert a[-1] < 1e-9 and b[-1] < 1e-9
+
+
+def _native_corrector(hip, Cn, prob, z, tau, zp, ds, theta, bls, nopt, pmin, pmax):
+    r = hip.newton_palc_native(prob, z, tau, zp, ds, theta, bls, tol=nopt.tol, max_iterations=nopt.max_iterations,
+                               p_min=pmin, p_max=pmax, norm_inf=True)
+    return Cn.NonLinearSolution(r["u"], r["residuals"], r["converged"], r["itnewton"], r["itlineartot"])

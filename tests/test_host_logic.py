@@ -1,0 +1,100 @@
+"""CPU test of the product's HOST logic (bifurcationkit.jl_amd/continuation.py + the generic BorderingBLS of
+hip.py): driven with a NumPy-backed vector type and oracle plugins it must reproduce the oracle's own
+continuation run.  This is the plugin contract of test/continuation/test-cont-non-vector.jl:55-99,133-176:
+a state type that is not an array, an opaque Jacobian, custom solvers returning (out, true, 1).
+The NumPy vector type lives HERE (test infrastructure); the product has no CPU backend."""
+import numpy as np
+import scipy.sparse.linalg as spla
+
+from bk_amd import continuation as C
+from bk_amd import hip
+from oracle import bordered, krylov, operators, palc
+
+
+class NumpyVec:
+    """Minimal VectorInterface carrier for the host-logic tests (cf. VI.MinimalMVec)."""
+
+    def __init__(self, a):
+        self.a = np.asarray(a, dtype=float)
+
+    def copy(self): return NumpyVec(self.a.copy())
+    def zerovector(self): return NumpyVec(np.zeros_like(self.a))
+    def similar(self): return NumpyVec(np.empty_like(self.a))
+    def copyto_(self, s): self.a[:] = s.a; return self
+    def scale_(self, c): self.a *= c; return self
+    def add_(self, x, a=1.0, b=1.0): self.a = b * self.a + a * x.a; return self
+    def inner(self, y): return float(self.a @ y.a)
+    def norm(self): return float(np.linalg.norm(self.a))
+    def norminf(self): return float(np.abs(self.a).max())
+    def __len__(self): return self.a.size
+
+
+class OpaqueJacobian:
+    def __init__(self, M): self.M = M
+    def __call__(self, dx): return NumpyVec(self.M @ dx.a)
+
+
+class Prob:
+    def __init__(self, sh, nu):
+        self.sh, self.nu = sh, nu
+        self.delta = palc.EPS_FD
+    def residual(self, x, p): return NumpyVec(self.sh.F(x.a, p, self.nu))
+    def jacobian(self, x, p): return OpaqueJacobian(self.sh.J(x.a, p, self.nu))
+
+
+def direct_ls(J, rhs, a0=0.0, a1=1.0):
+    x, ok, it = bordered.default_ls(J.M, rhs.a, a0, a1)
+    return NumpyVec(x), ok, it
+
+
+def test_generic_bordering_matches_oracle():
+    rng = np.random.default_rng(0)
+    n = 40
+    M = np.eye(n) + 0.1 * rng.random((n, n))
+    dR, dzu, R = rng.random(n), rng.random(n), rng.random(n)
+    bls = hip.BorderingBLS(direct_ls, check_precision=True, k=2)
+    dX, dl, ok, it = bls(OpaqueJacobian(M), NumpyVec(dR), NumpyVec(dzu), 0.3, NumpyVec(R), 0.7, 0.4, 0.6, shift=0.2)
+    rX, rl, _, _ = bordered.bordering_bls(bordered.default_ls, M, dR, dzu, 0.3, R, 0.7, 0.4, 0.6, shift=0.2, k=2)
+    assert ok and np.allclose(dX.a, rX, rtol=1e-12) and np.isclose(dl, rl, rtol=1e-12)
+
+
+def test_continuation_driver_matches_oracle():
+    sh = operators.SwiftHohenberg((9, 8), (3.0, 2.5))
+    x0 = 0.8 * sh.guess()
+    # oracle run
+    oprob = palc.Problem(F=lambda x, p: sh.F(x, p, 1.3), J=lambda x, p: sh.J(x, p, 1.3))
+    s0 = palc.newton(oprob, x0, -0.1, bordered.default_ls, tol=1e-10, max_iterations=30, normN=palc.norminf)
+    assert s0["converged"]
+    obls = lambda *a, **k: bordered.bordering_bls(bordered.default_ls, *a, check_precision=False, **k)
+    eig_o = lambda J, nev: krylov.default_eig(J, nev)
+    kw = dict(ds=0.002, dsmin=1e-4, dsmax=0.01, p_min=-0.3, p_max=0.3, max_steps=5, tol=1e-10, max_iterations=15)
+    bo = palc.continuation(oprob, s0["u"], -0.1, ls=bordered.default_ls, bls=obls, tangent="bordered",
+                           normC=palc.norminf, eig=eig_o, nev=4, **kw)
+    # product host logic with NumPy vectors and the same plugins
+    prob = Prob(sh, 1.3)
+    eig_p = lambda J, nev: krylov.default_eig(J.M, nev)
+    nopt = C.NewtonPar(tol=1e-10, max_iterations=15, linsolver=direct_ls, eigsolver=eig_p)
+    cp = C.ContinuationPar(ds=0.002, dsmin=1e-4, dsmax=0.01, p_min=-0.3, p_max=0.3, max_steps=5, nev=4,
+                           newton_options=nopt)
+    alg = C.PALC(tangent="bordered", theta=0.5, bls=hip.BorderingBLS(None, check_precision=False))
+    bp = C.continuation(prob, NumpyVec(s0["u"]), -0.1, alg, cp, normC=C.norminf)
+    assert len(bp.param) == len(bo.param) == 6
+    assert np.allclose(bp.param, bo.param, rtol=0, atol=1e-12)
+    assert bp.itnewton == bo.itnewton
+    assert bp.n_unstable == bo.n_unstable
+    assert np.allclose(bp.ds, bo.ds)
+    for a, b in zip(bp.residuals, bo.residuals):
+        assert np.allclose(a, b, rtol=1e-6, atol=1e-13)
+
+
+def test_step_size_control_and_stability():
+    cp = C.ContinuationPar(dsmin=1e-3, dsmax=0.1, a=0.5, newton_options=C.NewtonPar(max_iterations=10))
+    ds, stop = C.step_size_control(0.01, True, 2, cp)
+    assert np.isclose(ds, 0.01 * (1 + 0.5 * 0.8 ** 2)) and not stop
+    ds, stop = C.step_size_control(0.01, False, 10, cp)
+    assert np.isclose(ds, 0.005) and not stop
+    ds, stop = C.step_size_control(-1e-3, False, 10, cp)
+    assert stop
+    ds, stop = C.step_size_control(-0.09, True, 0, cp)
+    assert np.isclose(ds, -0.1)
+    assert C.is_stable(np.array([0.5 + 1j, 0.5 - 1j, 1e-11, -0.2]), 1e-10) == (2, 2)

@@ -1,0 +1,215 @@
+"""CPU tests: the oracle against the reference's own golden vector and test identities.
+
+Mirrors test/linear_solvers/test_linear.jl (:71-85 MatrixFreeBLSmap == block matrix, :106-169 every linear
+solver == J0\\rhs with and without shift, :172-244 every bordered solver == explicit (N+1) solve, :595-614
+literal eigen golden, :666-677 ShiftInvert vs eigvals), test/newton/test_newton.jl:23-52 and
+test/continuation/simple_continuation.jl:74-103.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from oracle import bordered, krylov, operators, palc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_golden_eig5x5():
+    g = json.load(open(os.path.join(HERE, "golden", "eig5x5.json")))
+    J0 = np.array(g["J0"])
+    vals = np.array([complex(*v) for v in g["vals"]])
+    vecs = np.array([[complex(*v) for v in r] for r in g["vecs"]])
+    w, V, cv, _ = krylov.default_eig(J0, 5)
+    assert cv
+    assert np.allclose(w, vals, rtol=1.5e-8, atol=0)          # `≈` = rtol sqrt(eps), test_linear.jl:603
+    assert np.abs(V - vecs).max() < 1e-6                      # test_linear.jl:609-613
+    # sorted by decreasing real part (_test_sorted)
+    assert np.all(np.diff(w.real) <= 1e-15)
+
+
+def test_second_difference_corners():
+    D = operators.second_difference(6, 3.0, operators.NEUMANN).toarray()
+    h = 1.0
+    assert D[0, 0] == -1.0 / h**2 and D[-1, -1] == -1.0 / h**2 and D[1, 1] == -2.0 / h**2
+    D = operators.second_difference(6, 3.0, operators.DIRICHLET).toarray()
+    assert D[0, 0] == -2.0 and D[0, 1] == 1.0
+
+
+def test_sh_jvp_matches_sparse_jacobian():
+    sh = operators.SwiftHohenberg((7, 6, 5), (np.pi, 2.0, 1.5))
+    rng = np.random.default_rng(1234)
+    u, du = rng.standard_normal(sh.N), rng.standard_normal(sh.N)
+    assert np.allclose(sh.dF(u, 0.1, 1.2, du), sh.J(u, 0.1, 1.2) @ du, rtol=1e-13, atol=1e-10)
+    # finite differences of F (d/dt F(u + t du))
+    eps = 1e-6
+    fd = (sh.F(u + eps * du, 0.1, 1.2) - sh.F(u - eps * du, 0.1, 1.2)) / (2 * eps)
+    assert np.allclose(fd, sh.dF(u, 0.1, 1.2, du), rtol=1e-6, atol=1e-5)
+    # x fastest: the 3-D guess is constant along z
+    g = sh.guess().reshape(5, 6, 7)
+    assert np.allclose(g[0], g[-1])
+
+
+def test_cgl_jacobian_fd():
+    c = operators.CGL2d((6, 5), (np.pi, np.pi / 2))
+    rng = np.random.default_rng(7)
+    u, du = 0.3 * rng.standard_normal(2 * c.n), rng.standard_normal(2 * c.n)
+    p = c.default_params()
+    eps = 1e-6
+    fd = (c.F(u + eps * du, **p) - c.F(u - eps * du, **p)) / (2 * eps)
+    assert np.allclose(fd, c.dF(u, du, **p), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("shift", [(0.0, 1.0), (0.1, 0.9)])
+def test_linear_solvers_vs_backslash(shift):
+    a0, a1 = shift
+    rng = np.random.default_rng(1234)
+    n = 100
+    J0 = np.eye(n) + 0.1 * rng.random((n, n))
+    rhs = rng.random(n)
+    ref = np.linalg.solve(a0 * np.eye(n) + a1 * J0, rhs)
+    x, ok, it, _ = krylov.gmres_krylovkit(J0, rhs, a0, a1, krylovdim=30, maxiter=100, atol=1e-12, rtol=1e-12)
+    assert ok and np.allclose(x, ref, rtol=1.5e-8)
+    x, ok, it = krylov.gmres_iterativesolvers(J0, rhs, a0, a1, reltol=1e-10, restart=100, maxiter=100)
+    assert ok and np.allclose(x, ref, rtol=1.5e-8)
+    x, ok, it = bordered.default_ls(J0, rhs, a0, a1)
+    assert np.allclose(x, ref)
+    # matrix-free operator form
+    x, ok, it, _ = krylov.gmres_krylovkit(lambda v: J0 @ v, rhs, a0, a1)
+    assert ok and np.allclose(x, ref, rtol=1.5e-8)
+
+
+def test_gmres_restart_and_numops():
+    rng = np.random.default_rng(3)
+    n = 60
+    A = np.eye(n) + 0.3 * rng.standard_normal((n, n)) / np.sqrt(n)
+    b = rng.standard_normal(n)
+    x, ok, nops, res = krylov.gmres_krylovkit(A, b, krylovdim=5, maxiter=200, atol=1e-12, rtol=1e-12)
+    assert ok and np.linalg.norm(A @ x - b) <= 1e-12 * max(1.0, np.linalg.norm(b)) * 1.01
+    assert nops > 10
+    # preconditioned branch semantics: (a0 + a1 P^-1 A) x = P^-1 b   (src/LinearSolver.jl:268-288)
+    P = np.diag(np.diag(A))
+    Pl = lambda v: np.linalg.solve(P, v)
+    x, ok, nops, _ = krylov.gmres_krylovkit(A, b, 0.2, 0.7, Pl=Pl)
+    ref = np.linalg.solve(0.2 * np.eye(n) + 0.7 * np.linalg.solve(P, A), Pl(b))
+    assert ok and np.allclose(x, ref, rtol=1e-9)
+
+
+def _bordered_system(rng, n):
+    J0 = np.eye(n) + 0.1 * rng.random((n, n))
+    return dict(J=J0, dR=rng.random(n), dzu=rng.random(n), dzp=rng.random(), R=rng.random(n), n=rng.random())
+
+
+@pytest.mark.parametrize("shift", [None, 0.2])
+@pytest.mark.parametrize("xi", [(1.0, 1.0), (0.4, 0.6)])
+def test_bordered_solvers_vs_explicit(shift, xi):
+    rng = np.random.default_rng(99)
+    n = 50
+    s = _bordered_system(rng, n)
+    xiu, xip = xi
+    A = np.block([[s["J"] + (0.0 if shift is None else shift) * np.eye(n), s["dR"][:, None]],
+                  [xiu * s["dzu"][None, :], np.array([[xip * s["dzp"]]])]])
+    ref = np.linalg.solve(A, np.concatenate([s["R"], [s["n"]]]))
+    args = (s["J"], s["dR"], s["dzu"], s["dzp"], s["R"], s["n"], xiu, xip)
+    dX, dl, ok, it = bordered.bordering_bls(bordered.default_ls, *args, shift=shift)
+    assert ok and np.allclose(dX, ref[:-1]) and np.isclose(dl, ref[-1])
+    dX, dl, ok, it = bordered.matrix_bls(*args, shift=shift)
+    assert np.allclose(dX, ref[:-1]) and np.isclose(dl, ref[-1])
+    ls = lambda J, r, a0=0.0, a1=1.0: krylov.gmres_krylovkit(J, r, a0, a1, krylovdim=n + 1)[:3]
+    dX, dl, ok, it = bordered.matrixfree_bls(ls, *args, shift=shift)
+    assert ok and np.allclose(dX, ref[:-1], rtol=1e-8) and np.isclose(dl, ref[-1], rtol=1e-6)
+    # MatrixFreeBLSmap == block matrix product (test_linear.jl:71-85)
+    op = bordered.matrixfree_blsmap(s["J"], s["dR"], xiu * s["dzu"], xip * s["dzp"], shift, np.dot)
+    v = rng.random(n + 1)
+    assert np.allclose(op(v), A @ v)
+
+
+def test_shift_invert_vs_eigvals():
+    rng = np.random.default_rng(5)
+    J = np.eye(10) + 0.1 * rng.random((10, 10))
+    ls = lambda J_, r, a0=0.0, a1=1.0: bordered.default_ls(J_, r, a0, a1)
+    eig = lambda Jmap, nev: krylov.eigsolve_krylovschur(Jmap, rng.random(10), nev, "LM", tol=1e-12, krylovdim=10)
+    vals, vecs, cv, _ = krylov.shift_invert(J, 10, 0.1, ls, eig)
+    ref = sorted(np.linalg.eigvals(J), key=lambda z: (-z.real, -z.imag))
+    got = sorted(vals, key=lambda z: (-z.real, -z.imag))
+    assert np.abs(np.array(ref) - np.array(got)).max() < 1e-9          # test_linear.jl:666-677
+    assert np.all(np.diff(vals.real) <= 1e-12)
+
+
+def test_krylovschur_restarts_nonsymmetric():
+    rng = np.random.default_rng(11)
+    n = 120
+    A = np.diag(np.linspace(0.1, 3.0, n)) + 0.05 * rng.standard_normal((n, n))
+    vals, vecs, nconv, nops = krylov.eigsolve_krylovschur(A, rng.random(n), 6, "LM", tol=1e-10, krylovdim=24,
+                                                          maxiter=200)
+    ref = sorted(np.linalg.eigvals(A), key=lambda z: -abs(z))[:6]
+    assert nconv >= 6
+    assert np.abs(np.sort_complex(np.array(ref)) - np.sort_complex(vals[:6])).max() < 1e-8
+    for lam, v in zip(vals[:6], vecs[:6]):
+        assert np.linalg.norm(A @ v - lam * v) < 1e-7 * np.linalg.norm(v)
+
+
+def test_newton_palc_cubic():
+    # test/newton/test_newton.jl:23-52 in spirit: F(x, p) = x^3 - x - p? use a fold-free scalar family
+    F = lambda x, p: x**3 + x - p
+    J = lambda x, p: sp.diags(3 * x**2 + 1.0).tocsr()
+    prob = palc.Problem(F, J)
+    bls = lambda *a, **k: bordered.matrix_bls(*a, shift=k.get("shift"), apply_xiu=None) if False else \
+        bordered.bordering_bls(bordered.default_ls, *a, **k)
+    n = 8
+    x0 = np.zeros(n)
+    z0 = (x0, 0.0)
+    s1 = palc.newton(prob, x0, 0.01, bordered.default_ls)
+    tau = palc.secant_tangent((s1["u"], 0.01), z0, 0.1, 0.5)
+    zp = palc.add_tangent(z0, tau, 0.1)
+    sol = palc.newton_palc(prob, z0, tau, zp, 0.1, 0.5, bls, tol=1e-12)
+    assert sol["converged"]
+    assert np.abs(F(sol["u"], sol["p"])).max() < 1e-12
+    # the arclength constraint holds
+    N = palc.arc_length_eq(sol["u"], z0[0], sol["p"] - z0[1], tau[0], tau[1], 0.5, 0.1)
+    assert abs(N) < 1e-12
+
+
+def test_palc_bls_vs_augmented_jacobian():
+    # test/continuation/simple_continuation.jl:74-103: the PALC bordered solve == solve with the explicit
+    # Jacobian of the augmented system [F; N]
+    sh = operators.SwiftHohenberg((6, 5), (2.0, 1.5))
+    rng = np.random.default_rng(2)
+    u = 0.2 * rng.standard_normal(sh.N)
+    tau_u, tau_p, theta = rng.standard_normal(sh.N), 0.7, 0.3
+    J = sh.J(u, -0.1, 1.3)
+    dFdp = u.copy()                 # dF/dl = u for SH
+    R, n = rng.standard_normal(sh.N), 0.37
+    bls = lambda *a, **k: bordered.bordering_bls(bordered.default_ls, *a, **k)
+    dX, dl, ok, _ = bordered.solve_bls_palc(bls, theta, tau_u, tau_p, J, dFdp, R, n)
+    A = np.block([[J.toarray(), dFdp[:, None]],
+                  [theta * tau_u[None, :] / sh.N, np.array([[(1 - theta) * tau_p]])]])
+    ref = np.linalg.solve(A, np.concatenate([R, [n]]))
+    assert np.allclose(dX, ref[:-1]) and np.isclose(dl, ref[-1])
+
+
+def test_sh3d_branch_preconditioned_gmres_matches_direct():
+    """examples/SH3d.jl:88-93,160-166 at 10^3: PALC + Bordered tangent + BorderingBLS(GMRES, Pl = L1^-1)
+    follows the same branch as the direct-solver run."""
+    sh = operators.SwiftHohenberg((10, 10, 10), (np.pi,) * 3)
+    prob_d = palc.Problem(F=lambda x, p: sh.F(x, p, 1.2), J=lambda x, p: sh.J(x, p, 1.2))
+    prob_mf = palc.Problem(F=lambda x, p: sh.F(x, p, 1.2), J=lambda x, p: (lambda dx: sh.dF(x, p, 1.2, dx)))
+    lu = spla.splu(sh.L1.tocsc())
+    Pl = lambda v: lu.solve(v)
+    ls = lambda J, r, a0=0.0, a1=1.0: krylov.gmres_krylovkit(J, r, a0, a1, krylovdim=30, maxiter=150, rtol=1e-9,
+                                                              atol=1e-12, Pl=Pl)[:3]
+    x0 = palc.newton(prob_d, sh.guess(), 0.1, bordered.default_ls, tol=1e-9, max_iterations=30,
+                     normN=palc.norminf)
+    assert x0["converged"]
+    kw = dict(ds=-0.001, dsmin=1e-4, dsmax=0.005, p_min=-0.1, p_max=0.15, max_steps=3, tol=1e-9,
+              max_iterations=15, tangent="bordered", normC=palc.norminf)
+    bd = lambda *a, **k: bordered.bordering_bls(bordered.default_ls, *a, check_precision=False, **k)
+    bg = lambda *a, **k: bordered.bordering_bls(ls, *a, check_precision=False, **k)
+    br_d = palc.continuation(prob_d, x0["u"], 0.1, ls=bordered.default_ls, bls=bd, **kw)
+    br_g = palc.continuation(prob_mf, x0["u"], 0.1, ls=ls, bls=bg, **kw)
+    assert len(br_d.param) == len(br_g.param) == 4
+    assert np.allclose(br_d.param, br_g.param, rtol=0, atol=1e-9)
+    assert br_d.itnewton == br_g.itnewton
