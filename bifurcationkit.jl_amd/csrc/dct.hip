@@ -160,32 +160,36 @@ int dct_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out) {
     const double* src = v;
     double* bufs[2] = {p->t1, p->t2};
     int cur = 0;
-    auto axis_pass = [&](int a, int inverse, const double* in, double* o) -> int {
-        const int N = p->n[a];
+    auto axis_pass = [&](int a, int inverse, const double* in, double* o, int fuse) -> int {
         if (use_fft && p->twid[a]) {
-            return dct_axis_fft(ctx, n0, n1, n2, a, inverse, p->twid[a], in, o, nullptr, nullptr, nullptr, 0.0, 0);
+            return dct_axis_fft(ctx, n0, n1, n2, a, inverse, p->twid[a], in, o, p->lam[0], p->lam[1],
+                                p->ndim == 3 ? p->lam[2] : nullptr, p->shift, fuse);
         }
-        (void)N;
         // forward: out[k] = sum_n T[k][n] in[n]  -> M[q=n][o=k] = TT ; inverse: out[n] = sum_k T[k][n] in[k] -> M = T
         hipLaunchKernelGGL(dct_axis_direct, dim3(grid), dim3(256), 0, ctx->stream, n0, n1, n2, a,
                            inverse ? p->T[a] : p->TT[a], in, o);
         BK_HIP(ctx, hipGetLastError());
         return 0;
     };
+    // the last forward pass applies the inverse symbol while storing when it runs on the fast path
+    const int last = p->ndim - 1;
+    const bool fused = use_fft && p->twid[last] != nullptr;
     for (int a = 0; a < p->ndim; ++a) {
-        BK_TRY(axis_pass(a, 0, src, bufs[cur]));
+        BK_TRY(axis_pass(a, 0, src, bufs[cur], (a == last && fused) ? 1 : 0));
         src = bufs[cur];
         cur ^= 1;
     }
     // src now holds the spectrum (in bufs[cur^1])
     double* spec = bufs[cur ^ 1];
-    hipLaunchKernelGGL(spectral_scale_kernel, dim3(grid), dim3(256), 0, ctx->stream, n0, n1, n2, p->lam[0], p->lam[1],
-                       p->ndim == 3 ? p->lam[2] : nullptr, p->shift, spec);
-    BK_HIP(ctx, hipGetLastError());
+    if (!fused) {
+        hipLaunchKernelGGL(spectral_scale_kernel, dim3(grid), dim3(256), 0, ctx->stream, n0, n1, n2, p->lam[0], p->lam[1],
+                           p->ndim == 3 ? p->lam[2] : nullptr, p->shift, spec);
+        BK_HIP(ctx, hipGetLastError());
+    }
     src = spec;
     for (int a = p->ndim - 1; a >= 0; --a) {
         double* dst = (a == 0) ? out : bufs[cur];
-        BK_TRY(axis_pass(a, 1, src, dst));
+        BK_TRY(axis_pass(a, 1, src, dst, 0));
         src = dst;
         cur ^= 1;
     }

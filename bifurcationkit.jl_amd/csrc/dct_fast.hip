@@ -1,14 +1,188 @@
-// Fast DCT axis passes (LDS-resident FFT per line tile).  Placeholder until the LDS kernel lands:
-// reports "unsupported" so dct.hip uses the direct O(N^2) kernels.
+// Fast DCT-II / DCT-III axis passes for the spectral preconditioner (dct.hip): one workgroup stages a tile of
+// LT lines of length N = 2^bits in LDS (two real lines per complex sequence), runs the radix-2 FFT of
+// dct_core.h there, and writes the tile back -- HBM traffic is exactly one read and one write of the array per
+// axis pass (16 B/point), everything else happens in LDS.
+//
+// Tiling.  The array is [n2][n1][n0] with n0 fastest.
+//   axis 0: a tile is LT consecutive rows (each row N = n0 contiguous doubles): global accesses are coalesced
+//           along the row.
+//   axis 1/2: a tile is LT consecutive x for one fixed (z) / (y): element n of line L sits at
+//           base + L + n*stride, so a wavefront reads LT contiguous doubles for several n -- 128-B segments for
+//           LT = 16 -- and the transform direction never has to be contiguous in memory.
+// The last forward pass can apply the inverse symbol 1/((1 + lam_x + lam_y + lam_z)^2 + shift) while storing
+// (fuse_scale), which removes the separate scaling pass.
+#include <cmath>
+
 #include "ops.h"
+#include "dct_core.h"
 
 namespace bk {
 
-bool dct_axis_fft_supported(int) { return false; }
+namespace {
 
-int dct_axis_fft(bk_ctx* ctx, int, int, int, int, int, const double*, const double*, double*, const double*,
-                 const double*, const double*, double, int) {
-    return set_error(ctx, "dct_axis_fft: not available");
+using dctc::c2;
+
+struct FftK {
+    int n0, n1, n2, axis, N, bits, LT, inverse;
+    const double* in;
+    double* out;
+    const double* twid;       // [N/2] complex exp(-2 pi i q/N), then [N] complex exp(-i pi k/2N)
+    const double* lam0;
+    const double* lam1;
+    const double* lam2;       // may be NULL (2-D)
+    double shift;
+    int fuse_scale;
+    int tiles_x;              // axis >= 1: number of LT-wide tiles along x
+};
+
+__global__ void __launch_bounds__(256) dct_fft_kernel(FftK P) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int N = P.N, bits = P.bits, LT = P.LT, half = N >> 1;
+    const int npairs = LT >> 1;
+    const int pstride = N + 1;                                // complex elements per pair (+1: bank skew)
+    c2* z = reinterpret_cast<c2*>(smem);
+    c2* tw = z + (size_t)npairs * pstride;                    // N/2 FFT twiddles
+    const c2* ew = reinterpret_cast<const c2*>(P.twid) + half;   // post twiddles stay in global (read once)
+    const int tid = threadIdx.x;
+
+    // ---- tile decode
+    size_t base, lstride, estride;
+    int nlines;                                               // valid lines in this tile
+    int ti0 = 0, ti1 = 0, ti2 = 0;                            // 3-D index of (line 0, element 0)
+    if (P.axis == 0) {
+        const size_t rows = (size_t)P.n1 * P.n2;
+        const size_t r0 = (size_t)blockIdx.x * LT;
+        nlines = (int)min((size_t)LT, rows - r0);
+        base = r0 * P.n0; lstride = P.n0; estride = 1;
+        ti1 = (int)(r0 % P.n1); ti2 = (int)(r0 / P.n1);
+    } else {
+        const int tx = blockIdx.x % P.tiles_x;
+        const int other = blockIdx.x / P.tiles_x;             // i2 (axis 1) or i1 (axis 2)
+        const int x0 = tx * LT;
+        nlines = min(LT, P.n0 - x0);
+        lstride = 1;
+        ti0 = x0;
+        if (P.axis == 1) { base = x0 + (size_t)P.n0 * P.n1 * other; estride = P.n0; ti2 = other; }
+        else { base = x0 + (size_t)P.n0 * other; estride = (size_t)P.n0 * P.n1; ti1 = other; }
+    }
+
+    for (int q = tid; q < half; q += 256) tw[q] = reinterpret_cast<const c2*>(P.twid)[q];
+
+    // ---- load (coalesced along the memory-contiguous direction), scatter into the FFT input order
+    const int total = LT * N;
+    for (int w = tid; w < total; w += 256) {
+        int L, n;
+        if (P.axis == 0) { L = w >> bits; n = w & (N - 1); }
+        else { L = w % LT; n = w / LT; }
+        const double v = (L < nlines) ? P.in[base + (size_t)L * lstride + (size_t)n * estride] : 0.0;
+        const int slot = P.inverse ? dctc::swz(n) : dctc::sample_slot(n, N, bits);
+        smem[2 * ((size_t)(L >> 1) * pstride + slot) + (L & 1)] = v;
+    }
+    __syncthreads();
+
+    const double s0 = sqrt(1.0 / N), s2 = sqrt(2.0 / N);
+    const int nbf = npairs * half;                            // butterflies per stage
+    if (!P.inverse) {
+        for (int lh = 0; lh < bits; ++lh) {
+            for (int w = tid; w < nbf; w += 256) {
+                const int p = w / half, j = w - p * half;
+                dctc::dit_butterfly(z + (size_t)p * pstride, bits, lh, j, tw);
+            }
+            __syncthreads();
+        }
+        const int npost = npairs * (half + 1);
+        for (int w = tid; w < npost; w += 256) {
+            const int p = w / (half + 1), k = w - p * (half + 1);
+            dctc::fwd_post(z + (size_t)p * pstride, N, k, ew, s0, s2);
+        }
+        __syncthreads();
+    } else {
+        const int npre = npairs * (half + 1);
+        for (int w = tid; w < npre; w += 256) {
+            const int p = w / (half + 1), k = w - p * (half + 1);
+            dctc::inv_pre(z + (size_t)p * pstride, N, k, ew, s0, s2);
+        }
+        __syncthreads();
+        for (int lh = bits - 1; lh >= 0; --lh) {
+            for (int w = tid; w < nbf; w += 256) {
+                const int p = w / half, j = w - p * half;
+                dctc::dif_butterfly_inv(z + (size_t)p * pstride, bits, lh, j, tw);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- store
+    for (int w = tid; w < total; w += 256) {
+        int L, n;
+        if (P.axis == 0) { L = w >> bits; n = w & (N - 1); }
+        else { L = w % LT; n = w / LT; }
+        if (L >= nlines) continue;
+        const int slot = P.inverse ? dctc::sample_slot(n, N, bits) : dctc::swz(n);
+        double v = smem[2 * ((size_t)(L >> 1) * pstride + slot) + (L & 1)];
+        if (P.fuse_scale) {
+            int i0, i1, i2;
+            if (P.axis == 0) { const size_t r = (size_t)ti1 + (size_t)ti2 * P.n1 + L; i0 = n; i1 = (int)(r % P.n1); i2 = (int)(r / P.n1); }
+            else if (P.axis == 1) { i0 = ti0 + L; i1 = n; i2 = ti2; }
+            else { i0 = ti0 + L; i1 = ti1; i2 = n; }
+            const double s = 1.0 + P.lam0[i0] + P.lam1[i1] + (P.lam2 ? P.lam2[i2] : 0.0);
+            v = v / (s * s + P.shift);
+        }
+        P.out[base + (size_t)L * lstride + (size_t)n * estride] = v;
+    }
+}
+
+inline int choose_lt(int N, int axis, int n0, size_t rows) {
+    // LDS budget 64 KiB for the line tile: LT * (N+1) * 8 B (two lines per complex)
+    int lt = (int)((64 * 1024) / ((size_t)(N + 1) * 8));
+    lt &= ~1;
+    if (lt > 64) lt = 64;
+    if (lt < 2) lt = 2;
+    if (axis == 0) {
+        if ((size_t)lt > rows) lt = (int)((rows + 1) & ~(size_t)1);
+    } else {
+        if (lt >= 16) lt = (lt / 16) * 16;                    // whole 128-B segments along x
+        const int n0e = (n0 + 1) & ~1;
+        if (lt > n0e) lt = n0e;
+    }
+    return lt < 2 ? 2 : lt;
+}
+
+}  // namespace
+
+bool dct_axis_fft_supported(int n) { return n >= 4 && n <= 1024 && (n & (n - 1)) == 0; }
+
+int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, const double* twid, const double* in,
+                 double* out, const double* lam0, const double* lam1, const double* lam2, double shift,
+                 int fuse_scale) {
+    FftK P;
+    P.n0 = n0; P.n1 = n1; P.n2 = n2; P.axis = axis;
+    P.N = axis == 0 ? n0 : (axis == 1 ? n1 : n2);
+    P.bits = 0;
+    while ((1 << P.bits) < P.N) ++P.bits;
+    if (!dct_axis_fft_supported(P.N)) return set_error(ctx, "dct_axis_fft: N=%d unsupported", P.N);
+    P.inverse = inverse; P.in = in; P.out = out; P.twid = twid;
+    P.lam0 = lam0; P.lam1 = lam1; P.lam2 = lam2; P.shift = shift; P.fuse_scale = fuse_scale;
+    const size_t rows = (size_t)n1 * n2;
+    P.LT = choose_lt(P.N, axis, n0, rows);
+    unsigned grid;
+    if (axis == 0) {
+        P.tiles_x = 0;
+        grid = (unsigned)((rows + P.LT - 1) / P.LT);
+    } else {
+        P.tiles_x = (n0 + P.LT - 1) / P.LT;
+        grid = (unsigned)((size_t)P.tiles_x * (axis == 1 ? n2 : n1));
+    }
+    const size_t lds = ((size_t)(P.LT / 2) * (P.N + 1) + (size_t)(P.N / 2)) * sizeof(c2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        BK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dct_fft_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(dct_fft_kernel, dim3(grid), dim3(256), lds, ctx->stream, P);
+    BK_HIP(ctx, hipGetLastError());
+    return 0;
 }
 
 }  // namespace bk

