@@ -191,6 +191,41 @@ int halo_exchange(bk_ctx* ctx, const double* v, size_t plane, int nplanes, int w
     return 0;
 }
 
+// ------------------------------------------------------------------ all-to-all (variable counts, doubles)
+// Used by the distributed DCT preconditioner to turn z-slabs into y-slabs and back.
+int comm_alltoallv(bk_ctx* ctx, const double* sendbuf, const size_t* scount, const size_t* sdispl, double* recvbuf,
+                   const size_t* rcount, const size_t* rdispl) {
+    const int R = ctx->nranks, me = ctx->rank;
+    if (R == 1) {
+        BK_HIP(ctx, hipMemcpyAsync(recvbuf + rdispl[0], sendbuf + sdispl[0], scount[0] * sizeof(double),
+                                   hipMemcpyDeviceToDevice, ctx->stream));
+        return 0;
+    }
+    if (ctx->comm == COMM_RCCL) {
+        BK_NCCL(ctx, ncclGroupStart());
+        for (int p = 0; p < R; ++p) {
+            if (scount[p]) BK_NCCL(ctx, ncclSend(sendbuf + sdispl[p], scount[p], ncclDouble, p, ctx->nccl, ctx->stream));
+            if (rcount[p]) BK_NCCL(ctx, ncclRecv(recvbuf + rdispl[p], rcount[p], ncclDouble, p, ctx->nccl, ctx->stream));
+        }
+        BK_NCCL(ctx, ncclGroupEnd());
+        return 0;
+    }
+    // host-staged test communicator: own block device-to-device, the others pairwise through the callback
+    BK_HIP(ctx, hipMemcpyAsync(recvbuf + rdispl[me], sendbuf + sdispl[me], scount[me] * sizeof(double),
+                               hipMemcpyDeviceToDevice, ctx->stream));
+    for (int s = 1; s < R; ++s) {
+        const int dst = (me + s) % R, src = (me - s + R) % R;
+        std::vector<double> sb(scount[dst]), rb(rcount[src]);
+        BK_HIP(ctx, hipMemcpyAsync(sb.data(), sendbuf + sdispl[dst], scount[dst] * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->h_sendrecv(ctx->h_user, sb.data(), sb.size(), dst, rb.data(), rb.size(), src) != 0)
+            return set_error(ctx, "host sendrecv callback failed");
+        BK_HIP(ctx, hipMemcpyAsync(recvbuf + rdispl[src], rb.data(), rcount[src] * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return 0;
+}
+
 static int ctx_init_common(bk_ctx* ctx, int device, void* stream) {
     ctx->device = device;
     BK_HIP(ctx, hipSetDevice(device));

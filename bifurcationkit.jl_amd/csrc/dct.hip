@@ -39,6 +39,17 @@ struct DctPlan {
     double* t1 = nullptr;
     double* t2 = nullptr;
     size_t total = 0;
+    // distributed (z-slab) variant: transposes to y-slabs for the z pass
+    bool dist = false;
+    int R = 1, rank = 0;
+    int zlo = 0, zhi = 0, ylo = 0, yhi = 0;
+    std::vector<int> zcut, ycut;              // slab boundaries per rank (R+1 entries)
+    std::vector<size_t> cnt_f, dsp_f, cnt_b, dsp_b;   // forward: send counts (to y-owners) / recv counts (from z-owners)
+    double* lam_yloc = nullptr;               // lam[1] + ylo (view)
+};
+
+struct Cuts {                                 // slab boundaries by value (kernel argument), up to 64 ranks
+    int c[65];
 };
 
 namespace {
@@ -76,6 +87,44 @@ __global__ void __launch_bounds__(256) spectral_scale_kernel(int n0, int n1, int
     const int i2 = (int)(idx / ((size_t)n0 * n1));
     const double s = 1.0 + lx[i0] + ly[i1] + (lz ? lz[i2] : 0.0);
     a[idx] = a[idx] / (s * s + shift);
+}
+
+}  // namespace
+
+namespace {
+
+__device__ __forceinline__ int owner_of(const Cuts& c, int R, int i) {
+    int r = 0;
+    while (r + 1 < R && i >= c.c[r + 1]) ++r;
+    return r;
+}
+
+// z-slab [nzl][ny][nx]  <->  per-destination blocks [d][zl][y - ycut[d]][x]   (dir 0: slab -> blocks)
+__global__ void __launch_bounds__(256) slab_blocks_kernel(int nx, int ny, int nzl, int R, Cuts ycut, const double* in,
+                                                          double* out, int dir) {
+    const size_t total = (size_t)nx * ny * nzl;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % nx), y = (int)((idx / nx) % ny), zl = (int)(idx / ((size_t)nx * ny));
+    const int d = owner_of(ycut, R, y);
+    const int y0 = ycut.c[d], nyd = ycut.c[d + 1] - y0;
+    const size_t off = (size_t)nx * nzl * y0 + ((size_t)zl * nyd + (y - y0)) * nx + x;   // blocks are laid out in rank order
+    if (dir == 0) out[off] = in[idx];
+    else out[idx] = in[off];
+}
+
+// per-source blocks [s][z - zcut[s]][yl][x]  <->  y-slab transposed layout T[yl][z][x]   (dir 0: blocks -> T)
+__global__ void __launch_bounds__(256) blocks_tr_kernel(int nx, int nyl, int nz, int R, Cuts zcut, const double* in,
+                                                        double* out, int dir) {
+    const size_t total = (size_t)nx * nyl * nz;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;      // index into T
+    if (idx >= total) return;
+    const int x = (int)(idx % nx), z = (int)((idx / nx) % nz), yl = (int)(idx / ((size_t)nx * nz));
+    const int sr = owner_of(zcut, R, z);
+    const int z0 = zcut.c[sr];
+    const size_t off = (size_t)nx * nyl * z0 + ((size_t)(z - z0) * nyl + yl) * nx + x;
+    if (dir == 0) out[idx] = in[off];
+    else out[off] = in[idx];
 }
 
 }  // namespace
@@ -196,11 +245,106 @@ int dct_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out) {
     return 0;
 }
 
+int dct_plan_create_dist(bk_ctx* ctx, const int n[3], const double ainv[3], double shift, int zlo, int zhi, DctPlan** out) {
+    if (ctx->nranks > 64) return set_error(ctx, "distributed DCT: at most 64 ranks");
+    DctPlan* p = nullptr;
+    BK_TRY(dct_plan_create(ctx, 3, n, ainv, shift, &p));       // tables for the GLOBAL extents (scratch resized below)
+    p->dist = true;
+    p->R = ctx->nranks; p->rank = ctx->rank;
+    const int R = p->R;
+    p->zcut.assign(R + 1, 0);
+    p->ycut.assign(R + 1, 0);
+    for (int r = 0; r <= R; ++r) {
+        auto cut = [&](int N) { const int base = N / R, rem = N % R; return r * base + (r < rem ? r : rem); };
+        p->zcut[r] = cut(n[2]);
+        p->ycut[r] = cut(n[1]);
+    }
+    if (p->zcut[p->rank] != zlo || p->zcut[p->rank + 1] != zhi) {
+        dct_plan_destroy(p);
+        return set_error(ctx, "distributed DCT: slab [%d,%d) does not match the balanced decomposition", zlo, zhi);
+    }
+    p->zlo = zlo; p->zhi = zhi; p->ylo = p->ycut[p->rank]; p->yhi = p->ycut[p->rank + 1];
+    const size_t nx = n[0], nzl = zhi - zlo, nyl = p->yhi - p->ylo;
+    const size_t loc_z = nx * n[1] * nzl, loc_y = nx * nyl * n[2];
+    p->cnt_f.resize(R); p->dsp_f.resize(R); p->cnt_b.resize(R); p->dsp_b.resize(R);
+    for (int r = 0; r < R; ++r) {
+        p->cnt_f[r] = nx * nzl * (size_t)(p->ycut[r + 1] - p->ycut[r]);   // my z-planes, rank r's y-rows
+        p->dsp_f[r] = nx * nzl * (size_t)p->ycut[r];
+        p->cnt_b[r] = nx * nyl * (size_t)(p->zcut[r + 1] - p->zcut[r]);   // rank r's z-planes, my y-rows
+        p->dsp_b[r] = nx * nyl * (size_t)p->zcut[r];
+    }
+    (void)hipFree(p->t1); (void)hipFree(p->t2);
+    p->t1 = p->t2 = nullptr;
+    const size_t cap = loc_z > loc_y ? loc_z : loc_y;
+    p->total = cap;
+    if (hipMalloc(&p->t1, sizeof(double) * cap) != hipSuccess || hipMalloc(&p->t2, sizeof(double) * cap) != hipSuccess) {
+        dct_plan_destroy(p);
+        return set_error(ctx, "distributed DCT: scratch allocation failed");
+    }
+    p->lam_yloc = p->lam[1] + p->ylo;
+    *out = p;
+    return 0;
+}
+
+// Distributed apply: x and y passes on the z-slab, all-to-all to y-slabs (layout [yl][z][x]), z pass forward with
+// the inverse symbol fused, z pass inverse, all-to-all back, y and x inverse passes.
+static int dct_apply_dist(bk_ctx* ctx, DctPlan* p, const double* v, double* out) {
+    const int nx = p->n[0], ny = p->n[1], nz = p->n[2];
+    const int nzl = p->zhi - p->zlo, nyl = p->yhi - p->ylo;
+    const size_t loc_z = (size_t)nx * ny * nzl, loc_y = (size_t)nx * nyl * nz;
+    const bool use_fft = ctx->opt("dct_fft", 1.0) != 0.0;
+    ProfScope ps(ctx, "precond", 16.0 * loc_z);
+    Cuts yc, zc;
+    for (int r = 0; r <= p->R; ++r) { yc.c[r] = p->ycut[r]; zc.c[r] = p->zcut[r]; }
+    auto pass = [&](int n0, int n1, int n2, int axis, int which, int inverse, const double* in, double* o, int fuse,
+                    const double* l0, const double* l1, const double* l2) -> int {
+        // `which` = index of the global axis being transformed (selects tables)
+        if (use_fft && p->twid[which])
+            return dct_axis_fft(ctx, n0, n1, n2, axis, inverse, p->twid[which], in, o, l0, l1, l2, p->shift, fuse);
+        const size_t tot = (size_t)n0 * n1 * n2;
+        hipLaunchKernelGGL(dct_axis_direct, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, n0, n1, n2, axis,
+                           inverse ? p->T[which] : p->TT[which], in, o);
+        BK_HIP(ctx, hipGetLastError());
+        return 0;
+    };
+    double *a = p->t1, *b = p->t2;
+    // forward x, y on the z-slab [nzl][ny][nx]
+    BK_TRY(pass(nx, ny, nzl, 0, 0, 0, v, a, 0, nullptr, nullptr, nullptr));
+    BK_TRY(pass(nx, ny, nzl, 1, 1, 0, a, b, 0, nullptr, nullptr, nullptr));
+    // z-slab -> blocks (a), all-to-all (b), blocks -> T (a)
+    hipLaunchKernelGGL(slab_blocks_kernel, dim3((unsigned)((loc_z + 255) / 256)), dim3(256), 0, ctx->stream, nx, ny, nzl, p->R, yc, b, a, 0);
+    BK_HIP(ctx, hipGetLastError());
+    BK_TRY(comm_alltoallv(ctx, a, p->cnt_f.data(), p->dsp_f.data(), b, p->cnt_b.data(), p->dsp_b.data()));
+    hipLaunchKernelGGL(blocks_tr_kernel, dim3((unsigned)((loc_y + 255) / 256)), dim3(256), 0, ctx->stream, nx, nyl, nz, p->R, zc, b, a, 0);
+    BK_HIP(ctx, hipGetLastError());
+    // z pass on T = [nyl][nz][nx]: axis 1 of (n0 = nx, n1 = nz, n2 = nyl); symbol indices (i0, i1, i2) = (kx, kz, ky_local)
+    const bool fused = use_fft && p->twid[2] != nullptr;
+    BK_TRY(pass(nx, nz, nyl, 1, 2, 0, a, b, fused ? 1 : 0, p->lam[0], p->lam[2], p->lam_yloc));
+    if (!fused) {
+        hipLaunchKernelGGL(spectral_scale_kernel, dim3((unsigned)((loc_y + 255) / 256)), dim3(256), 0, ctx->stream, nx, nz, nyl,
+                           p->lam[0], p->lam[2], p->lam_yloc, p->shift, b);
+        BK_HIP(ctx, hipGetLastError());
+    }
+    BK_TRY(pass(nx, nz, nyl, 1, 2, 1, b, a, 0, nullptr, nullptr, nullptr));
+    // T -> blocks (b), all-to-all back (a), blocks -> z-slab (b)
+    hipLaunchKernelGGL(blocks_tr_kernel, dim3((unsigned)((loc_y + 255) / 256)), dim3(256), 0, ctx->stream, nx, nyl, nz, p->R, zc, a, b, 1);
+    BK_HIP(ctx, hipGetLastError());
+    BK_TRY(comm_alltoallv(ctx, b, p->cnt_b.data(), p->dsp_b.data(), a, p->cnt_f.data(), p->dsp_f.data()));
+    hipLaunchKernelGGL(slab_blocks_kernel, dim3((unsigned)((loc_z + 255) / 256)), dim3(256), 0, ctx->stream, nx, ny, nzl, p->R, yc, a, b, 1);
+    BK_HIP(ctx, hipGetLastError());
+    // inverse y, x on the z-slab
+    BK_TRY(pass(nx, ny, nzl, 1, 1, 1, b, a, 0, nullptr, nullptr, nullptr));
+    BK_TRY(pass(nx, ny, nzl, 0, 0, 1, a, out, 0, nullptr, nullptr, nullptr));
+    return 0;
+}
+
 namespace {
 struct ShDctPrecond : bk_precond {
     DctPlan* plan = nullptr;
     ~ShDctPrecond() override { dct_plan_destroy(plan); }
-    int apply(const double* v, double* out) override { return dct_apply(ctx, plan, v, out); }
+    int apply(const double* v, double* out) override {
+        return plan->dist ? dct_apply_dist(ctx, plan, v, out) : dct_apply(ctx, plan, v, out);
+    }
 };
 }  // namespace
 
@@ -214,11 +358,12 @@ int bk_precond_sh_create(bk_problem* prob, double shift, bk_precond** out) {
     if (!prob || !out) return -1;
     bk_ctx* ctx = prob->ctx;
     if (prob->desc.pde != BK_PDE_SH) return set_error(ctx, "bk_precond_sh_create: Swift-Hohenberg 2-D/3-D only");
-    if (ctx->nranks > 1) return set_error(ctx, "bk_precond_sh_create: multi-GPU DCT transpose not implemented yet");
     ShDctPrecond* P = new ShDctPrecond();
     P->ctx = ctx;
     P->n = prob->nloc;
-    int s = dct_plan_create(ctx, prob->desc.ndim, prob->desc.n, prob->ainv, shift, &P->plan);
+    int s = ctx->nranks > 1
+                ? dct_plan_create_dist(ctx, prob->desc.n, prob->ainv, shift, prob->lo, prob->hi, &P->plan)
+                : dct_plan_create(ctx, prob->desc.ndim, prob->desc.n, prob->ainv, shift, &P->plan);
     if (s != 0) { delete P; return s; }
     *out = P;
     return 0;

@@ -70,6 +70,60 @@ BK_HD void dif_butterfly_inv(c2* z, int bits, int lh, int j, const c2* tw) {
     z[p1].y = w.x * dy - w.y * dx;
 }
 
+// R consecutive radix-2 DIT stages (lh .. lh+R-1) on the 2^R elements {base + (q << lh)} of group g, carried out in
+// registers: one LDS round trip per R stages instead of one per stage.  g in [0, N >> R).
+template <int R>
+BK_HD void dit_group(c2* z, int bits, int lh, int g, const c2* tw) {
+    constexpr int M = 1 << R;
+    const int lo = g & ((1 << lh) - 1);
+    const int base = ((g >> lh) << (lh + R)) + lo;
+    c2 v[M];
+#pragma unroll
+    for (int q = 0; q < M; ++q) v[q] = z[swz(base + (q << lh))];
+#pragma unroll
+    for (int s = 0; s < R; ++s) {
+#pragma unroll
+        for (int q = 0; q < M; ++q) {
+            if (q & (1 << s)) continue;
+            const int pos = ((q & ((1 << s) - 1)) << lh) + lo;
+            const c2 w = tw[pos << (bits - (lh + s) - 1)];
+            const c2 a = v[q], b = v[q | (1 << s)];
+            const double tx = w.x * b.x - w.y * b.y, ty = w.x * b.y + w.y * b.x;
+            v[q].x = a.x + tx; v[q].y = a.y + ty;
+            v[q | (1 << s)].x = a.x - tx; v[q | (1 << s)].y = a.y - ty;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < M; ++q) z[swz(base + (q << lh))] = v[q];
+}
+
+// R consecutive inverse DIF stages (lh+R-1 down to lh), same grouping.
+template <int R>
+BK_HD void dif_group_inv(c2* z, int bits, int lh, int g, const c2* tw) {
+    constexpr int M = 1 << R;
+    const int lo = g & ((1 << lh) - 1);
+    const int base = ((g >> lh) << (lh + R)) + lo;
+    c2 v[M];
+#pragma unroll
+    for (int q = 0; q < M; ++q) v[q] = z[swz(base + (q << lh))];
+#pragma unroll
+    for (int s = R - 1; s >= 0; --s) {
+#pragma unroll
+        for (int q = 0; q < M; ++q) {
+            if (q & (1 << s)) continue;
+            const int pos = ((q & ((1 << s) - 1)) << lh) + lo;
+            const c2 w = tw[pos << (bits - (lh + s) - 1)];
+            const c2 a = v[q], b = v[q | (1 << s)];
+            const double dx = a.x - b.x, dy = a.y - b.y;
+            v[q].x = a.x + b.x; v[q].y = a.y + b.y;
+            v[q | (1 << s)].x = w.x * dx + w.y * dy;
+            v[q | (1 << s)].y = w.x * dy - w.y * dx;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < M; ++q) z[swz(base + (q << lh))] = v[q];
+}
+
 // forward post-processing for k in [0, N/2]: in place, slots k and N-k.  ew[k] = exp(-i pi k / 2N).
 // On return z[swz(k)] = (Xa_k, Xb_k) and z[swz(N-k)] = (Xa_{N-k}, Xb_{N-k}) (orthonormal coefficients).
 BK_HD void fwd_post(c2* z, int N, int k, const c2* ew, double s0, double s2) {

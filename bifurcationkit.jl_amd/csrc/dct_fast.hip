@@ -1,6 +1,6 @@
 // Fast DCT-II / DCT-III axis passes for the spectral preconditioner (dct.hip): one workgroup stages a tile of
-// LT lines of length N = 2^bits in LDS (two real lines per complex sequence), runs the radix-2 FFT of
-// dct_core.h there, and writes the tile back -- HBM traffic is exactly one read and one write of the array per
+// LT lines of length N = 2^bits in LDS (two real lines per complex sequence), runs the FFT of dct_core.h there
+// (radix-8 register groups: three radix-2 stages per LDS round trip), and writes the tile back -- HBM traffic is exactly one read and one write of the array per
 // axis pass (16 B/point), everything else happens in LDS.
 //
 // Tiling.  The array is [n2][n1][n0] with n0 fastest.
@@ -23,7 +23,7 @@ namespace {
 using dctc::c2;
 
 struct FftK {
-    int n0, n1, n2, axis, N, bits, LT, inverse;
+    int n0, n1, n2, axis, N, bits, LT, ltbits, inverse;   // ltbits = log2(LT) if LT is a power of two, else -1
     const double* in;
     double* out;
     const double* twid;       // [N/2] complex exp(-2 pi i q/N), then [N] complex exp(-i pi k/2N)
@@ -73,6 +73,7 @@ __global__ void __launch_bounds__(256) dct_fft_kernel(FftK P) {
     for (int w = tid; w < total; w += 256) {
         int L, n;
         if (P.axis == 0) { L = w >> bits; n = w & (N - 1); }
+        else if (P.ltbits >= 0) { L = w & (LT - 1); n = w >> P.ltbits; }
         else { L = w % LT; n = w / LT; }
         const double v = (L < nlines) ? P.in[base + (size_t)L * lstride + (size_t)n * estride] : 0.0;
         const int slot = P.inverse ? dctc::swz(n) : dctc::sample_slot(n, N, bits);
@@ -81,34 +82,54 @@ __global__ void __launch_bounds__(256) dct_fft_kernel(FftK P) {
     __syncthreads();
 
     const double s0 = sqrt(1.0 / N), s2 = sqrt(2.0 / N);
-    const int nbf = npairs * half;                            // butterflies per stage
+    // FFT stages, three radix-2 stages per LDS round trip (radix-8 groups held in registers)
+    auto run_groups = [&](int lh, int R, bool inv) {
+        const int gbits = bits - R;                            // log2(groups per pair)
+        const int ngr = npairs << gbits;
+        for (int w = tid; w < ngr; w += 256) {
+            c2* zp = z + (size_t)(w >> gbits) * pstride;
+            const int g = w & ((1 << gbits) - 1);
+            if (!inv) {
+                if (R == 3) dctc::dit_group<3>(zp, bits, lh, g, tw);
+                else if (R == 2) dctc::dit_group<2>(zp, bits, lh, g, tw);
+                else dctc::dit_group<1>(zp, bits, lh, g, tw);
+            } else {
+                if (R == 3) dctc::dif_group_inv<3>(zp, bits, lh, g, tw);
+                else if (R == 2) dctc::dif_group_inv<2>(zp, bits, lh, g, tw);
+                else dctc::dif_group_inv<1>(zp, bits, lh, g, tw);
+            }
+        }
+        __syncthreads();
+    };
+    // pre/post twiddle phase: work item (pair, k) for k in [0, N/2); k = 0 also handles k = N/2
+    auto run_twiddle = [&](bool inv) {
+        const int nw = npairs << (bits - 1);
+        for (int w = tid; w < nw; w += 256) {
+            c2* zp = z + (size_t)(w >> (bits - 1)) * pstride;
+            const int k = w & (half - 1);
+            if (!inv) {
+                dctc::fwd_post(zp, N, k, ew, s0, s2);
+                if (k == 0) dctc::fwd_post(zp, N, half, ew, s0, s2);
+            } else {
+                dctc::inv_pre(zp, N, k, ew, s0, s2);
+                if (k == 0) dctc::inv_pre(zp, N, half, ew, s0, s2);
+            }
+        }
+        __syncthreads();
+    };
     if (!P.inverse) {
-        for (int lh = 0; lh < bits; ++lh) {
-            for (int w = tid; w < nbf; w += 256) {
-                const int p = w / half, j = w - p * half;
-                dctc::dit_butterfly(z + (size_t)p * pstride, bits, lh, j, tw);
-            }
-            __syncthreads();
+        for (int lh = 0; lh < bits;) {
+            const int R = bits - lh >= 3 ? 3 : bits - lh;
+            run_groups(lh, R, false);
+            lh += R;
         }
-        const int npost = npairs * (half + 1);
-        for (int w = tid; w < npost; w += 256) {
-            const int p = w / (half + 1), k = w - p * (half + 1);
-            dctc::fwd_post(z + (size_t)p * pstride, N, k, ew, s0, s2);
-        }
-        __syncthreads();
+        run_twiddle(false);
     } else {
-        const int npre = npairs * (half + 1);
-        for (int w = tid; w < npre; w += 256) {
-            const int p = w / (half + 1), k = w - p * (half + 1);
-            dctc::inv_pre(z + (size_t)p * pstride, N, k, ew, s0, s2);
-        }
-        __syncthreads();
-        for (int lh = bits - 1; lh >= 0; --lh) {
-            for (int w = tid; w < nbf; w += 256) {
-                const int p = w / half, j = w - p * half;
-                dctc::dif_butterfly_inv(z + (size_t)p * pstride, bits, lh, j, tw);
-            }
-            __syncthreads();
+        run_twiddle(true);
+        for (int top = bits; top > 0;) {
+            const int R = top >= 3 ? 3 : top;
+            run_groups(top - R, R, true);
+            top -= R;
         }
     }
 
@@ -116,6 +137,7 @@ __global__ void __launch_bounds__(256) dct_fft_kernel(FftK P) {
     for (int w = tid; w < total; w += 256) {
         int L, n;
         if (P.axis == 0) { L = w >> bits; n = w & (N - 1); }
+        else if (P.ltbits >= 0) { L = w & (LT - 1); n = w >> P.ltbits; }
         else { L = w % LT; n = w / LT; }
         if (L >= nlines) continue;
         const int slot = P.inverse ? dctc::sample_slot(n, N, bits) : dctc::swz(n);
@@ -133,15 +155,13 @@ __global__ void __launch_bounds__(256) dct_fft_kernel(FftK P) {
 }
 
 inline int choose_lt(int N, int axis, int n0, size_t rows) {
-    // LDS budget 64 KiB for the line tile: LT * (N+1) * 8 B (two lines per complex)
-    int lt = (int)((64 * 1024) / ((size_t)(N + 1) * 8));
-    lt &= ~1;
-    if (lt > 64) lt = 64;
-    if (lt < 2) lt = 2;
+    // 16 lines per tile (axis >= 1: one 128-B segment per line element), fewer only if the tile would not fit a
+    // 76 KiB LDS budget (two workgroups per CU): LT/2 pairs * (N+1) complex + N/2 twiddles, 16 B each
+    int lt = 16;
+    while (lt > 2 && ((size_t)(lt / 2) * (N + 1) + (size_t)(N / 2)) * 16 > 76 * 1024) lt -= 2;
     if (axis == 0) {
         if ((size_t)lt > rows) lt = (int)((rows + 1) & ~(size_t)1);
     } else {
-        if (lt >= 16) lt = (lt / 16) * 16;                    // whole 128-B segments along x
         const int n0e = (n0 + 1) & ~1;
         if (lt > n0e) lt = n0e;
     }
@@ -165,6 +185,8 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
     P.lam0 = lam0; P.lam1 = lam1; P.lam2 = lam2; P.shift = shift; P.fuse_scale = fuse_scale;
     const size_t rows = (size_t)n1 * n2;
     P.LT = choose_lt(P.N, axis, n0, rows);
+    P.ltbits = -1;
+    for (int b = 1; b <= 6; ++b) if ((1 << b) == P.LT) P.ltbits = b;
     unsigned grid;
     if (axis == 0) {
         P.tiles_x = 0;

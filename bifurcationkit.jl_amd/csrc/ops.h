@@ -9,6 +9,9 @@ namespace bk {
 int halo_exchange(bk_ctx* ctx, const double* v, size_t plane, int nplanes, int width, double* halo_lo,
                   double* halo_hi);
 
+int comm_alltoallv(bk_ctx* ctx, const double* sendbuf, const size_t* scount, const size_t* sdispl, double* recvbuf,
+                   const size_t* rcount, const size_t* rdispl);
+
 // ---- stencil launchers (stencil.hip) --------------------------------------------------------
 struct ShArgs {             // Swift-Hohenberg 2-D/3-D, Neumann-ghost (mirror) boundaries
     int nx, ny, nz;         // local extents (nz = planes owned by this rank; 1 in 2-D)
@@ -52,6 +55,8 @@ int sh1d_apply(bk_ctx* ctx, const Sh1dArgs& a);
 // ---- DCT preconditioner launchers (dct.hip) -------------------------------------------------
 struct DctPlan;
 int dct_plan_create(bk_ctx* ctx, int ndim, const int n[3], const double ainv[3], double shift, DctPlan** out);
+// distributed (z-slab) variant: n = GLOBAL extents; this rank owns planes [zlo, zhi)
+int dct_plan_create_dist(bk_ctx* ctx, const int n[3], const double ainv[3], double shift, int zlo, int zhi, DctPlan** out);
 void dct_plan_destroy(DctPlan* p);
 int dct_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out);
 

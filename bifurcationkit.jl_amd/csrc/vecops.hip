@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(kThreads) multidot_kernel(size_t n, const doub
 
 // ------------------------------------------------------------------ fused multi-axpy (+scale, +norm)
 // dst = scale * (src + sum_{j<k} c[j] V_j);  partials[block] = sum_chunk dst^2 (if want_norm).
-template <int KB, int VEC>
+template <int KB, int VEC, bool NT = false>
 __global__ void __launch_bounds__(kThreads) multiaxpy_kernel(size_t n, const double* __restrict__ V, size_t ldv, int k,
                                                              Coefs cf, const double* src, double scale, double* dst,
                                                              int want_norm, double* __restrict__ partials) {
@@ -211,7 +211,12 @@ __global__ void __launch_bounds__(kThreads) multiaxpy_kernel(size_t n, const dou
                 }
             }
             r.x *= scale; r.y *= scale;
-            reinterpret_cast<double2*>(dst)[i] = r;
+            if (NT) {
+                typedef double nt_d2 __attribute__((ext_vector_type(2)));
+                nt_d2 rr; rr.x = r.x; rr.y = r.y;
+                __builtin_nontemporal_store(rr, reinterpret_cast<nt_d2*>(dst) + i);
+            }
+            else reinterpret_cast<double2*>(dst)[i] = r;
             nn = fma(r.x, r.x, nn); nn = fma(r.y, r.y, nn);
         }
         if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -388,7 +393,9 @@ int v_multidot(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const 
 template <int KB>
 static void launch_multiaxpy(bk_ctx* ctx, bool vec, int grid, size_t n, const double* V, size_t ldv, int k, const Coefs& cf,
                              const double* src, double scale, double* dst, int want_norm) {
-    if (vec) hipLaunchKernelGGL((multiaxpy_kernel<KB, 2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials);
+    const bool nt = ctx->opt("axpy_nt", 0.0) != 0.0;
+    if (vec && nt) hipLaunchKernelGGL((multiaxpy_kernel<KB, 2, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials);
+    else if (vec) hipLaunchKernelGGL((multiaxpy_kernel<KB, 2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials);
     else hipLaunchKernelGGL((multiaxpy_kernel<KB, 1>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials);
 }
 
@@ -399,7 +406,9 @@ int v_multiaxpy(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const
     for (int j = 0; j < kMaxBasis; ++j) cf.c[j] = (j < k) ? c[j] : 0.0;
     const bool vec = aligned16(V) && aligned16(dst) && (!src || aligned16(src)) && (ldv % 2 == 0);
     const int want = nrm2sq ? 1 : 0;
-    const int grid = grid_for(n, vec ? 2 : 1, want ? kRedBlocks : 4096);
+    int cap = (int)ctx->opt("axpy_blocks", want ? kRedBlocks : 4096);
+    if (want && cap > kRedBlocks) cap = kRedBlocks;
+    const int grid = grid_for(n, vec ? 2 : 1, cap);
     {
         ProfScope ps(ctx, "multiaxpy", 8.0 * n * (k + 1 + (src ? 1 : 0)));
         if (k <= 4) launch_multiaxpy<4>(ctx, vec, grid, n, V, ldv, k, cf, src, scale, dst, want);

@@ -1,0 +1,320 @@
+# BifurcationKitHIP.jl -- the reference-side binding of libbkhip.so (C ABI: include/bkhip.h).
+#
+# Thin `ccall` layer that makes the MI355X-native corrector a drop-in behind BifurcationKit's own plugin
+# surface, so `continuation` / `newton` call into it unchanged:
+#
+#   HipVec                  state vector (device pointer + context) with the VectorInterface methods the PALC
+#                           path calls (checklist: SURVEY.md section 8b; src/BorderedArrays.jl:86-217)
+#   HipJacobian             what `prob.VF.J(x, p)` returns: an opaque operator handle (src/Problems.jl:98-101)
+#   HipGMRES                <: BK.AbstractIterativeLinearSolver   (src/LinearSolver.jl:8-12, 223-291)
+#   HipBorderingBLS         <: BK.AbstractBorderedLinearSolver    (src/LinearBorderSolver.jl:1-6, 59-166)
+#   HipMatrixFreeBLS        <: BK.AbstractBorderedLinearSolver    (src/LinearBorderSolver.jl:404-437)
+#   HipShiftInvert          <: BK.AbstractEigenSolver             (src/EigSolver.jl:4-12, 246-266)
+#
+# NOTE: there is no Julia in the build container of this repository, so this file has not been executed; the
+# identical call sequence is exercised through Python ctypes (bifurcationkit.jl_amd/_lib.py, tests/).  The
+# argument order of every ccall below is the order of the prototypes in include/bkhip.h.
+module BifurcationKitHIP
+
+using BifurcationKit
+import BifurcationKit: AbstractIterativeLinearSolver, AbstractBorderedLinearSolver, AbstractEigenSolver
+import LinearAlgebra
+import KrylovKit: VectorInterface
+const BK = BifurcationKit
+const VI = VectorInterface
+
+const libbkhip = Ref{String}(joinpath(@__DIR__, "..", "bifurcationkit.jl_amd", "lib", "libbkhip.so"))
+
+# ------------------------------------------------------------------------------------------------ C structs
+struct ProblemDesc
+    pde::Cint
+    ndim::Cint
+    n::NTuple{3, Cint}
+    l::NTuple{3, Cdouble}
+end
+struct GmresOpts
+    flavor::Cint; dim::Cint; maxiter::Cint; atol::Cdouble; rtol::Cdouble
+end
+struct BorderingOpts
+    tol::Cdouble; check_precision::Cint; k::Cint
+end
+struct EigOpts
+    sigma::Cdouble; krylovdim::Cint; maxiter::Cint; tol::Cdouble; hermitian::Cint; seed::Culonglong
+end
+
+const BK_PDE_SH, BK_PDE_SH1D, BK_PDE_CGL2D = Cint(1), Cint(2), Cint(3)
+
+# ------------------------------------------------------------------------------------------------ context
+mutable struct HipContext
+    h::Ptr{Cvoid}
+    function HipContext(device::Integer = 0)
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        st = ccall((:bk_ctx_create, libbkhip[]), Cint, (Ref{Ptr{Cvoid}}, Cint, Ptr{Cvoid}), r, device, C_NULL)
+        st == 0 || error("bk_ctx_create failed ($st)")
+        ctx = new(r[])
+        finalizer(c -> ccall((:bk_ctx_destroy, libbkhip[]), Cint, (Ptr{Cvoid},), c.h), ctx)
+    end
+end
+function check(ctx::HipContext, st::Cint, what = "")
+    st == 0 && return nothing
+    msg = unsafe_string(ccall((:bk_last_error, libbkhip[]), Cstring, (Ptr{Cvoid},), ctx.h))
+    error("$what failed with status $st: $msg")
+end
+
+# ------------------------------------------------------------------------------------------------ HipVec
+mutable struct HipVec
+    ctx::HipContext
+    p::Ptr{Cdouble}      # device pointer
+    n::Int               # local length (== global length on one GPU)
+    function HipVec(ctx::HipContext, n::Integer)
+        r = Ref{Ptr{Cdouble}}(C_NULL)
+        check(ctx, ccall((:bk_malloc, libbkhip[]), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cdouble}}), ctx.h, n, r), "bk_malloc")
+        v = new(ctx, r[], n)
+        finalizer(x -> ccall((:bk_free, libbkhip[]), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), x.ctx.h, x.p), v)
+    end
+end
+function HipVec(ctx::HipContext, a::Vector{Float64})
+    v = HipVec(ctx, length(a))
+    check(ctx, ccall((:bk_upload, libbkhip[]), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Csize_t), ctx.h, v.p, a, length(a)), "bk_upload")
+    v
+end
+function Base.Array(v::HipVec)
+    a = Vector{Float64}(undef, v.n)
+    check(v.ctx, ccall((:bk_download, libbkhip[]), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Csize_t), v.ctx.h, a, v.p, v.n), "bk_download")
+    a
+end
+Base.length(v::HipVec) = v.n
+Base.eltype(::HipVec) = Float64
+Base.similar(v::HipVec) = HipVec(v.ctx, v.n)
+
+_copy!(dst::HipVec, src::HipVec) = (check(dst.ctx, ccall((:bk_vec_copy, libbkhip[]), Cint, (Ptr{Cvoid}, Csize_t, Ptr{Cdouble}, Ptr{Cdouble}), dst.ctx.h, dst.n, src.p, dst.p)); dst)
+_axpby!(y::HipVec, x::HipVec, a, b) = (check(y.ctx, ccall((:bk_vec_axpby, libbkhip[]), Cint, (Ptr{Cvoid}, Csize_t, Cdouble, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}), y.ctx.h, y.n, a, x.p, b, y.p)); y)
+
+# VectorInterface (src/BorderedArrays.jl:86-217 is the template)
+VI.scalartype(::Type{HipVec}) = Float64
+VI.scalartype(::HipVec) = Float64
+function VI.zerovector(v::HipVec, ::Type{S} = Float64) where {S}
+    z = similar(v)
+    check(v.ctx, ccall((:bk_vec_zero, libbkhip[]), Cint, (Ptr{Cvoid}, Csize_t, Ptr{Cdouble}), v.ctx.h, z.n, z.p))
+    z
+end
+VI.zerovector!(v::HipVec) = (check(v.ctx, ccall((:bk_vec_zero, libbkhip[]), Cint, (Ptr{Cvoid}, Csize_t, Ptr{Cdouble}), v.ctx.h, v.n, v.p)); v)
+VI.zerovector!!(v::HipVec) = VI.zerovector!(v)
+VI.scale!(v::HipVec, a::Number) = (check(v.ctx, ccall((:bk_vec_scale, libbkhip[]), Cint, (Ptr{Cvoid}, Csize_t, Cdouble, Ptr{Cdouble}), v.ctx.h, v.n, a, v.p)); v)
+VI.scale!!(v::HipVec, a::Number) = VI.scale!(v, a)
+VI.scale(v::HipVec, a::Number) = VI.scale!(_copy!(similar(v), v), a)
+VI.scale!(y::HipVec, x::HipVec, a::Number) = VI.scale!(_copy!(y, x), a)
+VI.scale!!(y::HipVec, x::HipVec, a::Number) = VI.scale!(y, x, a)
+VI.add!(y::HipVec, x::HipVec, a::Number = 1, b::Number = 1) = _axpby!(y, x, a, b)      # y = b*y + a*x
+VI.add!!(y::HipVec, x::HipVec, a::Number = 1, b::Number = 1) = VI.add!(y, x, a, b)
+VI.add(y::HipVec, x::HipVec, a::Number = 1, b::Number = 1) = VI.add!(_copy!(similar(y), y), x, a, b)
+function VI.inner(x::HipVec, y::HipVec)
+    r = Ref{Cdouble}(0)
+    check(x.ctx, ccall((:bk_vec_dot, libbkhip[]), Cint, (Ptr{Cvoid}, Csize_t, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}), x.ctx.h, x.n, x.p, y.p, r))
+    r[]
+end
+function VI.norm(x::HipVec)
+    r = Ref{Cdouble}(0)
+    check(x.ctx, ccall((:bk_vec_nrm2, libbkhip[]), Cint, (Ptr{Cvoid}, Csize_t, Ptr{Cdouble}, Ref{Cdouble}), x.ctx.h, x.n, x.p, r))
+    r[]
+end
+function LinearAlgebra.norm(x::HipVec, p::Real = 2)
+    p == 2 && return VI.norm(x)
+    p == Inf || error("HipVec: only norm(x), norm(x, 2), norm(x, Inf)")
+    r = Ref{Cdouble}(0)
+    check(x.ctx, ccall((:bk_vec_nrminf, libbkhip[]), Cint, (Ptr{Cvoid}, Csize_t, Ptr{Cdouble}, Ref{Cdouble}), x.ctx.h, x.n, x.p, r))
+    r[]
+end
+LinearAlgebra.dot(x::HipVec, y::HipVec) = VI.inner(x, y)
+# the two internal helpers the engine calls on state vectors (src/BorderedArrays.jl:30-47)
+BK._copy(v::HipVec) = _copy!(similar(v), v)
+BK._copyto!(dst::HipVec, src::HipVec) = _copy!(dst, src)
+
+# ------------------------------------------------------------------------------------------------ problems
+mutable struct HipProblem
+    ctx::HipContext
+    h::Ptr{Cvoid}
+    nparams::Int
+end
+function HipProblem(ctx::HipContext, pde::Cint, dims::NTuple{N, Int}, ls::NTuple{N, Float64}) where {N}
+    n = ntuple(i -> Cint(i <= N ? dims[i] : 1), 3)
+    l = ntuple(i -> Cdouble(i <= N ? ls[i] : 1.0), 3)
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    d = Ref(ProblemDesc(pde, Cint(N), n, l))
+    check(ctx, ccall((:bk_problem_create, libbkhip[]), Cint, (Ptr{Cvoid}, Ref{ProblemDesc}, Ref{Ptr{Cvoid}}), ctx.h, d, r), "bk_problem_create")
+    p = HipProblem(ctx, r[], pde == BK_PDE_CGL2D ? 6 : 2)
+    finalizer(x -> ccall((:bk_problem_destroy, libbkhip[]), Cint, (Ptr{Cvoid},), x.h), p)
+end
+"Swift-Hohenberg 2-D/3-D (examples/SH3d.jl:16-53): params = (l, nu)"
+SwiftHohenberg(ctx, dims, ls) = HipProblem(ctx, BK_PDE_SH, dims, ls)
+
+# F(u, p) with p a NamedTuple whose fields are in the kernel's parameter order, e.g. (l = 0.1, ν = 1.2)
+function residual(prob::HipProblem, u::HipVec, par)
+    out = similar(u)
+    pv = Cdouble[Float64(x) for x in Tuple(par)][1:prob.nparams]
+    check(prob.ctx, ccall((:bk_residual, libbkhip[]), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cdouble}), prob.h, u.p, pv, length(pv), out.p), "bk_residual")
+    out
+end
+
+mutable struct HipJacobian
+    prob::HipProblem
+    h::Ptr{Cvoid}
+    x::HipVec            # kept alive: the handle references it, like `dx -> dF_sh(x, p, dx)` captures x
+end
+function jacobian(prob::HipProblem, u::HipVec, par)
+    pv = Cdouble[Float64(x) for x in Tuple(par)][1:prob.nparams]
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    check(prob.ctx, ccall((:bk_jacobian, libbkhip[]), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ref{Ptr{Cvoid}}), prob.h, u.p, pv, length(pv), r), "bk_jacobian")
+    J = HipJacobian(prob, r[], u)
+    finalizer(j -> ccall((:bk_op_destroy, libbkhip[]), Cint, (Ptr{Cvoid},), j.h), J)
+end
+# apply(J, dx): src/Utils.jl:191-195 dispatches to J(dx) for callables
+function (J::HipJacobian)(dx::HipVec)
+    out = similar(dx)
+    check(J.prob.ctx, ccall((:bk_op_apply, libbkhip[]), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Cdouble, Ptr{Cdouble}), J.h, dx.p, 0.0, 1.0, out.p), "bk_op_apply")
+    out
+end
+
+"BifurcationProblem whose F and J live on the device.  `par` must list the kernel parameters first."
+bifurcation_problem(prob::HipProblem, u0::HipVec, par, lens; kwargs...) =
+    BK.BifurcationProblem((u, p) -> residual(prob, u, p), u0, par, lens; J = (u, p) -> jacobian(prob, u, p), kwargs...)
+
+mutable struct HipDCTPreconditioner     # Pl = (L1 + shift I)^-1: cholesky(L1) of SH3d.jl:88 / lu(L1 + I) of SH2d-fronts.jl:121
+    prob::HipProblem
+    h::Ptr{Cvoid}
+end
+function HipDCTPreconditioner(prob::HipProblem, shift::Real = 0.0)
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    check(prob.ctx, ccall((:bk_precond_sh_create, libbkhip[]), Cint, (Ptr{Cvoid}, Cdouble, Ref{Ptr{Cvoid}}), prob.h, shift, r), "bk_precond_sh_create")
+    P = HipDCTPreconditioner(prob, r[])
+    finalizer(x -> ccall((:bk_precond_destroy, libbkhip[]), Cint, (Ptr{Cvoid},), x.h), P)
+end
+_plh(::Nothing) = C_NULL
+_plh(P::HipDCTPreconditioner) = P.h
+
+# ------------------------------------------------------------------------------------------------ linear solver
+"""
+    HipGMRES(; dim = 30, atol = 1e-12, rtol = 1e-12, maxiter = 100, Pl = nothing)
+
+Device-resident restarted GMRES with the fields and the semantics of `GMRESKrylovKit`
+(src/LinearSolver.jl:223-291): `ls(J, rhs; a₀, a₁) -> (x, success, numops)`.
+"""
+Base.@kwdef mutable struct HipGMRES{Tl} <: AbstractIterativeLinearSolver
+    dim::Int = 30
+    atol::Float64 = 1e-12
+    rtol::Float64 = 1e-12
+    maxiter::Int = 100
+    Pl::Tl = nothing
+end
+_opts(l::HipGMRES) = GmresOpts(Cint(0), l.dim, l.maxiter, l.atol, l.rtol)
+_num(a, default) = a isa Number ? Float64(a) : default          # VI.Zero() / VI.One() defaults of the engine
+
+function (l::HipGMRES)(J::HipJacobian, rhs::HipVec; a₀ = 0.0, a₁ = 1.0, kwargs...)
+    ctx = rhs.ctx
+    x = similar(rhs)
+    cv, it, rn = Ref{Cint}(0), Ref{Cint}(0), Ref{Cdouble}(0)
+    check(ctx, ccall((:bk_gmres, libbkhip[]), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Ref{GmresOpts}, Ptr{Cvoid}, Ref{Cint}, Ref{Cint}, Ref{Cdouble}),
+        ctx.h, J.h, rhs.p, x.p, _num(a₀, 0.0), _num(a₁, 1.0), Ref(_opts(l)), _plh(l.Pl), cv, it, rn), "bk_gmres")
+    return x, cv[] == 1, Int(it[])
+end
+# (ls)(J, rhs1, rhs2) keeps the default of src/LinearSolver.jl:15-19 (two calls of the method above).
+
+# ------------------------------------------------------------------------------------------------ bordered solvers
+"""
+    HipBorderingBLS(solver; tol = 1e-12, check_precision = true, k = 1)
+
+`BorderingBLS` (src/LinearBorderSolver.jl:59-166) as ONE library call per bordered solve.
+"""
+Base.@kwdef struct HipBorderingBLS{S <: Union{HipGMRES, Nothing}} <: AbstractBorderedLinearSolver
+    solver::S = nothing
+    tol::Float64 = 1e-12
+    check_precision::Bool = true
+    k::Int = 1
+end
+HipBorderingBLS(ls::HipGMRES) = HipBorderingBLS(solver = ls)
+BK.update_bls(lbs::HipBorderingBLS, ls) = HipBorderingBLS(ls, lbs.tol, lbs.check_precision, lbs.k)   # :490-493
+
+# dotp of the PALC call is NormalisedDot = dot/length (src/continuation/Palc.jl:1-6): pass it as `dotscale`.
+_dotscale(dotp, x) = dotp isa BK.NormalisedDot ? 1.0 / length(x) : 1.0
+
+function (lbs::HipBorderingBLS)(J::HipJacobian, dR::HipVec, dzu::HipVec, dzp::T, R::HipVec, n::T,
+                                ξu::Tξ = 1.0, ξp::Tξ = 1.0; shift = nothing, dotp = nothing, applyξu! = nothing) where {T, Tξ}
+    ctx = R.ctx
+    dX = similar(R)
+    dl, cv, it = Ref{Cdouble}(0), Ref{Cint}(0), zeros(Cint, 2)
+    bo = BorderingOpts(lbs.tol, lbs.check_precision, lbs.k)
+    check(ctx, ccall((:bk_bls_bordering, libbkhip[]), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Cdouble, Cdouble, Cdouble, Cint, Cdouble, Cdouble,
+         Ref{BorderingOpts}, Ref{GmresOpts}, Ptr{Cvoid}, Ptr{Cdouble}, Ref{Cdouble}, Ref{Cint}, Ptr{Cint}),
+        ctx.h, J.h, dR.p, dzu.p, dzp, R.p, n, ξu, ξp, isnothing(shift) ? 0 : 1, isnothing(shift) ? 0.0 : shift, _dotscale(dotp, R),
+        Ref(bo), Ref(_opts(lbs.solver)), _plh(lbs.solver.Pl), dX.p, dl, cv, it), "bk_bls_bordering")
+    return dX, dl[], cv[] == 1, (Int(it[1]), Int(it[2]))
+end
+
+"`MatrixFreeBLS` (src/LinearBorderSolver.jl:404-437): one GMRES on the (N+1) operator, border scalar on the host."
+struct HipMatrixFreeBLS{S <: Union{HipGMRES, Nothing}} <: AbstractBorderedLinearSolver
+    solver::S
+end
+HipMatrixFreeBLS() = HipMatrixFreeBLS(nothing)
+BK.update_bls(::HipMatrixFreeBLS, ls) = HipMatrixFreeBLS(ls)
+function (lbs::HipMatrixFreeBLS)(J::HipJacobian, dR::HipVec, dzu::HipVec, dzp::T, R::HipVec, n::T,
+                                 ξu::Tξ = 1.0, ξp::Tξ = 1.0; shift = nothing, dotp = nothing, applyξu! = nothing) where {T, Tξ}
+    ctx = R.ctx
+    dX = similar(R)
+    dl, cv, it = Ref{Cdouble}(0), Ref{Cint}(0), Ref{Cint}(0)
+    check(ctx, ccall((:bk_bls_matrixfree, libbkhip[]), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Cdouble, Cdouble, Cdouble, Cint, Cdouble, Cdouble,
+         Ref{GmresOpts}, Ptr{Cdouble}, Ref{Cdouble}, Ref{Cint}, Ref{Cint}),
+        ctx.h, J.h, dR.p, dzu.p, dzp, R.p, n, ξu, ξp, isnothing(shift) ? 0 : 1, isnothing(shift) ? 0.0 : shift, _dotscale(dotp, R),
+        Ref(_opts(lbs.solver)), dX.p, dl, cv, it), "bk_bls_matrixfree")
+    return dX, dl[], cv[] == 1, Int(it[])
+end
+
+# ------------------------------------------------------------------------------------------------ eigensolver
+"""
+    HipShiftInvert(σ, ls; tol = 1e-12, maxiter = 20, hermitian = false)
+
+`ShiftInvert` (src/EigSolver.jl:246-266) with a Krylov-Schur outer iteration; the `SH3dEig` of
+examples/SH3d.jl:96-113.  Returns `(vals::Vector{ComplexF64}, vecs::Vector{HipVec}, converged, numops)`,
+eigenvalues sorted by decreasing real part.
+"""
+Base.@kwdef struct HipShiftInvert <: AbstractEigenSolver
+    σ::Float64
+    ls::HipGMRES
+    tol::Float64 = 1e-12
+    maxiter::Int = 20
+    hermitian::Bool = false
+    seed::UInt64 = 1234
+end
+BK.geteigenvector(::HipShiftInvert, vecs, n::Union{Int, AbstractVector{Int64}}) = vecs[n]     # like SH3dEig, SH3d.jl:101
+
+function (e::HipShiftInvert)(J::HipJacobian, nev::Int; kwargs...)
+    ctx = J.prob.ctx
+    kd = min(max(30, nev + 30), 63)                                   # SH3d.jl:109
+    re, im = zeros(Cdouble, nev), zeros(Cdouble, nev)
+    n = J.x.n
+    ld = cld(n, 32) * 32
+    buf = HipVec(ctx, ld * nev)
+    nconv, nops = Ref{Cint}(0), Ref{Cint}(0)
+    eo = EigOpts(e.σ, kd, e.maxiter, e.tol, e.hermitian, e.seed)
+    check(ctx, ccall((:bk_eig_shiftinvert, libbkhip[]), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ref{EigOpts}, Ref{GmresOpts}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+         Csize_t, Ref{Cint}, Ref{Cint}),
+        ctx.h, J.h, nev, Ref(eo), Ref(_opts(e.ls)), _plh(e.ls.Pl), re, im, buf.p, C_NULL, ld, nconv, nops), "bk_eig_shiftinvert")
+    vecs = [(v = HipVec(ctx, n); ccall((:bk_vec_copy, libbkhip[]), Cint, (Ptr{Cvoid}, Csize_t, Ptr{Cdouble}, Ptr{Cdouble}),
+                                       ctx.h, n, buf.p + (i - 1) * ld * sizeof(Cdouble), v.p); v) for i in 1:nev]
+    return Complex.(re, im), vecs, nconv[] >= nev, Int(nops[])
+end
+
+# ------------------------------------------------------------------------------------------------ usage
+# ctx  = HipContext(0)
+# prob = SwiftHohenberg(ctx, (512, 512, 512), (16π, 16π, 16π))
+# Pl   = HipDCTPreconditioner(prob, 1.0)
+# ls   = HipGMRES(rtol = 1e-9, maxiter = 150, Pl = Pl)                         # examples/SH3d.jl:93
+# bp   = bifurcation_problem(prob, HipVec(ctx, vec(sol0)), (l = 0.1, ν = 1.2), (@optic _.l); issymmetric = true)
+# optn = NewtonPar(tol = 1e-8, max_iterations = 20, linsolver = ls, eigsolver = HipShiftInvert(σ = 0.1, ls = ls, hermitian = true))
+# br   = continuation(bp, PALC(tangent = Bordered(), bls = HipBorderingBLS(solver = ls, check_precision = false)),
+#                     ContinuationPar(dsmax = 0.005, ds = -0.001, newton_options = optn, nev = 15); normC = norminf)
+
+end # module

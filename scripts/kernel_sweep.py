@@ -78,6 +78,22 @@ if "krylov" in what:
         report("multiaxpy", timeit(f, reps=3, warm=1), 8.0 * N * (k + 2), k=k)
     del V
 
+if "axpy" in what:
+    ld = (N + 31) // 32 * 32
+    V = torch.rand(ld * 16, dtype=torch.float64, device="cuda", generator=g)
+    for k in (4, 16):
+        cc = (C.c_double * k)(*([0.01] * k))
+        f = lambda: ctx.check(ctx.lib.bk_krylov_multiaxpy(ctx.h, N, C.c_void_p(V.data_ptr()), ld, k, cc, C.c_void_p(v.t.data_ptr()),
+                                                          1.0, C.c_void_p(out.t.data_ptr()), None))
+        for nt in (0, 1):
+            for blocks in (1024, 2048, 4096, 8192, 16384, 65536):
+                ctx.set_option("axpy_nt", nt)
+                ctx.set_option("axpy_blocks", blocks)
+                report("multiaxpy", timeit(f, reps=3, warm=1), 8.0 * N * (k + 2), k=k, nt=nt, blocks=blocks)
+    ctx.set_option("axpy_nt", 0)
+    ctx.set_option("axpy_blocks", 4096)
+    del V
+
 if "precond" in what:
     P = hip.DCTPreconditioner(prob, 1.0)
     for fft in (0, 1):

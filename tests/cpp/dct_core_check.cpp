@@ -1,13 +1,14 @@
 // Host replay of the fast-DCT phases of bifurcationkit.jl_amd/csrc/dct_core.h for ONE pair of lines.
-// stdin: "inverse N" then N values of line a, N values of line b.  stdout: the two transformed lines.
+// stdin: "mode N" (mode 0/1 = forward/inverse radix-2, 2/3 = the same with grouped radix-8 stages) then N values of line a, N values of line b.  stdout: the two transformed lines.
 #include <cmath>
 #include <cstdio>
 #include <vector>
 #include "../../bifurcationkit.jl_amd/csrc/dct_core.h"
 using namespace bk::dctc;
 int main() {
-    int inverse, N;
+    int inverse, N, grouped = 0;
     if (scanf("%d %d", &inverse, &N) != 2) return 2;
+    if (inverse >= 2) { grouped = 1; inverse -= 2; }     // modes 2/3: radix-8 grouped stages
     int bits = 0;
     while ((1 << bits) < N) ++bits;
     std::vector<double> a(N), b(N);
@@ -19,6 +20,17 @@ int main() {
     const double s0 = std::sqrt(1.0 / N), s2 = std::sqrt(2.0 / N);
     if (!inverse) {
         for (int n = 0; n < N; ++n) { const int p = sample_slot(n, N, bits); z[p].x = a[n]; z[p].y = b[n]; }
+        if (inverse == 0 && grouped) {
+            for (int lh = 0; lh < bits;) {
+                const int R = bits - lh >= 3 ? 3 : bits - lh;
+                for (int g = 0; g < (N >> R); ++g) {
+                    if (R == 3) dit_group<3>(z.data(), bits, lh, g, tw.data());
+                    else if (R == 2) dit_group<2>(z.data(), bits, lh, g, tw.data());
+                    else dit_group<1>(z.data(), bits, lh, g, tw.data());
+                }
+                lh += R;
+            }
+        } else
         for (int lh = 0; lh < bits; ++lh)
             for (int j = 0; j < N / 2; ++j) dit_butterfly(z.data(), bits, lh, j, tw.data());
         for (int k = 0; k <= N / 2; ++k) fwd_post(z.data(), N, k, ew.data(), s0, s2);
@@ -26,6 +38,18 @@ int main() {
     } else {
         for (int k = 0; k < N; ++k) { z[swz(k)].x = a[k]; z[swz(k)].y = b[k]; }
         for (int k = 0; k <= N / 2; ++k) inv_pre(z.data(), N, k, ew.data(), s0, s2);
+        if (grouped) {
+            for (int top = bits; top > 0;) {
+                const int R = top >= 3 ? 3 : top;
+                const int lh = top - R;
+                for (int g = 0; g < (N >> R); ++g) {
+                    if (R == 3) dif_group_inv<3>(z.data(), bits, lh, g, tw.data());
+                    else if (R == 2) dif_group_inv<2>(z.data(), bits, lh, g, tw.data());
+                    else dif_group_inv<1>(z.data(), bits, lh, g, tw.data());
+                }
+                top -= R;
+            }
+        } else
         for (int lh = bits - 1; lh >= 0; --lh)
             for (int j = 0; j < N / 2; ++j) dif_butterfly_inv(z.data(), bits, lh, j, tw.data());
         for (int j = 0; j < N; ++j) { const int p = sample_slot(j, N, bits); printf("%.17g %.17g\n", z[p].x, z[p].y); }

@@ -1,0 +1,178 @@
+"""Worker for the 2-rank tests (spawned by tests/test_distributed.py with RANK / WORLD_SIZE / MASTER_* set).
+
+mode "cpu": gloo on CPU -- the slab decomposition of the ORACLE (2-plane halo exchange for the fused (I+Lap)^2
+            stencil, batched dot all-reduce, transposed DCT preconditioner) reproduces the serial oracle, and the
+            host-communicator callbacks move the right bytes.
+mode "gpu": both ranks share cuda:0 through the host-staged test communicator and run the HIP path (JVP, DCT
+            preconditioner, GMRES, bordered solve, eigensolver); results must equal the 1-rank HIP run.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from bk_amd import hostcomm  # noqa: E402
+from oracle import operators  # noqa: E402
+
+
+def gather_slabs(local, rank, world):
+    parts = [None] * world
+    dist.all_gather_object(parts, local)
+    return np.concatenate(parts)
+
+
+def exchange(blocks, rank, world):
+    """all-to-all of Python objects (test-only): blocks[d] goes to rank d; returns what this rank received."""
+    recv = [None] * world
+    for d in range(world):
+        lst = [None] * world
+        dist.all_gather_object(lst, blocks[d])
+        if d == rank:
+            recv = lst
+    return recv
+
+
+def main_cpu(rank, world):
+    # ---- callback plumbing
+    buf = np.array([rank + 1.0, 10.0 * (rank + 1)], dtype=np.float64)
+    p = buf.ctypes.data_as(C.POINTER(C.c_double))
+    assert hostcomm.allreduce(None, p, 2, 0) == 0
+    assert np.allclose(buf, [sum(range(1, world + 1)), 10.0 * sum(range(1, world + 1))])
+    buf[:] = rank
+    assert hostcomm.allreduce(None, p, 2, 1) == 0 and np.all(buf == world - 1)
+    s = np.full(5, float(rank))
+    r = np.zeros(5)
+    peer = 1 - rank
+    assert hostcomm.sendrecv(None, s.ctypes.data_as(C.POINTER(C.c_double)), 5, peer,
+                             r.ctypes.data_as(C.POINTER(C.c_double)), 5, peer) == 0
+    assert np.all(r == peer)
+    # ---- slab-decomposed oracle JVP == serial oracle
+    dims, ls = (9, 8, 11), (2.0, 1.5, 2.5)
+    sh = operators.SwiftHohenberg(dims, ls)
+    rng = np.random.default_rng(0)
+    u, v = rng.standard_normal(sh.N), rng.standard_normal(sh.N)
+    ref = sh.dF(u, 0.1, 1.2, v)
+    nx, ny, nz = dims
+    plane = nx * ny
+    lo, hi = hostcomm.slab(nz, rank, world)
+    vl = v[lo * plane:hi * plane].copy()
+    # 2-plane halos from the neighbours (the fused (I+Lap)^2 stencil reaches 2 planes); the mirror rule applies
+    # only at the physical boundaries
+    halo_lo = np.zeros(2 * plane)
+    halo_hi = np.zeros(2 * plane)
+    reqs = []
+    if rank > 0:
+        reqs += [dist.isend(torch.from_numpy(vl[:2 * plane].copy()), rank - 1),
+                 dist.irecv(torch.from_numpy(halo_lo), rank - 1)]
+    if rank < world - 1:
+        reqs += [dist.isend(torch.from_numpy(vl[-2 * plane:].copy()), rank + 1),
+                 dist.irecv(torch.from_numpy(halo_hi), rank + 1)]
+    for q in reqs:
+        q.wait()
+    ext_lo = lo - 2 if rank > 0 else lo
+    ext_hi = hi + 2 if rank < world - 1 else hi
+    ext = np.concatenate(([halo_lo] if rank > 0 else []) + [vl] + ([halo_hi] if rank < world - 1 else []))
+    assert np.array_equal(ext, v[ext_lo * plane:ext_hi * plane])
+    # rows of the global operator restricted to my planes only touch columns inside the extended slab
+    rows = slice(lo * plane, hi * plane)
+    Jrows = sh.J(u, 0.1, 1.2)[rows]
+    cols = Jrows.nonzero()[1]
+    assert cols.min() >= ext_lo * plane and cols.max() < ext_hi * plane
+    mine = Jrows[:, ext_lo * plane:ext_hi * plane] @ ext
+    assert np.allclose(mine, ref[rows], rtol=1e-13, atol=1e-11)
+    # ---- batched dot all-reduce: [V'w ; w'w] summed over ranks == serial
+    V = rng.standard_normal((4, sh.N))
+    loc = np.concatenate([V[:, rows] @ v[rows], [v[rows] @ v[rows]]])
+    t = torch.from_numpy(loc.copy())
+    dist.all_reduce(t)
+    assert np.allclose(t.numpy(), np.concatenate([V @ v, [v @ v]]), rtol=1e-12)
+    # ---- transposed DCT preconditioner: x,y transforms on the z-slab, all-to-all to y-slabs, z transform there
+    import scipy.fft as sfft
+    refP = operators.dct_preconditioner(dims, ls, 1.0)(v)
+    a = sfft.dctn(vl.reshape(hi - lo, ny, nx), type=2, norm="ortho", axes=(1, 2))
+    ylo, yhi = hostcomm.slab(ny, rank, world)
+    send = [np.ascontiguousarray(a[:, slice(*hostcomm.slab(ny, d, world)), :]) for d in range(world)]
+    T = np.concatenate(exchange(send, rank, world), axis=0)                  # [nz][nyl][nx]
+    T = sfft.dct(T, type=2, norm="ortho", axis=0)
+    lam = [-(4.0 / (2.0 * l / n) ** 2) * np.sin(np.pi * np.arange(n) / (2.0 * n)) ** 2 for n, l in zip(dims, ls)]
+    sym = (1.0 + lam[2][:, None, None] + lam[1][None, ylo:yhi, None] + lam[0][None, None, :]) ** 2 + 1.0
+    T = sfft.idct(T / sym, type=2, norm="ortho", axis=0)
+    back = exchange([np.ascontiguousarray(T[slice(*hostcomm.slab(nz, d, world))]) for d in range(world)], rank, world)
+    a = sfft.idctn(np.concatenate(back, axis=1), type=2, norm="ortho", axes=(1, 2))     # [nzl][ny][nx]
+    assert np.allclose(a.reshape(-1), refP[rows], rtol=1e-11, atol=1e-12)
+    print(f"rank {rank}: cpu distributed checks OK", flush=True)
+
+
+def main_gpu(rank, world):
+    from bk_amd import hip
+    dims, ls = (16, 12, 20), (2.0, 1.5, 2.5)
+    N = int(np.prod(dims))
+    rng = np.random.default_rng(1)
+    u, v, r = 0.5 * rng.standard_normal(N), rng.standard_normal(N), rng.standard_normal(N)
+    ctx = hip.Context(0, hostcomm.comm_tuple())
+    prob = hip.SwiftHohenberg(ctx, dims, ls)
+    assert prob.slab == hostcomm.slab(dims[2], rank, world)
+    U, V, Rv = prob.vec(u), prob.vec(v), prob.vec(r)
+    out = {}
+    out["dot"] = U.inner(V)
+    out["nrminf"] = V.norminf()
+    out["F"] = gather_slabs(prob.residual(U, 0.1).numpy(), rank, world)
+    J = prob.jacobian(U, 0.1)
+    out["Jv"] = gather_slabs(J(V, 0.2, 0.8).numpy(), rank, world)
+    ctx.set_option("sh_kernel", 0)
+    out["Jv_gather"] = gather_slabs(J(V, 0.2, 0.8).numpy(), rank, world)
+    ctx.set_option("sh_kernel", 1)
+    P = hip.DCTPreconditioner(prob, 1.0)
+    out["Pv"] = gather_slabs(P.ldiv(V).numpy(), rank, world)
+    lsol = hip.GMRESKrylovKit(dim=30, rtol=1e-10, atol=1e-13, maxiter=100, Pl=P)
+    x, ok, it = lsol(J, Rv)
+    out["x"], out["ok"], out["it"] = gather_slabs(x.numpy(), rank, world), ok, it
+    bls = hip.BorderingBLS(lsol, check_precision=False)
+    dX, dl, okb, itb = bls(J, V, U, 0.3, Rv, 0.7, 0.5, 0.5, dotscale=1.0 / N)
+    out["dX"], out["dl"] = gather_slabs(dX.numpy(), rank, world), dl
+    eig = hip.ShiftInvert(0.1, lsol, tol=1e-9, maxiter=10, hermitian=True, save_vectors=False)
+    vals, _, cv, nops = eig(J, 4)
+    out["eig"] = vals.real
+    ctx.close()
+    if rank == 0:
+        c1 = hip.Context(0)
+        p1 = hip.SwiftHohenberg(c1, dims, ls)
+        U1, V1, R1 = p1.vec(u), p1.vec(v), p1.vec(r)
+        assert np.isclose(out["dot"], U1.inner(V1), rtol=1e-13)
+        assert out["nrminf"] == V1.norminf()
+        assert np.allclose(out["F"], p1.residual(U1, 0.1).numpy(), rtol=1e-14, atol=1e-12)
+        J1 = p1.jacobian(U1, 0.1)
+        ref = J1(V1, 0.2, 0.8).numpy()
+        assert np.allclose(out["Jv"], ref, rtol=1e-14, atol=1e-11), np.abs(out["Jv"] - ref).max()
+        assert np.allclose(out["Jv_gather"], ref, rtol=1e-13, atol=1e-10)
+        P1 = hip.DCTPreconditioner(p1, 1.0)
+        assert np.allclose(out["Pv"], P1.ldiv(V1).numpy(), rtol=1e-12, atol=1e-14)
+        l1 = hip.GMRESKrylovKit(dim=30, rtol=1e-10, atol=1e-13, maxiter=100, Pl=P1)
+        x1, ok1, it1 = l1(J1, R1)
+        assert out["ok"] and ok1 and abs(out["it"] - it1) <= 1
+        assert np.allclose(out["x"], x1.numpy(), rtol=1e-7, atol=1e-9 * np.abs(x1.numpy()).max())
+        dX1, dl1, _, _ = hip.BorderingBLS(l1, check_precision=False)(J1, V1, U1, 0.3, R1, 0.7, 0.5, 0.5,
+                                                                     dotscale=1.0 / N)
+        assert np.isclose(out["dl"], dl1, rtol=1e-7)
+        assert np.allclose(out["dX"], dX1.numpy(), rtol=1e-6, atol=1e-8 * np.abs(dX1.numpy()).max())
+        e1 = hip.ShiftInvert(0.1, l1, tol=1e-9, maxiter=10, hermitian=True, save_vectors=False)(J1, 4)[0].real
+        assert np.allclose(out["eig"], e1, rtol=1e-7, atol=1e-8), (out["eig"], e1)
+        c1.close()
+    print(f"rank {rank}: gpu distributed checks OK", flush=True)
+
+
+if __name__ == "__main__":
+    mode = sys.argv[1]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        (main_cpu if mode == "cpu" else main_gpu)(rank, world)
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,49 @@
+"""Two-rank tests of the distributed path.  CPU (gloo): decomposition algorithm + communicator callbacks.
+GPU: both ranks on cuda:0 through the host-staged test communicator vs the 1-rank HIP result."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(mode, world=2, timeout=600):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   PYTHONPATH=ROOT, OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), mode], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
+        assert "checks OK" in o, o[-2000:]
+
+
+def test_two_rank_decomposition_gloo_cpu():
+    _run("cpu")
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_one_gpu_host_communicator():
+    _run("gpu")

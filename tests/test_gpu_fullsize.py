@@ -1,0 +1,116 @@
+"""GPU tests at BASELINE.json's FULL size (SH3d 512^3, 1 GiB vectors) through size-independent properties:
+symmetry and linearity of the Jacobian, the preconditioner round trip (L1 + I) Pl^-1 = I, determinism of the
+reductions, and the tiling property -- the reference cell's solution reflected to 16^3 cells is an exact discrete
+solution, so the 512^3 PALC corrector must reproduce the CPU oracle's ONE-CELL corrector (residual history, p)."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+N1 = int(os.environ.get("BK_FULLSIZE", "512"))
+NC = 32
+
+
+@pytest.fixture(scope="module")
+def big(ctx):
+    from bk_amd import hip
+    lx = math.pi * N1 / NC
+    prob = hip.SwiftHohenberg(ctx, (N1,) * 3, (lx,) * 3, l=0.1, nu=1.2)
+    return prob
+
+
+def _rand(ctx, prob, seed):
+    import torch
+    from bk_amd import hip
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return hip.HipVec(ctx, torch.rand(prob.nlocal, dtype=torch.float64, device="cuda", generator=g) - 0.5)
+
+
+def test_fullsize_jacobian_symmetric_linear_deterministic(ctx, big):
+    u, v, w = (_rand(ctx, big, s) for s in (1, 2, 3))
+    J = big.jacobian(u, 0.1)
+    Jv, Jw = J(v), J(w)
+    a, b = Jv.inner(w), v.inner(Jw)
+    assert abs(a - b) <= 1e-10 * max(abs(a), abs(b), 1.0), (a, b)          # issymmetric, SH3d.jl:123
+    lhs = J(v.copy().add_(w, -0.7, 2.0))
+    rhs = Jv.copy().add_(Jw, -0.7, 2.0)
+    assert lhs.add_(rhs, -1.0).norminf() <= 1e-9 * rhs.norminf()
+    assert Jv.inner(w) == Jv.inner(w) and Jv.norm() == Jv.norm()           # bitwise reproducible reductions
+    # both kernel variants agree at full size
+    ctx.set_option("sh_kernel", 0)
+    try:
+        Jv0 = J(v)
+    finally:
+        ctx.set_option("sh_kernel", 1)
+    assert Jv0.add_(Jv, -1.0).norminf() <= 1e-11 * Jv.norminf()
+
+
+def test_fullsize_preconditioner_roundtrip(ctx, big):
+    from bk_amd import hip
+    import torch
+    v = _rand(ctx, big, 4)
+    zero = hip.HipVec(ctx, torch.zeros(big.nlocal, dtype=torch.float64, device="cuda"))
+    prob0 = hip.SwiftHohenberg(ctx, big.dims, big.ls, l=0.0, nu=0.0)
+    J0 = prob0.jacobian(zero, 0.0)                       # J = -L1 at u = 0, l = 0
+    Mv = J0(v, 1.0, -1.0)                                # (I + L1) v
+    P = hip.DCTPreconditioner(big, 1.0)
+    back = P.ldiv(Mv)
+    assert back.add_(v, -1.0).norminf() <= 1e-10 * v.norminf()
+    # and the other way round: (I + L1) Pl^-1 v = v
+    Pv = P.ldiv(v)
+    again = J0(Pv, 1.0, -1.0)
+    assert again.add_(v, -1.0).norminf() <= 1e-9 * v.norminf()
+
+
+def test_fullsize_tiled_corrector_matches_cpu_oracle_cell(ctx, big):
+    import torch
+    import bench
+    from bk_amd import hip
+    from oracle import bordered, krylov, operators, palc
+    ds, theta, shift = -0.001, 0.5, 1.0
+    # CPU oracle on the one cell
+    cdims, cls_ = (NC,) * 3, (math.pi,) * 3
+    shc = operators.SwiftHohenberg(cdims, cls_)
+    Plc = operators.dct_preconditioner(cdims, cls_, shift)
+    ols = lambda J, r, a0=0.0, a1=1.0: krylov.gmres_krylovkit(J, r, a0, a1, krylovdim=30, maxiter=150, rtol=1e-9,
+                                                               atol=1e-12, Pl=Plc)[:3]
+    pc = palc.Problem(lambda x, p: shc.F(x, p, 1.2), lambda x, p: (lambda dx: shc.dF(x, p, 1.2, dx)))
+    c0 = palc.newton(pc, shc.guess(), 0.1, ols, tol=1e-10, max_iterations=40, normN=palc.norminf)
+    c1 = palc.newton(pc, c0["u"], 0.1 + ds / 150.0, ols, tol=1e-10, max_iterations=20, normN=palc.norminf)
+    assert c0["converged"] and c1["converged"]
+    z0, z1 = (c0["u"], 0.1), (c1["u"], 0.1 + ds / 150.0)
+    tau = palc.secant_tangent(z1, z0, ds, theta)
+    zp = palc.add_tangent(z0, tau, ds)
+    obls = lambda *a, **k: bordered.bordering_bls(ols, *a, check_precision=False, **k)
+    so = palc.newton_palc(pc, z0, tau, zp, ds, theta, obls, tol=1e-9, max_iterations=15, normN=palc.norminf)
+    assert so["converged"]
+    # the same points tiled to N1^3 on the device
+    dev = ctx.torch_device
+    tile = lambda a: hip.HipVec(ctx, bench.tile_cell(torch.from_numpy(a).to(dev), NC, N1, big.slab, dev), big.nglobal)
+    U0, U1 = tile(c0["u"]), tile(c1["u"])
+    assert big.residual(U0, 0.1).norminf() <= 1e-9               # exact discrete solution of the big problem
+    B = hip.BorderedArray
+    Z0, Z1 = B(U0, z0[1]), B(U1, z1[1])
+    T = Z1.copy().add_(Z0, -1.0)
+    nrm = math.sqrt(T.u.inner(T.u) / big.nglobal * theta + T.p * T.p * (1 - theta))
+    T.scale_(math.copysign(1.0, ds) / nrm)
+    assert abs(T.p - tau[1]) <= 1e-9 * abs(tau[1])
+    ZP = Z0.copy().add_(T, ds)
+    P = hip.DCTPreconditioner(big, shift)
+    ls = hip.GMRESKrylovKit(dim=30, rtol=1e-9, atol=1e-12, maxiter=150, Pl=P)
+    sg = hip.newton_palc_native(big, Z0, T, ZP, ds, theta, hip.BorderingBLS(ls, check_precision=False), tol=1e-9,
+                                max_iterations=15, p_min=-0.1, p_max=0.15, norm_inf=True)
+    assert sg["converged"] and sg["itnewton"] == so["itnewton"]
+    r0 = so["residuals"][0]
+    assert abs(sg["residuals"][0] - r0) <= 1e-10 * r0, (sg["residuals"], so["residuals"])   # 1e-10 relative
+    assert abs(sg["u"].p - so["p"]) <= 1e-9
+    # the corrected big state is the tiling of the corrected cell state
+    diff = sg["u"].u.copy().add_(tile(so["u"]), -1.0).norminf()
+    assert diff <= 1e-7, diff
