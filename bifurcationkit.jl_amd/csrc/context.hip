@@ -229,12 +229,10 @@ int comm_alltoallv(bk_ctx* ctx, const double* sendbuf, const size_t* scount, con
 static int ctx_init_common(bk_ctx* ctx, int device, void* stream) {
     ctx->device = device;
     BK_HIP(ctx, hipSetDevice(device));
-    if (stream) {
-        ctx->stream = (hipStream_t)stream;
-    } else {
-        BK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-        ctx->own_stream = true;
-    }
+    // NULL = the device's default (null) stream, so that work enqueued by the caller's runtime (PyTorch's default
+    // stream, Julia's AMDGPU default queue) is ordered with the library's kernels without explicit events.
+    ctx->stream = (hipStream_t)stream;
+    ctx->own_stream = false;
     BK_HIP(ctx, hipMalloc(&ctx->d_partials, sizeof(double) * kRedBlocks * (kMaxBasis + 2)));
     BK_HIP(ctx, hipMalloc(&ctx->d_red, sizeof(double) * kRedSlots));
     BK_HIP(ctx, hipHostMalloc(&ctx->h_red, sizeof(double) * kRedSlots, hipHostMallocDefault));

@@ -223,6 +223,26 @@ int dct_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out) {
     // the last forward pass applies the inverse symbol while storing when it runs on the fast path
     const int last = p->ndim - 1;
     const bool fused = use_fft && p->twid[last] != nullptr;
+    const bool roundtrip = fused && ctx->opt("dct_roundtrip", 1.0) != 0.0;
+    if (roundtrip) {
+        // forward on axes 0..last-1, ONE fused pass on the last axis (forward, symbol, inverse in LDS), inverse back
+        for (int a = 0; a < last; ++a) {
+            BK_TRY(axis_pass(a, 0, src, bufs[cur], 0));
+            src = bufs[cur];
+            cur ^= 1;
+        }
+        double* dst = (last == 0) ? out : bufs[cur];
+        BK_TRY(axis_pass(last, 0, src, dst, 2));
+        src = dst;
+        cur ^= 1;
+        for (int a = last - 1; a >= 0; --a) {
+            double* d2 = (a == 0) ? out : bufs[cur];
+            BK_TRY(axis_pass(a, 1, src, d2, 0));
+            src = d2;
+            cur ^= 1;
+        }
+        return 0;
+    }
     for (int a = 0; a < p->ndim; ++a) {
         BK_TRY(axis_pass(a, 0, src, bufs[cur], (a == last && fused) ? 1 : 0));
         src = bufs[cur];
@@ -319,13 +339,18 @@ static int dct_apply_dist(bk_ctx* ctx, DctPlan* p, const double* v, double* out)
     BK_HIP(ctx, hipGetLastError());
     // z pass on T = [nyl][nz][nx]: axis 1 of (n0 = nx, n1 = nz, n2 = nyl); symbol indices (i0, i1, i2) = (kx, kz, ky_local)
     const bool fused = use_fft && p->twid[2] != nullptr;
-    BK_TRY(pass(nx, nz, nyl, 1, 2, 0, a, b, fused ? 1 : 0, p->lam[0], p->lam[2], p->lam_yloc));
-    if (!fused) {
-        hipLaunchKernelGGL(spectral_scale_kernel, dim3((unsigned)((loc_y + 255) / 256)), dim3(256), 0, ctx->stream, nx, nz, nyl,
-                           p->lam[0], p->lam[2], p->lam_yloc, p->shift, b);
-        BK_HIP(ctx, hipGetLastError());
+    if (fused && ctx->opt("dct_roundtrip", 1.0) != 0.0) {
+        BK_TRY(pass(nx, nz, nyl, 1, 2, 0, a, b, 2, p->lam[0], p->lam[2], p->lam_yloc));   // forward, symbol, inverse in LDS
+        double* t = a; a = b; b = t;                       // result now in `a`, like the two-pass branch below
+    } else {
+        BK_TRY(pass(nx, nz, nyl, 1, 2, 0, a, b, fused ? 1 : 0, p->lam[0], p->lam[2], p->lam_yloc));
+        if (!fused) {
+            hipLaunchKernelGGL(spectral_scale_kernel, dim3((unsigned)((loc_y + 255) / 256)), dim3(256), 0, ctx->stream, nx, nz, nyl,
+                               p->lam[0], p->lam[2], p->lam_yloc, p->shift, b);
+            BK_HIP(ctx, hipGetLastError());
+        }
+        BK_TRY(pass(nx, nz, nyl, 1, 2, 1, b, a, 0, nullptr, nullptr, nullptr));
     }
-    BK_TRY(pass(nx, nz, nyl, 1, 2, 1, b, a, 0, nullptr, nullptr, nullptr));
     // T -> blocks (b), all-to-all back (a), blocks -> z-slab (b)
     hipLaunchKernelGGL(blocks_tr_kernel, dim3((unsigned)((loc_y + 255) / 256)), dim3(256), 0, ctx->stream, nx, nyl, nz, p->R, zc, a, b, 1);
     BK_HIP(ctx, hipGetLastError());

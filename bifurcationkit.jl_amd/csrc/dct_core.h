@@ -31,9 +31,13 @@ struct c2 {
 BK_HD int swz(int i) { return i ^ (((i >> 4) ^ (i >> 8)) & 15); }
 
 BK_HD int bitrev(int i, int bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int)(__builtin_bitreverse32((unsigned)i) >> (32 - bits));
+#else
     unsigned v = (unsigned)i, r = 0;
     for (int b = 0; b < bits; ++b) { r = (r << 1) | (v & 1u); v >>= 1; }
     return (int)r;
+#endif
 }
 
 BK_HD int makhoul(int n, int N) { return (n & 1) ? N - 1 - (n >> 1) : (n >> 1); }

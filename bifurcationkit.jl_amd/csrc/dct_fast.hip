@@ -31,11 +31,13 @@ struct FftK {
     const double* lam1;
     const double* lam2;       // may be NULL (2-D)
     double shift;
-    int fuse_scale;
+    int fuse_scale;           // 1: multiply by the inverse symbol while storing the forward result
+    int roundtrip;            // 1: forward, inverse symbol, inverse -- all in LDS, one read + one write of the array
     int tiles_x;              // axis >= 1: number of LT-wide tiles along x
 };
 
-__global__ void __launch_bounds__(256) dct_fft_kernel(FftK P) {
+template <int NT>
+__global__ void __launch_bounds__(NT) dct_fft_kernel(FftK P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int N = P.N, bits = P.bits, LT = P.LT, half = N >> 1;
     const int npairs = LT >> 1;
@@ -66,18 +68,33 @@ __global__ void __launch_bounds__(256) dct_fft_kernel(FftK P) {
         else { base = x0 + (size_t)P.n0 * other; estride = (size_t)P.n0 * P.n1; ti1 = other; }
     }
 
-    for (int q = tid; q < half; q += 256) tw[q] = reinterpret_cast<const c2*>(P.twid)[q];
+    for (int q = tid; q < half; q += NT) tw[q] = reinterpret_cast<const c2*>(P.twid)[q];
 
     // ---- load (coalesced along the memory-contiguous direction), scatter into the FFT input order
     const int total = LT * N;
-    for (int w = tid; w < total; w += 256) {
-        int L, n;
-        if (P.axis == 0) { L = w >> bits; n = w & (N - 1); }
-        else if (P.ltbits >= 0) { L = w & (LT - 1); n = w >> P.ltbits; }
-        else { L = w % LT; n = w / LT; }
-        const double v = (L < nlines) ? P.in[base + (size_t)L * lstride + (size_t)n * estride] : 0.0;
-        const int slot = P.inverse ? dctc::swz(n) : dctc::sample_slot(n, N, bits);
-        smem[2 * ((size_t)(L >> 1) * pstride + slot) + (L & 1)] = v;
+    {
+        // U independent global loads per lane are issued before the first LDS write: with two workgroups per CU the
+        // memory-level parallelism has to come from each lane (a one-load-per-iteration loop ran at 1.5 TB/s)
+        constexpr int U = 8;
+        for (int w0 = tid; w0 < total; w0 += NT * U) {
+            double v[U];
+            int dst[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int w = w0 + u * NT;
+                int L, n;
+                if (P.axis == 0) { L = w >> bits; n = w & (N - 1); }
+                else if (P.ltbits >= 0) { L = w & (LT - 1); n = w >> P.ltbits; }
+                else { L = w % LT; n = w / LT; }
+                const bool inside = w < total;
+                v[u] = (inside && L < nlines) ? P.in[base + (size_t)L * lstride + (size_t)n * estride] : 0.0;
+                const int slot = (P.inverse && !P.roundtrip) ? dctc::swz(n) : dctc::sample_slot(n, N, bits);
+                dst[u] = inside ? 2 * ((L >> 1) * pstride + slot) + (L & 1) : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (dst[u] >= 0) smem[dst[u]] = v[u];
+        }
     }
     __syncthreads();
 
@@ -86,7 +103,7 @@ __global__ void __launch_bounds__(256) dct_fft_kernel(FftK P) {
     auto run_groups = [&](int lh, int R, bool inv) {
         const int gbits = bits - R;                            // log2(groups per pair)
         const int ngr = npairs << gbits;
-        for (int w = tid; w < ngr; w += 256) {
+        for (int w = tid; w < ngr; w += NT) {
             c2* zp = z + (size_t)(w >> gbits) * pstride;
             const int g = w & ((1 << gbits) - 1);
             if (!inv) {
@@ -104,7 +121,7 @@ __global__ void __launch_bounds__(256) dct_fft_kernel(FftK P) {
     // pre/post twiddle phase: work item (pair, k) for k in [0, N/2); k = 0 also handles k = N/2
     auto run_twiddle = [&](bool inv) {
         const int nw = npairs << (bits - 1);
-        for (int w = tid; w < nw; w += 256) {
+        for (int w = tid; w < nw; w += NT) {
             c2* zp = z + (size_t)(w >> (bits - 1)) * pstride;
             const int k = w & (half - 1);
             if (!inv) {
@@ -117,39 +134,60 @@ __global__ void __launch_bounds__(256) dct_fft_kernel(FftK P) {
         }
         __syncthreads();
     };
-    if (!P.inverse) {
+    auto symbol_inv = [&](int L, int n) -> double {
+        int i0, i1, i2;
+        if (P.axis == 0) { const size_t r = (size_t)ti1 + (size_t)ti2 * P.n1 + L; i0 = n; i1 = (int)(r % P.n1); i2 = (int)(r / P.n1); }
+        else if (P.axis == 1) { i0 = ti0 + L; i1 = n; i2 = ti2; }
+        else { i0 = ti0 + L; i1 = ti1; i2 = n; }
+        const double sy = 1.0 + P.lam0[i0] + P.lam1[i1] + (P.lam2 ? P.lam2[i2] : 0.0);
+        return 1.0 / (sy * sy + P.shift);
+    };
+    auto forward = [&]() {
         for (int lh = 0; lh < bits;) {
             const int R = bits - lh >= 3 ? 3 : bits - lh;
             run_groups(lh, R, false);
             lh += R;
         }
         run_twiddle(false);
-    } else {
+    };
+    auto inverse = [&]() {
         run_twiddle(true);
         for (int top = bits; top > 0;) {
             const int R = top >= 3 ? 3 : top;
             run_groups(top - R, R, true);
             top -= R;
         }
+    };
+    bool out_is_samples = P.inverse != 0;                     // which slot order the result sits in
+    if (P.roundtrip) {
+        forward();
+        for (int w = tid; w < total; w += NT) {              // spectrum sits in natural slots swz(k)
+            int L, n;
+            if (P.axis == 0) { L = w >> bits; n = w & (N - 1); }
+            else if (P.ltbits >= 0) { L = w & (LT - 1); n = w >> P.ltbits; }
+            else { L = w % LT; n = w / LT; }
+            if (L >= nlines) continue;
+            smem[2 * ((size_t)(L >> 1) * pstride + dctc::swz(n)) + (L & 1)] *= symbol_inv(L, n);
+        }
+        __syncthreads();
+        inverse();
+        out_is_samples = true;
+    } else if (!P.inverse) {
+        forward();
+    } else {
+        inverse();
     }
 
     // ---- store
-    for (int w = tid; w < total; w += 256) {
+    for (int w = tid; w < total; w += NT) {
         int L, n;
         if (P.axis == 0) { L = w >> bits; n = w & (N - 1); }
         else if (P.ltbits >= 0) { L = w & (LT - 1); n = w >> P.ltbits; }
         else { L = w % LT; n = w / LT; }
         if (L >= nlines) continue;
-        const int slot = P.inverse ? dctc::sample_slot(n, N, bits) : dctc::swz(n);
+        const int slot = out_is_samples ? dctc::sample_slot(n, N, bits) : dctc::swz(n);
         double v = smem[2 * ((size_t)(L >> 1) * pstride + slot) + (L & 1)];
-        if (P.fuse_scale) {
-            int i0, i1, i2;
-            if (P.axis == 0) { const size_t r = (size_t)ti1 + (size_t)ti2 * P.n1 + L; i0 = n; i1 = (int)(r % P.n1); i2 = (int)(r / P.n1); }
-            else if (P.axis == 1) { i0 = ti0 + L; i1 = n; i2 = ti2; }
-            else { i0 = ti0 + L; i1 = ti1; i2 = n; }
-            const double s = 1.0 + P.lam0[i0] + P.lam1[i1] + (P.lam2 ? P.lam2[i2] : 0.0);
-            v = v / (s * s + P.shift);
-        }
+        if (P.fuse_scale && !P.roundtrip) v *= symbol_inv(L, n);
         P.out[base + (size_t)L * lstride + (size_t)n * estride] = v;
     }
 }
@@ -182,7 +220,9 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
     while ((1 << P.bits) < P.N) ++P.bits;
     if (!dct_axis_fft_supported(P.N)) return set_error(ctx, "dct_axis_fft: N=%d unsupported", P.N);
     P.inverse = inverse; P.in = in; P.out = out; P.twid = twid;
-    P.lam0 = lam0; P.lam1 = lam1; P.lam2 = lam2; P.shift = shift; P.fuse_scale = fuse_scale;
+    P.lam0 = lam0; P.lam1 = lam1; P.lam2 = lam2; P.shift = shift;
+    P.fuse_scale = fuse_scale == 1 ? 1 : 0;
+    P.roundtrip = fuse_scale == 2 ? 1 : 0;
     const size_t rows = (size_t)n1 * n2;
     P.LT = choose_lt(P.N, axis, n0, rows);
     P.ltbits = -1;
@@ -198,11 +238,16 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
     const size_t lds = ((size_t)(P.LT / 2) * (P.N + 1) + (size_t)(P.N / 2)) * sizeof(c2);
     static bool attr_set = false;
     if (!attr_set) {
-        BK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dct_fft_kernel),
+        BK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dct_fft_kernel<256>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        BK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dct_fft_kernel<512>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(dct_fft_kernel, dim3(grid), dim3(256), lds, ctx->stream, P);
+    // 512 lanes per tile when the tile is big enough to feed them (two workgroups per CU => 16 wavefronts)
+    const int nt = (int)ctx->opt("dct_threads", (size_t)P.LT * P.N >= 4096 ? 512.0 : 256.0);
+    if (nt == 512) hipLaunchKernelGGL(dct_fft_kernel<512>, dim3(grid), dim3(512), lds, ctx->stream, P);
+    else hipLaunchKernelGGL(dct_fft_kernel<256>, dim3(grid), dim3(256), lds, ctx->stream, P);
     BK_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -39,7 +39,8 @@ typedef struct bk_precond bk_precond; /* a left preconditioner Pl (GMRESKrylovKi
 #define BK_UNIQUE_ID_BYTES 128
 
 int bk_version(void);
-/* Create a single-GPU context on `device`; `stream` is a hipStream_t (NULL = create one).       */
+/* Create a single-GPU context on `device`; `stream` is the hipStream_t all work is enqueued on
+ * (NULL = the default stream, which orders the library with the caller's own default-stream work). */
 int bk_ctx_create(bk_ctx** ctx, int device, void* stream);
 /* Multi-GPU context: one process per GPU, RCCL communicator built from a unique id that rank 0
  * obtained with bk_comm_unique_id() and broadcast out-of-band (torch.distributed / MPI).

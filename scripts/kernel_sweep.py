@@ -96,7 +96,15 @@ if "axpy" in what:
 
 if "precond" in what:
     P = hip.DCTPreconditioner(prob, 1.0)
-    for fft in (0, 1):
-        ctx.set_option("dct_fft", fft)
-        f = lambda: ctx.check(ctx.lib.bk_precond_apply(P.h, C.c_void_p(v.t.data_ptr()), C.c_void_p(out.t.data_ptr())))
-        report("dct_precond", timeit(f, reps=2, warm=1), 16.0 * N, fft=fft)
+    f = lambda: ctx.check(ctx.lib.bk_precond_apply(P.h, C.c_void_p(v.t.data_ptr()), C.c_void_p(out.t.data_ptr())))
+    ctx.set_option("dct_fft", 0)
+    report("dct_precond", timeit(f, reps=1, warm=1), 16.0 * N, fft=0)
+    ctx.set_option("dct_fft", 1)
+    for rt in (0, 1):
+        for nt in (256, 512):
+            ctx.set_option("dct_roundtrip", rt)
+            ctx.set_option("dct_threads", nt)
+            passes = 5 if rt else 6
+            t = timeit(f, reps=3, warm=1)
+            report("dct_precond", t, 16.0 * N, fft=1, roundtrip=rt, threads=nt, passes=passes,
+                   hbm_gbs_all_passes=16.0 * N * passes / t / 1e9)

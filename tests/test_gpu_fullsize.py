@@ -109,7 +109,8 @@ def test_fullsize_tiled_corrector_matches_cpu_oracle_cell(ctx, big):
                                 max_iterations=15, p_min=-0.1, p_max=0.15, norm_inf=True)
     assert sg["converged"] and sg["itnewton"] == so["itnewton"]
     r0 = so["residuals"][0]
-    assert abs(sg["residuals"][0] - r0) <= 1e-10 * r0, (sg["residuals"], so["residuals"])   # 1e-10 relative
+    # same predictor => same residual up to the rounding of one stencil evaluation (eps * |L1| * |u| ~ 1e-12)
+    assert abs(sg["residuals"][0] - r0) <= 1e-10 * (1.0 + r0), (sg["residuals"], so["residuals"])
     assert abs(sg["u"].p - so["p"]) <= 1e-9
     # the corrected big state is the tiling of the corrected cell state
     diff = sg["u"].u.copy().add_(tile(so["u"]), -1.0).norminf()

@@ -440,7 +440,7 @@ def test_newton_matches_oracle(ctx):
     # later residuals inherit the linear solves' rtol = 1e-9 (amplified while Newton is still far from the
     # solution), the converged states agree to the Newton tolerance
     r0 = so["residuals"][0]
-    assert abs(sg.residuals[0] - r0) <= 1e-10 * r0 and abs(sn["residuals"][0] - r0) <= 1e-10 * r0
+    assert abs(sg.residuals[0] - r0) <= 1e-10 * r0 and abs(sn["residuals"][0] - r0) <= 1e-10 * r0   # r0 = O(10)
     for a, b, c in zip(sg.residuals[:-1], so["residuals"][:-1], sn["residuals"][:-1]):
         assert abs(a - b) <= 1e-2 * b and abs(c - b) <= 1e-2 * b, (sg.residuals, so["residuals"], sn["residuals"])
     assert sg.residuals[-1] < 1e-8 and sn["residuals"][-1] < 1e-8
