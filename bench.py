@@ -214,19 +214,32 @@ def main():
         dt = float(t.item())
 
     kernels = {}
-    for name in ("jvp", "residual", "multidot", "multiaxpy", "precond", "blas1", "combine"):
+    for name in ("jvp", "residual", "multidot", "multiaxpy", "dct_pass", "blas1", "combine", "transpose", "alltoall",
+                 "halo"):
         e = ctx.prof_get(name)
         if e["calls"]:
             kernels[name] = dict(ms_total=e["ms"], calls=e["calls"], avg_ms=e["ms"] / e["calls"],
                                  alg_gb_per_call=e["bytes"] / e["calls"] / 1e9,
                                  gbs=e["bytes"] / max(e["ms"], 1e-9) / 1e6)
-    dom = max(kernels, key=lambda k: kernels[k]["ms_total"]) if kernels else None
+    compute = {k: v for k, v in kernels.items() if k not in ("alltoall", "halo")}
+    dom = max(compute, key=lambda k: compute[k]["ms_total"]) if compute else None
     roofline = None
     if dom:
         k = kernels[dom]
+        traffic, tsrc = None, None
+        pmc_file = os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")
+        pmc_name = {"dct_pass": "dct_fft_kernel<512>", "jvp": "sh_stream_kernel<true>", "blas1": "axpbyz_kernel<2>"}.get(dom)
+        if world == 1 and n == 512 and os.path.exists(pmc_file):
+            pmc = json.load(open(pmc_file))
+            if pmc_name in pmc:
+                traffic = pmc[pmc_name]["read_bytes"] + pmc[pmc_name]["write_bytes"]
+                tsrc = "profiles/r1_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 on gfx950)"
+            elif dom in ("multidot", "multiaxpy"):
+                traffic = k["alg_gb_per_call"] * 1e9          # measured == algorithmic for these kernels
+                tsrc = "profiles/r1_pmc_hbm_traffic.txt: FETCH/WRITE == algorithmic bytes for every multidot/multiaxpy launch"
         roofline = dict(kernel=dom, bound="hbm", achieved=k["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=k["gbs"] / HBM_PEAK_GBS, traffic=None, avg_ms=k["avg_ms"], calls=k["calls"],
-                        alg_bytes_per_launch=k["alg_gb_per_call"] * 1e9)
+                        frac=k["gbs"] / HBM_PEAK_GBS, traffic=traffic, traffic_source=tsrc, avg_ms=k["avg_ms"],
+                        calls=k["calls"], alg_bytes_per_launch=k["alg_gb_per_call"] * 1e9)
 
     if rank == 0:
         ms = dt / max(args.steps, 1) * 1e3

@@ -204,12 +204,12 @@ int dct_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out) {
     const int n0 = p->n[0], n1 = p->n[1], n2 = p->n[2];
     const unsigned grid = (unsigned)((p->total + 255) / 256);
     const bool use_fft = ctx->opt("dct_fft", 1.0) != 0.0;
-    ProfScope ps(ctx, "precond", 16.0 * p->total);
     // forward along each axis: v -> t1 -> t2 -> ... ; then scale; then inverse in reverse order
     const double* src = v;
     double* bufs[2] = {p->t1, p->t2};
     int cur = 0;
     auto axis_pass = [&](int a, int inverse, const double* in, double* o, int fuse) -> int {
+        ProfScope ps(ctx, "dct_pass", 16.0 * p->total);          // one read + one write of the array per axis pass
         if (use_fft && p->twid[a]) {
             return dct_axis_fft(ctx, n0, n1, n2, a, inverse, p->twid[a], in, o, p->lam[0], p->lam[1],
                                 p->ndim == 3 ? p->lam[2] : nullptr, p->shift, fuse);
@@ -313,12 +313,12 @@ static int dct_apply_dist(bk_ctx* ctx, DctPlan* p, const double* v, double* out)
     const int nzl = p->zhi - p->zlo, nyl = p->yhi - p->ylo;
     const size_t loc_z = (size_t)nx * ny * nzl, loc_y = (size_t)nx * nyl * nz;
     const bool use_fft = ctx->opt("dct_fft", 1.0) != 0.0;
-    ProfScope ps(ctx, "precond", 16.0 * loc_z);
     Cuts yc, zc;
     for (int r = 0; r <= p->R; ++r) { yc.c[r] = p->ycut[r]; zc.c[r] = p->zcut[r]; }
     auto pass = [&](int n0, int n1, int n2, int axis, int which, int inverse, const double* in, double* o, int fuse,
                     const double* l0, const double* l1, const double* l2) -> int {
         // `which` = index of the global axis being transformed (selects tables)
+        ProfScope ps(ctx, "dct_pass", 16.0 * (double)n0 * n1 * n2);
         if (use_fft && p->twid[which])
             return dct_axis_fft(ctx, n0, n1, n2, axis, inverse, p->twid[which], in, o, l0, l1, l2, p->shift, fuse);
         const size_t tot = (size_t)n0 * n1 * n2;
@@ -332,11 +332,14 @@ static int dct_apply_dist(bk_ctx* ctx, DctPlan* p, const double* v, double* out)
     BK_TRY(pass(nx, ny, nzl, 0, 0, 0, v, a, 0, nullptr, nullptr, nullptr));
     BK_TRY(pass(nx, ny, nzl, 1, 1, 0, a, b, 0, nullptr, nullptr, nullptr));
     // z-slab -> blocks (a), all-to-all (b), blocks -> T (a)
+    { ProfScope ps(ctx, "transpose", 16.0 * loc_z);
     hipLaunchKernelGGL(slab_blocks_kernel, dim3((unsigned)((loc_z + 255) / 256)), dim3(256), 0, ctx->stream, nx, ny, nzl, p->R, yc, b, a, 0);
-    BK_HIP(ctx, hipGetLastError());
-    BK_TRY(comm_alltoallv(ctx, a, p->cnt_f.data(), p->dsp_f.data(), b, p->cnt_b.data(), p->dsp_b.data()));
+    BK_HIP(ctx, hipGetLastError()); }
+    { ProfScope ps(ctx, "alltoall", 8.0 * loc_z);
+    BK_TRY(comm_alltoallv(ctx, a, p->cnt_f.data(), p->dsp_f.data(), b, p->cnt_b.data(), p->dsp_b.data())); }
+    { ProfScope ps(ctx, "transpose", 16.0 * loc_y);
     hipLaunchKernelGGL(blocks_tr_kernel, dim3((unsigned)((loc_y + 255) / 256)), dim3(256), 0, ctx->stream, nx, nyl, nz, p->R, zc, b, a, 0);
-    BK_HIP(ctx, hipGetLastError());
+    BK_HIP(ctx, hipGetLastError()); }
     // z pass on T = [nyl][nz][nx]: axis 1 of (n0 = nx, n1 = nz, n2 = nyl); symbol indices (i0, i1, i2) = (kx, kz, ky_local)
     const bool fused = use_fft && p->twid[2] != nullptr;
     if (fused && ctx->opt("dct_roundtrip", 1.0) != 0.0) {
@@ -352,11 +355,14 @@ static int dct_apply_dist(bk_ctx* ctx, DctPlan* p, const double* v, double* out)
         BK_TRY(pass(nx, nz, nyl, 1, 2, 1, b, a, 0, nullptr, nullptr, nullptr));
     }
     // T -> blocks (b), all-to-all back (a), blocks -> z-slab (b)
+    { ProfScope ps(ctx, "transpose", 16.0 * loc_y);
     hipLaunchKernelGGL(blocks_tr_kernel, dim3((unsigned)((loc_y + 255) / 256)), dim3(256), 0, ctx->stream, nx, nyl, nz, p->R, zc, a, b, 1);
-    BK_HIP(ctx, hipGetLastError());
-    BK_TRY(comm_alltoallv(ctx, b, p->cnt_b.data(), p->dsp_b.data(), a, p->cnt_f.data(), p->dsp_f.data()));
+    BK_HIP(ctx, hipGetLastError()); }
+    { ProfScope ps(ctx, "alltoall", 8.0 * loc_y);
+    BK_TRY(comm_alltoallv(ctx, b, p->cnt_b.data(), p->dsp_b.data(), a, p->cnt_f.data(), p->dsp_f.data())); }
+    { ProfScope ps(ctx, "transpose", 16.0 * loc_z);
     hipLaunchKernelGGL(slab_blocks_kernel, dim3((unsigned)((loc_z + 255) / 256)), dim3(256), 0, ctx->stream, nx, ny, nzl, p->R, yc, a, b, 1);
-    BK_HIP(ctx, hipGetLastError());
+    BK_HIP(ctx, hipGetLastError()); }
     // inverse y, x on the z-slab
     BK_TRY(pass(nx, ny, nzl, 1, 1, 1, b, a, 0, nullptr, nullptr, nullptr));
     BK_TRY(pass(nx, ny, nzl, 0, 0, 1, a, out, 0, nullptr, nullptr, nullptr));

@@ -18,7 +18,10 @@ int bk_problem::apply(int mode, const double* v, const double* u, const double* 
         a.a0 = a0; a.a1 = a1; a.mode = mode;
         a.v = v; a.u = u; a.out = out;
         a.halo_lo = halo_lo; a.halo_hi = halo_hi;
-        if (ctx->nranks > 1) BK_TRY(halo_exchange(ctx, v, plane, a.nz, 2, halo_lo, halo_hi));
+        if (ctx->nranks > 1) {
+            ProfScope ps(ctx, "halo", 32.0 * plane * 2);
+            BK_TRY(halo_exchange(ctx, v, plane, a.nz, 2, halo_lo, halo_hi));
+        }
         return sh_apply(ctx, a);
     }
     if (d.pde == BK_PDE_CGL2D) {

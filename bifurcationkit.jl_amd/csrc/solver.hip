@@ -171,7 +171,10 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, double bt, double* x, dou
     double bnorm = 0.0;
     BK_TRY(vo.nrm2(b, bt, &bnorm));
     double beta = bnorm;                       // x0 = 0  =>  r0 = b
-    const double tol = kk ? std::max(o.atol, o.rtol * bnorm) : std::max(o.rtol * bnorm, o.atol);
+    // stopping rules: KrylovKit max(atol, rtol*||b||); IterativeSolvers max(reltol*||r0||, abstol); Krylov.jl
+    // atol + rtol*||r0||  
+    const double tol = kk ? std::max(o.atol, o.rtol * bnorm)
+                          : (o.flavor == BK_GMRES_KRYLOVJL ? o.atol + o.rtol * bnorm : std::max(o.rtol * bnorm, o.atol));
     int numops = kk ? 1 : 0;                   // KrylovKit applies A once to x0 to fix the scalar type
     int iters = 0;                             // IterativeSolvers counts inner iterations
     res->converged = 0;
@@ -345,7 +348,9 @@ extern "C" {
 void bk_gmres_default_opts(bk_gmres_opts* o, int flavor) {
     if (!o) return;
     o->flavor = flavor;
-    if (flavor == BK_GMRES_ITERATIVESOLVERS) {      // src/LinearSolver.jl:151-160
+    if (flavor == BK_GMRES_KRYLOVJL) {              // Krylov.jl gmres defaults: memory 20, atol = rtol = sqrt(eps)
+        o->dim = 20; o->maxiter = 2000; o->atol = 1.4901161193847656e-08; o->rtol = 1.4901161193847656e-08;
+    } else if (flavor == BK_GMRES_ITERATIVESOLVERS) {      // src/LinearSolver.jl:151-160
         o->dim = 200 > kMaxBasis - 1 ? kMaxBasis - 1 : 200;
         o->maxiter = 100; o->atol = 0.0; o->rtol = 1e-8;
     } else {                                        // KrylovDefaults, src/LinearSolver.jl:225-234

@@ -382,6 +382,27 @@ class GMRESIterativeSolvers(_GMRES):
         return self.reltol
 
 
+@dataclass
+class KrylovLS(_GMRES):
+    """KrylovLS / KrylovLSInplace with KrylovAlg = :gmres (src/LinearSolver.jl:316-414): Krylov.jl's stopping rule
+    ||r|| <= atol + rtol ||r0||, `memory` Krylov vectors (used as the restart length), `itmax` iterations,
+    left preconditioner M = Pl applied to the shifted operator."""
+    atol: float = 1.4901161193847656e-08
+    rtol: float = 1.4901161193847656e-08
+    memory: int = 20
+    itmax: int = 2000
+    Pl: DCTPreconditioner | None = None
+    flavor = L.BK_GMRES_KRYLOVJL
+
+    @property
+    def dim(self):
+        return self.memory
+
+    @property
+    def maxiter(self):
+        return self.itmax
+
+
 # ------------------------------------------------------------------------------------------ bordered solvers
 @dataclass
 class BorderedArray:

@@ -145,8 +145,11 @@ enum {
     BK_GMRES_KRYLOVKIT = 0,        /* GMRESKrylovKit semantics, src/LinearSolver.jl:223-291:
                                       maxiter = restart cycles, tol = max(atol, rtol*||b||),
                                       niter = numops (operator applications)                       */
-    BK_GMRES_ITERATIVESOLVERS = 1  /* GMRESIterativeSolvers semantics, :149-206: maxiter = inner
+    BK_GMRES_ITERATIVESOLVERS = 1, /* GMRESIterativeSolvers semantics, :149-206: maxiter = inner
                                       iterations, tol = max(rtol*||r0||, atol), niter = iterations */
+    BK_GMRES_KRYLOVJL = 2          /* KrylovLS / KrylovLSInplace with :gmres, :316-414: Krylov.jl stopping rule
+                                      ||r|| <= atol + rtol*||r0||, dim = `memory` used as restart length,
+                                      maxiter = itmax (inner iterations), niter = iterations; Pl = `M`      */
 };
 typedef struct {
     int flavor;      /* BK_GMRES_*                                                               */

@@ -276,7 +276,8 @@ def test_gmres_unpreconditioned_shift_and_restart(ctx):
     Jm = sh.J(u, 0.1, 1.2)
     a0 = 2.0 * abs(Jm).sum(axis=1).max()                              # diagonally dominant shifted system
     for ls in (hip.GMRESKrylovKit(dim=10, rtol=1e-11, atol=0.0, maxiter=100),
-               hip.GMRESIterativeSolvers(reltol=1e-11, restart=10, maxiter=500)):
+               hip.GMRESIterativeSolvers(reltol=1e-11, restart=10, maxiter=500),
+               hip.KrylovLS(atol=0.0, rtol=1e-11, memory=10, itmax=500)):
         x, ok, it = ls(J, prob.vec(rhs), a0, 1.0)
         ref = spla.spsolve((a0 * sp.identity(sh.N) + Jm).tocsc(), rhs)
         assert ok and it > 10                                         # restarted at least once
