@@ -136,7 +136,7 @@ def main():
     from bk_amd import hip
 
     comm = None
-    if world > 1:
+    if world > 1 or os.environ.get("BK_FORCE_DIST") == "1":        # BK_FORCE_DIST: exercise the RCCL bootstrap with 1 rank
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
@@ -281,7 +281,7 @@ def main():
                 cb = {"value": None, "unit": "steps/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
         out["cpu_baseline"] = cb
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
     ctx.close()
 

@@ -39,6 +39,8 @@ struct DctPlan {
     double* t1 = nullptr;
     double* t2 = nullptr;
     size_t total = 0;
+    int kind = 0;                             // 0: DCT-II / SH symbol 1/((1+sum lam)^2 + shift); 1: DST-I / 1/(sum lam - shift)
+    int batch = 1;                            // stacked fields sharing the transform (cGL: 2)
     // distributed (z-slab) variant: transposes to y-slabs for the z pass
     bool dist = false;
     int R = 1, rank = 0;
@@ -87,6 +89,18 @@ __global__ void __launch_bounds__(256) spectral_scale_kernel(int n0, int n1, int
     const int i2 = (int)(idx / ((size_t)n0 * n1));
     const double s = 1.0 + lx[i0] + ly[i1] + (lz ? lz[i2] : 0.0);
     a[idx] = a[idx] / (s * s + shift);
+}
+
+// Dirichlet Laplacian symbol: a[idx] /= (lam_x + lam_y - c), the same for every stacked field
+__global__ void __launch_bounds__(256) spectral_scale_lap_kernel(int n0, int n1, int nb, const double* __restrict__ lx,
+                                                                 const double* __restrict__ ly, double c,
+                                                                 double* __restrict__ a) {
+    const size_t total = (size_t)n0 * n1 * nb;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int i0 = (int)(idx % n0);
+    const int i1 = (int)((idx / n0) % n1);
+    a[idx] = a[idx] / (lx[i0] + ly[i1] - c);
 }
 
 }  // namespace
@@ -184,6 +198,63 @@ int dct_plan_create(bk_ctx* ctx, int ndim, const int n[3], const double ainv[3],
         return set_error(ctx, "dct plan: scratch allocation failed");
     }
     *out = p;
+    return 0;
+}
+
+// DST-I plan for the Dirichlet 5-point Laplacian of examples/cGL2d.jl:6-22: the 1-D operator tridiag(1,-2,1)/h^2 has
+// eigenvectors sqrt(2/(N+1)) sin(pi (k+1)(n+1)/(N+1)) and eigenvalues -(4/h^2) sin^2(pi (k+1) / 2(N+1)).
+int dst_plan_create(bk_ctx* ctx, const int n[2], const double ainv[2], double c, int batch, DctPlan** out) {
+    DctPlan* p = new DctPlan();
+    p->ndim = 2;
+    p->kind = 1;
+    p->batch = batch;
+    p->shift = c;
+    p->n[0] = n[0]; p->n[1] = n[1]; p->n[2] = batch;
+    p->total = (size_t)n[0] * n[1] * batch;
+    for (int a = 0; a < 2; ++a) {
+        const int N = n[a];
+        std::vector<double> T((size_t)N * N), lam(N);
+        const double s = std::sqrt(2.0 / (N + 1));
+        for (int k = 0; k < N; ++k) {
+            for (int q = 0; q < N; ++q) {
+                const long long arg = ((long long)(k + 1) * (q + 1)) % (2LL * (N + 1));
+                T[(size_t)k * N + q] = s * std::sin(M_PI * (double)arg / (N + 1));
+            }
+            const double sn = std::sin(M_PI * (k + 1) / (2.0 * (N + 1)));
+            lam[k] = -4.0 * ainv[a] * sn * sn;
+        }
+        if (hipMalloc(&p->T[a], sizeof(double) * N * N) != hipSuccess || hipMalloc(&p->lam[a], sizeof(double) * N) != hipSuccess) {
+            dct_plan_destroy(p);
+            return set_error(ctx, "dst plan: allocation failed");
+        }
+        (void)hipMemcpy(p->T[a], T.data(), sizeof(double) * N * N, hipMemcpyHostToDevice);
+        (void)hipMemcpy(p->lam[a], lam.data(), sizeof(double) * N, hipMemcpyHostToDevice);
+    }
+    if (hipMalloc(&p->t1, sizeof(double) * p->total) != hipSuccess || hipMalloc(&p->t2, sizeof(double) * p->total) != hipSuccess) {
+        dct_plan_destroy(p);
+        return set_error(ctx, "dst plan: scratch allocation failed");
+    }
+    *out = p;
+    return 0;
+}
+
+// (Lap - c)^-1 on every stacked field: the sine matrix is symmetric and its own inverse
+static int dst_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out) {
+    const int n0 = p->n[0], n1 = p->n[1], nb = p->batch;
+    const unsigned grid = (unsigned)((p->total + 255) / 256);
+    auto pass = [&](int a, const double* in, double* o) -> int {
+        ProfScope ps(ctx, "dct_pass", 16.0 * p->total);
+        hipLaunchKernelGGL(dct_axis_direct, dim3(grid), dim3(256), 0, ctx->stream, n0, n1, nb, a, p->T[a], in, o);
+        BK_HIP(ctx, hipGetLastError());
+        return 0;
+    };
+    BK_TRY(pass(0, v, p->t1));
+    BK_TRY(pass(1, p->t1, p->t2));
+    hipLaunchKernelGGL(spectral_scale_lap_kernel, dim3(grid), dim3(256), 0, ctx->stream, n0, n1, nb, p->lam[0], p->lam[1],
+                       p->shift, p->t2);
+    BK_HIP(ctx, hipGetLastError());
+    BK_TRY(pass(1, p->t2, p->t1));
+    BK_TRY(pass(0, p->t1, out));
     return 0;
 }
 
@@ -374,6 +445,7 @@ struct ShDctPrecond : bk_precond {
     DctPlan* plan = nullptr;
     ~ShDctPrecond() override { dct_plan_destroy(plan); }
     int apply(const double* v, double* out) override {
+        if (plan->kind == 1) return dst_apply(ctx, plan, v, out);
         return plan->dist ? dct_apply_dist(ctx, plan, v, out) : dct_apply(ctx, plan, v, out);
     }
 };
@@ -395,6 +467,20 @@ int bk_precond_sh_create(bk_problem* prob, double shift, bk_precond** out) {
     int s = ctx->nranks > 1
                 ? dct_plan_create_dist(ctx, prob->desc.n, prob->ainv, shift, prob->lo, prob->hi, &P->plan)
                 : dct_plan_create(ctx, prob->desc.ndim, prob->desc.n, prob->ainv, shift, &P->plan);
+    if (s != 0) { delete P; return s; }
+    *out = P;
+    return 0;
+}
+
+int bk_precond_lap_create(bk_problem* prob, double c, bk_precond** out) {
+    if (!prob || !out) return -1;
+    bk_ctx* ctx = prob->ctx;
+    if (prob->desc.pde != BK_PDE_CGL2D) return set_error(ctx, "bk_precond_lap_create: cGL2d problems only");
+    if (!(c > 0.0)) return set_error(ctx, "bk_precond_lap_create: c must be positive (Lap - c I is then definite)");
+    ShDctPrecond* P = new ShDctPrecond();
+    P->ctx = ctx;
+    P->n = prob->nloc;
+    int s = dst_plan_create(ctx, prob->desc.n, prob->ainv, c, 2, &P->plan);
     if (s != 0) { delete P; return s; }
     *out = P;
     return 0;

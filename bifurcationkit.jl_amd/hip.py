@@ -318,6 +318,17 @@ class DCTPreconditioner:
             pass
 
 
+class LaplacePreconditioner(DCTPreconditioner):
+    """``Pl`` = (Lap - c I)^-1 on both cGL fields (DST-I; Dirichlet Laplacian of examples/cGL2d.jl:6-22).  Matrix-free
+    stand-in for the sparse LU the reference uses on cGL2d (DefaultLS / ARPACK shift-invert, cGL2d.jl:96)."""
+
+    def __init__(self, prob: "CGL2d", c: float = 1.0):
+        self.ctx, self.prob = prob.ctx, prob
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.bk_precond_lap_create(prob.h, float(c), C.byref(h)), "bk_precond_lap_create")
+        self.h = h
+
+
 # ------------------------------------------------------------------------------------------ linear solvers
 class _GMRES:
     flavor = L.BK_GMRES_KRYLOVKIT

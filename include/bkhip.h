@@ -136,6 +136,11 @@ int bk_op_apply(bk_op* op, const double* v, double a0, double a1, double* out);
  * Neumann-ghost Laplacian.  shift = 0 is `Pl = cholesky(Symmetric(L1))` of examples/SH3d.jl:88;
  * shift = 1 is `lu(L1 + I)` of examples/SH2d-fronts.jl:121.                                      */
 int bk_precond_sh_create(bk_problem* prob, double shift, bk_precond** out);
+/* Pl^-1 = (Lap - c I)^-1 on both fields of a BK_PDE_CGL2D problem (Dirichlet 5-point Laplacian of
+ * examples/cGL2d.jl:6-22, diagonalised by the DST-I), c > 0.  The reference has no iterative counterpart here: its
+ * cGL2d runs use sparse LU (DefaultLS, and `EigArpack(1.0, :LM)` factorises J - sigma I inside ARPACK,
+ * examples/cGL2d.jl:96, src/EigSolver.jl:85); this is the matrix-free replacement that keeps GMRES mesh-independent. */
+int bk_precond_lap_create(bk_problem* prob, double c, bk_precond** out);
 int bk_precond_destroy(bk_precond* pc);
 int bk_precond_apply(bk_precond* pc, const double* v, double* out);   /* out = Pl \ v             */
 

@@ -487,3 +487,99 @@ def _native_corrector(hip, Cn, prob, z, tau, zp, ds, theta, bls, nopt, pmin, pma
     r = hip.newton_palc_native(prob, z, tau, zp, ds, theta, bls, tol=nopt.tol, max_iterations=nopt.max_iterations,
                                p_min=pmin, p_max=pmax, norm_inf=True)
     return Cn.NonLinearSolution(r["u"], r["residuals"], r["converged"], r["itnewton"], r["itlineartot"])
+
+
+# --------------------------------------------------------------------------------------------- configs C2 / C3
+def test_sh2d_palc_corrector_matches_oracle(ctx):
+    """BASELINE config 2 (examples/SH2d-fronts.jl operator): matrix-free JVP + preconditioned GMRES corrector in 2-D,
+    Pl = lu(L1 + I) (SH2d-fronts.jl:121), hexagon guess (:47-51), l = -0.1, nu = 1.3 (:55)."""
+    hip = _hip()
+    dims, ls_ = (64, 32), (8 * np.pi, 4 * np.pi / np.sqrt(3))
+    sh = operators.SwiftHohenberg(dims, ls_)
+    prob = hip.SwiftHohenberg(ctx, dims, ls_, l=-0.1, nu=1.3)
+    Plo = operators.dct_preconditioner(dims, ls_, 1.0)
+    ols = lambda J, r, a0=0.0, a1=1.0: krylov.gmres_krylovkit(J, r, a0, a1, krylovdim=30, maxiter=150, rtol=1e-9,
+                                                               atol=1e-12, Pl=Plo)[:3]
+    oprob = palc.Problem(lambda x, p: sh.F(x, p, 1.3), lambda x, p: (lambda dx: sh.dF(x, p, 1.3, dx)))
+    s0 = palc.newton(oprob, sh.guess(), -0.1, ols, tol=1e-9, max_iterations=40, normN=palc.norminf)
+    assert s0["converged"] and np.abs(s0["u"]).max() > 0.1
+    ds = 0.005
+    s1 = palc.newton(oprob, s0["u"], -0.1 + ds / 150, ols, tol=1e-9, max_iterations=20, normN=palc.norminf)
+    z0, z1 = (s0["u"], -0.1), (s1["u"], -0.1 + ds / 150)
+    tau = palc.secant_tangent(z1, z0, ds, 0.5)
+    zp = palc.add_tangent(z0, tau, ds)
+    obls = lambda *a, **k: bordered.bordering_bls(ols, *a, check_precision=False, **k)
+    so = palc.newton_palc(oprob, z0, tau, zp, ds, 0.5, obls, tol=1e-9, max_iterations=15, normN=palc.norminf)
+    P = hip.DCTPreconditioner(prob, 1.0)
+    gls = hip.GMRESKrylovKit(dim=30, rtol=1e-9, atol=1e-12, maxiter=150, Pl=P)
+    B = hip.BorderedArray
+    sg = hip.newton_palc_native(prob, B(prob.vec(z0[0]), z0[1]), B(prob.vec(tau[0]), tau[1]), B(prob.vec(zp[0]), zp[1]),
+                                ds, 0.5, hip.BorderingBLS(gls, check_precision=False), tol=1e-9, max_iterations=15,
+                                norm_inf=True)
+    assert so["converged"] and sg["converged"] and sg["itnewton"] == so["itnewton"] >= 1
+    assert abs(sg["residuals"][0] - so["residuals"][0]) <= 1e-10 * (1.0 + so["residuals"][0])
+    assert abs(sg["u"].p - so["p"]) <= 1e-9 and np.abs(sg["u"].u.numpy() - so["u"]).max() <= 1e-7
+
+
+def test_cgl_laplace_preconditioner_and_bordered_solve(ctx):
+    """BASELINE config 3 pieces (examples/cGL2d.jl): exactness of the DST preconditioner, preconditioned GMRES on the
+    non-symmetric cGL Jacobian vs sparse LU (the reference's DefaultLS), and the PALC bordered solve vs the explicit
+    (N+1) system (test_linear.jl:172-244)."""
+    hip = _hip()
+    dims, ls_ = (24, 13), (np.pi, np.pi / 2)
+    c = operators.CGL2d(dims, ls_)
+    prob = hip.CGL2d(ctx, dims, ls_)
+    rng = np.random.default_rng(21)
+    n2 = 2 * c.n
+    v = rng.standard_normal(n2)
+    P = hip.LaplacePreconditioner(prob, 1.0)
+    M = (c.Delta - sp.identity(n2)).tocsc()
+    ref = spla.splu(M).solve(v)
+    got = P.ldiv(prob.vec(v)).numpy()
+    assert np.abs(got - ref).max() <= 1e-11 * np.abs(ref).max()
+    u = 0.3 * rng.standard_normal(n2)
+    p = c.default_params()
+    p["r"] = 1.2
+    Jm = c.J(u, **p)
+    J = prob.jacobian(prob.vec(u), 1.2)
+    rhs = rng.standard_normal(n2)
+    ls = hip.GMRESIterativeSolvers(reltol=1e-12, restart=60, maxiter=600, Pl=P)
+    x, ok, it = ls(J, prob.vec(rhs))
+    xr = spla.spsolve(Jm.tocsc(), rhs)
+    assert ok and np.abs(x.numpy() - xr).max() <= 1e-8 * np.abs(xr).max()
+    # bordered (PALC) solve on the cGL Jacobian
+    dR, dzu, R = rng.standard_normal(n2), rng.standard_normal(n2), rng.standard_normal(n2)
+    theta = 0.5
+    A = np.block([[Jm.toarray(), dR[:, None]], [theta * dzu[None, :] / n2, np.array([[(1 - theta) * 0.4]])]])
+    refb = np.linalg.solve(A, np.concatenate([R, [0.3]]))
+    dX, dl, okb, itb = hip.BorderingBLS(ls, check_precision=True, k=2)(J, prob.vec(dR), prob.vec(dzu), 0.4, prob.vec(R), 0.3,
+                                                                      theta, 1 - theta, dotscale=1.0 / n2)
+    assert okb and np.abs(dX.numpy() - refb[:-1]).max() <= 1e-7 * np.abs(refb).max() and np.isclose(dl, refb[-1], rtol=1e-7)
+
+
+def test_cgl_hopf_detection_along_trivial_branch(ctx):
+    """examples/cGL2d.jl:96-100: continuation in r of the trivial state with shift-invert eigenvalues each step; the
+    number of unstable eigenvalues (complex pairs crossing: Hopf points) must follow the dense spectrum."""
+    hip = _hip()
+    from bk_amd import continuation as Cn
+    dims, ls_ = (16, 9), (np.pi, np.pi / 2)
+    c = operators.CGL2d(dims, ls_)
+    prob = hip.CGL2d(ctx, dims, ls_, r=0.5)
+    P = hip.LaplacePreconditioner(prob, 1.0)
+    ls = hip.GMRESIterativeSolvers(reltol=1e-11, restart=60, maxiter=600, Pl=P)
+    eig = hip.ShiftInvert(1.0, ls, tol=1e-9, maxiter=40, hermitian=False, save_vectors=False)     # EigArpack(1.0, :LM)
+    nopt = Cn.NewtonPar(tol=1e-9, max_iterations=20, linsolver=ls, eigsolver=eig)
+    cp = Cn.ContinuationPar(ds=0.2, dsmin=1e-3, dsmax=0.3, p_min=0.0, p_max=4.0, max_steps=12, nev=9, newton_options=nopt)
+    alg = Cn.PALC(tangent="secant", theta=0.5, bls=hip.BorderingBLS(None, check_precision=False))
+    n2 = 2 * c.n
+    br = Cn.continuation(prob, prob.vec(np.zeros(n2)), 0.5, alg, cp, normC=Cn.norminf)
+    assert len(br.param) >= 8 and br.param[-1] > 1.5
+    pars = c.default_params()
+    for r_, nu_, ev_ in zip(br.param, br.n_unstable, br.eig):
+        pars["r"] = r_
+        dense = np.linalg.eigvals(c.J(np.zeros(n2), **pars).toarray())
+        assert nu_ == int(np.sum(dense.real > 1e-10)), (r_, nu_, np.sort(dense.real)[-6:])
+        # the rightmost computed eigenvalues are eigenvalues of J
+        for lam in ev_[:4]:
+            assert np.abs(dense - lam).min() <= 1e-6
+    assert br.n_unstable[0] == 0 and br.n_unstable[-1] >= 2 and len(br.specialpoint) >= 1     # Hopf crossings detected

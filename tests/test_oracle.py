@@ -213,3 +213,32 @@ def test_sh3d_branch_preconditioned_gmres_matches_direct():
     assert len(br_d.param) == len(br_g.param) == 4
     assert np.allclose(br_d.param, br_g.param, rtol=0, atol=1e-9)
     assert br_d.itnewton == br_g.itnewton
+
+
+def test_config1_sh1d_snaking_palc_cpu():
+    """BASELINE config 1: 1-D Swift-Hohenberg snaking (examples/SHpde_snaking.jl) with N = 1024, l = 6*1024/200 so that
+    h = 0.06 as in the file (:8-11), lambda = -0.1, nu = 2, u0 = 1.1 cos(X) exp(-X^2/(2*5^2)) (the file's localised
+    guess, :30): PALC with the reference defaults (DefaultLS, MatrixBLS) vs BorderingBLS(GMRES) on the same branch --
+    the CPU plumbing of the plugin surface.  tol = 1e-8 in the inf-norm: eps/h^4 ~ 2e-11 per entry limits the residual."""
+    N, l = 1024, 6.0 * 1024 / 200
+    s1 = operators.SwiftHohenberg1D(N, l)
+    prob = palc.Problem(lambda x, p: s1.F(x, p, 2.0), lambda x, p: s1.J(x, p, 2.0))
+    guess = 1.1 * np.cos(s1.X) * np.exp(-s1.X**2 / (2 * 5.0**2))
+    x0 = palc.newton(prob, guess, -0.1, bordered.default_ls, tol=1e-8, max_iterations=40, normN=palc.norminf)
+    assert x0["converged"] and np.abs(x0["u"]).max() > 0.1                 # a localised (snaking-branch) state
+    kw = dict(ds=0.01, dsmin=1e-4, dsmax=0.02, p_min=-1.0, p_max=1.0, max_steps=6, tol=1e-8, max_iterations=15,
+              normC=palc.norminf)
+
+    def matrix_bls_palc(J, dR, dzu, dzp, R, n, xiu, xip, shift=None, dotp=None):
+        # MatrixBLS in the PALC call: last row xiu * applyxiu(dzu) with applyxiu = scale by 1/N (Palc.jl:6,41)
+        return bordered.matrix_bls(J, dR, dzu, dzp, R, n, xiu, xip, shift=shift, apply_xiu=lambda v: v / R.shape[0])
+
+    gm = lambda J, r, a0=0.0, a1=1.0: krylov.gmres_krylovkit(J, r, a0, a1, krylovdim=60, maxiter=20, rtol=1e-12, atol=1e-13,
+                                                              Pl=spla.splu(J.tocsc()).solve)[:3]
+    bord = lambda *a, **k: bordered.bordering_bls(gm, *a, **k)
+    b1 = palc.continuation(prob, x0["u"], -0.1, ls=bordered.default_ls, bls=matrix_bls_palc, **kw)
+    b2 = palc.continuation(prob, x0["u"], -0.1, ls=bordered.default_ls, bls=bord, **kw)
+    assert len(b1.param) == len(b2.param) == 7
+    assert np.allclose(b1.param, b2.param, rtol=0, atol=1e-8)
+    assert all(abs(a - b) <= 1 for a, b in zip(b1.itnewton, b2.itnewton))
+    assert all(r[-1] < 1e-8 for r in b1.residuals)
