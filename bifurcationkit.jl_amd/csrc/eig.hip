@@ -189,13 +189,22 @@ extern "C" int bk_eig_shiftinvert(bk_ctx* ctx, bk_op* J, int nev, const bk_eig_o
     const int nout = std::min(nev, meff);
     std::vector<cplx> lam(nout);
     std::vector<int> sel(nout);
+    // Only converged Ritz pairs are reported (ARPACK / KrylovKit's `converged` count): an unconverged Ritz value of the
+    // inverse can sit anywhere, and 1/mu + sigma would then fake an unstable eigenvalue.  Unconverged slots are NaN.
+    std::vector<char> okv(nout, 0);
+    int nok = 0;
     for (int jj = 0; jj < nout; ++jj) {
         sel[jj] = order[jj];
-        lam[jj] = cplx(1.0, 0.0) / mu[order[jj]] + eo->sigma;
+        okv[jj] = (breakdown || resid[jj] < eo->tol) ? 1 : 0;
+        nok += okv[jj];
+        lam[jj] = okv[jj] ? cplx(1.0, 0.0) / mu[order[jj]] + eo->sigma : cplx(NAN, NAN);
     }
     std::vector<int> perm(nout);
     for (int i = 0; i < nout; ++i) perm[i] = i;
-    std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) { return lam[x].real() > lam[y].real(); });
+    std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) {
+        if (okv[x] != okv[y]) return okv[x] > okv[y];                 // converged first, NaNs last
+        return okv[x] && lam[x].real() > lam[y].real();
+    });
     for (int i = 0; i < nout; ++i) {
         vals_re[i] = lam[perm[i]].real();
         vals_im[i] = lam[perm[i]].imag();
@@ -212,7 +221,7 @@ extern "C" int bk_eig_shiftinvert(bk_ctx* ctx, bk_op* J, int nev, const bk_eig_o
         BK_TRY(v_basis_combine(ctx, n, V, ld, meff, Qr.data(), nout, vecs, ldvecs));
         if (vecs_im) BK_TRY(v_basis_combine(ctx, n, V, ld, meff, Qi.data(), nout, vecs_im, ldvecs));
     }
-    if (nconv_out) *nconv_out = std::min(nconv, nout);
+    if (nconv_out) *nconv_out = nok;
     if (numops_out) *numops_out = A.solves;
     return 0;
 }

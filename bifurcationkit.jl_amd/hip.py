@@ -577,7 +577,7 @@ class ShiftInvert:
             ctx.h, J.h, nev, C.byref(eo), C.byref(lo), self.ls._pl(), re, im,
             _ptr(vr) if vr is not None else None, _ptr(vi) if vi is not None else None, ld,
             C.byref(nconv), C.byref(nops)), "bk_eig_shiftinvert")
-        vals = np.array([complex(re[i], im[i]) for i in range(nev)])
+        vals = np.array([complex(re[i], im[i]) for i in range(nev)])      # NaN = not converged (ignored by is_stable)
         vecs = None
         if vr is not None:
             vecs = [(HipVec(ctx, vr[i * ld:i * ld + n], J.prob.nglobal),
