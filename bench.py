@@ -9,14 +9,18 @@ preconditioner Pl = (L1 + I)^-1 (`lu(L1 + I)`, examples/SH2d-fronts.jl:121; the 
 512^2 GPU example, examples/SH2d-fronts-cuda.jl:63), PALC with theta = 0.5, ds = -0.001,
 BorderingBLS(check_precision = false) (SH3d.jl:160-163).
 
-Synthetic state with a checkable answer.  The branch point is built from the reference's own example cell:
-Newton-converge sol0 (SH3d.jl:77-80) on a `cell`^3 grid over [-pi, pi)^3, then tile it by even reflections to
-n^3 = (n/cell)^3 cells (h = 2 pi / cell; with cell = 32 that is h = 0.196 and 16 wavelengths per axis -- the
-grid spacing and domain of examples/SH2d-fronts-cuda.jl:66-69).  Because the Neumann-ghost boundary rule IS an
-even reflection, the tiled field is an exact discrete solution on the big grid, and every quantity of the big
-corrector (residual history, p, GMRES operator counts) must reproduce the single-cell run -- a size-independent
-parity check against the CPU oracle at full size (tests/test_gpu_fullsize.py).  The kernels do not know about
-the symmetry: every byte of every 1 GiB vector is streamed.
+Synthetic state with a checkable answer.  The branch point is the hexagon pattern of the reference's examples
+(`sol_hexa`, examples/SH3d.jl:127; guess cos x + cos(x/2) cos(sqrt(3) y/2), examples/SH2d-fronts.jl:47,
+SH2d-fronts-cuda.jl:71) as z-invariant hexagonal prisms: Newton-converge it on ONE periodic cell
+[-2pi, 2pi) x [-2pi/sqrt3, 2pi/sqrt3) x [-pi, pi) with 64 x 32 x 32 points (h = 0.196 in x -- the grid spacing of
+examples/SH2d-fronts-cuda.jl:66-69), then tile it by even reflections to 8 x 16 x 16 cells = 512^3.  Because the
+Neumann-ghost boundary rule IS an even reflection, the tiled field is an exact discrete solution on the big grid, and
+every quantity of the big corrector (residual history, p) must reproduce the single-cell run -- a size-independent
+parity check against the CPU oracle at full size (tests/test_gpu_fullsize.py).  The state is linearly stable (largest
+cell eigenvalue -0.17), so the preconditioned operator is well conditioned and the GMRES iteration count does not
+depend on rounding noise (the unstable square pattern cos x cos y of SH3d.jl:77 tiled the same way needs 47-146
+operator applications per step depending on the build: its Krylov spaces are polluted by growing asymmetric modes).
+The kernels do not know about the symmetry: every byte of every 1 GiB vector is streamed.
 
 One "step" = one pass through the corrector loop src/continuation/Palc.jl:237-295 from the PALC predictor:
 finite-difference dF/dp (1 residual), Jacobian handle, bordered solve (2 preconditioned GMRES solves to
@@ -48,61 +52,76 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=512, help="grid points per axis (BASELINE metric: 512)")
-    ap.add_argument("--cell", type=int, default=32, help="points per 2*pi cell (h = 2 pi / cell)")
     ap.add_argument("--shift", type=float, default=1.0, help="preconditioner (L1 + shift I)^-1")
-    ap.add_argument("--cpu-sample", type=int, default=96, help="grid size of the CPU-baseline sample (0: skip)")
+    ap.add_argument("--cpu-sample", type=int, default=3, help="CPU-baseline sample: tiles per axis of the cell (0: skip)")
     ap.add_argument("--no-precond", action="store_true")
     ap.add_argument("--sh-kernel", type=int, default=1)
     ap.add_argument("--dgks-eta", type=float, default=None)
+    ap.add_argument("--opt", action="append", default=[], help="library tuning option key=value (experiments)")
     return ap.parse_args()
 
 
-def tile_cell(cell_vec, nc, n, slab, device):
-    """Even-reflection tiling of a cell field (flat, x fastest, nc^3) to this rank's z-slab of the n^3 grid."""
+CELL = (64, 32, 32)                                            # points per cell (x, y, z)
+CELL_L = (2.0 * math.pi, 2.0 * math.pi / math.sqrt(3.0), math.pi)     # half-widths of the cell
+
+
+def tiles_for(n):
+    if any(n % c for c in CELL):
+        raise SystemExit(f"--size must be a multiple of {CELL}")
+    return tuple(n // c for c in CELL)
+
+
+def tile_cell(cell_vec, tiles, slab, device):
+    """Even-reflection tiling of a cell field (flat, x fastest) to this rank's z-slab of the big grid."""
     import torch
-    T = n // nc
-    idx = torch.cat([torch.arange(nc) if c % 2 == 0 else torch.arange(nc - 1, -1, -1) for c in range(T)]).to(device)
-    c = cell_vec.reshape(nc, nc, nc)                      # [z, y, x]
+    cx, cy, cz = CELL
+    def idx(nc, T):
+        return torch.cat([torch.arange(nc) if c % 2 == 0 else torch.arange(nc - 1, -1, -1) for c in range(T)]).to(device)
+    c = cell_vec.reshape(cz, cy, cx)                      # [z, y, x]
     lo, hi = slab
-    out = c[idx[lo:hi]][:, idx][:, :, idx]
+    out = c[idx(cz, tiles[2])[lo:hi]][:, idx(cy, tiles[1])][:, :, idx(cx, tiles[0])]
     return out.contiguous().reshape(-1)
 
 
-def cell_branch_points(ctx_cell, hip, nc, shift, ds, eta=150.0):
-    """Two Newton-converged points of the reference example on the nc^3 cell over [-pi, pi)^3 (device)."""
-    import torch
-    prob = hip.SwiftHohenberg(ctx_cell, (nc,) * 3, (math.pi,) * 3, l=0.1, nu=1.2)
+def hex_guess_np():
+    """0.5 (cos x + cos(x/2) cos(sqrt(3) y/2)), constant in z, on the cell grid (x fastest)."""
+    import numpy as np
+    ax = [-l + 2.0 * l / n * np.arange(n) for n, l in zip(CELL, CELL_L)]
+    X, Y, Z = np.meshgrid(*ax, indexing="ij")
+    s = 0.5 * (np.cos(X) + np.cos(X / 2.0) * np.cos(math.sqrt(3.0) * Y / 2.0)) + 0.0 * Z
+    return np.ascontiguousarray(s.reshape(-1, order="F"))
+
+
+def cell_branch_points(ctx_cell, hip, shift, ds, eta=150.0):
+    """Two Newton-converged points of the hexagon branch on the cell (device)."""
+    prob = hip.SwiftHohenberg(ctx_cell, CELL, CELL_L, l=0.1, nu=1.2)
     P = hip.DCTPreconditioner(prob, shift)
     ls = hip.GMRESKrylovKit(dim=30, rtol=1e-9, atol=1e-12, maxiter=150, Pl=P)
-    x = -math.pi + (2.0 * math.pi / nc) * torch.arange(nc, dtype=torch.float64, device=ctx_cell.torch_device)
-    s = torch.cos(x)[None, :] * torch.cos(x)[:, None]           # sol0, SH3d.jl:77-80 ([y, x]; constant in z)
-    s = s - s.min()
-    s = s / s.max()
-    s = s * 1.2
-    u0 = hip.HipVec(ctx_cell, s.reshape(1, nc, nc).expand(nc, nc, nc).contiguous().reshape(-1))
+    u0 = prob.vec(hex_guess_np())
     s0 = hip.newton_native(prob, u0, 0.1, ls, tol=1e-10, max_iterations=40, norm_inf=True)
     s1 = hip.newton_native(prob, s0["u"], 0.1 + ds / eta, ls, tol=1e-10, max_iterations=20, norm_inf=True)
     return prob, ls, s0, s1
 
 
-def cpu_baseline(ns, nc, shift, steps=1):
-    """Time the oracle's corrector step (reference formulation: assembled sparse L1, MGS2 GMRES) on an ns^3 tiling
-    of the nc^3 cell, single thread."""
+def cpu_baseline(tiles, shift, steps=1):
+    """Time the oracle's corrector step (reference formulation: assembled sparse L1, MGS2 GMRES) on a tiles[0] x
+    tiles[1] x tiles[2] tiling of the cell, single thread."""
     import numpy as np
     from oracle import bordered, krylov, operators, palc
     ds = -0.001
-    cdims, cls_ = (nc,) * 3, (math.pi,) * 3
-    shc = operators.SwiftHohenberg(cdims, cls_)
+    shc = operators.SwiftHohenberg(CELL, CELL_L)
     pc = palc.Problem(lambda x, p: shc.F(x, p, 1.2), lambda x, p: (lambda dx: shc.dF(x, p, 1.2, dx)))
-    Plc = operators.dct_preconditioner(cdims, cls_, shift)
+    Plc = operators.dct_preconditioner(CELL, CELL_L, shift)
     cls_s = lambda J, r, a0=0.0, a1=1.0: krylov.gmres_krylovkit(J, r, a0, a1, krylovdim=30, maxiter=150, rtol=1e-9,
                                                                  atol=1e-12, Pl=Plc)[:3]
-    c0 = palc.newton(pc, shc.guess(), 0.1, cls_s, tol=1e-10, max_iterations=40, normN=palc.norminf)
+    c0 = palc.newton(pc, hex_guess_np(), 0.1, cls_s, tol=1e-10, max_iterations=40, normN=palc.norminf)
     c1 = palc.newton(pc, c0["u"], 0.1 + ds / 150.0, cls_s, tol=1e-10, max_iterations=20, normN=palc.norminf)
-    T = ns // nc
-    idx = np.concatenate([np.arange(nc) if c % 2 == 0 else np.arange(nc)[::-1] for c in range(T)])
-    tile = lambda v: np.ascontiguousarray(v.reshape(nc, nc, nc)[np.ix_(idx, idx, idx)]).reshape(-1)
-    dims, ls = (ns,) * 3, (math.pi * T,) * 3
+    idx = [np.concatenate([np.arange(nc) if c % 2 == 0 else np.arange(nc)[::-1] for c in range(T)])
+           for nc, T in zip(CELL, tiles)]
+    cx, cy, cz = CELL
+    tile = lambda v: np.ascontiguousarray(v.reshape(cz, cy, cx)[np.ix_(idx[2], idx[1], idx[0])]).reshape(-1)
+    dims = tuple(c * t for c, t in zip(CELL, tiles))
+    ls = tuple(l * t for l, t in zip(CELL_L, tiles))
     sh = operators.SwiftHohenberg(dims, ls)
     Pl = operators.dct_preconditioner(dims, ls, shift)
     ols = lambda J, r, a0=0.0, a1=1.0: krylov.gmres_krylovkit(J, r, a0, a1, krylovdim=30, maxiter=150, rtol=1e-9,
@@ -118,7 +137,8 @@ def cpu_baseline(ns, nc, shift, steps=1):
         so = palc.newton_palc(prob, z0, tau, zp, ds, 0.5, bls, tol=0.0, max_iterations=1, normN=palc.norminf)
         itl = so["itlineartot"]
     dt = (time.perf_counter() - t0) / steps
-    return dict(seconds_per_step=dt, n=sh.N, itlinear=itl, residuals=so["residuals"])
+    return dict(seconds_per_step=dt, n=sh.N, dims=dims, itlinear=itl, residuals=so["residuals"],
+                cell_newton=(c0["converged"], c0["itnewton"]), umax=float(np.abs(c0["u"]).max()))
 
 
 def main():
@@ -147,18 +167,19 @@ def main():
     ctx.set_option("sh_kernel", args.sh_kernel)
     if args.dgks_eta is not None:
         ctx.set_option("dgks_eta", args.dgks_eta)
+    for kv in args.opt:
+        k_, v_ = kv.split("=")
+        ctx.set_option(k_, float(v_))
 
-    n, nc = args.size, args.cell
-    if n % nc != 0:
-        raise SystemExit("--size must be a multiple of --cell")
-    T = n // nc
-    lx = math.pi * T
+    n = args.size
+    tiles = tiles_for(n)
+    big_l = tuple(l * t for l, t in zip(CELL_L, tiles))
     ds, theta = -0.001, 0.5
     # ---- setup (untimed)
     t_setup = time.perf_counter()
     ctx_cell = ctx if world == 1 else hip.Context(local)
-    cprob, cls_, c0, c1 = cell_branch_points(ctx_cell, hip, nc, args.shift, ds)
-    prob = hip.SwiftHohenberg(ctx, (n, n, n), (lx,) * 3, l=0.1, nu=1.2)
+    cprob, cls_, c0, c1 = cell_branch_points(ctx_cell, hip, args.shift, ds)
+    prob = hip.SwiftHohenberg(ctx, (n, n, n), big_l, l=0.1, nu=1.2)
     P = None if args.no_precond else hip.DCTPreconditioner(prob, args.shift)
     ls = hip.GMRESKrylovKit(dim=30, rtol=1e-9, atol=1e-12, maxiter=150, Pl=P)       # SH3d.jl:93
     bls = hip.BorderingBLS(ls, check_precision=False)                               # SH3d.jl:163
@@ -170,8 +191,8 @@ def main():
         torch.cuda.synchronize()
 
     p0, p1 = 0.1, 0.1 + ds / 150.0
-    u0 = hip.HipVec(ctx, tile_cell(c0["u"].t, nc, n, prob.slab, ctx.torch_device), prob.nglobal)
-    u1 = hip.HipVec(ctx, tile_cell(c1["u"].t, nc, n, prob.slab, ctx.torch_device), prob.nglobal)
+    u0 = hip.HipVec(ctx, tile_cell(c0["u"].t, tiles, prob.slab, ctx.torch_device), prob.nglobal)
+    u1 = hip.HipVec(ctx, tile_cell(c1["u"].t, tiles, prob.slab, ctx.torch_device), prob.nglobal)
     res0 = prob.residual(u0, p0).norminf()           # the tiled field is an exact discrete solution
     res1 = prob.residual(u1, p1).norminf()
     z0, z1 = B(u0, p0), B(u1, p1)
@@ -252,7 +273,9 @@ def main():
                                    f"Pl = (L1+shift)^-1 (DCT), BorderingBLS",
                        "grid": [n, n, n], "unknowns": prob.nglobal, "parallelism": f"z-slabs x{world}",
                        "itlinear_per_step": last["itlineartot"], "residual_after_step": last["residuals"][-1],
-                       "cell": nc, "h": 2 * math.pi / nc, "precond_shift": args.shift,
+                       "cell": list(CELL), "tiles": list(tiles), "h": [2 * l / c for l, c in zip(CELL_L, CELL)],
+                       "precond_shift": args.shift, "state": "z-invariant hexagons (stable), l = 0.1, nu = 1.2",
+                       "cell_umax": c0["u"].norminf(),
                        "cell_newton": {"converged": c0["converged"], "itnewton": c0["itnewton"],
                                        "residual": c0["residuals"][-1]},
                        "tiled_state_residual_inf": [res0, res1],
@@ -269,10 +292,10 @@ def main():
         cb = None
         if world == 1 and args.cpu_sample > 0:
             try:
-                c = cpu_baseline(args.cpu_sample, nc, args.shift)
+                c = cpu_baseline((args.cpu_sample,) * 3, args.shift)
                 scaled = (1.0 / c["seconds_per_step"]) * (c["n"] / prob.nglobal)
                 cb = {"value": scaled, "unit": "steps/s", "cores": 1, "kind": "port",
-                      "sample": f"1 corrector step on SH3d {args.cpu_sample}^3 ({c['n']} unknowns, same cell tiling, h and "
+                      "sample": f"1 corrector step on SH3d {c['dims']} ({c['n']} unknowns, same cell tiling, h and "
                                 f"solver settings, {c['itlinear']} GMRES operator applications) took "
                                 f"{c['seconds_per_step']:.2f} s with the NumPy/SciPy oracle (assembled sparse L1, "
                                 f"MGS2 GMRES, DCT preconditioner), scaled by unknowns ratio to {n}^3; "

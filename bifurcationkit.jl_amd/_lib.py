@@ -105,7 +105,7 @@ SIGNATURES = {
     "bk_bls_matrixfree": (I, [VP, VP, VP, VP, D, VP, D, D, D, I, D, D, C.POINTER(GmresOpts), VP, c_double_p,
                               c_int_p, c_int_p]),
     "bk_eig_shiftinvert": (I, [VP, VP, I, C.POINTER(EigOpts), C.POINTER(GmresOpts), VP, c_double_p, c_double_p,
-                               VP, VP, SZ, c_int_p, c_int_p]),
+                               VP, VP, SZ, c_int_p, c_int_p, c_int_p]),
     "bk_newton": (I, [VP, VP, VP, c_double_p, I, C.POINTER(NewtonOpts), C.POINTER(GmresOpts), VP,
                       C.POINTER(NewtonResult)]),
     "bk_newton_palc": (I, [VP, VP, VP, c_double_p, VP, D, VP, D, D, D, c_double_p, I, I, D, D,

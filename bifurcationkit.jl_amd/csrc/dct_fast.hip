@@ -34,6 +34,7 @@ struct FftK {
     int fuse_scale;           // 1: multiply by the inverse symbol while storing the forward result
     int roundtrip;            // 1: forward, inverse symbol, inverse -- all in LDS, one read + one write of the array
     int tiles_x;              // axis >= 1: number of LT-wide tiles along x
+    int pairvec;              // axis >= 1 and 16-B aligned pairs: the two lines of a pair are loaded / stored as one double2
 };
 
 template <int NT>
@@ -70,30 +71,47 @@ __global__ void __launch_bounds__(NT) dct_fft_kernel(FftK P) {
 
     for (int q = tid; q < half; q += NT) tw[q] = reinterpret_cast<const c2*>(P.twid)[q];
 
-    // ---- load (coalesced along the memory-contiguous direction), scatter into the FFT input order
+    // ---- load: one work item = one complex LDS element = the same sample n of the two lines (2p, 2p+1) of a pair.
+    // axis 0: consecutive items walk along n (both rows coalesced); axis >= 1: consecutive items are consecutive pairs,
+    // i.e. consecutive x -- one 16-B load per item, 128-B segments per n.  U items per lane are in flight before the
+    // first LDS write (with two workgroups per CU the memory-level parallelism has to come from each lane).
     const int total = LT * N;
+    const int nitems = npairs << bits;
+    const int pbits = P.ltbits >= 1 ? P.ltbits - 1 : -1;       // log2(npairs) when LT is a power of two
+    auto decode = [&](int q, int& pr, int& n) {
+        if (P.axis == 0) { pr = q >> bits; n = q & (N - 1); }
+        else if (pbits >= 0) { pr = q & (npairs - 1); n = q >> pbits; }
+        else { pr = q % npairs; n = q / npairs; }
+    };
     {
-        // U independent global loads per lane are issued before the first LDS write: with two workgroups per CU the
-        // memory-level parallelism has to come from each lane (a one-load-per-iteration loop ran at 1.5 TB/s)
         constexpr int U = 8;
-        for (int w0 = tid; w0 < total; w0 += NT * U) {
-            double v[U];
+        for (int q0 = tid; q0 < nitems; q0 += NT * U) {
+            c2 v[U];
             int dst[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int w = w0 + u * NT;
-                int L, n;
-                if (P.axis == 0) { L = w >> bits; n = w & (N - 1); }
-                else if (P.ltbits >= 0) { L = w & (LT - 1); n = w >> P.ltbits; }
-                else { L = w % LT; n = w / LT; }
-                const bool inside = w < total;
-                v[u] = (inside && L < nlines) ? P.in[base + (size_t)L * lstride + (size_t)n * estride] : 0.0;
+                const int q = q0 + u * NT;
+                int pr, n;
+                decode(q, pr, n);
+                const bool inside = q < nitems;
+                const int L0 = 2 * pr;
+                const double* src = P.in + base + (size_t)L0 * lstride + (size_t)n * estride;
+                v[u].x = 0.0; v[u].y = 0.0;
+                if (inside) {
+                    if (P.pairvec && L0 + 1 < nlines) {
+                        const double2 t = *reinterpret_cast<const double2*>(src);
+                        v[u].x = t.x; v[u].y = t.y;
+                    } else {
+                        if (L0 < nlines) v[u].x = src[0];
+                        if (L0 + 1 < nlines) v[u].y = src[lstride];
+                    }
+                }
                 const int slot = (P.inverse && !P.roundtrip) ? dctc::swz(n) : dctc::sample_slot(n, N, bits);
-                dst[u] = inside ? 2 * ((L >> 1) * pstride + slot) + (L & 1) : -1;
+                dst[u] = inside ? pr * pstride + slot : -1;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (dst[u] >= 0) smem[dst[u]] = v[u];
+                if (dst[u] >= 0) z[dst[u]] = v[u];
         }
     }
     __syncthreads();
@@ -161,13 +179,15 @@ __global__ void __launch_bounds__(NT) dct_fft_kernel(FftK P) {
     bool out_is_samples = P.inverse != 0;                     // which slot order the result sits in
     if (P.roundtrip) {
         forward();
-        for (int w = tid; w < total; w += NT) {              // spectrum sits in natural slots swz(k)
-            int L, n;
-            if (P.axis == 0) { L = w >> bits; n = w & (N - 1); }
-            else if (P.ltbits >= 0) { L = w & (LT - 1); n = w >> P.ltbits; }
-            else { L = w % LT; n = w / LT; }
-            if (L >= nlines) continue;
-            smem[2 * ((size_t)(L >> 1) * pstride + dctc::swz(n)) + (L & 1)] *= symbol_inv(L, n);
+        for (int q = tid; q < nitems; q += NT) {             // spectrum sits in natural slots swz(k)
+            int pr, n;
+            decode(q, pr, n);
+            const int L0 = 2 * pr;
+            if (L0 >= nlines) continue;
+            c2 e = z[pr * pstride + dctc::swz(n)];
+            e.x *= symbol_inv(L0, n);
+            if (L0 + 1 < nlines) e.y *= symbol_inv(L0 + 1, n);
+            z[pr * pstride + dctc::swz(n)] = e;
         }
         __syncthreads();
         inverse();
@@ -178,18 +198,28 @@ __global__ void __launch_bounds__(NT) dct_fft_kernel(FftK P) {
         inverse();
     }
 
-    // ---- store
-    for (int w = tid; w < total; w += NT) {
-        int L, n;
-        if (P.axis == 0) { L = w >> bits; n = w & (N - 1); }
-        else if (P.ltbits >= 0) { L = w & (LT - 1); n = w >> P.ltbits; }
-        else { L = w % LT; n = w / LT; }
-        if (L >= nlines) continue;
+    // ---- store (same item -> address map as the load)
+    for (int q = tid; q < nitems; q += NT) {
+        int pr, n;
+        decode(q, pr, n);
+        const int L0 = 2 * pr;
+        if (L0 >= nlines) continue;
         const int slot = out_is_samples ? dctc::sample_slot(n, N, bits) : dctc::swz(n);
-        double v = smem[2 * ((size_t)(L >> 1) * pstride + slot) + (L & 1)];
-        if (P.fuse_scale && !P.roundtrip) v *= symbol_inv(L, n);
-        P.out[base + (size_t)L * lstride + (size_t)n * estride] = v;
+        c2 e = z[pr * pstride + slot];
+        const bool two = L0 + 1 < nlines;
+        if (P.fuse_scale && !P.roundtrip) {
+            e.x *= symbol_inv(L0, n);
+            if (two) e.y *= symbol_inv(L0 + 1, n);
+        }
+        double* dstp = P.out + base + (size_t)L0 * lstride + (size_t)n * estride;
+        if (P.pairvec && two) {
+            *reinterpret_cast<double2*>(dstp) = make_double2(e.x, e.y);
+        } else {
+            dstp[0] = e.x;
+            if (two) dstp[lstride] = e.y;
+        }
     }
+    (void)total;
 }
 
 inline int choose_lt(int N, int axis, int n0, size_t rows) {
@@ -235,6 +265,7 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
         P.tiles_x = (n0 + P.LT - 1) / P.LT;
         grid = (unsigned)((size_t)P.tiles_x * (axis == 1 ? n2 : n1));
     }
+    P.pairvec = (axis != 0 && (n0 % 2 == 0) && (((uintptr_t)in | (uintptr_t)out) & 15) == 0) ? 1 : 0;
     const size_t lds = ((size_t)(P.LT / 2) * (P.N + 1) + (size_t)(P.N / 2)) * sizeof(c2);
     static bool attr_set = false;
     if (!attr_set) {

@@ -56,7 +56,7 @@ using dense::cplx;
 
 extern "C" int bk_eig_shiftinvert(bk_ctx* ctx, bk_op* J, int nev, const bk_eig_opts* eo, const bk_gmres_opts* lsopts,
                                   bk_precond* pl, double* vals_re, double* vals_im, double* vecs, double* vecs_im,
-                                  size_t ldvecs, int* nconv_out, int* numops_out) {
+                                  size_t ldvecs, int* nvals_out, int* nconv_out, int* numops_out) {
     if (!ctx || !J || !eo || !lsopts || !vals_re || !vals_im || nev < 1) return -1;
     if (J->ntail != 0) return set_error(ctx, "bk_eig_shiftinvert: operator must be unbordered");
     const size_t n = J->n;
@@ -186,17 +186,25 @@ extern "C" int bk_eig_shiftinvert(bk_ctx* ctx, bk_op* J, int nev, const bk_eig_o
         k = kq;
     }
     // ---- back-transform 1/mu + sigma, sort by decreasing real part (__sort_spectrum, src/EigSolver.jl:16-19)
-    const int nout = std::min(nev, meff);
+    // number of values returned: nev, or nev + 1 when the cut would split a complex-conjugate pair (what ARPACK's
+    // dneupd and KrylovKit do for real non-symmetric problems) -- the caller's arrays hold nev + 1 entries
+    int nout = 0;
+    while (nout < nev && nout < meff) {
+        const cplx a = mu[order[nout]];
+        const bool pair = !eo->hermitian && nout + 1 < meff && std::fabs(a.imag()) > 1e-12 * std::abs(a) &&
+                          std::abs(a - std::conj(mu[order[nout + 1]])) <= 1e-8 * std::abs(a);
+        nout += pair ? 2 : 1;
+    }
     std::vector<cplx> lam(nout);
     std::vector<int> sel(nout);
     // Only converged Ritz pairs are reported (ARPACK / KrylovKit's `converged` count): an unconverged Ritz value of the
     // inverse can sit anywhere, and 1/mu + sigma would then fake an unstable eigenvalue.  Unconverged slots are NaN.
     std::vector<char> okv(nout, 0);
-    int nok = 0;
     for (int jj = 0; jj < nout; ++jj) {
         sel[jj] = order[jj];
-        okv[jj] = (breakdown || resid[jj] < eo->tol) ? 1 : 0;
-        nok += okv[jj];
+        // "usable": Ritz residual below tol, or below sqrt(eps)|mu| -- the level inexact inner solves (rtol 1e-9 in
+        // examples/SH3d.jl:115 against tol 1e-12) leave behind; the eigenvalue is then accurate to that level
+        okv[jj] = (breakdown || resid[jj] < std::max(eo->tol, 1.4901161193847656e-08 * std::abs(mu[order[jj]]))) ? 1 : 0;
         lam[jj] = okv[jj] ? cplx(1.0, 0.0) / mu[order[jj]] + eo->sigma : cplx(NAN, NAN);
     }
     std::vector<int> perm(nout);
@@ -209,7 +217,8 @@ extern "C" int bk_eig_shiftinvert(bk_ctx* ctx, bk_op* J, int nev, const bk_eig_o
         vals_re[i] = lam[perm[i]].real();
         vals_im[i] = lam[perm[i]].imag();
     }
-    for (int i = nout; i < nev; ++i) { vals_re[i] = NAN; vals_im[i] = NAN; }
+    for (int i = nout; i <= nev; ++i) { vals_re[i] = NAN; vals_im[i] = NAN; }
+    if (nvals_out) *nvals_out = nout;
     if (vecs) {
         if (ldvecs < n) return set_error(ctx, "bk_eig_shiftinvert: ldvecs < local length");
         std::vector<double> Qr((size_t)meff * nout), Qi((size_t)meff * nout);
@@ -221,7 +230,7 @@ extern "C" int bk_eig_shiftinvert(bk_ctx* ctx, bk_op* J, int nev, const bk_eig_o
         BK_TRY(v_basis_combine(ctx, n, V, ld, meff, Qr.data(), nout, vecs, ldvecs));
         if (vecs_im) BK_TRY(v_basis_combine(ctx, n, V, ld, meff, Qi.data(), nout, vecs_im, ldvecs));
     }
-    if (nconv_out) *nconv_out = nok;
+    if (nconv_out) *nconv_out = std::min(nconv, nout);      // strictly converged (resid < tol), as info.converged
     if (numops_out) *numops_out = A.solves;
     return 0;
 }

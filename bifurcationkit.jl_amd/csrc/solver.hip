@@ -53,49 +53,29 @@ struct VecOps {
 
 // One Arnoldi step: w = A V[j]; orthogonalise against V[0..j]; write V[j+1] = w / beta.
 // h[0..j] receives the projections, *beta the norm of the remainder (0 => breakdown, V[j+1] not written).
+// eta = DGKS threshold: a second Gram-Schmidt pass runs when the remainder keeps less than eta of ||w|| (eta > 1:
+// always, the choice for the eigensolver's outer Arnoldi where ghost Ritz values punish any loss of orthogonality).
 int arnoldi_step(bk_ctx* ctx, bk_op* A, Basis& B, int j, double* w, double* h, double* beta, double op_a0,
-                 double op_a1) {
+                 double op_a1, double eta) {
     const size_t n = A->n;
     const int nt = A->ntail;
     double wt = 0.0;
     BK_TRY(A->apply(B.vec(j), nt ? B.t[j] : 0.0, op_a0, op_a1, w, &wt));
     const int k = j + 1;
-    double hh[kMaxBasis + 1];
+    double hh[kMaxBasis + 1], c[kMaxBasis];
     BK_TRY(v_multidot(ctx, n, B.V, B.ld, k, w, hh));
     double ww = hh[k];
     if (nt) {
         for (int i = 0; i < k; ++i) hh[i] += B.t[i] * wt;
         ww += wt * wt;
     }
+    if (ww == 0.0) { *beta = 0.0; return 0; }
     double hsq = 0.0;
-    for (int i = 0; i < k; ++i) { h[i] = hh[i]; hsq += hh[i] * hh[i]; }
-    double b2 = ww - hsq;
-    // DGKS threshold: re-orthogonalise only when the remainder keeps less than eta of the norm.  One CGS pass leaves
-    // |V'v| <= ~eps/eta, so eta = 0.1 still gives orthogonality ~2e-15 while skipping the second pass on operators
-    // close to the identity (KrylovKit's IR variants use 1/sqrt(2); measured at 512^3: same residuals, half the time).
-    const double eta = ctx->opt("dgks_eta", 0.1);
-    const double tiny = 1e-28 * ww;
-    if (!(b2 > tiny) || ww == 0.0) {
-        // w lies (numerically) in span(V): verify with an explicit pass before declaring breakdown
-        double c[kMaxBasis];
-        for (int i = 0; i < k; ++i) c[i] = -h[i];
-        double nn = 0.0;
-        BK_TRY(v_multiaxpy(ctx, n, B.V, B.ld, k, c, w, 1.0, w, &nn));
-        if (nt) {
-            for (int i = 0; i < k; ++i) wt -= h[i] * B.t[i];
-            nn += wt * wt;
-        }
-        if (!(nn > 1e-30 * ww) || ww == 0.0) { *beta = 0.0; return 0; }
-        // not a breakdown after all: normalise and fall through to a re-orthogonalisation
-        const double bn = std::sqrt(nn);
-        BK_TRY(v_axpbyz(ctx, n, 1.0 / bn, w, 0.0, nullptr, B.vec(k)));
-        if (nt) B.t[k] = wt / bn;
-        b2 = nn;
-        *beta = bn;
-    } else {
+    for (int i = 0; i < k; ++i) { h[i] = hh[i]; hsq += hh[i] * hh[i]; c[i] = -hh[i]; }
+    const double b2 = ww - hsq;                 // Pythagoras: ||w - V h||^2, relative error ~ eps * ww / b2
+    if (b2 > 1e-8 * ww) {
+        // pass B with the normalisation folded in: v_{k} = (w - V h) / sqrt(b2)
         const double be = std::sqrt(b2);
-        double c[kMaxBasis];
-        for (int i = 0; i < k; ++i) c[i] = -h[i];
         BK_TRY(v_multiaxpy(ctx, n, B.V, B.ld, k, c, w, 1.0 / be, B.vec(k), nullptr));
         if (nt) {
             double t = wt;
@@ -103,9 +83,22 @@ int arnoldi_step(bk_ctx* ctx, bk_op* A, Basis& B, int j, double* w, double* h, d
             B.t[k] = t / be;
         }
         *beta = be;
-        if (b2 >= eta * eta * ww) return 0;          // DGKS: no cancellation, one pass is enough
+        if (b2 >= eta * eta * ww) return 0;      // DGKS: no cancellation, one pass is enough
+    } else {
+        // severe cancellation: the Pythagorean estimate is noise; take the norm of the remainder explicitly
+        double nn = 0.0;
+        BK_TRY(v_multiaxpy(ctx, n, B.V, B.ld, k, c, w, 1.0, w, &nn));
+        if (nt) {
+            for (int i = 0; i < k; ++i) wt -= h[i] * B.t[i];
+            nn += wt * wt;
+        }
+        if (!(nn > 1e-30 * ww)) { *beta = 0.0; return 0; }       // w is in span(V) to working precision: breakdown
+        const double bn = std::sqrt(nn);
+        BK_TRY(v_axpbyz(ctx, n, 1.0 / bn, w, 0.0, nullptr, B.vec(k)));
+        if (nt) B.t[k] = wt / bn;
+        *beta = bn;
     }
-    // re-orthogonalise v = V[k] (unit norm up to the cancellation error): s = V'v; v = (v - V s)/||.||
+    // second pass ("twice is enough"), with the norm of the result taken explicitly
     double ss[kMaxBasis + 1];
     BK_TRY(v_multidot(ctx, n, B.V, B.ld, k, B.vec(k), ss));
     double vv = ss[k];
@@ -113,19 +106,20 @@ int arnoldi_step(bk_ctx* ctx, bk_op* A, Basis& B, int j, double* w, double* h, d
         for (int i = 0; i < k; ++i) ss[i] += B.t[i] * B.t[k];
         vv += B.t[k] * B.t[k];
     }
-    double ssq = 0.0;
-    for (int i = 0; i < k; ++i) ssq += ss[i] * ss[i];
-    double c2 = vv - ssq;
-    if (!(c2 > 1e-28 * vv)) { *beta = 0.0; return 0; }
-    const double cn = std::sqrt(c2);
-    double c[kMaxBasis];
-    for (int i = 0; i < k; ++i) { c[i] = -ss[i]; h[i] += (*beta) * ss[i]; }
-    BK_TRY(v_multiaxpy(ctx, n, B.V, B.ld, k, c, B.vec(k), 1.0 / cn, B.vec(k), nullptr));
+    for (int i = 0; i < k; ++i) c[i] = -ss[i];
+    double nn2 = 0.0;
+    BK_TRY(v_multiaxpy(ctx, n, B.V, B.ld, k, c, B.vec(k), 1.0, B.vec(k), &nn2));
     if (nt) {
         double t = B.t[k];
         for (int i = 0; i < k; ++i) t -= ss[i] * B.t[i];
-        B.t[k] = t / cn;
+        B.t[k] = t;
+        nn2 += t * t;
     }
+    if (!(nn2 > 1e-30 * vv)) { *beta = 0.0; return 0; }
+    const double cn = std::sqrt(nn2);
+    BK_TRY(v_scale(ctx, n, 1.0 / cn, B.vec(k)));
+    if (nt) B.t[k] /= cn;
+    for (int i = 0; i < k; ++i) h[i] += (*beta) * ss[i];
     *beta = (*beta) * cn;
     return 0;
 }
@@ -139,7 +133,7 @@ int arnoldi_step_public(bk_ctx* ctx, bk_op* A, double* V, size_t ld, std::vector
     B.V = V;
     B.ld = ld;
     B.t.swap(tails);
-    const int s = arnoldi_step(ctx, A, B, j, w, h, beta, 0.0, 1.0);
+    const int s = arnoldi_step(ctx, A, B, j, w, h, beta, 0.0, 1.0, 2.0);      // eigensolver: always two passes
     B.t.swap(tails);
     return s;
 }
@@ -157,6 +151,10 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, double bt, double* x, dou
     const double op_a0 = kk ? 0.0 : alpha0, op_a1 = kk ? 1.0 : alpha1;
     const double s0 = kk ? alpha0 : 0.0, s1 = kk ? alpha1 : 1.0;
     VecOps vo{ctx, n, nt};
+    // DGKS threshold: re-orthogonalise only when the remainder keeps less than eta of the norm.  One CGS pass leaves
+    // |V'v| <= ~eps/eta, so eta = 0.1 still gives orthogonality ~2e-15 while skipping the second pass on operators
+    // close to the identity (KrylovKit's IR variants use 1/sqrt(2); measured at 512^3: same residuals, half the time).
+    const double eta = ctx->opt("dgks_eta", 0.1);
     WsGuard ws(ctx);
     Basis B;
     B.ld = round_up(n, 32);
@@ -195,7 +193,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, double bt, double* x, dou
     auto start_cycle = [&]() -> int {        // V[0] = r / beta ; first Arnoldi column
         BK_TRY(v_axpbyz(ctx, n, 1.0 / beta, r, 0.0, nullptr, B.vec(0)));
         if (nt) B.t[0] = rt / beta;
-        BK_TRY(arnoldi_step(ctx, A, B, 0, w, h.data(), &hnext, op_a0, op_a1));
+        BK_TRY(arnoldi_step(ctx, A, B, 0, w, h.data(), &hnext, op_a0, op_a1, eta));
         numops += 1;
         have_first = true;
         return 0;
@@ -230,7 +228,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, double bt, double* x, dou
             const bool conv = kk ? !(beta > tol) : (beta <= tol);
             if (conv || k >= m || hnext == 0.0) break;
             if (!kk && iters >= o.maxiter) { stop = true; break; }
-            BK_TRY(arnoldi_step(ctx, A, B, k, w, h.data(), &hnext, op_a0, op_a1));
+            BK_TRY(arnoldi_step(ctx, A, B, k, w, h.data(), &hnext, op_a0, op_a1, eta));
             numops += 1;
         }
         // solve R yk = y[0..k) and update x += V[0..k) yk

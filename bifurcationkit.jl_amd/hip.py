@@ -566,23 +566,24 @@ class ShiftInvert:
         eo = L.EigOpts(float(self.sigma), int(kd), int(self.maxiter), float(self.tol), 1 if self.hermitian else 0,
                        int(self.seed))
         lo = self.ls._opts()
-        re = (C.c_double * nev)()
-        im = (C.c_double * nev)()
+        re = (C.c_double * (nev + 1))()
+        im = (C.c_double * (nev + 1))()
         n = J.prob.nlocal
         ld = (n + 31) // 32 * 32
-        vr = ctx.empty(ld * nev) if self.save_vectors else None
-        vi = ctx.empty(ld * nev) if (self.save_vectors and not self.hermitian) else None
-        nconv, nops = C.c_int(), C.c_int()
+        vr = ctx.empty(ld * (nev + 1)) if self.save_vectors else None
+        vi = ctx.empty(ld * (nev + 1)) if (self.save_vectors and not self.hermitian) else None
+        nvals, nconv, nops = C.c_int(), C.c_int(), C.c_int()
         ctx.check(ctx.lib.bk_eig_shiftinvert(
             ctx.h, J.h, nev, C.byref(eo), C.byref(lo), self.ls._pl(), re, im,
             _ptr(vr) if vr is not None else None, _ptr(vi) if vi is not None else None, ld,
-            C.byref(nconv), C.byref(nops)), "bk_eig_shiftinvert")
-        vals = np.array([complex(re[i], im[i]) for i in range(nev)])      # NaN = not converged (ignored by is_stable)
+            C.byref(nvals), C.byref(nconv), C.byref(nops)), "bk_eig_shiftinvert")
+        m = nvals.value                                   # nev, or nev + 1 to keep a complex pair together
+        vals = np.array([complex(re[i], im[i]) for i in range(m)])        # NaN = not converged (ignored by is_stable)
         vecs = None
         if vr is not None:
             vecs = [(HipVec(ctx, vr[i * ld:i * ld + n], J.prob.nglobal),
                      HipVec(ctx, vi[i * ld:i * ld + n], J.prob.nglobal) if vi is not None else None)
-                    for i in range(nev)]
+                    for i in range(m)]
         return vals, vecs, nconv.value >= nev, nops.value
 
     @staticmethod

@@ -200,7 +200,9 @@ int bk_bls_matrixfree(bk_ctx* ctx, bk_op* J, const double* dR, const double* dzu
  * (eig::ShiftInvert)(J, nev) -> (vals, vecs, converged, niter): src/EigSolver.jl:246-266 with a
  * Krylov-Schur (KrylovKit.eigsolve-style) outer iteration; the SH3dEig of examples/SH3d.jl:96-113.
  * Eigenvalues come back sorted by decreasing real part (__sort_spectrum, src/EigSolver.jl:16-19).
- * vecs (may be NULL) receives nev device vectors of local length, stride ldvecs, real parts of
+ * vals_re / vals_im hold nev + 1 entries: *nvals = nev, or nev + 1 when the cut would split a complex-conjugate
+ * pair (as ARPACK / KrylovKit do); entries that did not converge to max(tol, sqrt(eps)|mu|) are NaN.
+ * vecs (may be NULL) receives up to nev + 1 device vectors of local length, stride ldvecs, real parts of
  * the eigenvectors (imaginary parts in vecs_im when not NULL; symmetric problems: zero).        */
 typedef struct {
     double sigma;      /* shift                                                                    */
@@ -212,8 +214,8 @@ typedef struct {
 } bk_eig_opts;
 int bk_eig_shiftinvert(bk_ctx* ctx, bk_op* J, int nev, const bk_eig_opts* eopts,
                        const bk_gmres_opts* lsopts, bk_precond* pl, double* vals_re,
-                       double* vals_im, double* vecs, double* vecs_im, size_t ldvecs, int* nconv,
-                       int* numops);
+                       double* vals_im, double* vecs, double* vecs_im, size_t ldvecs, int* nvals,
+                       int* nconv, int* numops);
 
 /* ------------------------------------------------------------------ Newton correctors ------ */
 typedef struct {

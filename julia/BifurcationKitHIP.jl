@@ -292,19 +292,20 @@ BK.geteigenvector(::HipShiftInvert, vecs, n::Union{Int, AbstractVector{Int64}}) 
 function (e::HipShiftInvert)(J::HipJacobian, nev::Int; kwargs...)
     ctx = J.prob.ctx
     kd = min(max(30, nev + 30), 63)                                   # SH3d.jl:109
-    re, im = zeros(Cdouble, nev), zeros(Cdouble, nev)
+    re, im = zeros(Cdouble, nev + 1), zeros(Cdouble, nev + 1)      # nev + 1: a complex pair is never split
     n = J.x.n
     ld = cld(n, 32) * 32
-    buf = HipVec(ctx, ld * nev)
-    nconv, nops = Ref{Cint}(0), Ref{Cint}(0)
+    buf = HipVec(ctx, ld * (nev + 1))
+    nvals, nconv, nops = Ref{Cint}(0), Ref{Cint}(0), Ref{Cint}(0)
     eo = EigOpts(e.σ, kd, e.maxiter, e.tol, e.hermitian, e.seed)
     check(ctx, ccall((:bk_eig_shiftinvert, libbkhip[]), Cint,
         (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ref{EigOpts}, Ref{GmresOpts}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
-         Csize_t, Ref{Cint}, Ref{Cint}),
-        ctx.h, J.h, nev, Ref(eo), Ref(_opts(e.ls)), _plh(e.ls.Pl), re, im, buf.p, C_NULL, ld, nconv, nops), "bk_eig_shiftinvert")
+         Csize_t, Ref{Cint}, Ref{Cint}, Ref{Cint}),
+        ctx.h, J.h, nev, Ref(eo), Ref(_opts(e.ls)), _plh(e.ls.Pl), re, im, buf.p, C_NULL, ld, nvals, nconv, nops), "bk_eig_shiftinvert")
+    m = Int(nvals[])
     vecs = [(v = HipVec(ctx, n); ccall((:bk_vec_copy, libbkhip[]), Cint, (Ptr{Cvoid}, Csize_t, Ptr{Cdouble}, Ptr{Cdouble}),
-                                       ctx.h, n, buf.p + (i - 1) * ld * sizeof(Cdouble), v.p); v) for i in 1:nev]
-    return Complex.(re, im), vecs, nconv[] >= nev, Int(nops[])
+                                       ctx.h, n, buf.p + (i - 1) * ld * sizeof(Cdouble), v.p); v) for i in 1:m]
+    return Complex.(re[1:m], im[1:m]), vecs, nconv[] >= nev, Int(nops[])
 end
 
 # ------------------------------------------------------------------------------------------------ usage
