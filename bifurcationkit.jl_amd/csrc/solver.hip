@@ -164,7 +164,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, double bt, double* x, dou
     BK_TRY(ws.get(B.ld, &w));
     BK_TRY(ws.get(B.ld, &r));
 
-    BK_TRY(v_zero(ctx, n, x));
+    bool x_zero = true;                        // x0 = 0 is never materialised: the first update writes x = V y
     double xtail = 0.0;
     double bnorm = 0.0;
     BK_TRY(vo.nrm2(b, bt, &bnorm));
@@ -177,25 +177,25 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, double bt, double* x, dou
     int iters = 0;                             // IterativeSolvers counts inner iterations
     res->converged = 0;
     if (kk ? (beta < tol) : (beta <= tol)) {
+        BK_TRY(v_zero(ctx, n, x));
         res->converged = 1; res->niter = kk ? numops : 0; res->resnorm = beta;
         if (xt) *xt = 0.0;
         return 0;
     }
-    BK_TRY(v_copy(ctx, n, b, r));
+    const double* rsrc = b;                    // first cycle: r0 = b, read in place (no copy)
     double rt = bt;
 
     std::vector<double> R((size_t)m * m, 0.0), y(m + 1, 0.0), cs(m, 0.0), sn(m, 0.0), h(m + 1, 0.0), col(m + 1, 0.0);
     auto Rat = [&](int i, int j) -> double& { return R[(size_t)i + (size_t)j * m]; };
     int numiter = 0;
     double hnext = 0.0;
-    bool have_first = false;
 
     auto start_cycle = [&]() -> int {        // V[0] = r / beta ; first Arnoldi column
-        BK_TRY(v_axpbyz(ctx, n, 1.0 / beta, r, 0.0, nullptr, B.vec(0)));
+        BK_TRY(v_axpbyz(ctx, n, 1.0 / beta, rsrc, 0.0, nullptr, B.vec(0)));
+        rsrc = r;
         if (nt) B.t[0] = rt / beta;
         BK_TRY(arnoldi_step(ctx, A, B, 0, w, h.data(), &hnext, op_a0, op_a1, eta));
         numops += 1;
-        have_first = true;
         return 0;
     };
 
@@ -238,7 +238,8 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, double bt, double* x, dou
             for (int j = i + 1; j < k; ++j) s -= Rat(i, j) * yk[j];
             yk[i] = s / Rat(i, i);
         }
-        BK_TRY(v_multiaxpy(ctx, n, B.V, B.ld, k, yk.data(), x, 1.0, x, nullptr));
+        BK_TRY(v_multiaxpy(ctx, n, B.V, B.ld, k, yk.data(), x_zero ? nullptr : x, 1.0, x, nullptr));
+        x_zero = false;
         if (nt) for (int i = 0; i < k; ++i) xtail += yk[i] * B.t[i];
 
         if (kk) {
@@ -281,7 +282,6 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, double bt, double* x, dou
             BK_TRY(start_cycle());
         }
     }
-    (void)have_first;
     res->niter = kk ? numops : iters;
     res->resnorm = beta;
     if (xt) *xt = xtail;
@@ -304,10 +304,19 @@ struct ShiftPrecOp : bk_op {
         if (!P) return J->apply(x, 0.0, b0 + b1 * a0, b1 * a1, out, nullptr);
         if (order == 0) {
             BK_TRY(J->apply(x, 0.0, 0.0, 1.0, tmp, nullptr));
+            const double cx = b0 + b1 * a0, ct = b1 * a1;
+            if (cx == 0.0) {                       // the common Arnoldi call (a0 = 0): Pl^-1 writes straight into out
+                BK_TRY(P->apply(tmp, out));
+                return ct == 1.0 ? 0 : v_scale(ctx, n, ct, out);
+            }
             BK_TRY(P->apply(tmp, tmp));
-            return v_axpbyz(ctx, n, b0 + b1 * a0, x, b1 * a1, tmp, out);
+            return v_axpbyz(ctx, n, cx, x, ct, tmp, out);
         }
         BK_TRY(J->apply(x, 0.0, a0, a1, tmp, nullptr));
+        if (b0 == 0.0) {
+            BK_TRY(P->apply(tmp, out));
+            return b1 == 1.0 ? 0 : v_scale(ctx, n, b1, out);
+        }
         BK_TRY(P->apply(tmp, tmp));
         return v_axpbyz(ctx, n, b0, x, b1, tmp, out);
     }
