@@ -152,11 +152,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if os.environ.get("BK_BENCH_HOSTCOMM") == "1":
+        local = 0                                   # test mode: all ranks share GPU 0
     torch.cuda.set_device(local)
     from bk_amd import hip
 
     comm = None
-    if world > 1 or os.environ.get("BK_FORCE_DIST") == "1":        # BK_FORCE_DIST: exercise the RCCL bootstrap with 1 rank
+    hostcomm_mode = os.environ.get("BK_BENCH_HOSTCOMM") == "1"     # test mode: ranks share GPU 0 over gloo + host staging
+    if hostcomm_mode:
+        from bk_amd import hostcomm
+        local = 0
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo")
+        comm = hostcomm.comm_tuple()
+    elif world > 1 or os.environ.get("BK_FORCE_DIST") == "1":       # BK_FORCE_DIST: exercise the RCCL bootstrap with 1 rank
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
@@ -230,7 +239,7 @@ def main():
     dt = time.perf_counter() - t0
     ctx.prof_enable(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if hostcomm_mode else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
