@@ -35,6 +35,7 @@ struct FftK {
     int roundtrip;            // 1: forward, inverse symbol, inverse -- all in LDS, one read + one write of the array
     int tiles_x;              // axis >= 1: number of LT-wide tiles along x
     int pairvec;              // axis >= 1 and 16-B aligned pairs: the two lines of a pair are loaded / stored as one double2
+    int fast;                 // full tiles, power-of-two shapes, < 2^31 elements: incremental addressing (host-checked)
 };
 
 template <int NT>
@@ -83,6 +84,42 @@ __global__ void __launch_bounds__(NT) dct_fft_kernel(FftK P) {
         else if (pbits >= 0) { pr = q & (npairs - 1); n = q >> pbits; }
         else { pr = q % npairs; n = q / npairs; }
     };
+    const bool fwd_slots = !(P.inverse && !P.roundtrip);     // which slot order the input goes to
+    if (P.fast) {
+        // Incremental addressing (no per-item decode): nitems / NT == 8 items per lane.
+        if (P.axis == 0) {
+            // NT is a multiple of N: lane owns one sample index n and walks over the pairs
+            const int n = tid & (N - 1);
+            const int slot = fwd_slots ? dctc::sample_slot(n, N, bits) : dctc::swz(n);
+            const int pr0 = tid >> bits, dpr = NT >> bits;
+            const double* src = P.in + base + n + (size_t)(2 * pr0) * P.n0;
+            const size_t inc = (size_t)(2 * dpr) * P.n0;
+            c2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (pr0 + u * dpr < npairs) { v[u].x = src[u * inc]; v[u].y = src[u * inc + P.n0]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (pr0 + u * dpr < npairs) z[(pr0 + u * dpr) * pstride + slot] = v[u];
+        } else {
+            // lane owns one pair (two adjacent x) and walks along the transform direction
+            const int pr = tid & (npairs - 1);
+            const int n0_ = tid >> pbits, dn = NT >> pbits;
+            const double* src = P.in + base + 2 * pr + (size_t)n0_ * estride;
+            const size_t inc = (size_t)dn * estride;
+            c2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (n0_ + u * dn < N) { const double2 t = *reinterpret_cast<const double2*>(src + u * inc); v[u].x = t.x; v[u].y = t.y; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int n = n0_ + u * dn;
+                if (n < N) z[pr * pstride + (fwd_slots ? dctc::sample_slot(n, N, bits) : dctc::swz(n))] = v[u];
+            }
+        }
+    } else
     {
         constexpr int U = 8;
         for (int q0 = tid; q0 < nitems; q0 += NT * U) {
@@ -199,6 +236,36 @@ __global__ void __launch_bounds__(NT) dct_fft_kernel(FftK P) {
     }
 
     // ---- store (same item -> address map as the load)
+    if (P.fast && !(P.fuse_scale && !P.roundtrip)) {
+        if (P.axis == 0) {
+            const int n = tid & (N - 1);
+            const int slot = out_is_samples ? dctc::sample_slot(n, N, bits) : dctc::swz(n);
+            const int pr0 = tid >> bits, dpr = NT >> bits;
+            double* dstp = P.out + base + n + (size_t)(2 * pr0) * P.n0;
+            const size_t inc = (size_t)(2 * dpr) * P.n0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (pr0 + u * dpr < npairs) {
+                    const c2 e = z[(pr0 + u * dpr) * pstride + slot];
+                    dstp[u * inc] = e.x;
+                    dstp[u * inc + P.n0] = e.y;
+                }
+            }
+        } else {
+            const int pr = tid & (npairs - 1);
+            const int n0_ = tid >> pbits, dn = NT >> pbits;
+            double* dstp = P.out + base + 2 * pr + (size_t)n0_ * estride;
+            const size_t inc = (size_t)dn * estride;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int n = n0_ + u * dn;
+                if (n < N) {
+                    const c2 e = z[pr * pstride + (out_is_samples ? dctc::sample_slot(n, N, bits) : dctc::swz(n))];
+                    *reinterpret_cast<double2*>(dstp + u * inc) = make_double2(e.x, e.y);
+                }
+            }
+        }
+    } else
     for (int q = tid; q < nitems; q += NT) {
         int pr, n;
         decode(q, pr, n);
@@ -266,6 +333,7 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
         grid = (unsigned)((size_t)P.tiles_x * (axis == 1 ? n2 : n1));
     }
     P.pairvec = (axis != 0 && (n0 % 2 == 0) && (((uintptr_t)in | (uintptr_t)out) & 15) == 0) ? 1 : 0;
+    P.fast = 0;            // decided after the thread count is known
     const size_t lds = ((size_t)(P.LT / 2) * (P.N + 1) + (size_t)(P.N / 2)) * sizeof(c2);
     static bool attr_set = false;
     if (!attr_set) {
@@ -277,6 +345,14 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
     }
     // 512 lanes per tile when the tile is big enough to feed them (two workgroups per CU => 16 wavefronts)
     const int nt = (int)ctx->opt("dct_threads", (size_t)P.LT * P.N >= 4096 ? 512.0 : 256.0);
+    {
+        const int npairs = P.LT / 2;
+        const size_t nitems = (size_t)npairs * P.N;
+        const bool full_tiles = axis == 0 ? (rows % P.LT == 0) : (n0 % P.LT == 0);
+        const bool shapes = P.ltbits >= 1 && nitems <= (size_t)nt * 8 &&
+                            (axis == 0 ? (nt % P.N == 0) : (nt % npairs == 0 && P.pairvec));
+        P.fast = (ctx->opt("dct_fastio", 1.0) != 0.0 && full_tiles && shapes) ? 1 : 0;
+    }
     if (nt == 512) hipLaunchKernelGGL(dct_fft_kernel<512>, dim3(grid), dim3(512), lds, ctx->stream, P);
     else hipLaunchKernelGGL(dct_fft_kernel<256>, dim3(grid), dim3(256), lds, ctx->stream, P);
     BK_HIP(ctx, hipGetLastError());

@@ -37,11 +37,6 @@ struct VecOps {
     bk_ctx* ctx;
     size_t n;
     int ntail;
-    int dot(const double* x, double xt, const double* y, double yt, double* out) {
-        BK_TRY(v_dot(ctx, n, x, y, out));
-        if (ntail) *out += xt * yt;
-        return 0;
-    }
     int nrm2(const double* x, double xt, double* out) {
         double s;
         BK_TRY(v_dot(ctx, n, x, x, &s));

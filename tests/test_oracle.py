@@ -153,12 +153,11 @@ def test_krylovschur_restarts_nonsymmetric():
 
 
 def test_newton_palc_cubic():
-    # test/newton/test_newton.jl:23-52 in spirit: F(x, p) = x^3 - x - p? use a fold-free scalar family
+    # test/newton/test_newton.jl:23-52 in spirit, on a fold-free cubic family
     F = lambda x, p: x**3 + x - p
     J = lambda x, p: sp.diags(3 * x**2 + 1.0).tocsr()
     prob = palc.Problem(F, J)
-    bls = lambda *a, **k: bordered.matrix_bls(*a, shift=k.get("shift"), apply_xiu=None) if False else \
-        bordered.bordering_bls(bordered.default_ls, *a, **k)
+    bls = lambda *a, **k: bordered.bordering_bls(bordered.default_ls, *a, **k)
     n = 8
     x0 = np.zeros(n)
     z0 = (x0, 0.0)
