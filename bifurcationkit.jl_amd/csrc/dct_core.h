@@ -128,6 +128,39 @@ BK_HD void dif_group_inv(c2* z, int bits, int lh, int g, const c2* tw) {
     for (int q = 0; q < M; ++q) z[swz(base + (q << lh))] = v[q];
 }
 
+// radix-8 register butterflies with the 7 twiddles [s0: 1][s1: 2][s2: 4] already gathered (r8_twiddles)
+BK_HD void r8_fwd_regs(c2* v, const c2* w7) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const c2* t = w7 + (s == 0 ? 0 : (s == 1 ? 1 : 3));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (q & (1 << s)) continue;
+            const c2 w = t[s == 0 ? 0 : (s == 1 ? (q & 1) : (q & 3))];
+            const c2 a = v[q], b = v[q | (1 << s)];
+            const double tx = w.x * b.x - w.y * b.y, ty = w.x * b.y + w.y * b.x;
+            v[q].x = a.x + tx; v[q].y = a.y + ty;
+            v[q | (1 << s)].x = a.x - tx; v[q | (1 << s)].y = a.y - ty;
+        }
+    }
+}
+BK_HD void r8_inv_regs(c2* v, const c2* w7) {
+#pragma unroll
+    for (int s = 2; s >= 0; --s) {
+        const c2* t = w7 + (s == 0 ? 0 : (s == 1 ? 1 : 3));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (q & (1 << s)) continue;
+            const c2 w = t[s == 0 ? 0 : (s == 1 ? (q & 1) : (q & 3))];
+            const c2 a = v[q], b = v[q | (1 << s)];
+            const double dx = a.x - b.x, dy = a.y - b.y;
+            v[q].x = a.x + b.x; v[q].y = a.y + b.y;
+            v[q | (1 << s)].x = w.x * dx + w.y * dy;
+            v[q | (1 << s)].y = w.x * dy - w.y * dx;
+        }
+    }
+}
+
 // forward post-processing for k in [0, N/2]: in place, slots k and N-k.  ew[k] = exp(-i pi k / 2N).
 // On return z[swz(k)] = (Xa_k, Xb_k) and z[swz(N-k)] = (Xa_{N-k}, Xb_{N-k}) (orthonormal coefficients).
 BK_HD void fwd_post(c2* z, int N, int k, const c2* ew, double s0, double s2) {
@@ -170,6 +203,255 @@ BK_HD void inv_pre(c2* z, int N, int k, const c2* ew, double s0, double s2) {
     const double vbx = e.x * cbk - e.y * cbn, vby = -e.x * cbn - e.y * cbk;
     z[pk].x = vax - vby; z[pk].y = vay + vbx;
     if (2 * k != N) { z[pn].x = vax + vby; z[pn].y = -vay + vbx; }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fused schedule (dct_fused_kernel): the first and the last radix-8 stage run on registers that are filled from /
+// drained to global memory directly, so a tile makes 2 LDS round trips per transform instead of 5:
+//   forward   first<-global | LDS | middle stages | LDS | last + post -> global
+//   inverse   global -> pre + first DIF | LDS | middle | LDS | last DIF -> global
+//   roundtrip first<-global | LDS | middle | LDS | last + post + symbol + pre + first DIF | LDS | middle | LDS | last -> global
+// The building blocks below are shared with the host replay (tests/cpp/dct_core_check.cpp modes 4..6).
+
+BK_HD int bitrev3(int r) { return ((r & 1) << 2) | (r & 2) | ((r >> 2) & 1); }
+
+// sample index whose Makhoul slot is m
+BK_HD int makhoul_inv(int m, int N) { return m < (N >> 1) ? 2 * m : 2 * (N - 1 - m) + 1; }
+
+// sample index feeding slot r (0..7, compile-time in the unrolled callers) of the first-stage group gp in [0, N/8):
+// Makhoul slot m = gp + r N/8, which is below N/2 exactly for r < 4
+BK_HD int first_sample(int gp, int r, int N) {
+    const int m = gp + (N >> 3) * r;
+    return r < 4 ? 2 * m : 2 * (N - 1 - m) + 1;
+}
+
+BK_HD c2 cmul(c2 w, c2 b) { c2 r; r.x = w.x * b.x - w.y * b.y; r.y = w.x * b.y + w.y * b.x; return r; }
+BK_HD c2 cmulc(c2 w, c2 d) { c2 r; r.x = w.x * d.x + w.y * d.y; r.y = w.x * d.y - w.y * d.x; return r; }   // d * conj(w)
+
+// DIT stages 0..2 (half sizes 1, 2, 4) on 8 consecutive bit-reversed positions: constant twiddles.
+BK_HD void r8_first(c2* v) {
+    const double c = 0.70710678118654752440;
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) {                      // s = 0: w = 1
+        const c2 a = v[q], b = v[q + 1];
+        v[q].x = a.x + b.x; v[q].y = a.y + b.y;
+        v[q + 1].x = a.x - b.x; v[q + 1].y = a.y - b.y;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q += 4) {                      // s = 1: w = 1, -i
+        c2 a = v[q], b = v[q + 2];
+        v[q].x = a.x + b.x; v[q].y = a.y + b.y;
+        v[q + 2].x = a.x - b.x; v[q + 2].y = a.y - b.y;
+        a = v[q + 1]; b = v[q + 3];                       // -i b = (b.y, -b.x)
+        v[q + 1].x = a.x + b.y; v[q + 1].y = a.y - b.x;
+        v[q + 3].x = a.x - b.y; v[q + 3].y = a.y + b.x;
+    }
+    {                                                     // s = 2: w = 1, (c,-c), -i, (-c,-c)
+        c2 a = v[0], b = v[4];
+        v[0].x = a.x + b.x; v[0].y = a.y + b.y; v[4].x = a.x - b.x; v[4].y = a.y - b.y;
+        a = v[1]; b = v[5];
+        double tx = c * (b.x + b.y), ty = c * (b.y - b.x);
+        v[1].x = a.x + tx; v[1].y = a.y + ty; v[5].x = a.x - tx; v[5].y = a.y - ty;
+        a = v[2]; b = v[6];
+        v[2].x = a.x + b.y; v[2].y = a.y - b.x; v[6].x = a.x - b.y; v[6].y = a.y + b.x;
+        a = v[3]; b = v[7];
+        tx = c * (b.y - b.x); ty = -c * (b.x + b.y);
+        v[3].x = a.x + tx; v[3].y = a.y + ty; v[7].x = a.x - tx; v[7].y = a.y - ty;
+    }
+}
+
+// inverse DIF stages 2..0 (conjugate twiddles) on 8 consecutive positions.
+BK_HD void r8_last_inv(c2* v) {
+    const double c = 0.70710678118654752440;
+    {                                                     // s = 2: conj w = 1, (c,c), i, (-c,c)
+        c2 a = v[0], b = v[4];
+        v[0].x = a.x + b.x; v[0].y = a.y + b.y; v[4].x = a.x - b.x; v[4].y = a.y - b.y;
+        a = v[1]; b = v[5];
+        double dx = a.x - b.x, dy = a.y - b.y;
+        v[1].x = a.x + b.x; v[1].y = a.y + b.y; v[5].x = c * (dx - dy); v[5].y = c * (dx + dy);
+        a = v[2]; b = v[6];
+        dx = a.x - b.x; dy = a.y - b.y;
+        v[2].x = a.x + b.x; v[2].y = a.y + b.y; v[6].x = -dy; v[6].y = dx;
+        a = v[3]; b = v[7];
+        dx = a.x - b.x; dy = a.y - b.y;
+        v[3].x = a.x + b.x; v[3].y = a.y + b.y; v[7].x = -c * (dx + dy); v[7].y = c * (dx - dy);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q += 4) {                      // s = 1: conj w = 1, i
+        c2 a = v[q], b = v[q + 2];
+        v[q].x = a.x + b.x; v[q].y = a.y + b.y; v[q + 2].x = a.x - b.x; v[q + 2].y = a.y - b.y;
+        a = v[q + 1]; b = v[q + 3];
+        const double dx = a.x - b.x, dy = a.y - b.y;
+        v[q + 1].x = a.x + b.x; v[q + 1].y = a.y + b.y; v[q + 3].x = -dy; v[q + 3].y = dx;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) {                      // s = 0
+        const c2 a = v[q], b = v[q + 1];
+        v[q].x = a.x + b.x; v[q].y = a.y + b.y; v[q + 1].x = a.x - b.x; v[q + 1].y = a.y - b.y;
+    }
+}
+
+// the 7 twiddles of a radix-8 group from 3 loads: stage s, pos p (< 2^s) uses W^{(p*2^lh + lo) << (bits-lh-s-1)}
+//   = b_s * exp(-2 pi i p / 2^{s+1}),  b_s = tw[lo << (bits-lh-s-1)]   (constant rotations: 1, -i, e^{-i pi/4}, e^{-3i pi/4})
+BK_HD void r8_twiddles(c2* w7, int lo, int sh, const c2* tw) {      // sh = bits - lh - 3
+    const double c = 0.70710678118654752440;
+    const c2 b0 = tw[lo << (sh + 2)], b1 = tw[lo << (sh + 1)], b2 = tw[lo << sh];
+    w7[0] = b0;
+    w7[1] = b1; w7[2].x = b1.y; w7[2].y = -b1.x;
+    w7[3] = b2;
+    w7[4].x = c * (b2.x + b2.y); w7[4].y = c * (b2.y - b2.x);
+    w7[5].x = b2.y; w7[5].y = -b2.x;
+    w7[6].x = w7[4].y; w7[6].y = -w7[4].x;
+}
+
+// radix-8 group through LDS (three stages lh .. lh+2), g in [0, N/8): 8 data + 3 twiddle reads, 8 writes
+BK_HD void r8_group_fwd(c2* z, int bits, int lh, int g, const c2* tw) {
+    const int lo = g & ((1 << lh) - 1);
+    const int base = ((g >> lh) << (lh + 3)) + lo;
+    c2 v[8], w[7];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = z[swz(base + (q << lh))];
+    r8_twiddles(w, lo, bits - lh - 3, tw);
+    r8_fwd_regs(v, w);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) z[swz(base + (q << lh))] = v[q];
+}
+BK_HD void r8_group_inv(c2* z, int bits, int lh, int g, const c2* tw) {
+    const int lo = g & ((1 << lh) - 1);
+    const int base = ((g >> lh) << (lh + 3)) + lo;
+    c2 v[8], w[7];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = z[swz(base + (q << lh))];
+    r8_twiddles(w, lo, bits - lh - 3, tw);
+    r8_inv_regs(v, w);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) z[swz(base + (q << lh))] = v[q];
+}
+
+// X_k = sc * (Re(e_k Va_k), Re(e_k Vb_k)),  Va = (Zk + conj Zn)/2, Vb = -i (Zk - conj Zn)/2, Zn = Z_{N-k};
+// sc carries the 1/2:  sc = s0/2 (k = 0, where Zn = Zk) or s2/2.   Valid for every k in [0, N).
+BK_HD c2 post_one(c2 Zk, c2 Zn, c2 e, double sc) {
+    const double vax = Zk.x + Zn.x, vay = Zk.y - Zn.y;
+    const double vbx = Zk.y + Zn.y, vby = Zn.x - Zk.x;
+    c2 r;
+    r.x = sc * (e.x * vax - e.y * vay);
+    r.y = sc * (e.x * vbx - e.y * vby);
+    return r;
+}
+// Z_k = Va_k + i Vb_k, V_k = conj(e_k) (C_k - i C_{N-k}), C_k = fk X_k, C_{N-k} = fn X_{N-k} (fn = 0 for k = 0)
+BK_HD c2 pre_one(c2 Xk, c2 Xn, c2 e, double fk, double fn) {
+    const double cak = Xk.x * fk, cbk = Xk.y * fk, can = Xn.x * fn, cbn = Xn.y * fn;
+    const double vax = e.x * cak - e.y * can, vay = -e.x * can - e.y * cak;
+    const double vbx = e.x * cbk - e.y * cbn, vby = -e.x * cbn - e.y * cbk;
+    c2 r;
+    r.x = vax - vby; r.y = vay + vbx;
+    return r;
+}
+
+// F1: first radix-8 stage of pair-line zp for natural group gp in [0, N/8): samples come from ld(slot, n) -> c2, slot =
+// 0..7 a compile-time position (lets the kernel hand over registers it prefetched in exactly this order).
+template <class Load>
+BK_HD void fused_first(c2* zp, int N, int bits, int gp, Load&& ld) {
+    c2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[bitrev3(r)] = ld(r, first_sample(gp, r, N));
+    r8_first(v);
+    const int sb = swz(bitrev(gp, bits - 3) << 3);          // swz(8g + q) == swz(8g) ^ q  (q < 8 never reaches bit 4)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) zp[sb ^ q] = v[q];
+}
+
+// I3: last inverse radix-8 stage, results handed to st(n, value).
+template <class Store>
+BK_HD void fused_last(const c2* zp, int N, int bits, int gp, Store&& st) {
+    const int sb = swz(bitrev(gp, bits - 3) << 3);
+    c2 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = zp[sb ^ q];
+    r8_last_inv(v);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) st(first_sample(gp, r, N), v[bitrev3(r)]);
+}
+
+// One (k, N-k) pair of the merged middle, in place: x = element k, y = element N-k, 0 < k < N, k != N/2.
+// e_{N-k} = -i conj(e_k) = (-e_k.y, -e_k.x).
+template <int MODE, bool UPPER, class Sym>      // UPPER: k > N/2 -- the table holds k <= N/2 only
+BK_HD void mid_pair(c2& x, c2& y, int k, int N, const c2* ew, double hs2, double f2, Sym&& sym) {
+    const c2 t = ew[UPPER ? N - k : k];
+    c2 e, en;
+    if (UPPER) { en = t; e.x = -t.y; e.y = -t.x; }
+    else { e = t; en.x = -t.y; en.y = -t.x; }
+    c2 X = x, Y = y;
+    if (MODE != 1) { X = post_one(x, y, e, hs2); Y = post_one(y, x, en, hs2); }
+    if (MODE == 2) {
+        c2 f = sym(k);
+        X.x *= f.x; X.y *= f.y;
+        f = sym(N - k);
+        Y.x *= f.x; Y.y *= f.y;
+    }
+    if (MODE != 0) { x = pre_one(X, Y, e, f2, f2); y = pre_one(Y, X, en, f2, f2); }
+    else { x = X; y = Y; }
+}
+// k = 0 or k = N/2: the partner is the element itself (k = 0: fn = 0, scales s0).
+template <int MODE, class Sym>
+BK_HD void mid_single(c2& x, int k, const c2* ew, double hs, double fk, double fn, Sym&& sym) {
+    const c2 e = ew[k];
+    c2 X = x;
+    if (MODE != 1) X = post_one(x, x, e, hs);
+    if (MODE == 2) { const c2 f = sym(k); X.x *= f.x; X.y *= f.y; }
+    if (MODE != 0) x = pre_one(X, X, e, fk, fn);
+    else x = X;
+}
+
+// Middle item t in [0, N/16): owns the two top groups ga = t, gb = N/8 - t (t = 0: the two self-paired groups 0 and
+// N/16), i.e. every spectral index k together with N-k.
+//   MODE 0: LDS -> top DIT stage -> post -> st(k, X_k)
+//   MODE 1: ld(slot, k) (slot 0..7: group a, 8..15: group b) -> pre -> top inverse DIF stage -> LDS
+//   MODE 2: LDS -> top DIT -> post -> X_k *= sym(k) (per line) -> pre -> top inverse DIF -> LDS
+template <int MODE, class Load, class Store, class Sym>
+BK_HD void fused_mid(c2* zp, int N, int t, const c2* tw, const c2* ew, double s0, double s2, Load&& ld, Store&& st,
+                     Sym&& sym) {
+    const int G = N >> 3;
+    const bool self = t == 0;
+    const int ga = t, gb = self ? (G >> 1) : G - t;
+    c2 va[8], vb[8];
+    if (MODE != 1) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) va[q] = zp[swz(ga + q * G)];
+        { c2 w[7]; r8_twiddles(w, ga, 0, tw); r8_fwd_regs(va, w); }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) vb[q] = zp[swz(gb + q * G)];
+        { c2 w[7]; r8_twiddles(w, gb, 0, tw); r8_fwd_regs(vb, w); }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { va[q] = ld(q, ga + q * G); vb[q] = ld(8 + q, gb + q * G); }
+    }
+    const double rN = 1.0 / N, f2 = rN / s2, f0 = rN / s0, hs2 = 0.5 * s2;
+    if (self) {
+        mid_single<MODE>(va[0], 0, ew, 0.5 * s0, f0, 0.0, sym);
+        mid_single<MODE>(va[4], N >> 1, ew, hs2, f2, f2, sym);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) mid_pair<MODE, false>(va[q], va[8 - q], q * G, N, ew, hs2, f2, sym);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mid_pair<MODE, false>(vb[q], vb[7 - q], gb + q * G, N, ew, hs2, f2, sym);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mid_pair<MODE, false>(va[q], vb[7 - q], ga + q * G, N, ew, hs2, f2, sym);
+#pragma unroll
+        for (int q = 4; q < 8; ++q) mid_pair<MODE, true>(va[q], vb[7 - q], ga + q * G, N, ew, hs2, f2, sym);
+    }
+    if (MODE == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { st(ga + q * G, va[q]); st(gb + q * G, vb[q]); }
+        return;
+    }
+    { c2 w[7]; r8_twiddles(w, ga, 0, tw); r8_inv_regs(va, w); }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) zp[swz(ga + q * G)] = va[q];
+    { c2 w[7]; r8_twiddles(w, gb, 0, tw); r8_inv_regs(vb, w); }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) zp[swz(gb + q * G)] = vb[q];
 }
 
 }  // namespace dctc

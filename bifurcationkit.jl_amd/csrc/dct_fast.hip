@@ -11,9 +11,17 @@
 //           LT = 16 -- and the transform direction never has to be contiguous in memory.
 // The last forward pass can apply the inverse symbol 1/((1 + lam_x + lam_y + lam_z)^2 + shift) while storing
 // (fuse_scale), which removes the separate scaling pass.
+#include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <vector>
 
 #include "ops.h"
+
+// The library is built with -ffp-contract=off (the stencil / Krylov kernels are compared with the CPU oracle to tight
+// tolerances); the FFT butterflies here are VALU-issue bound and gain from fused multiply-adds, and the DCT parity
+// tolerance (1e-13 relative) does not depend on the contraction.
+#pragma clang fp contract(fast)
 #include "dct_core.h"
 
 namespace bk {
@@ -35,6 +43,7 @@ struct FftK {
     int roundtrip;            // 1: forward, inverse symbol, inverse -- all in LDS, one read + one write of the array
     int tiles_x;              // axis >= 1: number of LT-wide tiles along x
     int pairvec;              // axis >= 1 and 16-B aligned pairs: the two lines of a pair are loaded / stored as one double2
+    long long* trace;         // debug (option dct_trace): per-tile phase timestamps, 8 per workgroup, or NULL
     int fast;                 // full tiles, power-of-two shapes, < 2^31 elements: incremental addressing (host-checked)
 };
 
@@ -289,6 +298,145 @@ __global__ void __launch_bounds__(NT) dct_fft_kernel(FftK P) {
     (void)total;
 }
 
+// Fused schedule for axis >= 1 passes over full power-of-two tiles (host-checked: P.fast, bits >= 6, pairvec): the
+// first radix-8 stage takes its inputs straight from global memory and the last one writes straight back, the top
+// stage of the forward FFT is merged with the DCT post-processing (and, for the roundtrip pass, with the symbol, the
+// inverse pre-processing and the top stage of the inverse FFT) on registers holding every index k together with
+// N-k.  A tile therefore makes 2 LDS round trips per transform instead of 5 (dct_core.h: fused_first / fused_mid /
+// fused_last).  Work items: (pair, natural group) for the outer stages, (pair, t) for the merged middle.
+// 1/d for d > 0 in the normal range: hardware reciprocal + two Newton steps (<= 1 ulp), a third of the cost of the
+// IEEE division sequence; the symbol is evaluated twice per grid point and pass, which made the divisions the largest
+// single VALU item of the roundtrip pass.
+__device__ __forceinline__ double rcp_nr(double d) {
+    double y = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-d, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+
+template <int NT, int MODE>      // MODE 0: forward, 1: inverse, 2: forward - symbol - inverse
+__global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int N = P.N, bits = P.bits, G = N >> 3;
+    const int npairs = P.LT >> 1, pbits = P.ltbits - 1;
+    const int pstride = N + 1;
+    c2* z = reinterpret_cast<c2*>(smem);
+    c2* tw = z + (size_t)npairs * pstride;                    // N/2 FFT twiddles
+    c2* ew = tw + (N >> 1);                                   // N/2 + 1 post twiddles exp(-i pi k / 2N), k <= N/2
+    double* lamk = reinterpret_cast<double*>(ew + (N >> 1) + 2);   // MODE 2: eigenvalues along the transform axis
+    const int tid = threadIdx.x;
+    const int nfirst = npairs * G, nmid = npairs * (G >> 1);  // work items of the outer stages / of the merged middle
+    // element stride along the transform axis; the host guarantees that the array is < 4 GiB, so that every access is
+    // (uniform tile base) + (32-bit per-lane byte offset) -- one VGPR per address instead of two
+    const unsigned estride = P.axis == 1 ? (unsigned)P.n0 : (unsigned)P.n0 * (unsigned)P.n1;
+
+    const int tx = blockIdx.x % P.tiles_x;
+    const int other = blockIdx.x / P.tiles_x;                 // i2 (axis 1) or i1 (axis 2)
+    const int x0 = tx * P.LT;
+    const size_t base = P.axis == 1 ? x0 + (size_t)P.n0 * P.n1 * other : x0 + (size_t)P.n0 * other;
+    const double* gin = P.in + base;
+    double* gout = P.out + base;
+    auto ldg = [&](unsigned el) {
+        const double2 t = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(gin) + (size_t)(el * 8u));
+        c2 r; r.x = t.x; r.y = t.y; return r;
+    };
+    auto stg = [&](unsigned el, c2 v) {
+        *reinterpret_cast<double2*>(reinterpret_cast<char*>(gout) + (size_t)(el * 8u)) = make_double2(v.x, v.y);
+    };
+    auto stamp = [&](int i) {
+        if (P.trace && tid == 0) P.trace[(size_t)blockIdx.x * 8 + i] = (long long)wall_clock64();
+    };
+
+    for (int q = tid; q < N + 1; q += NT) tw[q] = reinterpret_cast<const c2*>(P.twid)[q];
+    if (MODE == 2)
+        for (int q = tid; q < N; q += NT) lamk[q] = (P.axis == 1 ? P.lam1 : P.lam2)[q];
+    stamp(0);
+
+    const double s0 = sqrt(1.0 / N), s2 = sqrt(2.0 / N);
+    auto middle = [&](int lh, int R, bool inv) {
+        const int gbits = bits - R;
+        const int ngr = npairs << gbits;
+        for (int w = tid; w < ngr; w += NT) {
+            c2* zp = z + (size_t)(w >> gbits) * pstride;
+            const int g = w & ((1 << gbits) - 1);
+            if (!inv) {
+                if (R == 3) dctc::r8_group_fwd(zp, bits, lh, g, tw);
+                else if (R == 2) dctc::dit_group<2>(zp, bits, lh, g, tw);
+                else dctc::dit_group<1>(zp, bits, lh, g, tw);
+            } else {
+                if (R == 3) dctc::r8_group_inv(zp, bits, lh, g, tw);
+                else if (R == 2) dctc::dif_group_inv<2>(zp, bits, lh, g, tw);
+                else dctc::dif_group_inv<1>(zp, bits, lh, g, tw);
+            }
+        }
+        __syncthreads();
+    };
+    auto nold = [](int, int) { c2 r; r.x = 0.0; r.y = 0.0; return r; };
+    auto nosym = [](int) { c2 r; r.x = 0.0; r.y = 0.0; return r; };
+    auto nost = [](int, c2) {};
+
+    if (MODE != 1) {
+        for (int w = tid; w < nfirst; w += NT) {
+            const unsigned o = 2u * (w & (npairs - 1));
+            dctc::fused_first(z + (size_t)(w & (npairs - 1)) * pstride, N, bits, w >> pbits,
+                              [&](int, int n) { return ldg(o + (unsigned)n * estride); });
+        }
+        __syncthreads();                                      // also covers the twiddle copy
+        stamp(1);
+        for (int lh = 3; lh < bits - 3;) {
+            const int R = bits - 3 - lh >= 3 ? 3 : bits - 3 - lh;
+            middle(lh, R, false);
+            lh += R;
+        }
+        stamp(2);
+    } else {
+        __syncthreads();                                      // twiddles
+    }
+    for (int w = tid; w < nmid; w += NT) {
+        const int pr = w & (npairs - 1), t = w >> pbits;
+        const unsigned o = 2u * pr;
+        c2* zp = z + (size_t)pr * pstride;
+        if (MODE == 2) {
+            const int i0 = x0 + 2 * pr;
+            const double la = P.lam0[i0], lb = P.lam0[i0 + 1];
+            const double lo_ = P.axis == 1 ? (P.lam2 ? P.lam2[other] : 0.0) : P.lam1[other];
+            // same association as the generic kernel: ((1 + lam0) + lam1) + lam2
+            auto sym = [&](int k) {
+                const double lk = lamk[k];
+                double sa, sb;
+                if (P.axis == 1) { sa = 1.0 + la + lk + lo_; sb = 1.0 + lb + lk + lo_; }
+                else { sa = 1.0 + la + lo_ + lk; sb = 1.0 + lb + lo_ + lk; }
+                c2 r; r.x = rcp_nr(sa * sa + P.shift); r.y = rcp_nr(sb * sb + P.shift); return r;
+            };
+            dctc::fused_mid<2>(zp, N, t, tw, ew, s0, s2, nold, nost, sym);
+        } else if (MODE == 0) {
+            dctc::fused_mid<0>(zp, N, t, tw, ew, s0, s2, nold, [&](int k, c2 v) { stg(o + (unsigned)k * estride, v); }, nosym);
+        } else {
+            dctc::fused_mid<1>(zp, N, t, tw, ew, s0, s2, [&](int, int k) { return ldg(o + (unsigned)k * estride); }, nost, nosym);
+        }
+    }
+    stamp(3);
+    if (MODE == 0) {
+        if (P.trace) { __builtin_amdgcn_s_waitcnt(0); stamp(6); }
+        return;
+    }
+    __syncthreads();
+    stamp(4);
+    for (int top = bits - 3; top > 3;) {
+        const int R = top - 3 >= 3 ? 3 : top - 3;
+        middle(top - R, R, true);
+        top -= R;
+    }
+    stamp(5);
+    for (int w = tid; w < nfirst; w += NT) {
+        const unsigned o = 2u * (w & (npairs - 1));
+        dctc::fused_last(z + (size_t)(w & (npairs - 1)) * pstride, N, bits, w >> pbits,
+                         [&](int n, c2 v) { stg(o + (unsigned)n * estride, v); });
+    }
+    if (P.trace) { __builtin_amdgcn_s_waitcnt(0); stamp(6); }
+}
+
 inline int choose_lt(int N, int axis, int n0, size_t rows) {
     // 16 lines per tile (axis >= 1: one 128-B segment per line element), fewer only if the tile would not fit a
     // 76 KiB LDS budget (two workgroups per CU): LT/2 pairs * (N+1) complex + N/2 twiddles, 16 B each
@@ -322,6 +470,10 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
     P.roundtrip = fuse_scale == 2 ? 1 : 0;
     const size_t rows = (size_t)n1 * n2;
     P.LT = choose_lt(P.N, axis, n0, rows);
+    {
+        const int lt_opt = (int)ctx->opt("dct_lt", 0.0);      // experiment knob: lines per tile of the axis >= 1 passes
+        if (lt_opt >= 2 && axis != 0 && lt_opt <= P.LT) P.LT = lt_opt & ~1;
+    }
     P.ltbits = -1;
     for (int b = 1; b <= 6; ++b) if ((1 << b) == P.LT) P.ltbits = b;
     unsigned grid;
@@ -334,12 +486,19 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
     }
     P.pairvec = (axis != 0 && (n0 % 2 == 0) && (((uintptr_t)in | (uintptr_t)out) & 15) == 0) ? 1 : 0;
     P.fast = 0;            // decided after the thread count is known
+    P.trace = nullptr;
     const size_t lds = ((size_t)(P.LT / 2) * (P.N + 1) + (size_t)(P.N / 2)) * sizeof(c2);
     static bool attr_set = false;
     if (!attr_set) {
         BK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dct_fft_kernel<256>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         BK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dct_fft_kernel<512>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        BK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dct_fused_kernel<256, 0>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        BK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dct_fused_kernel<256, 1>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        BK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dct_fused_kernel<256, 2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;
     }
@@ -352,6 +511,47 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
         const bool shapes = P.ltbits >= 1 && nitems <= (size_t)nt * 8 &&
                             (axis == 0 ? (nt % P.N == 0) : (nt % npairs == 0 && P.pairvec));
         P.fast = (ctx->opt("dct_fastio", 1.0) != 0.0 && full_tiles && shapes) ? 1 : 0;
+    }
+    const int fused_nt = (int)ctx->opt("dct_fused", 256.0);       // 0: off, else threads per tile of the fused kernel
+    if (fused_nt != 0 && axis != 0 && P.bits >= 6 && P.bits <= 9 && (size_t)n0 * n1 * n2 * sizeof(double) < ((size_t)1 << 32) && P.pairvec && P.ltbits >= 1 && n0 % P.LT == 0 &&
+        !(P.fuse_scale && !P.roundtrip)) {
+        const size_t ldsf = lds + ((size_t)(P.N / 2 + 2) + (P.roundtrip ? P.N / 2 : 0)) * sizeof(c2);
+        const bool trace = ctx->opt("dct_trace", 0.0) != 0.0;
+        P.trace = nullptr;
+        if (trace) {
+            BK_HIP(ctx, hipMalloc(&P.trace, (size_t)grid * 8 * sizeof(long long)));
+            BK_HIP(ctx, hipMemsetAsync(P.trace, 0, (size_t)grid * 8 * sizeof(long long), ctx->stream));
+        }
+        if (P.roundtrip) hipLaunchKernelGGL((dct_fused_kernel<256, 2>), dim3(grid), dim3(256), ldsf, ctx->stream, P);
+        else if (P.inverse) hipLaunchKernelGGL((dct_fused_kernel<256, 1>), dim3(grid), dim3(256), ldsf, ctx->stream, P);
+        else hipLaunchKernelGGL((dct_fused_kernel<256, 0>), dim3(grid), dim3(256), ldsf, ctx->stream, P);
+        BK_HIP(ctx, hipGetLastError());
+        if (trace) {
+            // phase durations (wall_clock64 ticks of 10 ns) averaged over the tiles: stamps 0 start, 1 first stage done,
+            // 2 forward middle, 3 merged middle, 4 barrier, 5 inverse middle, 6 all stores retired
+            std::vector<long long> h((size_t)grid * 8);
+            BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            BK_HIP(ctx, hipMemcpy(h.data(), P.trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+            BK_HIP(ctx, hipFree(P.trace));
+            double acc[8] = {0};
+            long long tmin = h[0], tmax = 0;
+            for (unsigned b = 0; b < grid; ++b) {
+                long long prev = h[(size_t)b * 8];
+                tmin = std::min(tmin, prev);
+                for (int i = 1; i < 7; ++i) {
+                    const long long t = h[(size_t)b * 8 + i];
+                    if (t == 0) continue;
+                    acc[i] += (double)(t - prev);
+                    prev = t;
+                    tmax = std::max(tmax, t);
+                }
+            }
+            fprintf(stderr, "dct_trace axis=%d mode=%d tiles=%u span=%.1fus  phases[us]:", axis, P.roundtrip ? 2 : P.inverse, grid,
+                    (tmax - tmin) * 0.01);
+            for (int i = 1; i < 7; ++i) fprintf(stderr, " %d:%.2f", i, acc[i] / grid * 0.01);
+            fprintf(stderr, "\n");
+        }
+        return 0;
     }
     if (nt == 512) hipLaunchKernelGGL(dct_fft_kernel<512>, dim3(grid), dim3(512), lds, ctx->stream, P);
     else hipLaunchKernelGGL(dct_fft_kernel<256>, dim3(grid), dim3(256), lds, ctx->stream, P);

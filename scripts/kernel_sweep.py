@@ -16,6 +16,10 @@ from bk_amd import hip  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 what = sys.argv[2].split(",") if len(sys.argv) > 2 else ["jvp", "krylov", "blas", "precond"]
 ctx = hip.Context(0)
+import os
+for kv in os.environ.get("BK_OPTS", "").split(","):
+    if "=" in kv:
+        ctx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
 N = n ** 3
 prob = hip.SwiftHohenberg(ctx, (n, n, n), (math.pi * n / 32,) * 3)
 g = torch.Generator(device="cuda").manual_seed(0)
@@ -97,8 +101,9 @@ if "axpy" in what:
 if "precond" in what:
     P = hip.DCTPreconditioner(prob, 1.0)
     f = lambda: ctx.check(ctx.lib.bk_precond_apply(P.h, C.c_void_p(v.t.data_ptr()), C.c_void_p(out.t.data_ptr())))
-    ctx.set_option("dct_fft", 0)
-    report("dct_precond", timeit(f, reps=1, warm=1), 16.0 * N, fft=0)
+    if not os.environ.get("BK_SWEEP_FAST"):
+        ctx.set_option("dct_fft", 0)
+        report("dct_precond", timeit(f, reps=1, warm=1), 16.0 * N, fft=0)
     ctx.set_option("dct_fft", 1)
     for rt in (0, 1):
         for nt in (256, 512):

@@ -1,13 +1,14 @@
 // Host replay of the fast-DCT phases of bifurcationkit.jl_amd/csrc/dct_core.h for ONE pair of lines.
-// stdin: "mode N" (mode 0/1 = forward/inverse radix-2, 2/3 = the same with grouped radix-8 stages) then N values of line a, N values of line b.  stdout: the two transformed lines.
+// stdin: "mode N" (mode 0/1 = forward/inverse radix-2, 2/3 = the same with grouped radix-8 stages, 4/5/6 = fused schedule forward / inverse / forward-symbol-inverse) then N values of line a, N values of line b.  stdout: the two transformed lines.
 #include <cmath>
 #include <cstdio>
 #include <vector>
 #include "../../bifurcationkit.jl_amd/csrc/dct_core.h"
 using namespace bk::dctc;
 int main() {
-    int inverse, N, grouped = 0;
+    int inverse, N, grouped = 0, fused = 0;
     if (scanf("%d %d", &inverse, &N) != 2) return 2;
+    if (inverse >= 4) { fused = inverse - 3; inverse = 0; }   // 4: fused forward, 5: fused inverse, 6: fused roundtrip
     if (inverse >= 2) { grouped = 1; inverse -= 2; }     // modes 2/3: radix-8 grouped stages
     int bits = 0;
     while ((1 << bits) < N) ++bits;
@@ -18,6 +19,52 @@ int main() {
     for (int j = 0; j < N / 2; ++j) { tw[j].x = std::cos(2.0 * M_PI * j / N); tw[j].y = -std::sin(2.0 * M_PI * j / N); }
     for (int k = 0; k <= N / 2; ++k) { ew[k].x = std::cos(M_PI * k / (2.0 * N)); ew[k].y = -std::sin(M_PI * k / (2.0 * N)); }
     const double s0 = std::sqrt(1.0 / N), s2 = std::sqrt(2.0 / N);
+    if (fused) {
+        // modes 4/5/6: the fused schedule of dct_fused_kernel (first / last radix-8 stage on registers fed from "global")
+        std::vector<c2> out(N);
+        std::vector<c2>& ewf = ew;                          // half table k <= N/2
+        auto ldin = [&](int, int n) { c2 r; r.x = a[n]; r.y = b[n]; return r; };
+        auto stout = [&](int n, c2 v) { out[n] = v; };
+        auto sym = [&](int k) { c2 r; r.x = 1.0 / (1.0 + 0.01 * k); r.y = 1.0 / (2.0 + 0.02 * k * k); return r; };
+        auto middle_fwd = [&]() {
+            for (int lh = 3; lh < bits - 3;) {
+                const int R = bits - 3 - lh >= 3 ? 3 : bits - 3 - lh;
+                for (int g = 0; g < (N >> R); ++g) {
+                    if (R == 3) r8_group_fwd(z.data(), bits, lh, g, tw.data());
+                    else if (R == 2) dit_group<2>(z.data(), bits, lh, g, tw.data());
+                    else dit_group<1>(z.data(), bits, lh, g, tw.data());
+                }
+                lh += R;
+            }
+        };
+        auto middle_inv = [&]() {
+            for (int top = bits - 3; top > 3;) {
+                const int R = top - 3 >= 3 ? 3 : top - 3;
+                const int lh = top - R;
+                for (int g = 0; g < (N >> R); ++g) {
+                    if (R == 3) r8_group_inv(z.data(), bits, lh, g, tw.data());
+                    else if (R == 2) dif_group_inv<2>(z.data(), bits, lh, g, tw.data());
+                    else dif_group_inv<1>(z.data(), bits, lh, g, tw.data());
+                }
+                top -= R;
+            }
+        };
+        if (fused != 2) {                                  // forward or roundtrip: first stage from the samples
+            for (int gp = 0; gp < N / 8; ++gp) fused_first(z.data(), N, bits, gp, ldin);
+            middle_fwd();
+        }
+        for (int t = 0; t < N / 16; ++t) {
+            if (fused == 1) fused_mid<0>(z.data(), N, t, tw.data(), ewf.data(), s0, s2, ldin, stout, sym);
+            else if (fused == 2) fused_mid<1>(z.data(), N, t, tw.data(), ewf.data(), s0, s2, ldin, stout, sym);
+            else fused_mid<2>(z.data(), N, t, tw.data(), ewf.data(), s0, s2, ldin, stout, sym);
+        }
+        if (fused != 1) {
+            middle_inv();
+            for (int gp = 0; gp < N / 8; ++gp) fused_last(z.data(), N, bits, gp, stout);
+        }
+        for (int k = 0; k < N; ++k) printf("%.17g %.17g\n", out[k].x, out[k].y);
+        return 0;
+    }
     if (!inverse) {
         for (int n = 0; n < N; ++n) { const int p = sample_slot(n, N, bits); z[p].x = a[n]; z[p].y = b[n]; }
         if (inverse == 0 && grouped) {

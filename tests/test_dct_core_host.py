@@ -28,3 +28,24 @@ def test_dct_core_matches_scipy(exe, N, mode):
     o = np.array(list(map(float, out))).reshape(N, 2)
     f = (lambda x: sfft.idct(x, type=2, norm="ortho")) if mode & 1 else (lambda x: sfft.dct(x, type=2, norm="ortho"))
     assert np.abs(o[:, 0] - f(a)).max() < 1e-13 and np.abs(o[:, 1] - f(b)).max() < 1e-13
+
+
+@pytest.mark.parametrize("N", [64, 128, 256, 512, 1024])
+@pytest.mark.parametrize("mode", [4, 5, 6])           # fused schedule: forward / inverse / forward-symbol-inverse
+def test_dct_fused_schedule_matches_scipy(exe, N, mode):
+    rng = np.random.default_rng(N + mode)
+    a, b = rng.standard_normal(N), rng.standard_normal(N)
+    inp = f"{mode} {N}\n" + " ".join(map(repr, a.tolist())) + "\n" + " ".join(map(repr, b.tolist()))
+    out = subprocess.run([exe], input=inp, capture_output=True, text=True, check=True).stdout.split()
+    o = np.array(list(map(float, out))).reshape(N, 2)
+    dct = lambda x: sfft.dct(x, type=2, norm="ortho")
+    idct = lambda x: sfft.idct(x, type=2, norm="ortho")
+    k = np.arange(N)
+    sa, sb = 1.0 / (1.0 + 0.01 * k), 1.0 / (2.0 + 0.02 * k * k)          # the harness' test symbol
+    if mode == 4:
+        ra, rb = dct(a), dct(b)
+    elif mode == 5:
+        ra, rb = idct(a), idct(b)
+    else:
+        ra, rb = idct(sa * dct(a)), idct(sb * dct(b))
+    assert np.abs(o[:, 0] - ra).max() < 1e-13 and np.abs(o[:, 1] - rb).max() < 1e-13
