@@ -258,7 +258,7 @@ def main():
         k = kernels[dom]
         traffic, tsrc = None, None
         pmc_file = os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")
-        pmc_name = {"dct_pass": "dct_fft_kernel<512>", "jvp": "sh_stream_kernel<true>", "blas1": "axpbyz_kernel<2>"}.get(dom)
+        pmc_name = {"dct_pass": "dct_pass (all dct_f* kernels)", "jvp": "sh_stream_kernel<true>", "blas1": "axpbyz_kernel<2>"}.get(dom)
         if world == 1 and n == 512 and os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))
             if pmc_name in pmc:

@@ -104,6 +104,8 @@ SIGNATURES = {
                              C.POINTER(GmresOpts), VP, VP, c_double_p, c_int_p, c_int_p]),
     "bk_bls_matrixfree": (I, [VP, VP, VP, VP, D, VP, D, D, D, I, D, D, C.POINTER(GmresOpts), VP, c_double_p,
                               c_int_p, c_int_p]),
+    "bk_bls_block_bordering": (I, [VP, VP, I, C.POINTER(VP), C.POINTER(VP), c_double_p, VP, c_double_p,
+                                   C.POINTER(GmresOpts), VP, VP, c_double_p, c_int_p, c_int_p]),
     "bk_eig_shiftinvert": (I, [VP, VP, I, C.POINTER(EigOpts), C.POINTER(GmresOpts), VP, c_double_p, c_double_p,
                                VP, VP, SZ, c_int_p, c_int_p, c_int_p]),
     "bk_newton": (I, [VP, VP, VP, c_double_p, I, C.POINTER(NewtonOpts), C.POINTER(GmresOpts), VP,

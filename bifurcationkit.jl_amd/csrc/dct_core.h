@@ -374,6 +374,57 @@ BK_HD void fused_last(const c2* zp, int N, int bits, int gp, Store&& st) {
     for (int r = 0; r < 8; ++r) st(first_sample(gp, r, N), v[bitrev3(r)]);
 }
 
+// Contiguous-axis variants (the transform runs along the fastest index): a lane reads the two adjacent samples (2j, 2j+1)
+// of each line with one 16-B access.  The even one lands in Makhoul slot j, the odd one in slot N-1-j, i.e. for
+// j = gp + r N/8 (r < 4) in first-stage group gp (position r) and in group N/8-1-gp (position 7-r): an item owns BOTH
+// groups gp and gp' = N/8-1-gp, gp in [0, N/16).   ld2(j, ea, oa, eb, ob): samples 2j, 2j+1 of line a and of line b.
+template <class Load2>
+BK_HD void fused_first2(c2* zp, int N, int bits, int gp, Load2&& ld2) {
+    const int G = N >> 3, gq = G - 1 - gp;
+    c2 A[8], B[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        ld2(gp + G * r, A[r].x, B[7 - r].x, A[r].y, B[7 - r].y);
+        ld2(gq + G * r, B[r].x, A[7 - r].x, B[r].y, A[7 - r].y);
+    }
+    c2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[bitrev3(r)] = A[r];
+    r8_first(v);
+    int sb = swz(bitrev(gp, bits - 3) << 3);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) zp[sb ^ q] = v[q];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[bitrev3(r)] = B[r];
+    r8_first(v);
+    sb = swz(bitrev(gq, bits - 3) << 3);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) zp[sb ^ q] = v[q];
+}
+// st2(j, ea, oa, eb, ob): store samples 2j, 2j+1 of line a and line b.
+template <class Store2>
+BK_HD void fused_last2(const c2* zp, int N, int bits, int gp, Store2&& st2) {
+    const int G = N >> 3, gq = G - 1 - gp;
+    c2 A[8], B[8], v[8];
+    int sb = swz(bitrev(gp, bits - 3) << 3);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = zp[sb ^ q];
+    r8_last_inv(v);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) A[r] = v[bitrev3(r)];
+    sb = swz(bitrev(gq, bits - 3) << 3);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = zp[sb ^ q];
+    r8_last_inv(v);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) B[r] = v[bitrev3(r)];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        st2(gp + G * r, A[r].x, B[7 - r].x, A[r].y, B[7 - r].y);
+        st2(gq + G * r, B[r].x, A[7 - r].x, B[r].y, A[7 - r].y);
+    }
+}
+
 // One (k, N-k) pair of the merged middle, in place: x = element k, y = element N-k, 0 < k < N, k != N/2.
 // e_{N-k} = -i conj(e_k) = (-e_k.y, -e_k.x).
 template <int MODE, bool UPPER, class Sym>      // UPPER: k > N/2 -- the table holds k <= N/2 only

@@ -315,7 +315,9 @@ __device__ __forceinline__ double rcp_nr(double d) {
     return __builtin_fma(y, e, y);
 }
 
-template <int NT, int MODE>      // MODE 0: forward, 1: inverse, 2: forward - symbol - inverse
+// AX0: the transform runs along the contiguous index (a tile is LT consecutive rows); lanes then walk along the row
+// (dct_core.h: fused_first2 / fused_last2) instead of across the LT lines.
+template <int NT, int MODE, bool AX0>      // MODE 0: forward, 1: inverse, 2: forward - symbol - inverse (AX0: 0 / 1 only)
 __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int N = P.N, bits = P.bits, G = N >> 3;
@@ -326,15 +328,19 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
     c2* ew = tw + (N >> 1);                                   // N/2 + 1 post twiddles exp(-i pi k / 2N), k <= N/2
     double* lamk = reinterpret_cast<double*>(ew + (N >> 1) + 2);   // MODE 2: eigenvalues along the transform axis
     const int tid = threadIdx.x;
-    const int nfirst = npairs * G, nmid = npairs * (G >> 1);  // work items of the outer stages / of the merged middle
+    const int nfirst = AX0 ? npairs * (G >> 1) : npairs * G;  // work items of the outer stages ...
+    const int nmid = npairs * (G >> 1);                       // ... and of the merged middle
+    const int hbits = bits - 4;                               // log2(G / 2)
     // element stride along the transform axis; the host guarantees that the array is < 4 GiB, so that every access is
     // (uniform tile base) + (32-bit per-lane byte offset) -- one VGPR per address instead of two
-    const unsigned estride = P.axis == 1 ? (unsigned)P.n0 : (unsigned)P.n0 * (unsigned)P.n1;
+    const unsigned estride = AX0 ? 1u : (P.axis == 1 ? (unsigned)P.n0 : (unsigned)P.n0 * (unsigned)P.n1);
+    const unsigned lstride = AX0 ? (unsigned)P.n0 : 1u;       // line a -> line b of a pair
 
-    const int tx = blockIdx.x % P.tiles_x;
-    const int other = blockIdx.x / P.tiles_x;                 // i2 (axis 1) or i1 (axis 2)
+    const int tx = AX0 ? 0 : blockIdx.x % P.tiles_x;
+    const int other = AX0 ? 0 : blockIdx.x / P.tiles_x;       // i2 (axis 1) or i1 (axis 2)
     const int x0 = tx * P.LT;
-    const size_t base = P.axis == 1 ? x0 + (size_t)P.n0 * P.n1 * other : x0 + (size_t)P.n0 * other;
+    const size_t base = AX0 ? (size_t)blockIdx.x * P.LT * P.n0
+                            : (P.axis == 1 ? x0 + (size_t)P.n0 * P.n1 * other : x0 + (size_t)P.n0 * other);
     const double* gin = P.in + base;
     double* gout = P.out + base;
     auto ldg = [&](unsigned el) {
@@ -344,6 +350,11 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
     auto stg = [&](unsigned el, c2 v) {
         *reinterpret_cast<double2*>(reinterpret_cast<char*>(gout) + (size_t)(el * 8u)) = make_double2(v.x, v.y);
     };
+    // AX0 accessors: one double of line a / b (merged middle), or the adjacent samples (2j, 2j+1) of both lines
+    auto ld1 = [&](unsigned el) {
+        c2 r; r.x = gin[el]; r.y = gin[el + lstride]; return r;
+    };
+    auto st1 = [&](unsigned el, c2 v) { gout[el] = v.x; gout[el + lstride] = v.y; };
     auto stamp = [&](int i) {
         if (P.trace && tid == 0) P.trace[(size_t)blockIdx.x * 8 + i] = (long long)wall_clock64();
     };
@@ -378,9 +389,20 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
 
     if (MODE != 1) {
         for (int w = tid; w < nfirst; w += NT) {
-            const unsigned o = 2u * (w & (npairs - 1));
-            dctc::fused_first(z + (size_t)(w & (npairs - 1)) * pstride, N, bits, w >> pbits,
-                              [&](int, int n) { return ldg(o + (unsigned)n * estride); });
+            if (AX0) {
+                const int pr = w >> hbits;
+                const double* row = gin + (size_t)(2 * pr) * lstride;
+                dctc::fused_first2(z + (size_t)pr * pstride, N, bits, w & ((1 << hbits) - 1),
+                                   [&](int j, double& ea, double& oa, double& eb, double& ob) {
+                                       const double2 ta = *reinterpret_cast<const double2*>(row + 2 * j);
+                                       const double2 tb = *reinterpret_cast<const double2*>(row + lstride + 2 * j);
+                                       ea = ta.x; oa = ta.y; eb = tb.x; ob = tb.y;
+                                   });
+            } else {
+                const unsigned o = 2u * (w & (npairs - 1));
+                dctc::fused_first(z + (size_t)(w & (npairs - 1)) * pstride, N, bits, w >> pbits,
+                                  [&](int, int n) { return ldg(o + (unsigned)n * estride); });
+            }
         }
         __syncthreads();                                      // also covers the twiddle copy
         stamp(1);
@@ -394,8 +416,8 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
         __syncthreads();                                      // twiddles
     }
     for (int w = tid; w < nmid; w += NT) {
-        const int pr = w & (npairs - 1), t = w >> pbits;
-        const unsigned o = 2u * pr;
+        const int pr = AX0 ? w >> hbits : w & (npairs - 1), t = AX0 ? w & ((1 << hbits) - 1) : w >> pbits;
+        const unsigned o = AX0 ? (unsigned)(2 * pr) * lstride : 2u * pr;
         c2* zp = z + (size_t)pr * pstride;
         if (MODE == 2) {
             const int i0 = x0 + 2 * pr;
@@ -411,9 +433,11 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
             };
             dctc::fused_mid<2>(zp, N, t, tw, ew, s0, s2, nold, nost, sym);
         } else if (MODE == 0) {
-            dctc::fused_mid<0>(zp, N, t, tw, ew, s0, s2, nold, [&](int k, c2 v) { stg(o + (unsigned)k * estride, v); }, nosym);
+            if (AX0) dctc::fused_mid<0>(zp, N, t, tw, ew, s0, s2, nold, [&](int k, c2 v) { st1(o + (unsigned)k, v); }, nosym);
+            else dctc::fused_mid<0>(zp, N, t, tw, ew, s0, s2, nold, [&](int k, c2 v) { stg(o + (unsigned)k * estride, v); }, nosym);
         } else {
-            dctc::fused_mid<1>(zp, N, t, tw, ew, s0, s2, [&](int, int k) { return ldg(o + (unsigned)k * estride); }, nost, nosym);
+            if (AX0) dctc::fused_mid<1>(zp, N, t, tw, ew, s0, s2, [&](int, int k) { return ld1(o + (unsigned)k); }, nost, nosym);
+            else dctc::fused_mid<1>(zp, N, t, tw, ew, s0, s2, [&](int, int k) { return ldg(o + (unsigned)k * estride); }, nost, nosym);
         }
     }
     stamp(3);
@@ -430,9 +454,19 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
     }
     stamp(5);
     for (int w = tid; w < nfirst; w += NT) {
-        const unsigned o = 2u * (w & (npairs - 1));
-        dctc::fused_last(z + (size_t)(w & (npairs - 1)) * pstride, N, bits, w >> pbits,
-                         [&](int n, c2 v) { stg(o + (unsigned)n * estride, v); });
+        if (AX0) {
+            const int pr = w >> hbits;
+            double* row = gout + (size_t)(2 * pr) * lstride;
+            dctc::fused_last2(z + (size_t)pr * pstride, N, bits, w & ((1 << hbits) - 1),
+                              [&](int j, double ea, double oa, double eb, double ob) {
+                                  *reinterpret_cast<double2*>(row + 2 * j) = make_double2(ea, oa);
+                                  *reinterpret_cast<double2*>(row + lstride + 2 * j) = make_double2(eb, ob);
+                              });
+        } else {
+            const unsigned o = 2u * (w & (npairs - 1));
+            dctc::fused_last(z + (size_t)(w & (npairs - 1)) * pstride, N, bits, w >> pbits,
+                             [&](int n, c2 v) { stg(o + (unsigned)n * estride, v); });
+        }
     }
     if (P.trace) { __builtin_amdgcn_s_waitcnt(0); stamp(6); }
 }
@@ -494,12 +528,12 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         BK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dct_fft_kernel<512>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        BK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dct_fused_kernel<256, 0>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        BK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dct_fused_kernel<256, 1>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        BK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dct_fused_kernel<256, 2>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        const void* fused[] = {reinterpret_cast<const void*>(dct_fused_kernel<256, 0, false>),
+                               reinterpret_cast<const void*>(dct_fused_kernel<256, 1, false>),
+                               reinterpret_cast<const void*>(dct_fused_kernel<256, 2, false>),
+                               reinterpret_cast<const void*>(dct_fused_kernel<256, 0, true>),
+                               reinterpret_cast<const void*>(dct_fused_kernel<256, 1, true>)};
+        for (const void* f : fused) BK_HIP(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;
     }
     // 512 lanes per tile when the tile is big enough to feed them (two workgroups per CU => 16 wavefronts)
@@ -513,8 +547,11 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
         P.fast = (ctx->opt("dct_fastio", 1.0) != 0.0 && full_tiles && shapes) ? 1 : 0;
     }
     const int fused_nt = (int)ctx->opt("dct_fused", 256.0);       // 0: off, else threads per tile of the fused kernel
-    if (fused_nt != 0 && axis != 0 && P.bits >= 6 && P.bits <= 9 && (size_t)n0 * n1 * n2 * sizeof(double) < ((size_t)1 << 32) && P.pairvec && P.ltbits >= 1 && n0 % P.LT == 0 &&
-        !(P.fuse_scale && !P.roundtrip)) {
+    const bool ax0_ok = axis == 0 && !P.roundtrip && rows % P.LT == 0 && n0 % 2 == 0 &&
+                        (((uintptr_t)in | (uintptr_t)out) & 15) == 0 && ctx->opt("dct_fused_ax0", 1.0) != 0.0;
+    const bool ax12_ok = axis != 0 && P.pairvec && n0 % P.LT == 0;
+    if (fused_nt != 0 && (ax0_ok || ax12_ok) && P.bits >= 6 && P.bits <= 9 && P.ltbits >= 1 &&
+        (size_t)n0 * n1 * n2 * sizeof(double) < ((size_t)1 << 32) && !(P.fuse_scale && !P.roundtrip)) {
         const size_t ldsf = lds + ((size_t)(P.N / 2 + 2) + (P.roundtrip ? P.N / 2 : 0)) * sizeof(c2);
         const bool trace = ctx->opt("dct_trace", 0.0) != 0.0;
         P.trace = nullptr;
@@ -522,9 +559,12 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
             BK_HIP(ctx, hipMalloc(&P.trace, (size_t)grid * 8 * sizeof(long long)));
             BK_HIP(ctx, hipMemsetAsync(P.trace, 0, (size_t)grid * 8 * sizeof(long long), ctx->stream));
         }
-        if (P.roundtrip) hipLaunchKernelGGL((dct_fused_kernel<256, 2>), dim3(grid), dim3(256), ldsf, ctx->stream, P);
-        else if (P.inverse) hipLaunchKernelGGL((dct_fused_kernel<256, 1>), dim3(grid), dim3(256), ldsf, ctx->stream, P);
-        else hipLaunchKernelGGL((dct_fused_kernel<256, 0>), dim3(grid), dim3(256), ldsf, ctx->stream, P);
+        if (axis == 0) {
+            if (P.inverse) hipLaunchKernelGGL((dct_fused_kernel<256, 1, true>), dim3(grid), dim3(256), ldsf, ctx->stream, P);
+            else hipLaunchKernelGGL((dct_fused_kernel<256, 0, true>), dim3(grid), dim3(256), ldsf, ctx->stream, P);
+        } else if (P.roundtrip) hipLaunchKernelGGL((dct_fused_kernel<256, 2, false>), dim3(grid), dim3(256), ldsf, ctx->stream, P);
+        else if (P.inverse) hipLaunchKernelGGL((dct_fused_kernel<256, 1, false>), dim3(grid), dim3(256), ldsf, ctx->stream, P);
+        else hipLaunchKernelGGL((dct_fused_kernel<256, 0, false>), dim3(grid), dim3(256), ldsf, ctx->stream, P);
         BK_HIP(ctx, hipGetLastError());
         if (trace) {
             // phase durations (wall_clock64 ticks of 10 ns) averaged over the tiles: stamps 0 start, 1 first stage done,

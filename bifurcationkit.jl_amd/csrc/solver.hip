@@ -504,6 +504,62 @@ int bk_bls_matrixfree(bk_ctx* ctx, bk_op* J, const double* dR, const double* dzu
     return 0;
 }
 
+// solve_bls_block(::BorderingBLS, J, b::NTuple{M}, c::NTuple{M}, d::Matrix, rhst, rhsb), src/LinearBorderSolver.jl:173-206:
+//   [ J   b ] [u1]   [rhst]        x1 = J^-1 rhst, x2_j = J^-1 b_j,  S_ij = d_ij - <c_i, x2_j>,  h_i = rhsb_i - <c_i, x1>,
+//   [ c'  d ] [u2] = [rhsb]        u2 = S \ h,  u1 = x1 - sum_j u2_j x2_j.
+// As in the reference the convergence flag of the x1 solve is dropped (`cv = true` after it, :186-189): only the m
+// border solves are AND-ed; their iteration counts are returned.
+int bk_bls_block_bordering(bk_ctx* ctx, bk_op* J, int m, const double* const* b, const double* const* c, const double* d,
+                           const double* rhst, const double* rhsb, const bk_gmres_opts* lsopts, bk_precond* pl,
+                           double* u1, double* u2, int* converged, int* itlinear) {
+    if (!ctx || !J || !b || !c || !d || !rhst || !rhsb || !lsopts || !u1 || !u2) return -1;
+    if (m < 1 || m > BK_MAX_BORDER) return set_error(ctx, "Linear bordered solver, wrong sizes! (1 <= m <= %d)", BK_MAX_BORDER);
+    if (u1 == rhst) return set_error(ctx, "bk_bls_block_bordering: u1 must be a fresh buffer");
+    const size_t n = J->n;
+    WsGuard ws(ctx);
+    double* x2[BK_MAX_BORDER];
+    GmresResult g;
+    BK_TRY(linsolve(ctx, J, rhst, u1, 0.0, 1.0, *lsopts, pl, &g));
+    int cv = 1;
+    for (int j = 0; j < m; ++j) {
+        if (!b[j] || !c[j]) return -1;
+        BK_TRY(ws.get(n, &x2[j]));
+        BK_TRY(linsolve(ctx, J, b[j], x2[j], 0.0, 1.0, *lsopts, pl, &g));
+        cv &= g.converged;
+        if (itlinear) itlinear[j] = g.niter;
+    }
+    double S[BK_MAX_BORDER][BK_MAX_BORDER + 1];          // augmented [S | h]
+    for (int i = 0; i < m; ++i) {
+        double t;
+        for (int j = 0; j < m; ++j) {
+            BK_TRY(v_dot(ctx, n, c[i], x2[j], &t));
+            S[i][j] = d[i * m + j] - t;
+        }
+        BK_TRY(v_dot(ctx, n, c[i], u1, &t));
+        S[i][m] = rhsb[i] - t;
+    }
+    for (int k = 0; k < m; ++k) {                          // S \ h: LU with partial pivoting
+        int piv = k;
+        for (int i = k + 1; i < m; ++i)
+            if (std::fabs(S[i][k]) > std::fabs(S[piv][k])) piv = i;
+        if (S[piv][k] == 0.0) return set_error(ctx, "bk_bls_block_bordering: singular Schur complement");
+        if (piv != k)
+            for (int j = 0; j <= m; ++j) std::swap(S[k][j], S[piv][j]);
+        for (int i = k + 1; i < m; ++i) {
+            const double f = S[i][k] / S[k][k];
+            for (int j = k; j <= m; ++j) S[i][j] -= f * S[k][j];
+        }
+    }
+    for (int i = m - 1; i >= 0; --i) {
+        double t = S[i][m];
+        for (int j = i + 1; j < m; ++j) t -= S[i][j] * u2[j];
+        u2[i] = t / S[i][i];
+    }
+    for (int j = 0; j < m; ++j) BK_TRY(v_axpby(ctx, n, -u2[j], x2[j], 1.0, u1));
+    if (converged) *converged = cv;
+    return 0;
+}
+
 }  // extern "C"
 
 // ================================================================== Newton correctors

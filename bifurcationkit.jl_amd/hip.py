@@ -485,6 +485,30 @@ class BorderingBLS:
             return dX, dl.value, bool(cv.value), (it[0], it[1])
         return self._generic(J, dR, dzu, dzp, R, n, xiu, xip, shift, dotp or (lambda x, y: x.inner(y)))
 
+    def solve_block(self, J, b, c, d, rhst, rhsb):
+        """solve_bls_block(lbs::BorderingBLS, J, b::NTuple, c::NTuple, d, rhst, rhsb) -> (u1, u2, cv, its),
+        src/LinearBorderSolver.jl:173-206 (m-column border: normal forms / Bogdanov-Takens)."""
+        if not isinstance(self.solver, _GMRES):
+            raise TypeError("solve_block (HIP) needs a native GMRES solver")
+        d = np.atleast_2d(np.asarray(d, dtype=np.float64))
+        m = d.shape[0]
+        if not (len(b) == len(c) == m == d.shape[1]):
+            raise ValueError("Linear bordered solver, wrong sizes!")
+        ctx = rhst.ctx
+        u1 = rhst.similar()
+        bp = (C.c_void_p * m)(*[x.t.data_ptr() for x in b])
+        cp = (C.c_void_p * m)(*[x.t.data_ptr() for x in c])
+        dd = (C.c_double * (m * m))(*d.ravel().tolist())
+        rb = (C.c_double * m)(*[float(v) for v in rhsb])
+        u2 = (C.c_double * m)()
+        its = (C.c_int * m)()
+        cv = C.c_int()
+        lo = self.solver._opts()
+        ctx.check(ctx.lib.bk_bls_block_bordering(ctx.h, J.h, m, bp, cp, dd, _ptr(rhst.t), rb, C.byref(lo),
+                                                 self.solver._pl(), _ptr(u1.t), u2, C.byref(cv), its),
+                  "bk_bls_block_bordering")
+        return u1, np.array(list(u2)), bool(cv.value), tuple(its)
+
     # generic path: BEC / residualBEC exactly as written in the reference
     def _bec(self, J, dR, dzu, dzp, R, n, xiu, xip, shift, dotp):
         kw = {} if shift is None else dict(a0=shift)

@@ -196,6 +196,17 @@ int bk_bls_matrixfree(bk_ctx* ctx, bk_op* J, const double* dR, const double* dzu
                       double shift, double dotscale, const bk_gmres_opts* lsopts, double* dX,
                       double* dl, int* converged, int* itlinear);        /* MatrixFreeBLS :424-437 */
 
+/* solve_bls_block(::BorderingBLS, ...) for an m-column border (normal forms, Bogdanov-Takens; :173-206):
+ *     [ J   b ] [u1]   [rhst]      b, c: m device vectors each; d: m x m host, row-major d[i*m + j];
+ *     [ c'  d ] [u2] = [rhsb]      plain inner products (VI.inner), no shift.
+ * u1 (device, fresh buffer) and u2[m] (host) receive the solution, itlinear[m] the iteration counts of the m
+ * border solves, *converged their AND (the flag of the J u = rhst solve is dropped, as in the reference).      */
+#define BK_MAX_BORDER 8
+int bk_bls_block_bordering(bk_ctx* ctx, bk_op* J, int m, const double* const* b, const double* const* c,
+                           const double* d, const double* rhst, const double* rhsb,
+                           const bk_gmres_opts* lsopts, bk_precond* pl, double* u1, double* u2,
+                           int* converged, int* itlinear);
+
 /* ------------------------------------------------------------------ eigensolver ------------
  * (eig::ShiftInvert)(J, nev) -> (vals, vecs, converged, niter): src/EigSolver.jl:246-266 with a
  * Krylov-Schur (KrylovKit.eigsolve-style) outer iteration; the SH3dEig of examples/SH3d.jl:96-113.

@@ -73,6 +73,29 @@ def bordering_bls(ls, J, dR, dzu, dzp, R, n, xiu=1.0, xip=1.0, *, shift=None, do
     return dX, dl, cv, itl
 
 
+def bordering_bls_block(ls, J, b, c, d, rhst, rhsb):
+    """solve_bls_block(::BorderingBLS, J, b::NTuple, c::NTuple, d::Matrix, rhst, rhsb),
+    src/LinearBorderSolver.jl:173-206 -> (u1, u2, cv, its).  The flag of the J x1 = rhst solve is overwritten by
+    `cv = true` (:186-189), exactly as written there."""
+    d = np.atleast_2d(np.asarray(d, dtype=float))
+    m = d.shape[0]
+    if not (len(b) == len(c) == m):
+        raise ValueError("Linear bordered solver, wrong sizes!")
+    x1, cv, it = ls(J, rhst)
+    x2s, its, cv = [], [], True
+    for bi in b:
+        x2, flag, it = ls(J, bi)
+        x2s.append(x2); its.append(it)
+        cv = cv and flag
+    S = np.array([[d[i, j] - np.dot(c[i], x2s[j]) for j in range(m)] for i in range(m)])
+    h = np.array([rhsb[i] - np.dot(c[i], x1) for i in range(m)])
+    u2 = np.linalg.solve(S, h)
+    u1 = x1.copy()
+    for i in range(m):
+        u1 -= u2[i] * x2s[i]
+    return u1, u2, cv, tuple(its)
+
+
 def matrixfree_blsmap(J, a, b, c, shift, dot):
     """MatrixFreeBLSmap on a flat vector, src/LinearBorderSolver.jl:308-322."""
     def op(x):

@@ -25,6 +25,9 @@ for d, cname in ((fetch_dir, "FETCH_SIZE"), (write_dir, "WRITE_SIZE")):
     agg = collections.defaultdict(list)
     for k, v in rows:
         agg[clean(k)].append(v)
+    allv = [x for k, v in agg.items() if k.startswith("dct_f") for x in v]
+    if allv:
+        agg["dct_pass (all dct_f* kernels)"] = allv
     for k, v in agg.items():
         med[k][cname] = (len(v), statistics.median(v), min(v), max(v))
 
@@ -34,19 +37,20 @@ lines = ["# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --ke
          "# Units: the counters are in KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports 1/2 of",
          "# the bytes of wide coalesced reads -> read_bytes = 2 * FETCH_SIZE * 1024.  WRITE_SIZE * 1024 matches the known",
          "# 1 GiB output of every kernel exactly (axpbyz / copyBuffer write 1 GiB -> 1048576.0 KiB), so it is used as is.",
-         "# Read-side calibration: dct_fft_kernel reads its 1 GiB input exactly once -> FETCH_SIZE = 0.500 GiB.",
-         "", f"{'kernel':34s} {'n':>4s} {'FETCH_KiB(med)':>15s} {'read_GiB(x2)':>13s} {'WRITE_KiB(med)':>15s} {'write_GiB':>10s}"]
+         "# Read-side calibration: every DCT pass kernel reads its 1 GiB input exactly once -> FETCH_SIZE = 0.500 GiB.",
+         "", f"{'kernel':40s} {'n':>4s} {'FETCH_KiB(med)':>15s} {'read_GiB(x2)':>13s} {'WRITE_KiB(med)':>15s} {'write_GiB':>10s}"]
 out = {}
 for k in sorted(med):
     f_ = med[k].get("FETCH_SIZE", (0, 0.0, 0, 0))
     w_ = med[k].get("WRITE_SIZE", (0, 0.0, 0, 0))
-    lines.append(f"{k[:34]:34s} {f_[0]:4d} {f_[1]:15.1f} {2 * f_[1] / 1048576:13.3f} {w_[1]:15.1f} {w_[1] / 1048576:10.3f}")
+    lines.append(f"{k[:40]:40s} {f_[0]:4d} {f_[1]:15.1f} {2 * f_[1] / 1048576:13.3f} {w_[1]:15.1f} {w_[1] / 1048576:10.3f}")
     out[k] = dict(n=f_[0], read_bytes=2 * f_[1] * 1024, write_bytes=w_[1] * 1024, read_bytes_min=2 * f_[2] * 1024,
                   read_bytes_max=2 * f_[3] * 1024)
 lines += ["", "# sh_stream_kernel<true>: the JVP launches read ~2.5 GiB against 2 GiB algorithmic (v + u): +25 % = the 2-cell halo of",
           "#   the 64x16 tile and the z-chunk priming planes, which miss L2; writes 1.00 GiB; total 1.17x algorithmic.",
           "# multidot<KB> / multiaxpy<KB>: the median launch has k+1 = read_GiB vectors; traffic == algorithmic bytes.",
-          "# axpbyz, dct_fft_kernel, copyBuffer: traffic == algorithmic bytes (1 GiB read, 1 GiB written)."]
+          "# axpbyz, dct_fused_kernel<NT, MODE, AX0> / dct_fft_kernel, copyBuffer: traffic == algorithmic bytes (1 GiB read,",
+          "#   1 GiB written; MODE 2 = forward + symbol + inverse of the last axis in one pass)."]
 open(out_prefix + "_pmc_hbm_traffic.txt", "w").write("\n".join(lines) + "\n")
 json.dump(out, open(out_prefix + "_pmc_hbm_traffic.json", "w"), indent=1)
 print("\n".join(lines))

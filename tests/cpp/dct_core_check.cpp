@@ -1,5 +1,5 @@
 // Host replay of the fast-DCT phases of bifurcationkit.jl_amd/csrc/dct_core.h for ONE pair of lines.
-// stdin: "mode N" (mode 0/1 = forward/inverse radix-2, 2/3 = the same with grouped radix-8 stages, 4/5/6 = fused schedule forward / inverse / forward-symbol-inverse) then N values of line a, N values of line b.  stdout: the two transformed lines.
+// stdin: "mode N" (mode 0/1 = forward/inverse radix-2, 2/3 = the same with grouped radix-8 stages, 4/5/6 = fused schedule forward / inverse / forward-symbol-inverse, 7/8/9 = the same with the contiguous-axis outer stages) then N values of line a, N values of line b.  stdout: the two transformed lines.
 #include <cmath>
 #include <cstdio>
 #include <vector>
@@ -8,6 +8,8 @@ using namespace bk::dctc;
 int main() {
     int inverse, N, grouped = 0, fused = 0;
     if (scanf("%d %d", &inverse, &N) != 2) return 2;
+    int contiguous = 0;
+    if (inverse >= 7) { contiguous = 1; inverse -= 3; }        // 7/8/9: the same with the contiguous-axis first / last stage
     if (inverse >= 4) { fused = inverse - 3; inverse = 0; }   // 4: fused forward, 5: fused inverse, 6: fused roundtrip
     if (inverse >= 2) { grouped = 1; inverse -= 2; }     // modes 2/3: radix-8 grouped stages
     int bits = 0;
@@ -50,6 +52,12 @@ int main() {
             }
         };
         if (fused != 2) {                                  // forward or roundtrip: first stage from the samples
+            if (contiguous)
+                for (int gp = 0; gp < N / 16; ++gp)
+                    fused_first2(z.data(), N, bits, gp, [&](int j, double& ea, double& oa, double& eb, double& ob) {
+                        ea = a[2 * j]; oa = a[2 * j + 1]; eb = b[2 * j]; ob = b[2 * j + 1];
+                    });
+            else
             for (int gp = 0; gp < N / 8; ++gp) fused_first(z.data(), N, bits, gp, ldin);
             middle_fwd();
         }
@@ -60,6 +68,12 @@ int main() {
         }
         if (fused != 1) {
             middle_inv();
+            if (contiguous)
+                for (int gp = 0; gp < N / 16; ++gp)
+                    fused_last2(z.data(), N, bits, gp, [&](int j, double ea, double oa, double eb, double ob) {
+                        out[2 * j].x = ea; out[2 * j + 1].x = oa; out[2 * j].y = eb; out[2 * j + 1].y = ob;
+                    });
+            else
             for (int gp = 0; gp < N / 8; ++gp) fused_last(z.data(), N, bits, gp, stout);
         }
         for (int k = 0; k < N; ++k) printf("%.17g %.17g\n", out[k].x, out[k].y);

@@ -340,6 +340,32 @@ def test_bordered_solvers_vs_explicit(ctx, shift, xi):
         assert np.isclose(dlm, ref[-1], rtol=1e-6, atol=1e-8)           # p-component rtol 1e-6, test_linear.jl:~230
 
 
+@pytest.mark.parametrize("m", [1, 2, 3])
+def test_bordering_block_vs_explicit_and_oracle(ctx, m):
+    """solve_bls_block (LinearBorderSolver.jl:173-206): m-column border == explicit (N+m) solve == oracle."""
+    hip = _hip()
+    sh, prob, rng, u = _sh_setup(ctx, (10, 8, 6), (np.pi, 2.5, 2.0), seed=11 + m)
+    n = sh.N
+    Jm = sh.J(u, 0.1, 1.2).toarray()
+    b = [rng.standard_normal(n) for _ in range(m)]
+    c = [rng.standard_normal(n) / n for _ in range(m)]
+    d = rng.standard_normal((m, m))
+    rhst, rhsb = rng.standard_normal(n), rng.standard_normal(m)
+    A = np.block([[Jm, np.stack(b, 1)], [np.stack(c, 0), d]])
+    ref = np.linalg.solve(A, np.concatenate([rhst, rhsb]))
+    ou1, ou2, ook, _ = bordered.bordering_bls_block(bordered.default_ls, Jm, b, c, d, rhst, rhsb)
+    assert ook and np.allclose(ou1, ref[:n], rtol=1e-9, atol=1e-11) and np.allclose(ou2, ref[n:], rtol=1e-9)
+    ls = hip.GMRESKrylovKit(dim=40, rtol=1e-12, atol=1e-13, maxiter=100, Pl=hip.DCTPreconditioner(prob, 0.0))
+    J = prob.jacobian(prob.vec(u), 0.1)
+    u1, u2, ok, its = hip.BorderingBLS(ls).solve_block(J, [prob.vec(x) for x in b], [prob.vec(x) for x in c], d,
+                                                       prob.vec(rhst), rhsb)
+    assert ok and len(its) == m and all(i > 0 for i in its)
+    assert np.abs(u1.numpy() - ref[:n]).max() <= 1e-7 * np.abs(ref).max()
+    assert np.allclose(u2, ref[n:], rtol=1e-7, atol=1e-9)
+    with pytest.raises(ValueError):
+        hip.BorderingBLS(ls).solve_block(J, [prob.vec(b[0])] * (m + 1), [prob.vec(x) for x in c], d, prob.vec(rhst), rhsb)
+
+
 # --------------------------------------------------------------------------------------------- eigensolver
 def test_shift_invert_vs_dense(ctx):
     """test_linear.jl:666-677 (ShiftInvert vs eigvals < 1e-9) with the SH3dEig settings of

@@ -127,6 +127,24 @@ def test_bordered_solvers_vs_explicit(shift, xi):
     assert np.allclose(op(v), A @ v)
 
 
+@pytest.mark.parametrize("m", [1, 2, 3])
+def test_bordering_block_vs_explicit(m):
+    """solve_bls_block (LinearBorderSolver.jl:173-206) == the explicit (N+m) solve (test_linear.jl:246-300 pattern)."""
+    rng = np.random.default_rng(7 + m)
+    n = 40
+    J0 = np.eye(n) + 0.1 * rng.random((n, n))
+    b = [rng.random(n) for _ in range(m)]
+    c = [rng.random(n) for _ in range(m)]
+    d = rng.random((m, m))
+    rhst, rhsb = rng.random(n), rng.random(m)
+    A = np.block([[J0, np.stack(b, 1)], [np.stack(c, 0), d]])
+    ref = np.linalg.solve(A, np.concatenate([rhst, rhsb]))
+    u1, u2, ok, its = bordered.bordering_bls_block(bordered.default_ls, J0, b, c, d, rhst, rhsb)
+    assert ok and len(its) == m and np.allclose(u1, ref[:n]) and np.allclose(u2, ref[n:])
+    with pytest.raises(ValueError):
+        bordered.bordering_bls_block(bordered.default_ls, J0, b, c[:-1] if m > 1 else c + c, d, rhst, rhsb)
+
+
 def test_shift_invert_vs_eigvals():
     rng = np.random.default_rng(5)
     J = np.eye(10) + 0.1 * rng.random((10, 10))
