@@ -50,6 +50,24 @@ class NewtonResult(C.Structure):
                 ("residuals", C.c_double * (BK_MAX_NEWTON_ITER + 1))]
 
 
+BK_MAX_NEV = 62
+
+
+class ContOpts(C.Structure):
+    _fields_ = [("ds", C.c_double), ("dsmin", C.c_double), ("dsmax", C.c_double), ("a", C.c_double),
+                ("theta", C.c_double), ("p_min", C.c_double), ("p_max", C.c_double), ("tangent", C.c_int),
+                ("detect", C.c_int), ("nev", C.c_int), ("tol_stability", C.c_double)]
+
+
+class ContStepResult(C.Structure):
+    _fields_ = [("converged", C.c_int), ("itnewton", C.c_int), ("itlinear", C.c_int),
+                ("residuals", C.c_double * (BK_MAX_NEWTON_ITER + 1)), ("p", C.c_double), ("ds_used", C.c_double),
+                ("ds_next", C.c_double), ("step", C.c_int), ("stop", C.c_int), ("n_unstable", C.c_int),
+                ("n_imag", C.c_int), ("bifurcation", C.c_int), ("nvals", C.c_int), ("eig_converged", C.c_int),
+                ("eig_numops", C.c_int), ("vals_re", C.c_double * (BK_MAX_NEV + 1)),
+                ("vals_im", C.c_double * (BK_MAX_NEV + 1)), ("tangent_converged", C.c_int)]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, c_double_p, C.c_int, C.c_int)
 SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, c_double_p, C.c_size_t, C.c_int, c_double_p, C.c_size_t, C.c_int)
 
@@ -110,6 +128,12 @@ SIGNATURES = {
                                VP, VP, SZ, c_int_p, c_int_p, c_int_p]),
     "bk_newton": (I, [VP, VP, VP, c_double_p, I, C.POINTER(NewtonOpts), C.POINTER(GmresOpts), VP,
                       C.POINTER(NewtonResult)]),
+    "bk_cont_create": (I, [VP, VP, c_double_p, I, I, VP, D, VP, D, C.POINTER(ContOpts), C.POINTER(NewtonOpts),
+                           C.POINTER(BorderingOpts), C.POINTER(GmresOpts), VP, C.POINTER(EigOpts),
+                           C.POINTER(GmresOpts), VP, C.POINTER(ContStepResult), C.POINTER(VP)]),
+    "bk_cont_step": (I, [VP, C.POINTER(ContStepResult)]),
+    "bk_cont_get": (I, [VP, VP, c_double_p, VP, c_double_p, c_double_p]),
+    "bk_cont_destroy": (I, [VP]),
     "bk_newton_palc": (I, [VP, VP, VP, c_double_p, VP, D, VP, D, D, D, c_double_p, I, I, D, D,
                            C.POINTER(NewtonOpts), C.POINTER(BorderingOpts), C.POINTER(GmresOpts), VP,
                            C.POINTER(NewtonResult)]),

@@ -280,3 +280,87 @@ def continuation(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm2, verb
                 tau, _ = bordered_tangent(prob, z, tau, alg.theta, alg.bls)
         z_pred = z.copy().add_(tau, ds)
     return br
+
+
+def continuation_native(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm2, verbosity=0, save_sol=False) -> ContResult:
+    """The same branch with every step issued as ONE library call (``bk_cont_step``: corrector, eigenvalues, step-size
+    control, tangent and predictor -- the body of ``iterate``, src/Continuation.jl:458-504) and the two initial Newton
+    solves as ``bk_newton``.  Needs the native solver types (GMRES* + BorderingBLS + ShiftInvert); ``normC`` must be
+    ``norm2`` or ``norminf``.  Returns the same record as :func:`continuation`."""
+    import ctypes as C
+
+    from . import _lib as L
+    from . import hip
+
+    alg = alg.update(cp)
+    nopt = cp.newton_options
+    ls, bls = nopt.linsolver, alg.bls
+    if normC not in (norm2, norminf):
+        raise TypeError("continuation_native: normC must be norm2 or norminf")
+    inf = normC is norminf
+    ctx = prob.ctx
+    eig = nopt.eigsolver if cp.detect_bifurcation > 0 else None
+    s0 = hip.newton_native(prob, x0, p0, ls, nopt.tol, nopt.max_iterations, inf)
+    if not s0["converged"]:
+        raise RuntimeError("Newton failed to converge for the initial guess on the branch")
+    p1 = p0 + cp.ds / cp.eta
+    s1 = hip.newton_native(prob, s0["u"], p1, ls, nopt.tol, nopt.max_iterations, inf)
+    if not s1["converged"]:
+        raise RuntimeError("Newton failed to converge. Required for the computation of the initial tangent")
+    big = 1.7e308
+    co = L.ContOpts(cp.ds, cp.dsmin, cp.dsmax, cp.a, alg.theta, max(cp.p_min, -big), min(cp.p_max, big),
+                    0 if alg.tangent == "secant" else 1, 1 if eig is not None else 0, cp.nev, cp.tol_stability)
+    no = L.NewtonOpts(float(nopt.tol), int(nopt.max_iterations), 1 if inf else 0)
+    bo = L.BorderingOpts(bls.tol, 1 if bls.check_precision else 0, bls.k)
+    lo = bls.solver._opts()
+    eo = elo = None
+    epl = None
+    if eig is not None:
+        kd = eig.krylovdim if eig.krylovdim is not None else 0
+        eo = L.EigOpts(float(eig.sigma), int(min(kd, 63)), int(eig.maxiter), float(eig.tol), 1 if eig.hermitian else 0,
+                       int(eig.seed))
+        elo, epl = eig.ls._opts(), eig.ls._pl()
+    pv = prob._pvec(p0)
+    arr = (C.c_double * len(pv))(*pv)
+    h = C.c_void_p()
+    r = L.ContStepResult()
+    ctx.check(ctx.lib.bk_cont_create(
+        ctx.h, prob.h, arr, len(pv), prob.ipar, hip._ptr(s0["u"].t), float(p0), hip._ptr(s1["u"].t), float(p1),
+        C.byref(co), C.byref(no), C.byref(bo), C.byref(lo), bls.solver._pl(),
+        C.byref(eo) if eo is not None else None, C.byref(elo) if elo is not None else None, epl, C.byref(r),
+        C.byref(h)), "bk_cont_create")
+    br = ContResult()
+
+    def vals_of(r):
+        return np.array([complex(r.vals_re[i], r.vals_im[i]) for i in range(r.nvals)]) if eig is not None else None
+
+    def record(r, itnewton, itlinear, residuals):
+        br.param.append(r.p); br.itnewton.append(itnewton); br.itlinear.append(itlinear)
+        br.ds.append(r.ds_used); br.n_unstable.append(r.n_unstable); br.n_imag.append(r.n_imag)
+        br.residuals.append(residuals); br.eig.append(vals_of(r))
+        if save_sol:
+            u = s0["u"].similar()
+            ctx.check(ctx.lib.bk_cont_get(h, hip._ptr(u.t), None, None, None, None), "bk_cont_get")
+            br.sol.append(u)
+
+    try:
+        record(r, s0["itnewton"], s0["itlineartot"], list(s0["residuals"]))
+        step = 0
+        while step < cp.max_steps:
+            prev_unst = r.n_unstable
+            ctx.check(ctx.lib.bk_cont_step(h, C.byref(r)), "bk_cont_step")
+            if r.stop == 2:
+                break
+            if verbosity:
+                print(f"step {step:3d} ds={r.ds_used:+.3e} -> p={r.p:+.6f} conv={bool(r.converged)} "
+                      f"itnewton={r.itnewton} itlinear={r.itlinear}")
+            if r.converged:
+                if r.bifurcation:
+                    br.specialpoint.append(dict(step=step + 1, param=r.p, n_unstable=(prev_unst, r.n_unstable)))
+                step += 1
+                record(r, r.itnewton, r.itlinear, [r.residuals[i] for i in range(r.itnewton + 1)])
+            if r.stop:
+                break
+    finally:
+        ctx.lib.bk_cont_destroy(h)
+    return br

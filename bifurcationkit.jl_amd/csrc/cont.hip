@@ -1,0 +1,259 @@
+// Native PALC continuation step: the body of `iterate` (src/Continuation.jl:458-504) as one library call --
+// corrector! (newton_palc, Palc.jl:187-305), compute_eigenvalues! (Utils.jl:67-104) + is_stable
+// (Bifurcations.jl:5-19), _step_size_control! (Contbase.jl:77-102), gettangent! (Secant Tangents.jl:28-54 /
+// Bordered :71-104) and getpredictor! / addtangent! (Tangents.jl:8-15).  Everything is composed from the public
+// entry points of bkhip.h, so a step issued here is call-for-call the sequence the Julia engine (or the Python
+// mirror continuation.py) would issue through the plugin surface; what it removes is the host round trips
+// between them.
+#include <cmath>
+#include <vector>
+
+#include "ops.h"
+
+using namespace bk;
+
+struct bk_cont {
+    bk_ctx* ctx = nullptr;
+    bk_problem* prob = nullptr;
+    size_t n = 0;
+    double Nglob = 1.0;
+    double params[BK_MAX_PARAMS];
+    int nparams = 0, ipar = 0;
+    bk_cont_opts co;
+    bk_newton_opts no;
+    bk_bordering_opts bo;
+    bk_gmres_opts lo;
+    bk_precond* pl = nullptr;
+    bool has_eig = false;
+    bk_eig_opts eo;
+    bk_gmres_opts elo;
+    bk_precond* epl = nullptr;
+    // state (Continuation.jl ContState: z, z_old, tau, z_pred, ds, n_unstable, n_imag, step)
+    double *zu = nullptr, *zoldu = nullptr, *tauu = nullptr, *predu = nullptr, *work = nullptr, *work2 = nullptr;
+    double zp = 0, zoldp = 0, taup = 0, predp = 0, ds = 0;
+    int n_unstable = -1, n_imag = -1, step = 0;
+};
+
+namespace {
+
+int dot_theta(bk_cont* c, const double* u1, const double* u2, double p1, double p2, double* out) {
+    double d;
+    BK_TRY(v_dot(c->ctx, c->n, u1, u2, &d));               // DotTheta with NormalisedDot, Palc.jl:1-6, 35
+    *out = d / c->Nglob * c->co.theta + p1 * p2 * (1.0 - c->co.theta);
+    return 0;
+}
+
+double copysign1(double x) { return std::copysign(1.0, x); }
+
+// _secant_tangent!, Tangents.jl:28-42: tau = (z1 - z0) * sign(ds) / ||z1 - z0||_theta
+int secant_tangent(bk_cont* c, const double* z1u, double z1p, const double* z0u, double z0p, double ds) {
+    BK_TRY(v_copy(c->ctx, c->n, z1u, c->tauu));
+    BK_TRY(v_axpby(c->ctx, c->n, -1.0, z0u, 1.0, c->tauu));
+    c->taup = z1p - z0p;
+    double nn;
+    BK_TRY(dot_theta(c, c->tauu, c->tauu, c->taup, c->taup, &nn));
+    const double a = copysign1(ds) / std::sqrt(nn);
+    BK_TRY(v_scale(c->ctx, c->n, a, c->tauu));
+    c->taup *= a;
+    return 0;
+}
+
+// gettangent!(::Bordered), Tangents.jl:71-104
+int bordered_tangent(bk_cont* c, int* converged) {
+    const double eps = 1.4901161193847656e-08;             // getdelta = sqrt(eps), src/Problems.jl:69-70
+    double par[BK_MAX_PARAMS];
+    for (int i = 0; i < c->nparams; ++i) par[i] = c->params[i];
+    double* dFdl = c->work;
+    double* f0 = c->work2;
+    par[c->ipar] = c->zp + eps;
+    BK_TRY(bk_residual(c->prob, c->zu, par, c->nparams, dFdl));
+    par[c->ipar] = c->zp;
+    BK_TRY(bk_residual(c->prob, c->zu, par, c->nparams, f0));
+    BK_TRY(v_axpby(c->ctx, c->n, -1.0 / eps, f0, 1.0 / eps, dFdl));
+    BK_TRY(v_zero(c->ctx, c->n, f0));                      // rhs (0, 1), Tangents.jl:90-94
+    bk_op* J = nullptr;
+    BK_TRY(bk_jacobian(c->prob, c->zu, par, c->nparams, &J));
+    double tp = 0.0;
+    int cv = 0, it[2] = {0, 0};
+    double* tu = c->predu;                                  // the predictor is rebuilt right after the tangent
+    const int s = bk_bls_bordering(c->ctx, J, dFdl, c->tauu, c->taup, f0, 1.0, c->co.theta, 1.0 - c->co.theta, 0, 0.0,
+                                   1.0 / c->Nglob, &c->bo, &c->lo, c->pl, tu, &tp, &cv, it);
+    bk_op_destroy(J);
+    if (s != 0) return s;
+    double nn, sg;
+    BK_TRY(dot_theta(c, tu, tu, tp, tp, &nn));
+    BK_TRY(dot_theta(c, c->tauu, tu, c->taup, tp, &sg));
+    const double a = copysign1(sg) / std::sqrt(nn);
+    BK_TRY(v_copy(c->ctx, c->n, tu, c->tauu));
+    BK_TRY(v_scale(c->ctx, c->n, a, c->tauu));
+    c->taup = tp * a;
+    if (converged) *converged = cv;
+    return 0;
+}
+
+int predictor(bk_cont* c) {                                 // z_pred = z + ds * tau, Tangents.jl:8-15
+    BK_TRY(v_copy(c->ctx, c->n, c->zu, c->predu));
+    BK_TRY(v_axpby(c->ctx, c->n, c->ds, c->tauu, 1.0, c->predu));
+    c->predp = c->zp + c->ds * c->taup;
+    return 0;
+}
+
+// compute_eigenvalues (Utils.jl:67-104: nev_ = max(n_unstable + 5, nev)) + is_stable (Bifurcations.jl:5-19)
+int eigen(bk_cont* c, bk_cont_step_result* r) {
+    double par[BK_MAX_PARAMS];
+    for (int i = 0; i < c->nparams; ++i) par[i] = c->params[i];
+    par[c->ipar] = c->zp;
+    int nev = std::max(std::max(c->n_unstable, 0) + 5, c->co.nev);
+    nev = std::min(nev, BK_MAX_NEV);
+    bk_eig_opts eo = c->eo;
+    if (eo.krylovdim <= 0) eo.krylovdim = std::max(30, nev + 30);      // examples/SH3d.jl:109
+    eo.krylovdim = std::min(eo.krylovdim, 63);
+    nev = std::min(nev, eo.krylovdim);
+    bk_op* J = nullptr;
+    BK_TRY(bk_jacobian(c->prob, c->zu, par, c->nparams, &J));
+    int nvals = 0, nconv = 0, nops = 0;
+    const int s = bk_eig_shiftinvert(c->ctx, J, nev, &eo, &c->elo, c->epl, r->vals_re, r->vals_im, nullptr, nullptr, 0,
+                                     &nvals, &nconv, &nops);
+    bk_op_destroy(J);
+    if (s != 0) return s;
+    int nu = 0, ni = 0;
+    for (int i = 0; i < nvals; ++i) {                       // NaN (unconverged) compares false, as in the mirror
+        if (r->vals_re[i] > c->co.tol_stability) {
+            ++nu;
+            if (std::fabs(r->vals_im[i]) > c->co.tol_stability) ++ni;
+        }
+    }
+    r->nvals = nvals;
+    r->eig_converged = nconv >= nev;
+    r->eig_numops = nops;
+    c->n_unstable = nu;
+    c->n_imag = ni;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bk_cont_create(bk_ctx* ctx, bk_problem* prob, const double* params, int nparams, int ipar, const double* u0,
+                   double p0, const double* u1, double p1, const bk_cont_opts* copts, const bk_newton_opts* nopts,
+                   const bk_bordering_opts* bopts, const bk_gmres_opts* lsopts, bk_precond* pl,
+                   const bk_eig_opts* eopts, const bk_gmres_opts* eig_lsopts, bk_precond* eig_pl,
+                   bk_cont_step_result* init, bk_cont** out) {
+    if (!ctx || !prob || !params || !u0 || !u1 || !copts || !nopts || !bopts || !lsopts || !out) return -1;
+    if (ipar < 0 || ipar >= nparams || nparams > BK_MAX_PARAMS) return set_error(ctx, "bad parameter index");
+    if (copts->detect && (!eopts || !eig_lsopts)) return set_error(ctx, "bk_cont_create: detect needs eigensolver options");
+    if (nopts->max_iterations > BK_MAX_NEWTON_ITER) return set_error(ctx, "max_iterations > %d", BK_MAX_NEWTON_ITER);
+    bk_cont* c = new bk_cont();
+    c->ctx = ctx; c->prob = prob; c->n = prob->nloc;
+    for (int a = 0; a < prob->desc.ndim; ++a) c->Nglob *= prob->desc.n[a];
+    if (prob->desc.pde == BK_PDE_CGL2D) c->Nglob *= 2.0;
+    for (int i = 0; i < BK_MAX_PARAMS; ++i) c->params[i] = i < nparams ? params[i] : 0.0;
+    c->nparams = nparams; c->ipar = ipar;
+    c->co = *copts; c->no = *nopts; c->bo = *bopts; c->lo = *lsopts; c->pl = pl;
+    c->has_eig = copts->detect != 0;
+    if (c->has_eig) { c->eo = *eopts; c->elo = *eig_lsopts; c->epl = eig_pl; }
+    double** bufs[] = {&c->zu, &c->zoldu, &c->tauu, &c->predu, &c->work, &c->work2};
+    for (double** b : bufs)
+        if (hipMalloc(b, c->n * sizeof(double)) != hipSuccess) {
+            bk_cont_destroy(c);
+            return set_error(ctx, "bk_cont_create: device allocation failed");
+        }
+    // initialize!, Palc.jl:112-123 after the two Newton solves of Continuation.jl:349-456
+    int s = 0;
+    c->ds = copts->ds;
+    if ((s = v_copy(ctx, c->n, u0, c->zu)) || (s = v_copy(ctx, c->n, u0, c->zoldu))) { bk_cont_destroy(c); return s; }
+    c->zp = c->zoldp = p0;
+    bk_cont_step_result r0 = {};
+    r0.converged = 1; r0.p = p0; r0.ds_used = c->ds; r0.n_unstable = -1; r0.n_imag = -1;
+    if (c->has_eig && (s = eigen(c, &r0))) { bk_cont_destroy(c); return s; }
+    r0.n_unstable = c->n_unstable; r0.n_imag = c->n_imag;
+    if ((s = secant_tangent(c, u1, p1, u0, p0, c->ds)) || (s = predictor(c))) { bk_cont_destroy(c); return s; }
+    r0.ds_next = c->ds;
+    if (init) *init = r0;
+    *out = c;
+    return 0;
+}
+
+int bk_cont_destroy(bk_cont* c) {
+    if (!c) return 0;
+    double* bufs[] = {c->zu, c->zoldu, c->tauu, c->predu, c->work, c->work2};
+    for (double* b : bufs)
+        if (b) (void)hipFree(b);
+    delete c;
+    return 0;
+}
+
+int bk_cont_step(bk_cont* c, bk_cont_step_result* r) {
+    if (!c || !r) return -1;
+    bk_ctx* ctx = c->ctx;
+    *r = bk_cont_step_result{};
+    r->n_unstable = c->n_unstable; r->n_imag = c->n_imag;
+    r->p = c->zp; r->ds_used = c->ds; r->ds_next = c->ds;
+    if (c->predp <= c->co.p_min || c->predp >= c->co.p_max) {          // the mirror stops here (Palc.jl:157-160 switches
+        r->stop = 2;                                                    // to a Natural corrector at the clamped p)
+        return 0;
+    }
+    // corrector!: newton_palc from the predictor; z (the last point) and tau are inputs
+    double* x = c->work;
+    BK_TRY(v_copy(ctx, c->n, c->predu, x));
+    double p = c->predp;
+    bk_newton_result nr = {};
+    BK_TRY(bk_newton_palc(ctx, c->prob, x, &p, c->zu, c->zp, c->tauu, c->taup, c->ds, c->co.theta, c->params, c->nparams,
+                          c->ipar, c->co.p_min, c->co.p_max, &c->no, &c->bo, &c->lo, c->pl, &nr));
+    r->converged = nr.converged; r->itnewton = nr.itnewton; r->itlinear = nr.itlinear;
+    for (int i = 0; i <= nr.itnewton && i <= BK_MAX_NEWTON_ITER; ++i) r->residuals[i] = nr.residuals[i];
+    const int prev_unst = c->n_unstable;
+    if (nr.converged) {
+        BK_TRY(v_copy(ctx, c->n, c->zu, c->zoldu));
+        c->zoldp = c->zp;
+        BK_TRY(v_copy(ctx, c->n, x, c->zu));
+        c->zp = p;
+        if (c->has_eig) {
+            BK_TRY(eigen(c, r));
+            if (prev_unst != -1 && c->n_unstable != prev_unst) r->bifurcation = 1;      // Bifurcations.jl:22-28
+        }
+        c->step += 1;
+    }
+    r->p = c->zp;
+    r->n_unstable = c->n_unstable; r->n_imag = c->n_imag;
+    r->step = c->step;
+    // _step_size_control!, Contbase.jl:77-102
+    double ds = c->ds;
+    if (!nr.converged) {
+        if (std::fabs(ds) <= c->co.dsmin) {
+            r->stop = 1;
+            return 0;
+        }
+        ds = std::copysign(std::max(std::fabs(ds) / 2.0, c->co.dsmin), ds);
+    } else {
+        const double Nmax = c->no.max_iterations;
+        const double factor = (Nmax - nr.itnewton) / Nmax;
+        ds = ds * (1.0 + c->co.a * factor * factor);
+    }
+    ds = std::copysign(std::min(std::max(std::fabs(ds), c->co.dsmin), c->co.dsmax), ds);          // clamp_ds
+    c->ds = ds;
+    r->ds_next = ds;
+    if (nr.converged) {                                                 // Palc.jl:140-143
+        if (c->co.tangent == 0) {
+            BK_TRY(secant_tangent(c, c->zu, c->zp, c->zoldu, c->zoldp, ds));
+            r->tangent_converged = 1;
+        } else {
+            BK_TRY(bordered_tangent(c, &r->tangent_converged));
+        }
+    }
+    BK_TRY(predictor(c));
+    return 0;
+}
+
+int bk_cont_get(bk_cont* c, double* u, double* p, double* tauu, double* taup, double* ds) {
+    if (!c) return -1;
+    if (u) BK_TRY(v_copy(c->ctx, c->n, c->zu, u));
+    if (tauu) BK_TRY(v_copy(c->ctx, c->n, c->tauu, tauu));
+    if (p) *p = c->zp;
+    if (taup) *taup = c->taup;
+    if (ds) *ds = c->ds;
+    return 0;
+}
+
+}  // extern "C"

@@ -254,6 +254,47 @@ int bk_newton_palc(bk_ctx* ctx, bk_problem* prob, double* x, double* p, const do
                    const bk_newton_opts* nopts, const bk_bordering_opts* bopts,
                    const bk_gmres_opts* lsopts, bk_precond* pl, bk_newton_result* res);
 
+/* ------------------------------------------------------------------ continuation step -----------
+ * The body of `iterate` (src/Continuation.jl:458-504) as one call: corrector! (newton_palc), compute_eigenvalues!
+ * + is_stable (src/Utils.jl:67-104, src/Bifurcations.jl:5-19), _step_size_control! (src/continuation/Contbase.jl:77-102),
+ * gettangent! (Secant / Bordered, src/continuation/Tangents.jl:28-104) and the predictor (addtangent!, :8-15).
+ * bk_cont_create takes the two converged points of src/Continuation.jl:349-456 ((u0, p0) and (u1, p1 = p0 + ds/eta))
+ * and performs initialize! (Palc.jl:112-123): secant tangent, first predictor and, with detect != 0, the eigenvalues
+ * at (u0, p0) (returned in *init).  SURVEY section 8(f) item 2.                                                   */
+#define BK_MAX_NEV 62
+typedef struct {
+    double ds, dsmin, dsmax;   /* ContinuationPar.ds / dsmin / dsmax   (src/ContParameters.jl)                      */
+    double a;                  /* step-size aggressiveness ContinuationPar.a                                        */
+    double theta;              /* PALC.theta                                                                         */
+    double p_min, p_max;       /* ContinuationPar.p_min / p_max                                                      */
+    int tangent;               /* 0: Secant(), 1: Bordered()                                                         */
+    int detect;                /* detect_bifurcation > 0: eigenvalues after every converged step                    */
+    int nev;                   /* ContinuationPar.nev                                                                */
+    double tol_stability;      /* ContinuationPar.tol_stability                                                      */
+} bk_cont_opts;
+typedef struct {
+    int converged, itnewton, itlinear;           /* corrector (NonLinearSolution)                                   */
+    double residuals[BK_MAX_NEWTON_ITER + 1];
+    double p;                                    /* parameter of the current point z after the step                  */
+    double ds_used, ds_next;                     /* arclength step of this corrector / of the next predictor         */
+    int step;                                    /* number of accepted steps so far                                  */
+    int stop;                                    /* 0 continue, 1 |ds| <= dsmin after a failed corrector, 2 predictor left [p_min, p_max] */
+    int n_unstable, n_imag, bifurcation;         /* is_stable counts; bifurcation = 1 when n_unstable changed        */
+    int nvals, eig_converged, eig_numops;        /* eigensolver return values; vals sorted by decreasing real part   */
+    double vals_re[BK_MAX_NEV + 1], vals_im[BK_MAX_NEV + 1];
+    int tangent_converged;                       /* Bordered(): convergence flag of the tangent's bordered solve     */
+} bk_cont_step_result;
+typedef struct bk_cont bk_cont;
+int bk_cont_create(bk_ctx* ctx, bk_problem* prob, const double* params, int nparams, int ipar,
+                   const double* u0, double p0, const double* u1, double p1, const bk_cont_opts* copts,
+                   const bk_newton_opts* nopts, const bk_bordering_opts* bopts, const bk_gmres_opts* lsopts,
+                   bk_precond* pl, const bk_eig_opts* eopts, const bk_gmres_opts* eig_lsopts,
+                   bk_precond* eig_pl, bk_cont_step_result* init, bk_cont** out);
+int bk_cont_step(bk_cont* c, bk_cont_step_result* res);
+/* copies of the current point / tangent (device buffers of the local length, any may be NULL) */
+int bk_cont_get(bk_cont* c, double* u, double* p, double* tauu, double* taup, double* ds);
+int bk_cont_destroy(bk_cont* c);
+
 #ifdef __cplusplus
 }
 #endif

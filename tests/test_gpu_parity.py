@@ -509,6 +509,58 @@ def test_palc_branch_matches_oracle(ctx):
             assert a[-1] < 1e-9 and b[-1] < 1e-9
 
 
+@pytest.mark.parametrize("tangent", ["secant", "bordered"])
+def test_native_continuation_step_matches_mirror(ctx, tangent):
+    """bk_cont_step (the body of iterate, Continuation.jl:458-504, as one call) reproduces the branch driven call by
+    call through the plugin surface (continuation.py, itself checked against the oracle above): same parameters, step
+    sizes, Newton / linear iteration counts, eigenvalues and stability counts -- with an eigensolve every step."""
+    hip = _hip()
+    from bk_amd import continuation as Cn
+    dims, ls_ = (12, 12, 12), (np.pi,) * 3
+    sh, prob, rng, u = _sh_setup(ctx, dims, ls_)
+    P = hip.DCTPreconditioner(prob, 0.0)
+    ls = hip.GMRESKrylovKit(dim=30, rtol=1e-9, atol=1e-12, maxiter=150, Pl=P)
+    eig = hip.ShiftInvert(0.1, ls, tol=1e-10, maxiter=20, hermitian=True, save_vectors=False)
+    nopt = Cn.NewtonPar(tol=1e-9, max_iterations=15, linsolver=ls, eigsolver=eig)
+    cp = Cn.ContinuationPar(ds=-0.001, dsmin=1e-4, dsmax=0.005, p_min=-0.1, p_max=0.15, max_steps=5, nev=6,
+                            detect_bifurcation=3, newton_options=nopt)
+    alg = Cn.PALC(tangent=tangent, theta=0.5, bls=hip.BorderingBLS(None, check_precision=False))
+    x0 = prob.vec(u)
+    bm = Cn.continuation(prob, x0, 0.1, alg, cp, normC=Cn.norminf,
+                         corrector=lambda prob_, z, tau, zp, ds, th, bls, no, pmin, pmax, nrm:
+                         _native_corrector(hip, Cn, prob_, z, tau, zp, ds, th, bls, no, pmin, pmax))
+    bn = Cn.continuation_native(prob, x0, 0.1, alg, cp, normC=Cn.norminf, save_sol=True)
+    assert len(bn.param) == len(bm.param) == 6
+    # identical call sequence on identical inputs -> identical results (deterministic reductions)
+    assert np.allclose(bn.param, bm.param, rtol=0, atol=1e-13), (bn.param, bm.param)
+    assert np.allclose(bn.ds, bm.ds, rtol=1e-13) and bn.itnewton == bm.itnewton and bn.itlinear == bm.itlinear
+    assert bn.n_unstable == bm.n_unstable and bn.n_imag == bm.n_imag
+    for a, b in zip(bn.eig, bm.eig):
+        assert len(a) == len(b) and np.allclose(a.real, b.real, rtol=0, atol=1e-10, equal_nan=True)
+    for a, b in zip(bn.residuals, bm.residuals):
+        assert len(a) == len(b) and np.allclose(a, b, rtol=1e-6, atol=1e-13)
+    # the saved solutions are points of the branch: F(u, p) = 0 to the Newton tolerance
+    for u_, p_ in zip(bn.sol, bn.param):
+        assert np.abs(sh.F(u_.numpy(), p_, 1.2)).max() < 1e-8
+
+
+def test_native_continuation_stops_at_parameter_bound(ctx):
+    """p_max reached: the native loop reports stop = 2 where the mirror breaks (predictor outside [p_min, p_max])."""
+    hip = _hip()
+    from bk_amd import continuation as Cn
+    dims, ls_ = (12, 12, 12), (np.pi,) * 3
+    sh, prob, rng, u = _sh_setup(ctx, dims, ls_)
+    ls = hip.GMRESKrylovKit(dim=30, rtol=1e-9, atol=1e-12, maxiter=150, Pl=hip.DCTPreconditioner(prob, 0.0))
+    nopt = Cn.NewtonPar(tol=1e-9, max_iterations=15, linsolver=ls)
+    cp = Cn.ContinuationPar(ds=0.004, dsmin=1e-4, dsmax=0.005, p_min=-0.1, p_max=0.108, max_steps=50,
+                            detect_bifurcation=0, newton_options=nopt)
+    alg = Cn.PALC(tangent="secant", theta=0.5, bls=hip.BorderingBLS(None, check_precision=False))
+    bm = Cn.continuation(prob, prob.vec(u), 0.1, alg, cp, normC=Cn.norminf)
+    bn = Cn.continuation_native(prob, prob.vec(u), 0.1, alg, cp, normC=Cn.norminf)
+    assert 2 <= len(bn.param) < 50 and len(bn.param) == len(bm.param)
+    assert np.allclose(bn.param, bm.param, rtol=0, atol=1e-10) and max(bn.param) < 0.108
+
+
 def _native_corrector(hip, Cn, prob, z, tau, zp, ds, theta, bls, nopt, pmin, pmax):
     r = hip.newton_palc_native(prob, z, tau, zp, ds, theta, bls, tol=nopt.tol, max_iterations=nopt.max_iterations,
                                p_min=pmin, p_max=pmax, norm_inf=True)
