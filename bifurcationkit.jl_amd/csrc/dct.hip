@@ -24,10 +24,6 @@
 
 namespace bk {
 
-int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, const double* twid, const double* in,
-                 double* out, const double* symx, const double* symy, const double* symz, double shift, int fuse_scale);
-bool dct_axis_fft_supported(int n);
-
 struct DctPlan {
     int ndim = 0;
     int n[3] = {1, 1, 1};
@@ -36,6 +32,7 @@ struct DctPlan {
     double* TT[3] = {nullptr, nullptr, nullptr};   // TT[n*N + k] = same, transposed
     double* lam[3] = {nullptr, nullptr, nullptr};  // eigenvalues lambda_k per axis
     double* twid[3] = {nullptr, nullptr, nullptr}; // fast path: twiddle tables
+    unsigned* kmap = nullptr;                 // distributed, uniform y split: y index -> element offset in the block layout
     double* t1 = nullptr;
     double* t2 = nullptr;
     size_t total = 0;
@@ -125,20 +122,6 @@ __global__ void __launch_bounds__(256) slab_blocks_kernel(int nx, int ny, int nz
     const size_t off = (size_t)nx * nzl * y0 + ((size_t)zl * nyd + (y - y0)) * nx + x;   // blocks are laid out in rank order
     if (dir == 0) out[off] = in[idx];
     else out[idx] = in[off];
-}
-
-// per-source blocks [s][z - zcut[s]][yl][x]  <->  y-slab transposed layout T[yl][z][x]   (dir 0: blocks -> T)
-__global__ void __launch_bounds__(256) blocks_tr_kernel(int nx, int nyl, int nz, int R, Cuts zcut, const double* in,
-                                                        double* out, int dir) {
-    const size_t total = (size_t)nx * nyl * nz;
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;      // index into T
-    if (idx >= total) return;
-    const int x = (int)(idx % nx), z = (int)((idx / nx) % nz), yl = (int)(idx / ((size_t)nx * nz));
-    const int sr = owner_of(zcut, R, z);
-    const int z0 = zcut.c[sr];
-    const size_t off = (size_t)nx * nyl * z0 + ((size_t)(z - z0) * nyl + yl) * nx + x;
-    if (dir == 0) out[idx] = in[off];
-    else out[off] = in[idx];
 }
 
 }  // namespace
@@ -265,6 +248,7 @@ void dct_plan_destroy(DctPlan* p) {
         if (p->TT[a]) (void)hipFree(p->TT[a]);
         if (p->lam[a]) (void)hipFree(p->lam[a]);
         if (p->twid[a]) (void)hipFree(p->twid[a]);
+        if (a == 0 && p->kmap) (void)hipFree(p->kmap);
     }
     if (p->t1) (void)hipFree(p->t1);
     if (p->t2) (void)hipFree(p->t2);
@@ -373,25 +357,42 @@ int dct_plan_create_dist(bk_ctx* ctx, const int n[3], const double ainv[3], doub
         return set_error(ctx, "distributed DCT: scratch allocation failed");
     }
     p->lam_yloc = p->lam[1] + p->ylo;
+    if (n[1] % R == 0 && nx * (size_t)n[1] * nzl < ((size_t)1 << 29)) {
+        // every rank owns nyl = ny / R rows: block r = [zl][yl][x] starts at nx * nzl * nyl * r, so the element
+        // (x, y, zl) of the z-slab sits at kmap[y] + zl * (nyl * nx) + x with kmap[y] = nx * (nzl * nyl * r + yl)
+        std::vector<unsigned> km(n[1]);
+        for (int y = 0; y < n[1]; ++y) {
+            const size_t r = (size_t)y / nyl, yl = (size_t)y % nyl;
+            km[y] = (unsigned)(nx * (nzl * nyl * r + yl));
+        }
+        if (hipMalloc(&p->kmap, sizeof(unsigned) * km.size()) != hipSuccess) {
+            dct_plan_destroy(p);
+            return set_error(ctx, "distributed DCT: kmap allocation failed");
+        }
+        (void)hipMemcpy(p->kmap, km.data(), sizeof(unsigned) * km.size(), hipMemcpyHostToDevice);
+    }
     *out = p;
     return 0;
 }
 
-// Distributed apply: x and y passes on the z-slab, all-to-all to y-slabs (layout [yl][z][x]), z pass forward with
-// the inverse symbol fused, z pass inverse, all-to-all back, y and x inverse passes.
+// Distributed apply: x and y passes on the z-slab [nzl][ny][nx]; all-to-all of per-rank blocks [zl][yl_r][x]; the
+// received buffer IS the y-slab array [nz][nyl][nx] (block s holds the planes zcut[s]..zcut[s+1] in order), so the z pass
+// (forward, symbol, inverse) runs on it directly as an axis-2 pass; all-to-all back; inverse y and x passes.  With a
+// uniform y split and the fused y kernel the forward y pass writes the block layout itself and the inverse y pass reads
+// it (DctSplit), so no pack / unpack kernel runs at all; otherwise slab_blocks_kernel packs / unpacks.
 static int dct_apply_dist(bk_ctx* ctx, DctPlan* p, const double* v, double* out) {
     const int nx = p->n[0], ny = p->n[1], nz = p->n[2];
     const int nzl = p->zhi - p->zlo, nyl = p->yhi - p->ylo;
     const size_t loc_z = (size_t)nx * ny * nzl, loc_y = (size_t)nx * nyl * nz;
     const bool use_fft = ctx->opt("dct_fft", 1.0) != 0.0;
-    Cuts yc, zc;
-    for (int r = 0; r <= p->R; ++r) { yc.c[r] = p->ycut[r]; zc.c[r] = p->zcut[r]; }
+    Cuts yc;
+    for (int r = 0; r <= p->R; ++r) yc.c[r] = p->ycut[r];
     auto pass = [&](int n0, int n1, int n2, int axis, int which, int inverse, const double* in, double* o, int fuse,
-                    const double* l0, const double* l1, const double* l2) -> int {
+                    const double* l0, const double* l1, const double* l2, const DctSplit* split) -> int {
         // `which` = index of the global axis being transformed (selects tables)
         ProfScope ps(ctx, "dct_pass", 16.0 * (double)n0 * n1 * n2);
         if (use_fft && p->twid[which])
-            return dct_axis_fft(ctx, n0, n1, n2, axis, inverse, p->twid[which], in, o, l0, l1, l2, p->shift, fuse);
+            return dct_axis_fft(ctx, n0, n1, n2, axis, inverse, p->twid[which], in, o, l0, l1, l2, p->shift, fuse, split);
         const size_t tot = (size_t)n0 * n1 * n2;
         hipLaunchKernelGGL(dct_axis_direct, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, n0, n1, n2, axis,
                            inverse ? p->T[which] : p->TT[which], in, o);
@@ -399,44 +400,49 @@ static int dct_apply_dist(bk_ctx* ctx, DctPlan* p, const double* v, double* out)
         return 0;
     };
     double *a = p->t1, *b = p->t2;
-    // forward x, y on the z-slab [nzl][ny][nx]
-    BK_TRY(pass(nx, ny, nzl, 0, 0, 0, v, a, 0, nullptr, nullptr, nullptr));
-    BK_TRY(pass(nx, ny, nzl, 1, 1, 0, a, b, 0, nullptr, nullptr, nullptr));
-    // z-slab -> blocks (a), all-to-all (b), blocks -> T (a)
-    { ProfScope ps(ctx, "transpose", 16.0 * loc_z);
-    hipLaunchKernelGGL(slab_blocks_kernel, dim3((unsigned)((loc_z + 255) / 256)), dim3(256), 0, ctx->stream, nx, ny, nzl, p->R, yc, b, a, 0);
-    BK_HIP(ctx, hipGetLastError()); }
+    const bool direct = p->kmap && use_fft && p->twid[1] && ctx->opt("dct_dist_direct", 1.0) != 0.0 &&
+                        dct_axis_fused_ok(ctx, nx, ny, nzl, 1, a, b, 0);
+    const DctSplit sp = {p->kmap, (unsigned)((size_t)nyl * nx)};
+    // forward x, y on the z-slab; the send buffer (blocks in rank order) ends up in `b`
+    BK_TRY(pass(nx, ny, nzl, 0, 0, 0, v, a, 0, nullptr, nullptr, nullptr, nullptr));
+    if (direct) {
+        BK_TRY(pass(nx, ny, nzl, 1, 1, 0, a, b, 0, nullptr, nullptr, nullptr, &sp));
+    } else {
+        BK_TRY(pass(nx, ny, nzl, 1, 1, 0, a, b, 0, nullptr, nullptr, nullptr, nullptr));
+        ProfScope ps(ctx, "transpose", 16.0 * loc_z);
+        hipLaunchKernelGGL(slab_blocks_kernel, dim3((unsigned)((loc_z + 255) / 256)), dim3(256), 0, ctx->stream, nx, ny, nzl, p->R, yc, b, a, 0);
+        BK_HIP(ctx, hipGetLastError());
+        double* t = a; a = b; b = t;
+    }
     { ProfScope ps(ctx, "alltoall", 8.0 * loc_z);
-    BK_TRY(comm_alltoallv(ctx, a, p->cnt_f.data(), p->dsp_f.data(), b, p->cnt_b.data(), p->dsp_b.data())); }
-    { ProfScope ps(ctx, "transpose", 16.0 * loc_y);
-    hipLaunchKernelGGL(blocks_tr_kernel, dim3((unsigned)((loc_y + 255) / 256)), dim3(256), 0, ctx->stream, nx, nyl, nz, p->R, zc, b, a, 0);
-    BK_HIP(ctx, hipGetLastError()); }
-    // z pass on T = [nyl][nz][nx]: axis 1 of (n0 = nx, n1 = nz, n2 = nyl); symbol indices (i0, i1, i2) = (kx, kz, ky_local)
+    BK_TRY(comm_alltoallv(ctx, b, p->cnt_f.data(), p->dsp_f.data(), a, p->cnt_b.data(), p->dsp_b.data())); }
+    // z pass on the y-slab a = [nz][nyl][nx]: axis 2 of (nx, nyl, nz); symbol indices (kx, ky_local, kz)
     const bool fused = use_fft && p->twid[2] != nullptr;
     if (fused && ctx->opt("dct_roundtrip", 1.0) != 0.0) {
-        BK_TRY(pass(nx, nz, nyl, 1, 2, 0, a, b, 2, p->lam[0], p->lam[2], p->lam_yloc));   // forward, symbol, inverse in LDS
-        double* t = a; a = b; b = t;                       // result now in `a`, like the two-pass branch below
+        BK_TRY(pass(nx, nyl, nz, 2, 2, 0, a, b, 2, p->lam[0], p->lam_yloc, p->lam[2], nullptr));  // forward, symbol, inverse in LDS
     } else {
-        BK_TRY(pass(nx, nz, nyl, 1, 2, 0, a, b, fused ? 1 : 0, p->lam[0], p->lam[2], p->lam_yloc));
+        BK_TRY(pass(nx, nyl, nz, 2, 2, 0, a, b, fused ? 1 : 0, p->lam[0], p->lam_yloc, p->lam[2], nullptr));
         if (!fused) {
-            hipLaunchKernelGGL(spectral_scale_kernel, dim3((unsigned)((loc_y + 255) / 256)), dim3(256), 0, ctx->stream, nx, nz, nyl,
-                               p->lam[0], p->lam[2], p->lam_yloc, p->shift, b);
+            hipLaunchKernelGGL(spectral_scale_kernel, dim3((unsigned)((loc_y + 255) / 256)), dim3(256), 0, ctx->stream, nx, nyl, nz,
+                               p->lam[0], p->lam_yloc, p->lam[2], p->shift, b);
             BK_HIP(ctx, hipGetLastError());
         }
-        BK_TRY(pass(nx, nz, nyl, 1, 2, 1, b, a, 0, nullptr, nullptr, nullptr));
+        BK_TRY(pass(nx, nyl, nz, 2, 2, 1, b, a, 0, nullptr, nullptr, nullptr, nullptr));
+        double* t = a; a = b; b = t;
     }
-    // T -> blocks (b), all-to-all back (a), blocks -> z-slab (b)
-    { ProfScope ps(ctx, "transpose", 16.0 * loc_y);
-    hipLaunchKernelGGL(blocks_tr_kernel, dim3((unsigned)((loc_y + 255) / 256)), dim3(256), 0, ctx->stream, nx, nyl, nz, p->R, zc, a, b, 1);
-    BK_HIP(ctx, hipGetLastError()); }
+    // all-to-all back: b (y-slab) -> a (blocks), then inverse y (reading the blocks, or after the unpack) and x
     { ProfScope ps(ctx, "alltoall", 8.0 * loc_y);
     BK_TRY(comm_alltoallv(ctx, b, p->cnt_b.data(), p->dsp_b.data(), a, p->cnt_f.data(), p->dsp_f.data())); }
-    { ProfScope ps(ctx, "transpose", 16.0 * loc_z);
-    hipLaunchKernelGGL(slab_blocks_kernel, dim3((unsigned)((loc_z + 255) / 256)), dim3(256), 0, ctx->stream, nx, ny, nzl, p->R, yc, a, b, 1);
-    BK_HIP(ctx, hipGetLastError()); }
-    // inverse y, x on the z-slab
-    BK_TRY(pass(nx, ny, nzl, 1, 1, 1, b, a, 0, nullptr, nullptr, nullptr));
-    BK_TRY(pass(nx, ny, nzl, 0, 0, 1, a, out, 0, nullptr, nullptr, nullptr));
+    if (direct) {
+        BK_TRY(pass(nx, ny, nzl, 1, 1, 1, a, b, 0, nullptr, nullptr, nullptr, &sp));
+    } else {
+        { ProfScope ps(ctx, "transpose", 16.0 * loc_z);
+        hipLaunchKernelGGL(slab_blocks_kernel, dim3((unsigned)((loc_z + 255) / 256)), dim3(256), 0, ctx->stream, nx, ny, nzl, p->R, yc, a, b, 1);
+        BK_HIP(ctx, hipGetLastError()); }
+        BK_TRY(pass(nx, ny, nzl, 1, 1, 1, b, a, 0, nullptr, nullptr, nullptr, nullptr));
+        double* t = a; a = b; b = t;
+    }
+    BK_TRY(pass(nx, ny, nzl, 0, 0, 1, b, out, 0, nullptr, nullptr, nullptr, nullptr));
     return 0;
 }
 

@@ -43,6 +43,9 @@ struct FftK {
     int roundtrip;            // 1: forward, inverse symbol, inverse -- all in LDS, one read + one write of the array
     int tiles_x;              // axis >= 1: number of LT-wide tiles along x
     int pairvec;              // axis >= 1 and 16-B aligned pairs: the two lines of a pair are loaded / stored as one double2
+    const unsigned* kmap;     // axis-1 fused passes of the distributed plan: element offset of index k in the per-rank
+    unsigned split_plane;     //   block layout (kmap[k] + other * split_plane + x); split 1: on the output, 2: on the input
+    int split;
     long long* trace;         // debug (option dct_trace): per-tile phase timestamps, 8 per workgroup, or NULL
     int fast;                 // full tiles, power-of-two shapes, < 2^31 elements: incremental addressing (host-checked)
 };
@@ -341,8 +344,10 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
     const int x0 = tx * P.LT;
     const size_t base = AX0 ? (size_t)blockIdx.x * P.LT * P.n0
                             : (P.axis == 1 ? x0 + (size_t)P.n0 * P.n1 * other : x0 + (size_t)P.n0 * other);
-    const double* gin = P.in + base;
-    double* gout = P.out + base;
+    // distributed plan: one side of the y pass lives in the all-to-all block layout (dct.hip, dct_apply_dist)
+    const size_t sbase = (size_t)x0 + (size_t)other * P.split_plane;
+    const double* gin = P.in + (!AX0 && P.split == 2 ? sbase : base);
+    double* gout = P.out + (!AX0 && P.split == 1 ? sbase : base);
     auto ldg = [&](unsigned el) {
         const double2 t = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(gin) + (size_t)(el * 8u));
         c2 r; r.x = t.x; r.y = t.y; return r;
@@ -434,9 +439,11 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
             dctc::fused_mid<2>(zp, N, t, tw, ew, s0, s2, nold, nost, sym);
         } else if (MODE == 0) {
             if (AX0) dctc::fused_mid<0>(zp, N, t, tw, ew, s0, s2, nold, [&](int k, c2 v) { st1(o + (unsigned)k, v); }, nosym);
+            else if (P.split == 1) dctc::fused_mid<0>(zp, N, t, tw, ew, s0, s2, nold, [&](int k, c2 v) { stg(o + P.kmap[k], v); }, nosym);
             else dctc::fused_mid<0>(zp, N, t, tw, ew, s0, s2, nold, [&](int k, c2 v) { stg(o + (unsigned)k * estride, v); }, nosym);
         } else {
             if (AX0) dctc::fused_mid<1>(zp, N, t, tw, ew, s0, s2, [&](int, int k) { return ld1(o + (unsigned)k); }, nost, nosym);
+            else if (P.split == 2) dctc::fused_mid<1>(zp, N, t, tw, ew, s0, s2, [&](int, int k) { return ldg(o + P.kmap[k]); }, nost, nosym);
             else dctc::fused_mid<1>(zp, N, t, tw, ew, s0, s2, [&](int, int k) { return ldg(o + (unsigned)k * estride); }, nost, nosym);
         }
     }
@@ -489,10 +496,33 @@ inline int choose_lt(int N, int axis, int n0, size_t rows) {
 
 bool dct_axis_fft_supported(int n) { return n >= 4 && n <= 1024 && (n & (n - 1)) == 0; }
 
+// fused-kernel eligibility of a pass (shared with the distributed plan, which may route one side of its y passes
+// through the all-to-all block layout only when the fused kernel runs)
+bool dct_axis_fused_ok(bk_ctx* ctx, int n0, int n1, int n2, int axis, const double* in, const double* out, int fuse_scale) {
+    const int N = axis == 0 ? n0 : (axis == 1 ? n1 : n2);
+    int bits = 0;
+    while ((1 << bits) < N) ++bits;
+    if ((1 << bits) != N || bits < 6 || bits > 9) return false;
+    if (ctx->opt("dct_fused", 256.0) == 0.0 || ctx->opt("dct_fft", 1.0) == 0.0 || fuse_scale == 1) return false;
+    if ((size_t)n0 * n1 * n2 * sizeof(double) >= ((size_t)1 << 32)) return false;
+    if (n0 % 2 != 0 || (((uintptr_t)in | (uintptr_t)out) & 15) != 0) return false;
+    const size_t rows = (size_t)n1 * n2;
+    const int LT = choose_lt(N, axis, n0, rows);
+    if (LT != 16) return false;
+    if (axis == 0) return fuse_scale != 2 && rows % LT == 0 && ctx->opt("dct_fused_ax0", 1.0) != 0.0;
+    return n0 % LT == 0;
+}
+
 int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, const double* twid, const double* in,
                  double* out, const double* lam0, const double* lam1, const double* lam2, double shift,
-                 int fuse_scale) {
+                 int fuse_scale, const DctSplit* split) {
     FftK P;
+    P.kmap = nullptr; P.split_plane = 0; P.split = 0;
+    if (split) {
+        if (axis != 1 || fuse_scale != 0 || !dct_axis_fused_ok(ctx, n0, n1, n2, axis, in, out, fuse_scale))
+            return set_error(ctx, "dct_axis_fft: block-layout pass needs the fused y-axis kernel");
+        P.kmap = split->kmap; P.split_plane = split->plane; P.split = inverse ? 2 : 1;
+    }
     P.n0 = n0; P.n1 = n1; P.n2 = n2; P.axis = axis;
     P.N = axis == 0 ? n0 : (axis == 1 ? n1 : n2);
     P.bits = 0;
@@ -546,12 +576,7 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
                             (axis == 0 ? (nt % P.N == 0) : (nt % npairs == 0 && P.pairvec));
         P.fast = (ctx->opt("dct_fastio", 1.0) != 0.0 && full_tiles && shapes) ? 1 : 0;
     }
-    const int fused_nt = (int)ctx->opt("dct_fused", 256.0);       // 0: off, else threads per tile of the fused kernel
-    const bool ax0_ok = axis == 0 && !P.roundtrip && rows % P.LT == 0 && n0 % 2 == 0 &&
-                        (((uintptr_t)in | (uintptr_t)out) & 15) == 0 && ctx->opt("dct_fused_ax0", 1.0) != 0.0;
-    const bool ax12_ok = axis != 0 && P.pairvec && n0 % P.LT == 0;
-    if (fused_nt != 0 && (ax0_ok || ax12_ok) && P.bits >= 6 && P.bits <= 9 && P.ltbits >= 1 &&
-        (size_t)n0 * n1 * n2 * sizeof(double) < ((size_t)1 << 32) && !(P.fuse_scale && !P.roundtrip)) {
+    if (dct_axis_fused_ok(ctx, n0, n1, n2, axis, in, out, fuse_scale) && P.LT == 16) {
         const size_t ldsf = lds + ((size_t)(P.N / 2 + 2) + (P.roundtrip ? P.N / 2 : 0)) * sizeof(c2);
         const bool trace = ctx->opt("dct_trace", 0.0) != 0.0;
         P.trace = nullptr;

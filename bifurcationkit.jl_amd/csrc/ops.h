@@ -59,6 +59,18 @@ int dct_plan_create(bk_ctx* ctx, int ndim, const int n[3], const double ainv[3],
 int dct_plan_create_dist(bk_ctx* ctx, const int n[3], const double ainv[3], double shift, int zlo, int zhi, DctPlan** out);
 void dct_plan_destroy(DctPlan* p);
 int dct_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out);
+// axis pass of the LDS FFT kernels (dct_fast.hip).  fuse_scale 0: plain, 1: forward + inverse symbol, 2: forward,
+// symbol, inverse in one pass.  split (distributed plan, y passes only): the output (forward) / input (inverse) side
+// uses the all-to-all block layout: element (x, k, other) at kmap[k] + other * plane + x.
+struct DctSplit {
+    const unsigned* kmap;
+    unsigned plane;
+};
+int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, const double* twid, const double* in,
+                 double* out, const double* symx, const double* symy, const double* symz, double shift, int fuse_scale,
+                 const DctSplit* split = nullptr);
+bool dct_axis_fft_supported(int n);
+bool dct_axis_fused_ok(bk_ctx* ctx, int n0, int n1, int n2, int axis, const double* in, const double* out, int fuse_scale);
 
 }  // namespace bk
 

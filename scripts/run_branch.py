@@ -2,7 +2,7 @@
 (examples/SH3d.jl:160-166: Bordered tangent, BorderingBLS(check_precision = false), ds = -0.001, dsmax = 0.005,
 newton tol 1e-9, normC = norminf, eigensolve every step with sigma = 0.1, nev = 15, Krylov dimension 45), driven by
 the restated continuation engine through the plugin surface.  Prints one JSON line.
-Usage: python scripts/run_branch.py [size=256] [steps=3] [nev=15]"""
+Usage: python scripts/run_branch.py [size=256] [steps=3] [nev=15] [native=0]   (native=1: every step is one bk_cont_step call)"""
 import json
 import math
 import os
@@ -20,6 +20,7 @@ from bk_amd import hip  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 nev = int(sys.argv[3]) if len(sys.argv) > 3 else 15
+native = len(sys.argv) > 4 and sys.argv[4] == "1"
 ctx = hip.Context(0)
 tiles = bench.tiles_for(n)
 cprob, cls_, c0, c1 = bench.cell_branch_points(ctx, hip, 1.0, -0.001)
@@ -34,9 +35,9 @@ cp = Cn.ContinuationPar(ds=-0.001, dsmin=1e-4, dsmax=0.005, p_min=-0.1, p_max=0.
 alg = Cn.PALC(tangent="bordered", theta=0.5, bls=hip.BorderingBLS(None, check_precision=False))
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-br = Cn.continuation(prob, x0, 0.1, alg, cp, normC=Cn.norminf, verbosity=1)
+br = (Cn.continuation_native if native else Cn.continuation)(prob, x0, 0.1, alg, cp, normC=Cn.norminf, verbosity=1)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print(json.dumps(dict(size=n, steps=len(br.param) - 1, seconds=dt, seconds_per_continuation_step=dt / max(1, len(br.param) - 1),
+print(json.dumps(dict(driver="bk_cont_step" if native else "python mirror", size=n, steps=len(br.param) - 1, seconds=dt, seconds_per_continuation_step=dt / max(1, len(br.param) - 1),
                       param=br.param, itnewton=br.itnewton, itlinear=br.itlinear, ds=br.ds, n_unstable=br.n_unstable,
                       rightmost=[[float(v.real) for v in e[:4]] if e is not None else None for e in br.eig])))
