@@ -252,6 +252,24 @@ function (lbs::HipBorderingBLS)(J::HipJacobian, dR::HipVec, dzu::HipVec, dzp::T,
     return dX, dl[], cv[] == 1, (Int(it[1]), Int(it[2]))
 end
 
+# m-column border (normal forms / Bogdanov-Takens), src/LinearBorderSolver.jl:173-206
+function BK.solve_bls_block(lbs::HipBorderingBLS, J::HipJacobian, b::NTuple{M, HipVec}, c::NTuple{M, HipVec},
+                            d::AbstractMatrix, rhst::HipVec, rhsb) where {M}
+    m = size(d, 1)
+    (length(b) == length(c) == m == M) || error("Linear bordered solver, wrong sizes!")
+    ctx = rhst.ctx
+    u1 = similar(rhst)
+    bp = [x.p for x in b]; cp = [x.p for x in c]
+    dd = collect(Cdouble, permutedims(d))                 # row-major d[i*m + j]
+    u2 = zeros(Cdouble, m); its = zeros(Cint, m); cv = Ref{Cint}(0)
+    check(ctx, ccall((:bk_bls_block_bordering, libbkhip[]), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Ptr{Cdouble}}, Ptr{Ptr{Cdouble}}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+         Ref{GmresOpts}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Cint}, Ptr{Cint}),
+        ctx.h, J.h, m, bp, cp, dd, rhst.p, collect(Cdouble, rhsb), Ref(_opts(lbs.solver)), _plh(lbs.solver.Pl),
+        u1.p, u2, cv, its), "bk_bls_block_bordering")
+    return u1, u2, cv[] == 1, Tuple(Int.(its))
+end
+
 "`MatrixFreeBLS` (src/LinearBorderSolver.jl:404-437): one GMRES on the (N+1) operator, border scalar on the host."
 struct HipMatrixFreeBLS{S <: Union{HipGMRES, Nothing}} <: AbstractBorderedLinearSolver
     solver::S
