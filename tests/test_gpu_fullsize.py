@@ -1,4 +1,5 @@
-"""GPU tests at BASELINE.json's FULL size (SH3d 512^3, 1 GiB vectors) through size-independent properties:
+"""GPU tests at BASELINE.json's FULL sizes (SH3d 256^3 = config 4 and 512^3 = config 5, 1 GiB vectors) through
+size-independent properties:
 symmetry and linearity of the Jacobian, the preconditioner round trip (L1 + I) Pl^-1 = I, determinism of the
 reductions, and the tiling property -- the reference cell's solution reflected to 16^3 cells is an exact discrete
 solution, so the 512^3 PALC corrector must reproduce the CPU oracle's ONE-CELL corrector (residual history, p)."""
@@ -14,16 +15,21 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-N1 = int(os.environ.get("BK_FULLSIZE", "512"))
+# BASELINE configs 4 (256^3) and 5 (512^3); BK_FULLSIZE=<n> restricts the run to one size
+SIZES = [int(os.environ["BK_FULLSIZE"])] if os.environ.get("BK_FULLSIZE") else [256, 512]
 
 
-@pytest.fixture(scope="module")
-def big(ctx):
+@pytest.fixture(scope="module", params=SIZES)
+def big(ctx, request):
     import bench
     from bk_amd import hip
-    tiles = bench.tiles_for(N1)
-    prob = hip.SwiftHohenberg(ctx, (N1,) * 3, tuple(l * t for l, t in zip(bench.CELL_L, tiles)), l=0.1, nu=1.2)
-    return prob
+    n1 = request.param
+    tiles = bench.tiles_for(n1)
+    prob = hip.SwiftHohenberg(ctx, (n1,) * 3, tuple(l * t for l, t in zip(bench.CELL_L, tiles)), l=0.1, nu=1.2)
+    yield prob
+    del prob
+    import torch
+    torch.cuda.empty_cache()
 
 
 def _rand(ctx, prob, seed):
@@ -77,7 +83,7 @@ def test_fullsize_tiled_corrector_matches_cpu_oracle_cell(ctx, big):
     from bk_amd import hip
     from oracle import bordered, krylov, operators, palc
     ds, theta, shift = -0.001, 0.5, 1.0
-    tiles = bench.tiles_for(N1)
+    tiles = bench.tiles_for(big.dims[0])
     # CPU oracle on the one cell
     shc = operators.SwiftHohenberg(bench.CELL, bench.CELL_L)
     Plc = operators.dct_preconditioner(bench.CELL, bench.CELL_L, shift)
@@ -93,7 +99,7 @@ def test_fullsize_tiled_corrector_matches_cpu_oracle_cell(ctx, big):
     obls = lambda *a, **k: bordered.bordering_bls(ols, *a, check_precision=False, **k)
     so = palc.newton_palc(pc, z0, tau, zp, ds, theta, obls, tol=1e-9, max_iterations=15, normN=palc.norminf)
     assert so["converged"]
-    # the same points tiled to N1^3 on the device
+    # the same points tiled to the full grid on the device
     dev = ctx.torch_device
     tile = lambda a: hip.HipVec(ctx, bench.tile_cell(torch.from_numpy(a).to(dev), tiles, big.slab, dev), big.nglobal)
     U0, U1 = tile(c0["u"]), tile(c1["u"])
