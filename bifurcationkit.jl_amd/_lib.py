@@ -134,6 +134,8 @@ SIGNATURES = {
     "bk_cont_step": (I, [VP, C.POINTER(ContStepResult)]),
     "bk_cont_get": (I, [VP, VP, c_double_p, VP, c_double_p, c_double_p]),
     "bk_cont_destroy": (I, [VP]),
+    "bk_newton_deflated": (I, [VP, VP, VP, c_double_p, I, C.POINTER(VP), I, D, D, I, D, C.POINTER(NewtonOpts),
+                               C.POINTER(GmresOpts), VP, C.POINTER(NewtonResult)]),
     "bk_newton_palc": (I, [VP, VP, VP, c_double_p, VP, D, VP, D, D, D, c_double_p, I, I, D, D,
                            C.POINTER(NewtonOpts), C.POINTER(BorderingOpts), C.POINTER(GmresOpts), VP,
                            C.POINTER(NewtonResult)]),

@@ -257,3 +257,107 @@ int bk_cont_get(bk_cont* c, double* u, double* p, double* tauu, double* taup, do
 }
 
 }  // extern "C"
+
+// ================================================================== deflated Newton
+namespace {
+
+struct Deflation {
+    bk_ctx* ctx;
+    size_t n;
+    const double* const* roots;
+    int nroots;
+    double power, alpha, delta;
+    int mean;
+    double* tmp;
+    // M(u) = acc_i ( <u - r_i, u - r_i>^-power + alpha ), src/DeflationOperator.jl:124-138 (in-place version)
+    int M(const double* u, double* out) const {
+        if (nroots == 0) { *out = 1.0; return 0; }
+        double acc = 0.0;
+        for (int i = 0; i < nroots; ++i) {
+            double d;
+            BK_TRY(v_axpbyz(ctx, n, 1.0, u, -1.0, roots[i], tmp));
+            BK_TRY(v_dot(ctx, n, tmp, tmp, &d));
+            const double m = 1.0 / std::pow(d, power) + alpha;
+            acc = i == 0 ? m : (mean ? acc + m : acc * m);
+        }
+        if (mean) acc /= nroots;
+        *out = acc;
+        return 0;
+    }
+    // dM(u) . du by finite differences, Val(:dMwithTmp) :160-169 with autodiff = false; `up` is scratch
+    int dM(const double* u, const double* du, double Mu, double* up, double* out) const {
+        if (nroots == 0) { *out = 0.0; return 0; }
+        double Mp;
+        BK_TRY(v_axpbyz(ctx, n, 1.0, u, delta, du, up));
+        BK_TRY(M(up, &Mp));
+        *out = (Mp - Mu) / delta;
+        return 0;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+// solve(prob, defOp, options, DeflatedProblemCustomLS()), src/DeflationOperator.jl:340-355: _newton (src/Newton.jl:66-114)
+// on the deflated functional M(u) F(u); every linear solve is DeflatedProblemCustomLS (:264-312): two solves with the
+// plain Jacobian (ls(J, rhs, Fu), src/LinearSolver.jl:15-19) recombined as h = (h1 - z h2) / M(u), z = dM.h1 / (M + dM.h2).
+int bk_newton_deflated(bk_ctx* ctx, bk_problem* prob, double* x, const double* params, int nparams,
+                       const double* const* roots, int nroots, double power, double alpha, int accumulator_mean,
+                       double delta, const bk_newton_opts* no, const bk_gmres_opts* lsopts, bk_precond* pl,
+                       bk_newton_result* res) {
+    if (!ctx || !prob || !x || !params || !no || !lsopts || !res || (nroots > 0 && !roots)) return -1;
+    if (no->max_iterations > BK_MAX_NEWTON_ITER) return set_error(ctx, "max_iterations > %d", BK_MAX_NEWTON_ITER);
+    const size_t n = prob->nloc;
+    WsGuard ws(ctx);
+    double *Fu = nullptr, *fx = nullptr, *h1 = nullptr, *h2 = nullptr, *tmp = nullptr, *up = nullptr;
+    BK_TRY(ws.get(n, &Fu)); BK_TRY(ws.get(n, &fx)); BK_TRY(ws.get(n, &h1)); BK_TRY(ws.get(n, &h2));
+    BK_TRY(ws.get(n, &tmp)); BK_TRY(ws.get(n, &up));
+    Deflation D{ctx, n, roots, nroots, power, alpha, delta, accumulator_mean, tmp};
+    const bool inf = no->norm_inf != 0;
+    auto deflated_residual = [&](double* Mu, double* r) -> int {      // (dfp)(u, par), :194-198
+        BK_TRY(bk_residual(prob, x, params, nparams, Fu));
+        BK_TRY(D.M(x, Mu));
+        BK_TRY(v_copy(ctx, n, Fu, fx));
+        BK_TRY(v_scale(ctx, n, *Mu, fx));
+        return inf ? v_nrminf(ctx, n, fx, r) : v_nrm2(ctx, n, fx, r);
+    };
+    double Mu, r;
+    BK_TRY(deflated_residual(&Mu, &r));
+    int step = 0, itlin = 0;
+    res->residuals[0] = r;
+    while (step < no->max_iterations && r > no->tol) {
+        bk_op* J = nullptr;
+        BK_TRY(bk_jacobian(prob, x, params, nparams, &J));
+        int s = 0, cv = 0, it[2] = {0, 0};
+        if (nroots == 0) {
+            int it1 = 0;
+            double rn;
+            s = bk_gmres(ctx, J, fx, h1, 0.0, 1.0, lsopts, pl, &cv, &it1, &rn);
+            itlin += it1;
+        } else {
+            s = bk_gmres2(ctx, J, fx, Fu, h1, h2, 0.0, 1.0, lsopts, pl, &cv, it);
+            itlin += it[0] + it[1];
+        }
+        bk_op_destroy(J);
+        if (s != 0) return s;
+        if (nroots > 0) {
+            double z1, z2;
+            BK_TRY(D.dM(x, h1, Mu, up, &z1));
+            BK_TRY(D.dM(x, h2, Mu, up, &z2));
+            const double z = z1 / (Mu + z2);
+            BK_TRY(v_axpby(ctx, n, -z, h2, 1.0, h1));            // h = (h1 - z h2) / Mu
+            BK_TRY(v_scale(ctx, n, 1.0 / Mu, h1));
+        }
+        BK_TRY(v_axpby(ctx, n, -1.0, h1, 1.0, x));                // x = minus!!(x, u), src/Newton.jl:97
+        BK_TRY(deflated_residual(&Mu, &r));
+        step += 1;
+        res->residuals[step] = r;
+    }
+    res->converged = res->residuals[step] < no->tol;
+    res->itnewton = step;
+    res->itlinear = itlin;
+    return 0;
+}
+
+}  // extern "C"

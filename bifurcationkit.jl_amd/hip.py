@@ -21,7 +21,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 
 import numpy as np
 import torch
@@ -651,3 +651,90 @@ def newton_palc_native(prob: _PdeProblem, z0: BorderedArray, tau: BorderedArray,
         C.byref(bo), C.byref(lo), bls.solver._pl(), C.byref(res)), "bk_newton_palc")
     return dict(u=BorderedArray(x, p.value), converged=bool(res.converged), itnewton=res.itnewton,
                 itlineartot=res.itlinear, residuals=[res.residuals[i] for i in range(res.itnewton + 1)])
+
+
+# ------------------------------------------------------------------------------------------ deflation
+@dataclass
+class DeflationOperator:
+    """DeflationOperator(power, dot = VI.inner, alpha, roots; accumulator) of src/DeflationOperator.jl:61-141 on device
+    vectors: ``M(u) = prod_i(<u - root_i, u - root_i>^-power + alpha)`` (or the mean), ``dM`` by finite differences
+    (autodiff = false, delta = 1e-8, :160-169)."""
+    power: float
+    alpha: float
+    roots: list = field(default_factory=list)
+    accumulator: str = "prod"
+    delta: float = 1e-8
+
+    def push(self, v):
+        self.roots.append(v)
+
+    def __len__(self):
+        return len(self.roots)
+
+    def __call__(self, u: HipVec) -> float:
+        if not self.roots:
+            return 1.0
+        out = None
+        for r in self.roots:
+            d = u.copy().add_(r, -1.0)
+            m = 1.0 / d.inner(d) ** self.power + self.alpha
+            out = m if out is None else (out * m if self.accumulator == "prod" else out + m)
+        return out / len(self.roots) if self.accumulator == "mean" else out
+
+    def dM(self, u: HipVec, du: HipVec) -> float:
+        if not self.roots:
+            return 0.0
+        return (self(u.copy().add_(du, self.delta)) - self(u)) / self.delta
+
+
+def deflated_custom_ls(ls, prob, defop: DeflationOperator, u: HipVec, p, rhs: HipVec):
+    """(dfl::DeflatedProblemCustomLS)(J = (u, p, defPb), rhs), src/DeflationOperator.jl:264-312, line by line on the
+    plugin surface: two solves with the plain Jacobian, then h = (h1 - z h2)/M(u)."""
+    Fu = prob.residual(u, p)
+    Mu = defop(u)
+    Ju = prob.jacobian(u, p)
+    if len(defop) == 0:
+        h1, _, it1 = ls(Ju, rhs)
+        return h1, True, (it1, 0)
+    h1, h2, _, (it1, it2) = ls.solve2(Ju, rhs, Fu)
+    z1 = defop.dM(u, h1)
+    z2 = defop.dM(u, h2)
+    z = z1 / (Mu + z2)
+    return h1.add_(h2, -z).scale_(1.0 / Mu), True, (it1, it2)
+
+
+def newton_deflated(prob, defop: DeflationOperator, x0: HipVec, p, ls, tol=1e-12, max_iterations=25, norm_inf=False):
+    """solve(prob, defOp, options, DeflatedProblemCustomLS()) (:340-355) driven call by call through the plugin surface."""
+    nrm = (lambda v: v.norminf()) if norm_inf else (lambda v: v.norm())
+    x = x0.copy()
+    fx = prob.residual(x, p).scale_(defop(x))
+    res = [nrm(fx)]
+    step, itlin = 0, 0
+    while step < max_iterations and res[-1] > tol:
+        h, _, it = deflated_custom_ls(ls, prob, defop, x, p, fx)
+        itlin += int(np.sum(it))
+        x.add_(h, -1.0)
+        fx = prob.residual(x, p).scale_(defop(x))
+        res.append(nrm(fx))
+        step += 1
+    return dict(u=x, converged=res[-1] < tol, itnewton=step, itlineartot=itlin, residuals=res)
+
+
+def newton_deflated_native(prob: _PdeProblem, defop: DeflationOperator, x0: HipVec, p: float, ls: _GMRES, tol=1e-12,
+                           max_iterations=25, norm_inf=False):
+    """The same as one library call (bk_newton_deflated)."""
+    ctx = prob.ctx
+    x = x0.copy()
+    pv = prob._pvec(p)
+    arr = (C.c_double * len(pv))(*pv)
+    no = L.NewtonOpts(float(tol), int(max_iterations), 1 if norm_inf else 0)
+    lo = ls._opts()
+    res = L.NewtonResult()
+    m = len(defop)
+    rp = (C.c_void_p * max(m, 1))(*[r.t.data_ptr() for r in defop.roots])
+    ctx.check(ctx.lib.bk_newton_deflated(ctx.h, prob.h, _ptr(x.t), arr, len(pv), rp, m, float(defop.power),
+                                         float(defop.alpha), 1 if defop.accumulator == "mean" else 0,
+                                         float(defop.delta), C.byref(no), C.byref(lo), ls._pl(), C.byref(res)),
+              "bk_newton_deflated")
+    return dict(u=x, converged=bool(res.converged), itnewton=res.itnewton, itlineartot=res.itlinear,
+                residuals=[res.residuals[i] for i in range(res.itnewton + 1)])

@@ -295,6 +295,16 @@ int bk_cont_step(bk_cont* c, bk_cont_step_result* res);
 int bk_cont_get(bk_cont* c, double* u, double* p, double* tauu, double* taup, double* ds);
 int bk_cont_destroy(bk_cont* c);
 
+/* ------------------------------------------------------------------ deflated Newton --------------
+ * solve(prob, defOp, options, DeflatedProblemCustomLS()) (src/DeflationOperator.jl:340-355): Newton on M(u) F(u) with
+ * M(u) = prod_i ( <u - root_i, u - root_i>^-power + alpha ) (accumulator_mean != 0: the mean, Val(:Mean)), dM by finite
+ * differences of step delta (:160-169), every linear solve = two solves with the plain Jacobian (ls(J, rhs, Fu)) and the
+ * Sherman-Morrison style recombination of :264-312.  x: guess on entry, solution on exit.  SURVEY section 8(f) item 4. */
+int bk_newton_deflated(bk_ctx* ctx, bk_problem* prob, double* x, const double* params, int nparams,
+                       const double* const* roots, int nroots, double power, double alpha,
+                       int accumulator_mean, double delta, const bk_newton_opts* nopts,
+                       const bk_gmres_opts* lsopts, bk_precond* pl, bk_newton_result* res);
+
 #ifdef __cplusplus
 }
 #endif

@@ -567,6 +567,60 @@ def _native_corrector(hip, Cn, prob, z, tau, zp, ds, theta, bls, nopt, pmin, pma
     return Cn.NonLinearSolution(r["u"], r["residuals"], r["converged"], r["itnewton"], r["itlineartot"])
 
 
+# --------------------------------------------------------------------------------------------- deflated Newton
+@pytest.mark.parametrize("acc", ["prod", "mean"])
+def test_deflated_newton_matches_oracle(ctx, acc):
+    """solve(prob, defOp, options, DeflatedProblemCustomLS()) (src/DeflationOperator.jl:258-355): with the trivial
+    state (and, for two roots, a converged pattern) deflated, Newton from a small-amplitude guess must leave u = 0 and
+    reach a different solution; the plugin-surface mirror, the native call and the oracle walk the same iterates."""
+    from oracle import deflation
+    hip = _hip()
+    dims, ls_ = (16, 16, 16), (np.pi,) * 3
+    sh, prob, rng, u = _sh_setup(ctx, dims, ls_)
+    oprob = palc.Problem(lambda x, p: sh.F(x, p, 1.2), lambda x, p: sh.J(x, p, 1.2))
+    x0 = 0.4 * sh.guess()
+    roots = [np.zeros(sh.N)]
+    if acc == "mean":                                   # a second root: the solution Newton finds from the full guess
+        s_ = palc.newton(oprob, sh.guess(), 0.1, bordered.default_ls, tol=1e-10, max_iterations=40, normN=palc.norminf)
+        assert s_["converged"]
+        roots.append(s_["u"])
+    od = deflation.DeflationOperator(2, 1.0, roots, accumulator=acc)
+    so = deflation.deflated_newton(oprob, od, x0, 0.1, bordered.default_ls, tol=1e-9, max_iterations=80,
+                                   normN=palc.norminf)
+    P = hip.DCTPreconditioner(prob, 0.0)
+    ls = hip.GMRESKrylovKit(dim=40, rtol=1e-11, atol=1e-13, maxiter=200, Pl=P)
+    gd = hip.DeflationOperator(2, 1.0, [prob.vec(r) for r in roots], accumulator=acc)
+    assert np.isclose(gd(prob.vec(x0)), od(x0), rtol=1e-12)
+    dv = rng.standard_normal(sh.N)
+    assert np.isclose(gd.dM(prob.vec(x0), prob.vec(dv)), od.dM(x0, dv), rtol=1e-4, atol=1e-9)    # 1e-8 finite difference
+    sm = hip.newton_deflated(prob, gd, prob.vec(x0), 0.1, ls, tol=1e-9, max_iterations=80, norm_inf=True)
+    sn = hip.newton_deflated_native(prob, gd, prob.vec(x0), 0.1, ls, tol=1e-9, max_iterations=64, norm_inf=True)
+    assert so["converged"] == sm["converged"] == sn["converged"]
+    if so["converged"]:
+        # the first iterates are reproduced closely; later ones inherit the 1e-8 finite-difference noise of dM
+        for k in range(min(3, len(so["residuals"]))):
+            assert abs(sm["residuals"][k] - so["residuals"][k]) <= 1e-5 * so["residuals"][k] + 1e-12
+            assert abs(sn["residuals"][k] - so["residuals"][k]) <= 1e-5 * so["residuals"][k] + 1e-12
+        for s_ in (sm, sn):
+            un = s_["u"].numpy()
+            assert np.abs(sh.F(un, 0.1, 1.2)).max() <= 1e-7                       # a root of the ORIGINAL problem ...
+            assert all(np.abs(un - r).max() > 1e-2 for r in roots)                # ... that is none of the deflated ones
+        assert abs(sm["itnewton"] - so["itnewton"]) <= 2 and abs(sn["itnewton"] - so["itnewton"]) <= 2
+        assert np.abs(sn["u"].numpy() - sm["u"].numpy()).max() <= 1e-6
+
+
+def test_deflated_newton_without_roots_is_newton(ctx):
+    """length(defOp) == 0 (DeflationOperator.jl:285-288): plain Newton."""
+    hip = _hip()
+    sh, prob, rng, u = _sh_setup(ctx, (16, 16, 16), (np.pi,) * 3)
+    ls = hip.GMRESKrylovKit(dim=40, rtol=1e-11, atol=1e-13, maxiter=200, Pl=hip.DCTPreconditioner(prob, 0.0))
+    a = hip.newton_native(prob, prob.vec(u), 0.1, ls, tol=1e-9, max_iterations=40, norm_inf=True)
+    b = hip.newton_deflated_native(prob, hip.DeflationOperator(2, 1.0, []), prob.vec(u), 0.1, ls, tol=1e-9,
+                                   max_iterations=40, norm_inf=True)
+    assert a["converged"] and b["converged"] and a["itnewton"] == b["itnewton"]
+    assert np.array_equal(a["u"].numpy(), b["u"].numpy())
+
+
 # --------------------------------------------------------------------------------------------- configs C2 / C3
 def test_sh2d_palc_corrector_matches_oracle(ctx):
     """BASELINE config 2 (examples/SH2d-fronts.jl operator): matrix-free JVP + preconditioned GMRES corrector in 2-D,

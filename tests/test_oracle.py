@@ -259,3 +259,29 @@ def test_config1_sh1d_snaking_palc_cpu():
     assert np.allclose(b1.param, b2.param, rtol=0, atol=1e-8)
     assert all(abs(a - b) <= 1 for a, b in zip(b1.itnewton, b2.itnewton))
     assert all(r[-1] < 1e-8 for r in b1.residuals)
+
+
+def test_deflated_newton_leaves_the_deflated_root():
+    """DeflatedProblemCustomLS (src/DeflationOperator.jl:258-312): the Sherman-Morrison recombination solves the
+    deflated Jacobian system, and deflated Newton converges to a root different from the deflated ones
+    (test/newton/test-deflation.jl pattern)."""
+    from oracle import deflation
+    rng = np.random.default_rng(5)
+    F = lambda x, p: x ** 3 - p * x                       # componentwise pitchfork: roots 0, +-sqrt(p)
+    J = lambda x, p: np.diag(3 * x ** 2 - p)
+    prob = palc.Problem(F, J)
+    n = 6
+    d = deflation.DeflationOperator(2, 1.0, [np.zeros(n)])
+    u = 0.3 + 0.1 * rng.random(n)
+    # the custom solver inverts the deflated Jacobian  M J + F dM^T  (dM by finite differences)
+    rhs = rng.random(n)
+    h, _, _ = deflation.custom_ls(bordered.default_ls, prob, d, u, 1.0, rhs)
+    Jd = d(u) * J(u, 1.0) + np.outer(F(u, 1.0), [d.dM(u, e) for e in np.eye(n)])
+    assert np.allclose(Jd @ h, rhs, rtol=1e-5, atol=1e-7)
+    s = deflation.deflated_newton(prob, d, u, 1.0, bordered.default_ls, tol=1e-10, max_iterations=60)
+    # a root of F (every component in {0, +-1}) which is not the deflated zero VECTOR
+    assert s["converged"] and np.abs(F(s["u"], 1.0)).max() < 1e-9 and np.linalg.norm(s["u"]) > 0.9
+    # no roots: plain Newton
+    s0 = deflation.deflated_newton(prob, deflation.DeflationOperator(2, 1.0, []), u, 1.0, bordered.default_ls, tol=1e-10)
+    s1 = palc.newton(prob, u, 1.0, bordered.default_ls, tol=1e-10)
+    assert np.array_equal(s0["u"], s1["u"])
