@@ -141,6 +141,55 @@ def cpu_baseline(tiles, shift, steps=1):
                 cell_newton=(c0["converged"], c0["itnewton"]), umax=float(np.abs(c0["u"]).max()))
 
 
+def cpu_baseline_cpp(tiles, shift):
+    """Time oracle/cpu_ref.cpp -- the C++/OpenMP restatement of the reference's CSR formulation (assembled L1 = A*A,
+    SpMV, MGS2 GMRES(30), Bordering) -- on all host cores, on a tiling of the cell.  The cell solutions come from the
+    NumPy oracle; the binary is rebuilt with -march=native for the machine it runs on (falls back to the portable
+    build of oracle/Makefile)."""
+    import shutil
+    import subprocess
+    import tempfile
+    import numpy as np
+    from oracle import krylov, operators, palc
+    odir = os.path.join(ROOT, "oracle")
+    exe = os.path.join(odir, "_build", "cpu_ref_native")
+    try:
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        subprocess.run(["g++", "-O3", "-march=native", "-fopenmp", "-std=c++17", os.path.join(odir, "cpu_ref.cpp"), "-o", exe],
+                       check=True, capture_output=True, timeout=300)
+    except Exception:
+        exe = os.path.join(odir, "_build", "cpu_ref")
+        if not os.path.exists(exe):
+            raise RuntimeError("oracle/_build/cpu_ref missing (run __graft_entry__.build())")
+    ds = -0.001
+    shc = operators.SwiftHohenberg(CELL, CELL_L)
+    pc = palc.Problem(lambda x, p: shc.F(x, p, 1.2), lambda x, p: (lambda dx: shc.dF(x, p, 1.2, dx)))
+    Plc = operators.dct_preconditioner(CELL, CELL_L, shift)
+    cls_s = lambda J, r, a0=0.0, a1=1.0: krylov.gmres_krylovkit(J, r, a0, a1, krylovdim=30, maxiter=150, rtol=1e-9,
+                                                                 atol=1e-12, Pl=Plc)[:3]
+    c0 = palc.newton(pc, hex_guess_np(), 0.1, cls_s, tol=1e-10, max_iterations=40, normN=palc.norminf)
+    c1 = palc.newton(pc, c0["u"], 0.1 + ds / 150.0, cls_s, tol=1e-10, max_iterations=20, normN=palc.norminf)
+    idx = [np.concatenate([np.arange(nc) if c % 2 == 0 else np.arange(nc)[::-1] for c in range(T)])
+           for nc, T in zip(CELL, tiles)]
+    cx, cy, cz = CELL
+    tile = lambda v: np.ascontiguousarray(v.reshape(cz, cy, cx)[np.ix_(idx[2], idx[1], idx[0])]).reshape(-1)
+    dims = tuple(c * t for c, t in zip(CELL, tiles))
+    ls = tuple(l * t for l, t in zip(CELL_L, tiles))
+    tmp = tempfile.mkdtemp(prefix="bk_cpu_ref_")
+    try:
+        f0, f1 = os.path.join(tmp, "u0.bin"), os.path.join(tmp, "u1.bin")
+        tile(c0["u"]).tofile(f0)
+        tile(c1["u"]).tofile(f1)
+        env = dict(os.environ, OMP_NUM_THREADS=str(os.cpu_count() or 1))
+        r = subprocess.run([exe, *map(str, dims), *map(repr, ls), "0.1", "1.2", repr(float(shift)), repr(ds), "0.5", f0,
+                            "0.1", f1, repr(0.1 + ds / 150.0)], capture_output=True, text=True, timeout=900, env=env, check=True)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    out["dims"] = dims
+    return out
+
+
 def main():
     args = parse()
     import torch
@@ -303,12 +352,24 @@ def main():
             try:
                 c = cpu_baseline((args.cpu_sample,) * 3, args.shift)
                 scaled = (1.0 / c["seconds_per_step"]) * (c["n"] / prob.nglobal)
-                cb = {"value": scaled, "unit": "steps/s", "cores": 1, "kind": "port",
-                      "sample": f"1 corrector step on SH3d {c['dims']} ({c['n']} unknowns, same cell tiling, h and "
-                                f"solver settings, {c['itlinear']} GMRES operator applications) took "
-                                f"{c['seconds_per_step']:.2f} s with the NumPy/SciPy oracle (assembled sparse L1, "
-                                f"MGS2 GMRES, DCT preconditioner), scaled by unknowns ratio to {n}^3; "
-                                f"CPU restatement of the reference path, not Julia"}
+                note_np = (f"NumPy/SciPy oracle, 1 thread: 1 corrector step on SH3d {c['dims']} ({c['n']} unknowns, same "
+                           f"cell tiling, h and solver settings, {c['itlinear']} GMRES operator applications) took "
+                           f"{c['seconds_per_step']:.2f} s -> {scaled:.3e} steps/s scaled by the unknowns ratio to {n}^3")
+                cb = {"value": scaled, "unit": "steps/s", "cores": 1, "kind": "port", "sample": note_np +
+                      "; CPU restatement of the reference path (assembled sparse L1, MGS2 GMRES, DCT preconditioner), not Julia"}
+                try:                                  # second baseline, SURVEY 8(d)(ii): C++/OpenMP on all host cores
+                    cc = cpu_baseline_cpp((args.cpu_sample + 1,) * 3, args.shift)
+                    scaled_c = (1.0 / cc["seconds_per_step"]) * (cc["n"] / prob.nglobal)
+                    cb = {"value": scaled_c, "unit": "steps/s", "cores": cc["threads"], "kind": "port",
+                          "numpy_1thread_value": scaled,
+                          "sample": f"C++/OpenMP restatement of the reference's CSR formulation (oracle/cpu_ref.cpp: assembled "
+                                    f"L1 = A*A with {cc['nnz_L1']} nonzeros, SpMV, MGS2 GMRES(30), Bordering, dense-DCT "
+                                    f"preconditioner) on {cc['threads']} threads: 1 corrector step on SH3d {cc['dims']} "
+                                    f"({cc['n']} unknowns, {cc['itlinear']} operator applications) took "
+                                    f"{cc['seconds_per_step']:.2f} s, scaled by the unknowns ratio to {n}^3; " + note_np +
+                                    "; CPU restatements of the reference path, not Julia"}
+                except Exception as e:
+                    cb["sample"] += f"; (C++/OpenMP baseline unavailable: {e!r})"
             except Exception as e:  # the baseline must not take the bench line down
                 cb = {"value": None, "unit": "steps/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
         out["cpu_baseline"] = cb

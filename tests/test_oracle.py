@@ -285,3 +285,39 @@ def test_deflated_newton_leaves_the_deflated_root():
     s0 = deflation.deflated_newton(prob, deflation.DeflationOperator(2, 1.0, []), u, 1.0, bordered.default_ls, tol=1e-10)
     s1 = palc.newton(prob, u, 1.0, bordered.default_ls, tol=1e-10)
     assert np.array_equal(s0["u"], s1["u"])
+
+
+def test_cpu_ref_cpp_matches_numpy_oracle(tmp_path):
+    """oracle/cpu_ref.cpp (C++/OpenMP restatement of the reference's CSR formulation, the second CPU baseline of
+    bench.py) walks the same corrector pass as the NumPy oracle: same predictor residual, same number of GMRES
+    operator applications, same corrected parameter."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    exe = str(tmp_path / "cpu_ref")
+    subprocess.run(["g++", "-O2", "-fopenmp", "-std=c++17", os.path.join(root, "oracle", "cpu_ref.cpp"), "-o", exe], check=True)
+    ref = bench.cpu_baseline((1, 1, 1), 1.0)                         # NumPy oracle on the cell (64 x 32 x 32)
+    # the same two branch points, written for the binary
+    ds = -0.001
+    shc = operators.SwiftHohenberg(bench.CELL, bench.CELL_L)
+    pc = palc.Problem(lambda x, p: shc.F(x, p, 1.2), lambda x, p: (lambda dx: shc.dF(x, p, 1.2, dx)))
+    Plc = operators.dct_preconditioner(bench.CELL, bench.CELL_L, 1.0)
+    ls = lambda J, r, a0=0.0, a1=1.0: krylov.gmres_krylovkit(J, r, a0, a1, krylovdim=30, maxiter=150, rtol=1e-9,
+                                                              atol=1e-12, Pl=Plc)[:3]
+    c0 = palc.newton(pc, bench.hex_guess_np(), 0.1, ls, tol=1e-10, max_iterations=40, normN=palc.norminf)
+    c1 = palc.newton(pc, c0["u"], 0.1 + ds / 150.0, ls, tol=1e-10, max_iterations=20, normN=palc.norminf)
+    f0, f1 = str(tmp_path / "u0.bin"), str(tmp_path / "u1.bin")
+    c0["u"].tofile(f0)
+    c1["u"].tofile(f1)
+    r = subprocess.run([exe, *map(str, bench.CELL), *map(repr, bench.CELL_L), "0.1", "1.2", "1.0", repr(ds), "0.5", f0, "0.1",
+                        f1, repr(0.1 + ds / 150.0)], capture_output=True, text=True, check=True,
+                       env=dict(os.environ, OMP_NUM_THREADS="2"))
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["n"] == ref["n"] == 65536 and out["nnz_L1"] > 20 * out["n"]          # 25-point rows away from the faces
+    assert abs(out["residuals"][0] - ref["residuals"][0]) <= 1e-9 * ref["residuals"][0]
+    assert abs(out["itlinear"] - ref["itlinear"]) <= 2
+    assert out["residuals"][1] < 1e-9 and ref["residuals"][1] < 1e-9
