@@ -110,6 +110,7 @@ SIGNATURES = {
     "bk_residual": (I, [VP, VP, c_double_p, I, VP]),
     "bk_jacobian": (I, [VP, VP, c_double_p, I, C.POINTER(VP)]),
     "bk_op_destroy": (I, [VP]),
+    "bk_jacobian_adjoint": (I, [VP, VP, c_double_p, I, C.POINTER(VP)]),
     "bk_op_apply": (I, [VP, VP, D, D, VP]),
     "bk_precond_sh_create": (I, [VP, D, C.POINTER(VP)]),
     "bk_precond_lap_create": (I, [VP, D, C.POINTER(VP)]),
@@ -124,6 +125,11 @@ SIGNATURES = {
                               c_int_p, c_int_p]),
     "bk_bls_block_bordering": (I, [VP, VP, I, C.POINTER(VP), C.POINTER(VP), c_double_p, VP, c_double_p,
                                    C.POINTER(GmresOpts), VP, VP, c_double_p, c_int_p, c_int_p]),
+    "bk_bls_block_matrixfree": (I, [VP, VP, I, C.POINTER(VP), C.POINTER(VP), c_double_p, VP, c_double_p, I, D, D,
+                                    C.POINTER(GmresOpts), VP, c_double_p, c_int_p, c_int_p]),
+    "bk_gmres_cshift": (I, [VP, VP, VP, VP, VP, VP, D, D, D, C.POINTER(GmresOpts), VP, c_int_p, c_int_p, c_double_p]),
+    "bk_bls_bordering_cshift": (I, [VP, VP, VP, VP, VP, VP, D, D, VP, VP, D, D, D, D, D, D, D, C.POINTER(GmresOpts),
+                                    VP, VP, VP, c_double_p, c_int_p, c_int_p]),
     "bk_eig_shiftinvert": (I, [VP, VP, I, C.POINTER(EigOpts), C.POINTER(GmresOpts), VP, c_double_p, c_double_p,
                                VP, VP, SZ, c_int_p, c_int_p, c_int_p]),
     "bk_newton": (I, [VP, VP, VP, c_double_p, I, C.POINTER(NewtonOpts), C.POINTER(GmresOpts), VP,

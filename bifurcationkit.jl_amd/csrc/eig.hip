@@ -23,8 +23,8 @@ namespace {
 struct ShiftedOp : bk_op {
     bk_op* J;
     double sigma;
-    int apply(const double* x, double, double b0, double b1, double* out, double*) override {
-        return J->apply(x, 0.0, b0 - b1 * sigma, b1, out, nullptr);
+    int apply(const double* x, const double*, double b0, double b1, double* out, double*) override {
+        return J->apply(x, nullptr, b0 - b1 * sigma, b1, out, nullptr);
     }
 };
 
@@ -37,7 +37,7 @@ struct ShiftInvertOp : bk_op {
     bk_gmres_opts ls;
     bk_precond* pl;
     int solves = 0, failed = 0, inner_ops = 0;
-    int apply(const double* x, double, double b0, double b1, double* out, double*) override {
+    int apply(const double* x, const double*, double b0, double b1, double* out, double*) override {
         if (b0 != 0.0 || b1 != 1.0) return set_error(ctx, "ShiftInvertOp: only plain application is supported");
         GmresResult r;
         BK_TRY(linsolve(ctx, &Js, x, out, 0.0, 1.0, ls, pl, &r));

@@ -93,7 +93,7 @@ struct bk_op {              // a linear operator on (device vector [+ one host t
     int ntail = 0;          // 0, or 1 for bordered (N+1) operators
     virtual ~bk_op() {}
     // out = a0*x + a1*A(x)
-    virtual int apply(const double* x, double xt, double a0, double a1, double* out, double* outt) = 0;
+    virtual int apply(const double* x, const double* xt, double a0, double a1, double* out, double* outt) = 0;   // xt / outt: ntail host scalars (bordered operators), else NULL
 };
 
 struct bk_precond {
@@ -109,7 +109,8 @@ struct PdeJacobian : bk_op {          // J(u, params) of a bk_problem; reference
     bk_problem* prob;
     const double* u;
     double params[BK_MAX_PARAMS];
-    int apply(const double* x, double xt, double a0, double a1, double* out, double* outt) override;
+    bool adjoint = false;             // J' (cGL only; the SH Jacobians are symmetric)
+    int apply(const double* x, const double* xt, double a0, double a1, double* out, double* outt) override;
 };
 
 // GMRES core on an operator (solver.hip)
@@ -118,8 +119,8 @@ struct GmresResult {
     int niter = 0;
     double resnorm = 0.0;
 };
-// Solve (alpha0 + alpha1 A) x = b, x0 = 0.  Tails (bt in, *xt out) only when A->ntail == 1.
-int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, double bt, double* x, double* xt, double alpha0,
+// Solve (alpha0 + alpha1 A) x = b, x0 = 0.  Tails (bt in, xt out: A->ntail host scalars) only for bordered operators.
+int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double* x, double* xt, double alpha0,
                double alpha1, const bk_gmres_opts& o, GmresResult* res);
 // The public linear solve with optional left preconditioner (reference branch semantics)
 int linsolve(bk_ctx* ctx, bk_op* J, const double* rhs, double* x, double a0, double a1, const bk_gmres_opts& o,

@@ -45,8 +45,9 @@ int bk_problem::apply(int mode, const double* v, const double* u, const double* 
     return set_error(ctx, "unknown pde kind %d", d.pde);
 }
 
-int PdeJacobian::apply(const double* x, double, double a0, double a1, double* out, double*) {
-    return prob->apply(0, x, u, params, a0, a1, out);
+int PdeJacobian::apply(const double* x, const double*, double a0, double a1, double* out, double*) {
+    // the SH Jacobians are symmetric (issymmetric = true, examples/SH3d.jl:123): only cGL has a distinct adjoint
+    return prob->apply(adjoint && prob->desc.pde == BK_PDE_CGL2D ? 2 : 0, x, u, params, a0, a1, out);
 }
 
 static int nparams_of(int pde) { return pde == BK_PDE_CGL2D ? 6 : 2; }
@@ -138,6 +139,12 @@ int bk_jacobian(bk_problem* p, const double* u, const double* params, int nparam
     return 0;
 }
 
+int bk_jacobian_adjoint(bk_problem* p, const double* u, const double* params, int nparams, bk_op** out) {
+    BK_TRY(bk_jacobian(p, u, params, nparams, out));
+    static_cast<PdeJacobian*>(*out)->adjoint = true;
+    return 0;
+}
+
 int bk_op_destroy(bk_op* op) {
     delete op;
     return 0;
@@ -147,7 +154,7 @@ int bk_op_apply(bk_op* op, const double* v, double a0, double a1, double* out) {
     if (!op || !v || !out) return -1;
     if (op->ntail != 0) return set_error(op->ctx, "bk_op_apply: bordered operators are internal");
     if (v == out) return set_error(op->ctx, "bk_op_apply: out must not alias v");
-    return op->apply(v, 0.0, a0, a1, out, nullptr);
+    return op->apply(v, nullptr, a0, a1, out, nullptr);
 }
 
 }  // extern "C"

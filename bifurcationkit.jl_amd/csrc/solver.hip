@@ -25,11 +25,14 @@ namespace {
 
 inline size_t round_up(size_t n, size_t m) { return (n + m - 1) / m * m; }
 
-struct Basis {                 // (m+1) device vectors + host tails
+struct Basis {                 // (m+1) device vectors + host tails (nt scalars per vector: the border block)
     double* V = nullptr;
     size_t ld = 0;
-    std::vector<double> t;     // tails
+    int nt = 0;
+    std::vector<double> t;     // tails, t[i * nt + q]
     double* vec(int i) { return V + (size_t)i * ld; }
+    double* tail(int i) { return t.data() + (size_t)i * nt; }
+    double tdot(int i, const double* y) { double s = 0.0; for (int q = 0; q < nt; ++q) s += t[(size_t)i * nt + q] * y[q]; return s; }
 };
 
 // ---------------------------------------------------------------- bordered-vector helpers
@@ -37,10 +40,10 @@ struct VecOps {
     bk_ctx* ctx;
     size_t n;
     int ntail;
-    int nrm2(const double* x, double xt, double* out) {
+    int nrm2(const double* x, const double* xt, double* out) {
         double s;
         BK_TRY(v_dot(ctx, n, x, x, &s));
-        if (ntail) s += xt * xt;
+        for (int q = 0; q < ntail; ++q) s += xt[q] * xt[q];
         *out = std::sqrt(s);
         return 0;
     }
@@ -54,15 +57,15 @@ int arnoldi_step(bk_ctx* ctx, bk_op* A, Basis& B, int j, double* w, double* h, d
                  double op_a1, double eta) {
     const size_t n = A->n;
     const int nt = A->ntail;
-    double wt = 0.0;
-    BK_TRY(A->apply(B.vec(j), nt ? B.t[j] : 0.0, op_a0, op_a1, w, &wt));
+    double wt[BK_MAX_BORDER] = {0.0};
+    BK_TRY(A->apply(B.vec(j), nt ? B.tail(j) : nullptr, op_a0, op_a1, w, wt));
     const int k = j + 1;
     double hh[kMaxBasis + 1], c[kMaxBasis];
     BK_TRY(v_multidot(ctx, n, B.V, B.ld, k, w, hh));
     double ww = hh[k];
     if (nt) {
-        for (int i = 0; i < k; ++i) hh[i] += B.t[i] * wt;
-        ww += wt * wt;
+        for (int i = 0; i < k; ++i) hh[i] += B.tdot(i, wt);
+        for (int q = 0; q < nt; ++q) ww += wt[q] * wt[q];
     }
     if (ww == 0.0) { *beta = 0.0; return 0; }
     double hsq = 0.0;
@@ -72,10 +75,10 @@ int arnoldi_step(bk_ctx* ctx, bk_op* A, Basis& B, int j, double* w, double* h, d
         // pass B with the normalisation folded in: v_{k} = (w - V h) / sqrt(b2)
         const double be = std::sqrt(b2);
         BK_TRY(v_multiaxpy(ctx, n, B.V, B.ld, k, c, w, 1.0 / be, B.vec(k), nullptr));
-        if (nt) {
-            double t = wt;
-            for (int i = 0; i < k; ++i) t -= h[i] * B.t[i];
-            B.t[k] = t / be;
+        for (int q = 0; q < nt; ++q) {
+            double t = wt[q];
+            for (int i = 0; i < k; ++i) t -= h[i] * B.tail(i)[q];
+            B.tail(k)[q] = t / be;
         }
         *beta = be;
         if (b2 >= eta * eta * ww) return 0;      // DGKS: no cancellation, one pass is enough
@@ -83,14 +86,14 @@ int arnoldi_step(bk_ctx* ctx, bk_op* A, Basis& B, int j, double* w, double* h, d
         // severe cancellation: the Pythagorean estimate is noise; take the norm of the remainder explicitly
         double nn = 0.0;
         BK_TRY(v_multiaxpy(ctx, n, B.V, B.ld, k, c, w, 1.0, w, &nn));
-        if (nt) {
-            for (int i = 0; i < k; ++i) wt -= h[i] * B.t[i];
-            nn += wt * wt;
+        for (int q = 0; q < nt; ++q) {
+            for (int i = 0; i < k; ++i) wt[q] -= h[i] * B.tail(i)[q];
+            nn += wt[q] * wt[q];
         }
         if (!(nn > 1e-30 * ww)) { *beta = 0.0; return 0; }       // w is in span(V) to working precision: breakdown
         const double bn = std::sqrt(nn);
         BK_TRY(v_axpbyz(ctx, n, 1.0 / bn, w, 0.0, nullptr, B.vec(k)));
-        if (nt) B.t[k] = wt / bn;
+        for (int q = 0; q < nt; ++q) B.tail(k)[q] = wt[q] / bn;
         *beta = bn;
     }
     // second pass ("twice is enough"), with the norm of the result taken explicitly
@@ -98,22 +101,22 @@ int arnoldi_step(bk_ctx* ctx, bk_op* A, Basis& B, int j, double* w, double* h, d
     BK_TRY(v_multidot(ctx, n, B.V, B.ld, k, B.vec(k), ss));
     double vv = ss[k];
     if (nt) {
-        for (int i = 0; i < k; ++i) ss[i] += B.t[i] * B.t[k];
-        vv += B.t[k] * B.t[k];
+        for (int i = 0; i < k; ++i) ss[i] += B.tdot(i, B.tail(k));
+        vv += B.tdot(k, B.tail(k));
     }
     for (int i = 0; i < k; ++i) c[i] = -ss[i];
     double nn2 = 0.0;
     BK_TRY(v_multiaxpy(ctx, n, B.V, B.ld, k, c, B.vec(k), 1.0, B.vec(k), &nn2));
-    if (nt) {
-        double t = B.t[k];
-        for (int i = 0; i < k; ++i) t -= ss[i] * B.t[i];
-        B.t[k] = t;
+    for (int q = 0; q < nt; ++q) {
+        double t = B.tail(k)[q];
+        for (int i = 0; i < k; ++i) t -= ss[i] * B.tail(i)[q];
+        B.tail(k)[q] = t;
         nn2 += t * t;
     }
     if (!(nn2 > 1e-30 * vv)) { *beta = 0.0; return 0; }
     const double cn = std::sqrt(nn2);
     BK_TRY(v_scale(ctx, n, 1.0 / cn, B.vec(k)));
-    if (nt) B.t[k] /= cn;
+    for (int q = 0; q < nt; ++q) B.tail(k)[q] /= cn;
     for (int i = 0; i < k; ++i) h[i] += (*beta) * ss[i];
     *beta = (*beta) * cn;
     return 0;
@@ -127,6 +130,7 @@ int arnoldi_step_public(bk_ctx* ctx, bk_op* A, double* V, size_t ld, std::vector
     Basis B;
     B.V = V;
     B.ld = ld;
+    B.nt = A->ntail;
     B.t.swap(tails);
     const int s = arnoldi_step(ctx, A, B, j, w, h, beta, 0.0, 1.0, 2.0);      // eigensolver: always two passes
     B.t.swap(tails);
@@ -134,7 +138,7 @@ int arnoldi_step_public(bk_ctx* ctx, bk_op* A, double* V, size_t ld, std::vector
 }
 
 // ================================================================== GMRES
-int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, double bt, double* x, double* xt, double alpha0,
+int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double* x, double* xt, double alpha0,
                double alpha1, const bk_gmres_opts& o, GmresResult* res) {
     const size_t n = A->n;
     const int nt = A->ntail;
@@ -154,13 +158,14 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, double bt, double* x, dou
     Basis B;
     B.ld = round_up(n, 32);
     BK_TRY(ws.get(B.ld * (size_t)(m + 1), &B.V));
-    B.t.assign(m + 1, 0.0);
+    B.nt = nt;
+    B.t.assign((size_t)(m + 1) * (nt > 0 ? nt : 1), 0.0);
     double *w = nullptr, *r = nullptr;
     BK_TRY(ws.get(B.ld, &w));
     BK_TRY(ws.get(B.ld, &r));
 
     bool x_zero = true;                        // x0 = 0 is never materialised: the first update writes x = V y
-    double xtail = 0.0;
+    double xtail[BK_MAX_BORDER] = {0.0};
     double bnorm = 0.0;
     BK_TRY(vo.nrm2(b, bt, &bnorm));
     double beta = bnorm;                       // x0 = 0  =>  r0 = b
@@ -174,11 +179,12 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, double bt, double* x, dou
     if (kk ? (beta < tol) : (beta <= tol)) {
         BK_TRY(v_zero(ctx, n, x));
         res->converged = 1; res->niter = kk ? numops : 0; res->resnorm = beta;
-        if (xt) *xt = 0.0;
+        if (xt) for (int q = 0; q < nt; ++q) xt[q] = 0.0;
         return 0;
     }
     const double* rsrc = b;                    // first cycle: r0 = b, read in place (no copy)
-    double rt = bt;
+    double rt[BK_MAX_BORDER] = {0.0};
+    for (int q = 0; q < nt; ++q) rt[q] = bt[q];
 
     std::vector<double> R((size_t)m * m, 0.0), y(m + 1, 0.0), cs(m, 0.0), sn(m, 0.0), h(m + 1, 0.0), col(m + 1, 0.0);
     auto Rat = [&](int i, int j) -> double& { return R[(size_t)i + (size_t)j * m]; };
@@ -188,7 +194,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, double bt, double* x, dou
     auto start_cycle = [&]() -> int {        // V[0] = r / beta ; first Arnoldi column
         BK_TRY(v_axpbyz(ctx, n, 1.0 / beta, rsrc, 0.0, nullptr, B.vec(0)));
         rsrc = r;
-        if (nt) B.t[0] = rt / beta;
+        for (int q = 0; q < nt; ++q) B.tail(0)[q] = rt[q] / beta;
         BK_TRY(arnoldi_step(ctx, A, B, 0, w, h.data(), &hnext, op_a0, op_a1, eta));
         numops += 1;
         return 0;
@@ -235,7 +241,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, double bt, double* x, dou
         }
         BK_TRY(v_multiaxpy(ctx, n, B.V, B.ld, k, yk.data(), x_zero ? nullptr : x, 1.0, x, nullptr));
         x_zero = false;
-        if (nt) for (int i = 0; i < k; ++i) xtail += yk[i] * B.t[i];
+        for (int q = 0; q < nt; ++q) for (int i = 0; i < k; ++i) xtail[q] += yk[i] * B.tail(i)[q];
 
         if (kk) {
             if (beta > tol && hnext != 0.0) {
@@ -249,14 +255,14 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, double bt, double* x, dou
                 }
                 for (int i = 0; i <= k; ++i) z[i] *= y[k];
                 BK_TRY(v_multiaxpy(ctx, n, B.V, B.ld, k + 1, z.data(), nullptr, 1.0, r, nullptr));
-                if (nt) { rt = 0.0; for (int i = 0; i <= k; ++i) rt += z[i] * B.t[i]; }
+                for (int q = 0; q < nt; ++q) { rt[q] = 0.0; for (int i = 0; i <= k; ++i) rt[q] += z[i] * B.tail(i)[q]; }
             } else {
                 // explicit residual r = b - (a0 + a1 A) x, "to ensure that no numerical errors have accumulated"
-                double wt = 0.0;
-                BK_TRY(A->apply(x, xtail, alpha0, alpha1, w, &wt));
+                double wt[BK_MAX_BORDER] = {0.0};
+                BK_TRY(A->apply(x, nt ? xtail : nullptr, alpha0, alpha1, w, wt));
                 numops += 1;
                 BK_TRY(v_axpbyz(ctx, n, 1.0, b, -1.0, w, r));
-                if (nt) rt = bt - wt;
+                for (int q = 0; q < nt; ++q) rt[q] = bt[q] - wt[q];
                 BK_TRY(vo.nrm2(r, rt, &beta));
                 if (beta < tol) { res->converged = 1; break; }
             }
@@ -268,10 +274,10 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, double bt, double* x, dou
         } else {
             if (beta <= tol) { res->converged = 1; break; }
             if (stop || iters >= o.maxiter) break;
-            double wt = 0.0;
-            BK_TRY(A->apply(x, xtail, alpha0, alpha1, w, &wt));
+            double wt[BK_MAX_BORDER] = {0.0};
+            BK_TRY(A->apply(x, nt ? xtail : nullptr, alpha0, alpha1, w, wt));
             BK_TRY(v_axpbyz(ctx, n, 1.0, b, -1.0, w, r));
-            if (nt) rt = bt - wt;
+            for (int q = 0; q < nt; ++q) rt[q] = bt[q] - wt[q];
             BK_TRY(vo.nrm2(r, rt, &beta));
             if (beta <= tol) { res->converged = 1; break; }
             BK_TRY(start_cycle());
@@ -279,7 +285,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, double bt, double* x, dou
     }
     res->niter = kk ? numops : iters;
     res->resnorm = beta;
-    if (xt) *xt = xtail;
+    if (xt) for (int q = 0; q < nt; ++q) xt[q] = xtail[q];
     return 0;
 }
 
@@ -294,11 +300,11 @@ struct ShiftPrecOp : bk_op {
     double a0, a1;
     int order;
     double* tmp;
-    int apply(const double* x, double, double b0, double b1, double* out, double*) override {
+    int apply(const double* x, const double*, double b0, double b1, double* out, double*) override {
         // out = b0 x + b1 * W(x)
-        if (!P) return J->apply(x, 0.0, b0 + b1 * a0, b1 * a1, out, nullptr);
+        if (!P) return J->apply(x, nullptr, b0 + b1 * a0, b1 * a1, out, nullptr);
         if (order == 0) {
-            BK_TRY(J->apply(x, 0.0, 0.0, 1.0, tmp, nullptr));
+            BK_TRY(J->apply(x, nullptr, 0.0, 1.0, tmp, nullptr));
             const double cx = b0 + b1 * a0, ct = b1 * a1;
             if (cx == 0.0) {                       // the common Arnoldi call (a0 = 0): Pl^-1 writes straight into out
                 BK_TRY(P->apply(tmp, out));
@@ -307,7 +313,7 @@ struct ShiftPrecOp : bk_op {
             BK_TRY(P->apply(tmp, tmp));
             return v_axpbyz(ctx, n, cx, x, ct, tmp, out);
         }
-        BK_TRY(J->apply(x, 0.0, a0, a1, tmp, nullptr));
+        BK_TRY(J->apply(x, nullptr, a0, a1, tmp, nullptr));
         if (b0 == 0.0) {
             BK_TRY(P->apply(tmp, out));
             return b1 == 1.0 ? 0 : v_scale(ctx, n, b1, out);
@@ -324,7 +330,7 @@ int linsolve(bk_ctx* ctx, bk_op* J, const double* rhs, double* x, double a0, dou
     if (J->ntail != 0) return set_error(ctx, "linsolve: operator must be unbordered");
     if (x == rhs) return set_error(ctx, "linsolve: x must not alias rhs");
     const bool kk = (o.flavor == BK_GMRES_KRYLOVKIT);
-    if (!pl && kk) return gmres_core(ctx, J, rhs, 0.0, x, nullptr, a0, a1, o, res);
+    if (!pl && kk) return gmres_core(ctx, J, rhs, nullptr, x, nullptr, a0, a1, o, res);
     WsGuard ws(ctx);
     ShiftPrecOp W;
     W.ctx = ctx; W.n = J->n; W.ntail = 0;
@@ -337,7 +343,7 @@ int linsolve(bk_ctx* ctx, bk_op* J, const double* rhs, double* x, double a0, dou
         BK_TRY(pl->apply(rhs, prhs));            // ldiv!(similar(rhs), Pl, copy(rhs)) :278
         b = prhs;
     }
-    return gmres_core(ctx, &W, b, 0.0, x, nullptr, 0.0, 1.0, o, res);
+    return gmres_core(ctx, &W, b, nullptr, x, nullptr, 0.0, 1.0, o, res);
 }
 
 }  // namespace bk
@@ -433,7 +439,7 @@ int bls_bordering(bk_ctx* ctx, bk_op* J, const double* dR, const double* dzu, do
     while (bo.check_precision && k < bo.k && fail) {
         // residualBEC, :146-166: dXr = R - (shift + J) dX - dl dR ; dlr = n - xip dzp dl - xiu dotp(dzu, dX)
         if (!dXr) { BK_TRY(ws.get(n, &dXr)); BK_TRY(ws.get(n, &dX1)); }
-        BK_TRY(J->apply(dX, 0.0, has_shift ? shift : 0.0, 1.0, dXr, nullptr));
+        BK_TRY(J->apply(dX, nullptr, has_shift ? shift : 0.0, 1.0, dXr, nullptr));
         BK_TRY(v_axpby(ctx, n, *dl, dR, 1.0, dXr));
         BK_TRY(v_axpby(ctx, n, 1.0, R, -1.0, dXr));
         double dd, nr;
@@ -454,21 +460,30 @@ int bls_bordering(bk_ctx* ctx, bk_op* J, const double* dR, const double* dzu, do
     return 0;
 }
 
-// MatrixFreeBLSmap on BorderedArray, src/LinearBorderSolver.jl:326-335
+// MatrixFreeBLSmap on BorderedArray, src/LinearBorderSolver.jl:326-335 (scalar border) and :338-352 (m-column border:
+// a, b tuples of m vectors, c an m x m matrix): out.u = J x.u + shift x.u + sum_i x.p[i] a_i,
+// out.p = c x.p + [dot(b_i, x.u)]_i.
 struct BorderedMapOp : bk_op {
     bk_op* J;
-    const double* a;      // dR
-    const double* bvec;   // dzu (scaled by xiu * dotscale through `bscale`)
-    double bscale, c;
+    const double* a[BK_MAX_BORDER];      // columns (dR for the PALC system)
+    const double* bvec[BK_MAX_BORDER];   // rows (dzu, scaled by xiu * dotscale through `bscale`)
+    double bscale;
+    double c[BK_MAX_BORDER * BK_MAX_BORDER];     // row-major m x m
     bool has_shift;
     double shift;
-    int apply(const double* x, double xt, double b0, double b1, double* out, double* outt) override {
-        // out.u = b0 x + b1 (J x + shift x + xt a) ; out.p = b0 xt + b1 (bscale <b, x> + c xt)
-        BK_TRY(J->apply(x, 0.0, b0 + b1 * (has_shift ? shift : 0.0), b1, out, nullptr));
-        if (xt != 0.0 && b1 != 0.0) BK_TRY(v_axpby(ctx, n, b1 * xt, a, 1.0, out));
-        double d;
-        BK_TRY(v_dot(ctx, n, bvec, x, &d));
-        *outt = b0 * xt + b1 * (bscale * d + c * xt);
+    int apply(const double* x, const double* xt, double b0, double b1, double* out, double* outt) override {
+        // out.u = b0 x + b1 (J x + shift x + sum xt_i a_i) ; out.p = b0 xt + b1 (bscale <b_i, x> + c xt)
+        const int m = ntail;
+        BK_TRY(J->apply(x, nullptr, b0 + b1 * (has_shift ? shift : 0.0), b1, out, nullptr));
+        for (int i = 0; i < m; ++i)
+            if (xt[i] != 0.0 && b1 != 0.0) BK_TRY(v_axpby(ctx, n, b1 * xt[i], a[i], 1.0, out));
+        for (int i = 0; i < m; ++i) {
+            double d;
+            BK_TRY(v_dot(ctx, n, bvec[i], x, &d));
+            double cx = 0.0;
+            for (int j = 0; j < m; ++j) cx += c[i * m + j] * xt[j];
+            outt[i] = b0 * xt[i] + b1 * (bscale * d + cx);
+        }
         return 0;
     }
 };
@@ -495,10 +510,10 @@ int bk_bls_matrixfree(bk_ctx* ctx, bk_op* J, const double* dR, const double* dzu
     if (dX == R || dX == dR || dX == dzu) return set_error(ctx, "bk_bls_matrixfree: dX must be a fresh buffer");
     BorderedMapOp M;
     M.ctx = ctx; M.n = J->n; M.ntail = 1;
-    M.J = J; M.a = dR; M.bvec = dzu; M.bscale = xiu * dotscale; M.c = dzp * xip;
+    M.J = J; M.a[0] = dR; M.bvec[0] = dzu; M.bscale = xiu * dotscale; M.c[0] = dzp * xip;
     M.has_shift = has_shift != 0; M.shift = shift;
     GmresResult r;
-    BK_TRY(gmres_core(ctx, &M, R, n, dX, dl, 0.0, 1.0, *lsopts, &r));
+    BK_TRY(gmres_core(ctx, &M, R, &n, dX, dl, 0.0, 1.0, *lsopts, &r));
     if (converged) *converged = r.converged;
     if (itlinear) *itlinear = r.niter;
     return 0;
@@ -557,6 +572,31 @@ int bk_bls_block_bordering(bk_ctx* ctx, bk_op* J, int m, const double* const* b,
     }
     for (int j = 0; j < m; ++j) BK_TRY(v_axpby(ctx, n, -u2[j], x2[j], 1.0, u1));
     if (converged) *converged = cv;
+    return 0;
+}
+
+// solve_bls_block(::MatrixFreeBLS, J, a, b, c, rhst, rhsb; shift, dotp), src/LinearBorderSolver.jl:440-450: ONE GMRES
+// on the (N + m) operator MatrixFreeBLSmap (:338-352) over BorderedArray(u, p::Vector) -- the m border scalars live on
+// the host next to the Krylov basis tails.
+int bk_bls_block_matrixfree(bk_ctx* ctx, bk_op* J, int m, const double* const* a, const double* const* b, const double* c,
+                            const double* rhst, const double* rhsb, int has_shift, double shift, double dotscale,
+                            const bk_gmres_opts* lsopts, double* u1, double* u2, int* converged, int* itlinear) {
+    if (!ctx || !J || !a || !b || !c || !rhst || !rhsb || !lsopts || !u1 || !u2) return -1;
+    if (m < 1 || m > BK_MAX_BORDER) return set_error(ctx, "Linear bordered solver, wrong sizes! (1 <= m <= %d)", BK_MAX_BORDER);
+    if (u1 == rhst) return set_error(ctx, "bk_bls_block_matrixfree: u1 must be a fresh buffer");
+    BorderedMapOp M;
+    M.ctx = ctx; M.n = J->n; M.ntail = m;
+    M.J = J; M.bscale = dotscale;
+    for (int i = 0; i < m; ++i) {
+        if (!a[i] || !b[i]) return -1;
+        M.a[i] = a[i]; M.bvec[i] = b[i];
+        for (int j = 0; j < m; ++j) M.c[i * m + j] = c[i * m + j];
+    }
+    M.has_shift = has_shift != 0; M.shift = shift;
+    GmresResult r;
+    BK_TRY(gmres_core(ctx, &M, rhst, rhsb, u1, u2, 0.0, 1.0, *lsopts, &r));
+    if (converged) *converged = r.converged;
+    if (itlinear) *itlinear = r.niter;
     return 0;
 }
 

@@ -327,16 +327,17 @@ __global__ void __launch_bounds__(256) cgl_kernel(CglK P) {
     const double x1 = v1[idx], x2 = v2[idx];
     const double r = P.r, mu = P.mu, nu = P.nu, c3 = P.c3, c5 = P.c5;
     double o1, o2;
-    if (P.mode == 0) {
-        // closed-form Jacobian block of the nonlinearity: Jcgl, examples/cGL2d.jl:66-69
+    if (P.mode == 0 || P.mode == 2) {
+        // closed-form Jacobian block of the nonlinearity: Jcgl, examples/cGL2d.jl:66-69 (mode 2: its transpose, the
+        // adjoint Jacobian of the Hopf machinery -- the Laplacian part is symmetric)
         const double u1 = P.u[idx], u2 = P.u[idx + n];
         const double ua = u1 * u1 + u2 * u2;
         const double f1u = r - 2 * u1 * (c3 * u1 - mu * u2) - c3 * ua - 4 * c5 * ua * u1 * u1 - c5 * ua * ua;
         const double f1v = -nu - 2 * u2 * (c3 * u1 - mu * u2) + mu * ua - 4 * c5 * ua * u1 * u2;
         const double f2u = nu - 2 * u1 * (c3 * u2 + mu * u1) - mu * ua - 4 * c5 * ua * u1 * u2;
         const double f2v = r - 2 * u2 * (c3 * u2 + mu * u1) - c3 * ua - 4 * c5 * ua * u2 * u2 - c5 * ua * ua;
-        o1 = d1 + f1u * x1 + f1v * x2;
-        o2 = d2 + f2u * x1 + f2v * x2;
+        o1 = d1 + f1u * x1 + (P.mode == 0 ? f1v : f2u) * x2;
+        o2 = d2 + (P.mode == 0 ? f2u : f1v) * x1 + f2v * x2;
     } else {
         // NL, examples/cGL2d.jl:24-40
         const double ua = x1 * x1 + x2 * x2;
@@ -429,7 +430,7 @@ int sh_apply(bk_ctx* ctx, const ShArgs& a) {
 int cgl_apply(bk_ctx* ctx, const CglArgs& a) {
     CglK P{a.nx, a.ny, a.ax, a.ay, a.r, a.mu, a.nu, a.c3, a.c5, a.gamma, a.a0, a.a1, a.mode, a.v, a.u, a.out};
     const size_t n = (size_t)a.nx * a.ny;
-    ProfScope ps(ctx, a.mode == 0 ? "jvp" : "residual", (a.mode == 0 ? 48.0 : 32.0) * n);
+    ProfScope ps(ctx, a.mode != 1 ? "jvp" : "residual", (a.mode != 1 ? 48.0 : 32.0) * n);
     hipLaunchKernelGGL(cgl_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, P);
     BK_HIP(ctx, hipGetLastError());
     return 0;

@@ -186,11 +186,12 @@ class HipJacobian:
     """What ``jacobian(prob, x, p)`` returns: an opaque operator handle (``bk_op``).  Keeps ``x`` alive, like
     the Julia closure ``dx -> dF_sh(x, p, dx)`` (examples/SH3d.jl:119) captures it."""
 
-    def __init__(self, prob, x: HipVec, params):
+    def __init__(self, prob, x: HipVec, params, adjoint=False):
         self.prob, self.ctx, self.x = prob, prob.ctx, x
         arr = (C.c_double * len(params))(*params)
         h = C.c_void_p()
-        self.ctx.check(self.ctx.lib.bk_jacobian(prob.h, _ptr(x.t), arr, len(params), C.byref(h)), "bk_jacobian")
+        fn = self.ctx.lib.bk_jacobian_adjoint if adjoint else self.ctx.lib.bk_jacobian
+        self.ctx.check(fn(prob.h, _ptr(x.t), arr, len(params), C.byref(h)), "bk_jacobian")
         self.h = h
 
     def __call__(self, dx: HipVec, a0=0.0, a1=1.0) -> HipVec:      # apply(J, dx), src/Utils.jl:191-195
@@ -249,6 +250,10 @@ class _PdeProblem:
 
     def jacobian(self, x: HipVec, p: float) -> HipJacobian:
         return HipJacobian(self, x, self._pvec(p))
+
+    def jacobian_adjoint(self, x: HipVec, p: float) -> HipJacobian:
+        """J(x, p)' (the JAd of src/codim2/MinAugHopf.jl:66-80)."""
+        return HipJacobian(self, x, self._pvec(p), adjoint=True)
 
     def vec(self, a_global: np.ndarray) -> HipVec:
         """Scatter a global NumPy state (x fastest) to this rank's slab."""
@@ -351,6 +356,20 @@ class _GMRES:
                                    C.byref(cv), C.byref(it), C.byref(rn)), "bk_gmres")
         self.last_resnorm = rn.value
         return x, bool(cv.value), it.value
+
+    def solve_complex(self, J: HipJacobian, rhs, a0: complex, a1: float = 1.0):
+        """(ls)(J, rhs; a0::Complex, a1) on a complex right-hand side given as ``(re, im)`` HipVecs (``im`` may be
+        None): src/NormalForms.jl:1053.  Returns ((x_re, x_im), success, niter)."""
+        rr, ri = rhs
+        ctx = rr.ctx
+        xr, xi = rr.similar(), rr.similar()
+        cv, it, rn = C.c_int(), C.c_int(), C.c_double()
+        lo = self._opts()
+        a0 = complex(a0)
+        ctx.check(ctx.lib.bk_gmres_cshift(ctx.h, J.h, _ptr(rr.t), _ptr(ri.t) if ri is not None else None, _ptr(xr.t),
+                                          _ptr(xi.t), a0.real, a0.imag, float(a1), C.byref(lo), self._pl(),
+                                          C.byref(cv), C.byref(it), C.byref(rn)), "bk_gmres_cshift")
+        return (xr, xi), bool(cv.value), it.value
 
     def solve2(self, J, rhs1, rhs2, a0=0.0, a1=1.0):
         """(ls)(J, rhs1, rhs2): src/LinearSolver.jl:15-19."""
@@ -485,6 +504,23 @@ class BorderingBLS:
             return dX, dl.value, bool(cv.value), (it[0], it[1])
         return self._generic(J, dR, dzu, dzp, R, n, xiu, xip, shift, dotp or (lambda x, y: x.inner(y)))
 
+    def solve_complex(self, J, dR, dzu, dzp, R, n, xiu=1.0, xip=1.0, *, shift: complex, dotscale=1.0):
+        """(lbs::BorderingBLS)(J, dR, dzu, dzp, R, n; shift::Complex) on complex data ((re, im) pairs of HipVecs; ``im``
+        may be None), one BEC pass: src/codim2/MinAugHopf.jl:17, 72-76.  Returns ((dX_re, dX_im), dl::complex, cv, its)."""
+        ctx = R[0].ctx
+        xr, xi = R[0].similar(), R[0].similar()
+        p = lambda v: _ptr(v.t) if v is not None else None
+        dl = (C.c_double * 2)()
+        it = (C.c_int * 2)()
+        cv = C.c_int()
+        lo = self.solver._opts()
+        dzp, n, shift = complex(dzp), complex(n), complex(shift)
+        ctx.check(ctx.lib.bk_bls_bordering_cshift(
+            ctx.h, J.h, p(dR[0]), p(dR[1]), p(dzu[0]), p(dzu[1]), dzp.real, dzp.imag, p(R[0]), p(R[1]), n.real, n.imag,
+            float(xiu), float(xip), shift.real, shift.imag, float(dotscale), C.byref(lo), self.solver._pl(), p(xr), p(xi),
+            dl, C.byref(cv), it), "bk_bls_bordering_cshift")
+        return (xr, xi), complex(dl[0], dl[1]), bool(cv.value), (it[0], it[1])
+
     def solve_block(self, J, b, c, d, rhst, rhsb):
         """solve_bls_block(lbs::BorderingBLS, J, b::NTuple, c::NTuple, d, rhst, rhsb) -> (u1, u2, cv, its),
         src/LinearBorderSolver.jl:173-206 (m-column border: normal forms / Bogdanov-Takens)."""
@@ -565,6 +601,28 @@ class MatrixFreeBLS:
             1.0 if dotscale is None else float(dotscale), C.byref(lo), _ptr(dX.t), C.byref(dl), C.byref(cv),
             C.byref(it)), "bk_bls_matrixfree")
         return dX, dl.value, bool(cv.value), it.value
+
+
+    def solve_block(self, J, a, b, c, rhst, rhsb, *, shift=None, dotscale=1.0):
+        """solve_bls_block(lbs::MatrixFreeBLS, J, a, b, c, rhst, rhsb; shift, dotp) -> (u1, u2, cv, it),
+        src/LinearBorderSolver.jl:440-450: one GMRES on the (N + m) operator."""
+        c = np.atleast_2d(np.asarray(c, dtype=np.float64))
+        m = c.shape[0]
+        if not (len(a) == len(b) == m == c.shape[1]):
+            raise ValueError("Linear bordered solver, wrong sizes!")
+        ctx = rhst.ctx
+        u1 = rhst.similar()
+        ap = (C.c_void_p * m)(*[x.t.data_ptr() for x in a])
+        bp = (C.c_void_p * m)(*[x.t.data_ptr() for x in b])
+        cc = (C.c_double * (m * m))(*c.ravel().tolist())
+        rb = (C.c_double * m)(*[float(v) for v in rhsb])
+        u2 = (C.c_double * m)()
+        cv, it = C.c_int(), C.c_int()
+        lo = self.solver._opts()
+        ctx.check(ctx.lib.bk_bls_block_matrixfree(ctx.h, J.h, m, ap, bp, cc, _ptr(rhst.t), rb, 0 if shift is None else 1,
+                                                  0.0 if shift is None else float(shift), float(dotscale), C.byref(lo),
+                                                  _ptr(u1.t), u2, C.byref(cv), C.byref(it)), "bk_bls_block_matrixfree")
+        return u1, np.array(list(u2)), bool(cv.value), it.value
 
 
 # ------------------------------------------------------------------------------------------ eigensolver

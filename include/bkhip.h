@@ -127,6 +127,9 @@ int bk_residual(bk_problem* prob, const double* u, const double* params, int npa
  * examples/SH3d.jl:119 / the opaque Jacobian object of src/Problems.jl:98-101.  Like the Julia
  * closure it REFERENCES u (no copy): u must stay alive and unchanged while the handle is used. */
 int bk_jacobian(bk_problem* prob, const double* u, const double* params, int nparams, bk_op** out);
+/* the adjoint Jacobian J(u, p)' (JAd_at_xp of src/codim2/MinAugHopf.jl:66-80): the transposed pointwise block for
+ * cGL2d, J itself for the (symmetric) Swift-Hohenberg problems.                                                   */
+int bk_jacobian_adjoint(bk_problem* p, const double* u, const double* params, int nparams, bk_op** out);
 int bk_op_destroy(bk_op* op);
 /* out = a0*v + a1*J*v : _axpy_op, src/LinearSolver.jl:46-64 (a0=0,a1=1: apply, src/Utils.jl:191) */
 int bk_op_apply(bk_op* op, const double* v, double a0, double a1, double* out);
@@ -207,6 +210,14 @@ int bk_bls_block_bordering(bk_ctx* ctx, bk_op* J, int m, const double* const* b,
                            const bk_gmres_opts* lsopts, bk_precond* pl, double* u1, double* u2,
                            int* converged, int* itlinear);
 
+/* solve_bls_block(::MatrixFreeBLS, J, a, b, c, rhst, rhsb; shift, dotp) (:440-450): ONE GMRES on the (N + m) operator
+ * MatrixFreeBLSmap (:338-352) acting on BorderedArray(u, p::Vector{m}):
+ *     out.u = (J + shift) u + sum_i p_i a_i ,   out.p = c p + [dotscale <b_i, u>]_i          c: m x m row-major.   */
+int bk_bls_block_matrixfree(bk_ctx* ctx, bk_op* J, int m, const double* const* a, const double* const* b,
+                            const double* c, const double* rhst, const double* rhsb, int has_shift,
+                            double shift, double dotscale, const bk_gmres_opts* lsopts, double* u1,
+                            double* u2, int* converged, int* itlinear);
+
 /* ------------------------------------------------------------------ eigensolver ------------
  * (eig::ShiftInvert)(J, nev) -> (vals, vecs, converged, niter): src/EigSolver.jl:246-266 with a
  * Krylov-Schur (KrylovKit.eigsolve-style) outer iteration; the SH3dEig of examples/SH3d.jl:96-113.
@@ -253,6 +264,23 @@ int bk_newton_palc(bk_ctx* ctx, bk_problem* prob, double* x, double* p, const do
                    const double* params, int nparams, int ipar, double p_min, double p_max,
                    const bk_newton_opts* nopts, const bk_bordering_opts* bopts,
                    const bk_gmres_opts* lsopts, bk_precond* pl, bk_newton_result* res);
+
+/* ------------------------------------------------------------------ complex shifts (Hopf) ----------
+ * The Hopf normal form and the minimally augmented Hopf system call the same plugin surface with a COMPLEX shift on
+ * complex vectors and a real Jacobian: ls(L, rhs; a0 = Complex(0, 2w), a1 = -1) (src/NormalForms.jl:1053),
+ * bls(J, a, b, 0, 0, 1; shift = Complex(0, -w)) (src/codim2/MinAugHopf.jl:17, 72-76).  Complex device vectors are
+ * (re, im) pairs; *_im inputs may be NULL (= 0).  The solve runs on the real-equivalent 2N system with the real GMRES
+ * (iteration counts can differ from a complex-arithmetic GMRES; same residual tolerance).  SURVEY section 8(f) item 3. */
+int bk_gmres_cshift(bk_ctx* ctx, bk_op* J, const double* rhs_re, const double* rhs_im, double* x_re,
+                    double* x_im, double a0_re, double a0_im, double a1, const bk_gmres_opts* opts,
+                    bk_precond* pl, int* converged, int* niter, double* resnorm);
+/* BorderingBLS, one BEC pass (check_precision = false), dotp(x, y) = dotscale * conj(x).y; dl[2] = (re, im).           */
+int bk_bls_bordering_cshift(bk_ctx* ctx, bk_op* J, const double* dR_re, const double* dR_im,
+                            const double* dzu_re, const double* dzu_im, double dzp_re, double dzp_im,
+                            const double* R_re, const double* R_im, double n_re, double n_im, double xiu,
+                            double xip, double shift_re, double shift_im, double dotscale,
+                            const bk_gmres_opts* lsopts, bk_precond* pl, double* dX_re, double* dX_im,
+                            double dl[2], int* converged, int itlinear[2]);
 
 /* ------------------------------------------------------------------ continuation step -----------
  * The body of `iterate` (src/Continuation.jl:458-504) as one call: corrector! (newton_palc), compute_eigenvalues!

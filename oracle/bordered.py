@@ -96,6 +96,25 @@ def bordering_bls_block(ls, J, b, c, d, rhst, rhsb):
     return u1, u2, cv, tuple(its)
 
 
+def matrixfree_bls_block(ls, J, a, b, c, rhst, rhsb, *, shift=None, dotp=np.dot):
+    """solve_bls_block(::MatrixFreeBLS, J, a, b, c, rhst, rhsb; shift, dotp), src/LinearBorderSolver.jl:440-450, with the
+    m-column MatrixFreeBLSmap of :338-352 on the flat vector [u; p]: one linear solve on the (N + m) operator."""
+    c = np.atleast_2d(np.asarray(c, dtype=float))
+    m, n = c.shape[0], rhst.shape[0]
+
+    def op(x):
+        xu, xp = x[:n], x[n:]
+        out = np.empty_like(x)
+        out[:n] = apply(J, xu) + sum(xp[i] * a[i] for i in range(m))
+        if shift is not None:
+            out[:n] += shift * xu
+        out[n:] = c @ xp + np.array([dotp(b[i], xu) for i in range(m)])
+        return out
+
+    sol, cv, it = ls(op, np.concatenate([rhst, np.asarray(rhsb, dtype=float)]))
+    return sol[:n], sol[n:], cv, it
+
+
 def matrixfree_blsmap(J, a, b, c, shift, dot):
     """MatrixFreeBLSmap on a flat vector, src/LinearBorderSolver.jl:308-322."""
     def op(x):

@@ -364,6 +364,15 @@ def test_bordering_block_vs_explicit_and_oracle(ctx, m):
     assert np.allclose(u2, ref[n:], rtol=1e-7, atol=1e-9)
     with pytest.raises(ValueError):
         hip.BorderingBLS(ls).solve_block(J, [prob.vec(b[0])] * (m + 1), [prob.vec(x) for x in c], d, prob.vec(rhst), rhsb)
+    # MatrixFreeBLS block variant (:440-450): one GMRES on the (N + m) operator, with a shift (unpreconditioned, as the
+    # scalar MatrixFreeBLS: accept either convergence to the explicit solution or an honest failure flag)
+    refs = np.linalg.solve(A + np.diag(np.concatenate([0.3 * np.ones(n), np.zeros(m)])), np.concatenate([rhst, rhsb]))
+    mf = hip.MatrixFreeBLS(hip.GMRESKrylovKit(dim=63, rtol=1e-12, atol=1e-13, maxiter=900))
+    v1, v2, okm, itm = mf.solve_block(J, [prob.vec(x) for x in b], [prob.vec(x) for x in c], d, prob.vec(rhst), rhsb, shift=0.3)
+    assert itm > 0
+    if okm:
+        assert np.abs(v1.numpy() - refs[:n]).max() <= 1e-6 * np.abs(refs).max()
+        assert np.allclose(v2, refs[n:], rtol=1e-6, atol=1e-8)
 
 
 # --------------------------------------------------------------------------------------------- eigensolver
@@ -565,6 +574,83 @@ def _native_corrector(hip, Cn, prob, z, tau, zp, ds, theta, bls, nopt, pmin, pma
     r = hip.newton_palc_native(prob, z, tau, zp, ds, theta, bls, tol=nopt.tol, max_iterations=nopt.max_iterations,
                                p_min=pmin, p_max=pmax, norm_inf=True)
     return Cn.NonLinearSolution(r["u"], r["residuals"], r["converged"], r["itnewton"], r["itlineartot"])
+
+
+# --------------------------------------------------------------------------------------------- complex shifts (Hopf)
+def test_complex_shift_linear_solve_vs_dense(ctx):
+    """ls(L, rhs; a0 = Complex(0, 2w), a1 = -1) (src/NormalForms.jl:1053) on a complex right-hand side: (re, im) pairs,
+    real-equivalent 2N GMRES.  IterativeSolvers flavor: Pl^-1 (a0 + a1 J) x = Pl^-1 rhs == the plain shifted system;
+    KrylovKit flavor with Pl: the reference's quirk (a0 + a1 Pl^-1 J) x = Pl^-1 rhs (src/LinearSolver.jl:268-277)."""
+    hip = _hip()
+    sh, prob, rng, u = _sh_setup(ctx, (10, 8, 6), (np.pi, 2.5, 2.0), seed=31)
+    n = sh.N
+    Jm = sh.J(u, 0.1, 1.2).toarray()
+    rhs = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    a0, a1 = complex(0.3, 2.0), -1.0
+    J = prob.jacobian(prob.vec(u), 0.1)
+    P = hip.DCTPreconditioner(prob, 1.0)
+    R = (prob.vec(rhs.real.copy()), prob.vec(rhs.imag.copy()))
+    ls = hip.GMRESIterativeSolvers(reltol=1e-12, restart=60, maxiter=2000, Pl=P)
+    (xr, xi), ok, it = ls.solve_complex(J, R, a0, a1)
+    ref = np.linalg.solve(a0 * np.eye(n) + a1 * Jm, rhs)
+    assert ok and it > 0
+    assert np.abs(xr.numpy() + 1j * xi.numpy() - ref).max() <= 1e-8 * np.abs(ref).max()
+    # real right-hand side (im = None) and the unpreconditioned KrylovKit flavor: the plain shifted system again
+    lk = hip.GMRESKrylovKit(dim=63, rtol=1e-11, atol=1e-13, maxiter=400)
+    (yr, yi), ok2, _ = lk.solve_complex(J, (R[0], None), a0, a1)
+    ref2 = np.linalg.solve(a0 * np.eye(n) + a1 * Jm, rhs.real)
+    if ok2:
+        assert np.abs(yr.numpy() + 1j * yi.numpy() - ref2).max() <= 1e-7 * np.abs(ref2).max()
+    # KrylovKit flavor with Pl: (a0 I + a1 Pl^-1 J) x = Pl^-1 rhs
+    Pm = np.linalg.inv(sh.L1.toarray() + np.eye(n))
+    lkp = hip.GMRESKrylovKit(dim=40, rtol=1e-12, atol=1e-13, maxiter=200, Pl=P)
+    (zr, zi), ok3, _ = lkp.solve_complex(J, R, a0, a1)
+    ref3 = np.linalg.solve(a0 * np.eye(n) + a1 * Pm @ Jm, Pm @ rhs)
+    assert ok3 and np.abs(zr.numpy() + 1j * zi.numpy() - ref3).max() <= 1e-8 * np.abs(ref3).max()
+
+
+def test_complex_shift_bordered_solve_cgl_vs_dense(ctx):
+    """bls(J, a, b, 0, 0, 1; shift = Complex(0, -w)) (src/codim2/MinAugHopf.jl:17, 72-76) on the non-symmetric cGL
+    Jacobian: (J - iw) v + a sigma = 0, <b, v> = 1, against the explicit complex (N+1) system and the oracle's BEC."""
+    hip = _hip()
+    dims, ls_ = (24, 14), (np.pi, np.pi / 2)
+    c = operators.CGL2d(dims, ls_)
+    prob = hip.CGL2d(ctx, dims, ls_)
+    rng = np.random.default_rng(33)
+    n2 = 2 * c.n
+    u = 0.3 * rng.standard_normal(n2)
+    pars = c.default_params()
+    pars["r"] = 1.2
+    Jm = c.J(u, **pars).toarray()
+    J = prob.jacobian(prob.vec(u), 1.2)
+    w = 0.9
+    a = rng.standard_normal(n2) + 1j * rng.standard_normal(n2)
+    b = rng.standard_normal(n2) + 1j * rng.standard_normal(n2)
+    A = np.block([[Jm - 1j * w * np.eye(n2), a[:, None]], [b.conj()[None, :], np.zeros((1, 1))]])
+    ref = np.linalg.solve(A, np.concatenate([np.zeros(n2), [1.0]]))
+    ov, osig, ook, _ = bordered.bordering_bls(bordered.default_ls, Jm, a, b, 0.0, np.zeros(n2, dtype=complex), 1.0,
+                                              shift=-1j * w, dotp=np.vdot, check_precision=False)
+    assert np.allclose(ov, ref[:-1], rtol=1e-9, atol=1e-11) and np.isclose(osig, ref[-1], rtol=1e-9)
+    P = hip.LaplacePreconditioner(prob, 1.0)
+    ls = hip.GMRESIterativeSolvers(reltol=1e-12, restart=60, maxiter=3000, Pl=P)
+    pair = lambda z: (prob.vec(z.real.copy()), prob.vec(z.imag.copy()))
+    zero = (prob.vec(np.zeros(n2)), None)
+    (vr, vi), sig, ok, its = hip.BorderingBLS(ls, check_precision=False).solve_complex(J, pair(a), pair(b), 0.0, zero, 1.0,
+                                                                                       shift=-1j * w)
+    assert ok and its[0] == 0 and its[1] > 0            # R = 0: the first BEC solve is trivial
+    v = vr.numpy() + 1j * vi.numpy()
+    assert np.abs(v - ref[:-1]).max() <= 1e-7 * np.abs(ref).max() and abs(sig - ref[-1]) <= 1e-7 * abs(ref[-1]) + 1e-10
+    assert abs(np.vdot(b, v) - 1.0) <= 1e-8                               # the normalisation row <b, v> = 1
+    # the adjoint system of :76: (J + iw)' w_ + b sigma = 0, <a, w_> = 1 with the adjoint Jacobian handle
+    Jad = prob.jacobian_adjoint(prob.vec(u), 1.2)
+    x = rng.standard_normal(n2)
+    assert np.abs(Jad(prob.vec(x)).numpy() - Jm.T @ x).max() <= 1e-11 * np.abs(Jm.T @ x).max()
+    Aad = np.block([[Jm.T + 1j * w * np.eye(n2), b[:, None]], [a.conj()[None, :], np.zeros((1, 1))]])
+    refa = np.linalg.solve(Aad, np.concatenate([np.zeros(n2), [1.0]]))
+    (wr, wi), siga, oka, _ = hip.BorderingBLS(ls, check_precision=False).solve_complex(Jad, pair(b), pair(a), 0.0, zero,
+                                                                                       1.0, shift=1j * w)
+    assert oka and np.abs(wr.numpy() + 1j * wi.numpy() - refa[:-1]).max() <= 1e-7 * np.abs(refa).max()
+    assert abs(siga - refa[-1]) <= 1e-7 * abs(refa[-1]) + 1e-10
 
 
 # --------------------------------------------------------------------------------------------- deflated Newton

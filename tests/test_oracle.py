@@ -143,6 +143,12 @@ def test_bordering_block_vs_explicit(m):
     assert ok and len(its) == m and np.allclose(u1, ref[:n]) and np.allclose(u2, ref[n:])
     with pytest.raises(ValueError):
         bordered.bordering_bls_block(bordered.default_ls, J0, b, c[:-1] if m > 1 else c + c, d, rhst, rhsb)
+    # the MatrixFreeBLS block variant (:440-450): one GMRES on the (N + m) operator, with a shift
+    ls = lambda J, r, a0=0.0, a1=1.0: krylov.gmres_krylovkit(J, r, a0, a1, krylovdim=n + m + 1)[:3]
+    Ash = A + np.diag(np.concatenate([0.3 * np.ones(n), np.zeros(m)]))
+    refs = np.linalg.solve(Ash, np.concatenate([rhst, rhsb]))
+    v1, v2, okm, _ = bordered.matrixfree_bls_block(ls, J0, b, c, d, rhst, rhsb, shift=0.3)
+    assert okm and np.allclose(v1, refs[:n], rtol=1e-8) and np.allclose(v2, refs[n:], rtol=1e-7)
 
 
 def test_shift_invert_vs_eigvals():
@@ -321,3 +327,21 @@ def test_cpu_ref_cpp_matches_numpy_oracle(tmp_path):
     assert abs(out["residuals"][0] - ref["residuals"][0]) <= 1e-9 * ref["residuals"][0]
     assert abs(out["itlinear"] - ref["itlinear"]) <= 2
     assert out["residuals"][1] < 1e-9 and ref["residuals"][1] < 1e-9
+
+
+def test_bordered_solver_complex_shift():
+    """BEC with shift = Complex(0, -w) on complex borders (src/codim2/MinAugHopf.jl:17, 72-76; dot conjugates its
+    first argument) == the explicit complex (N+1) system; complex a0 in DefaultLS (src/NormalForms.jl:1053)."""
+    rng = np.random.default_rng(8)
+    n, w = 30, 0.7
+    J0 = np.eye(n) + 0.3 * rng.random((n, n))
+    a = rng.random(n) + 1j * rng.random(n)
+    b = rng.random(n) + 1j * rng.random(n)
+    A = np.block([[J0 - 1j * w * np.eye(n), a[:, None]], [b.conj()[None, :], np.zeros((1, 1))]])
+    ref = np.linalg.solve(A, np.concatenate([np.zeros(n), [1.0]]))
+    v, sig, ok, _ = bordered.bordering_bls(bordered.default_ls, J0, a, b, 0.0, np.zeros(n, dtype=complex), 1.0,
+                                           shift=-1j * w, dotp=np.vdot, check_precision=False)
+    assert ok and np.allclose(v, ref[:-1]) and np.isclose(sig, ref[-1]) and np.isclose(np.vdot(b, v), 1.0)
+    rhs = rng.random(n) + 1j * rng.random(n)
+    x, _, _ = bordered.default_ls(J0, rhs, a0=2j * w, a1=-1.0)
+    assert np.allclose((2j * w * np.eye(n) - J0) @ x, rhs)
