@@ -330,6 +330,14 @@ def main():
                                  alg_gb_per_call=e["bytes"] / e["calls"] / 1e9,
                                  gbs=e["bytes"] / max(e["ms"], 1e-9) / 1e6)
     compute = {k: v for k, v in kernels.items() if k not in ("alltoall", "halo")}
+    # the JVP + GMRES inner loop as a whole (north-star target: >= 60 % of peak HBM): algorithmic bytes of every profiled
+    # kernel of the timed steps over the sum of their durations
+    inner = None
+    if compute:
+        gb = sum(v["alg_gb_per_call"] * v["calls"] for v in compute.values())
+        ms = sum(v["ms_total"] for v in compute.values())
+        inner = dict(alg_gb=gb, kernel_ms=ms, gbs=gb / max(ms, 1e-9) * 1e3, frac_of_peak=gb / max(ms, 1e-9) * 1e3 / HBM_PEAK_GBS,
+                     kernel_time_share_of_wall=ms / max(dt * 1e3, 1e-9))
     dom = max(compute, key=lambda k: compute[k]["ms_total"]) if compute else None
     roofline = None
     if dom:
@@ -374,7 +382,7 @@ def main():
                                           "p": cfull["u"].p},
                        "setup_seconds": t_setup, "sh_kernel": args.sh_kernel,
                        "preconditioner": "none" if P is None else "dct"},
-            "roofline": roofline, "kernels": kernels,
+            "roofline": roofline, "inner_loop": inner, "kernels": kernels,
         }
         cb = None
         if world == 1 and args.cpu_sample > 0:

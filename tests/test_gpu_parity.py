@@ -802,3 +802,41 @@ def test_cgl_hopf_detection_along_trivial_branch(ctx):
         for lam in ev_[~np.isnan(ev_.real)]:
             assert np.abs(dense - lam).min() <= 1e-6, (r_, lam)
     assert br.n_unstable[0] == 0 and br.n_unstable[-1] >= 2 and len(br.specialpoint) >= 1     # Hopf crossings detected
+
+
+# --------------------------------------------------------------------------------------------- error behaviour
+def test_error_and_nonconvergence_behaviour(ctx):
+    """The contract of SURVEY 8(b): misuse -> negative status + message (raised by the binding); non-convergence is NOT an
+    error but `success = false` (src/LinearSolver.jl:289, src/Newton.jl:93); inputs are never written; outputs are fresh."""
+    hip = _hip()
+    from bk_amd._lib import BkHipError
+    sh, prob, rng, u = _sh_setup(ctx, (10, 8, 6), (np.pi, 2.5, 2.0), seed=41)
+    n = sh.N
+    J = prob.jacobian(prob.vec(u), 0.1)
+    rhs = prob.vec(rng.standard_normal(n))
+    keep = rhs.numpy().copy()
+    # non-convergence: unpreconditioned GMRES with a tiny budget
+    x, ok, it = hip.GMRESKrylovKit(dim=5, rtol=1e-14, atol=1e-16, maxiter=2)(J, rhs)
+    assert not ok and it > 0 and np.isfinite(x.numpy()).all()
+    x2, ok2, it2 = hip.GMRESIterativeSolvers(reltol=1e-14, restart=5, maxiter=7)(J, rhs)
+    assert not ok2 and it2 == 7
+    assert np.array_equal(rhs.numpy(), keep)                               # the right-hand side is never written
+    # zero right-hand side: immediate success, zero solution
+    z, okz, itz = hip.GMRESIterativeSolvers(reltol=1e-8, restart=20, maxiter=50)(J, prob.vec(np.zeros(n)))
+    assert okz and itz == 0 and np.abs(z.numpy()).max() == 0.0
+    # misuse: Krylov dimension beyond the basis capacity, aliasing output, Newton iteration budget beyond the record
+    with pytest.raises(BkHipError, match="Krylov dimension"):
+        hip.GMRESKrylovKit(dim=200, rtol=1e-8, atol=1e-12, maxiter=3)(J, rhs)
+    with pytest.raises(BkHipError, match="alias"):
+        ctx.check(ctx.lib.bk_op_apply(J.h, C.c_void_p(rhs.t.data_ptr()), 0.0, 1.0, C.c_void_p(rhs.t.data_ptr())), "bk_op_apply")
+    with pytest.raises(BkHipError, match="max_iterations"):
+        hip.newton_native(prob, prob.vec(u), 0.1, hip.GMRESKrylovKit(dim=10, rtol=1e-8, atol=1e-12, maxiter=3), tol=1e-9,
+                          max_iterations=1000)
+    with pytest.raises(BkHipError, match="positive"):
+        hip.BorderingBLS(hip.GMRESKrylovKit(dim=10, rtol=1e-8, atol=1e-12, maxiter=3), k=0)(J, rhs, rhs, 0.1, rhs, 0.2,
+                                                                                               dotscale=1.0)
+    # Newton that cannot converge within its budget reports converged = false and keeps the residual history
+    s = hip.newton_native(prob, prob.vec(5.0 * u), 0.1,
+                          hip.GMRESKrylovKit(dim=30, rtol=1e-9, atol=1e-12, maxiter=50, Pl=hip.DCTPreconditioner(prob, 1.0)),
+                          tol=1e-14, max_iterations=2, norm_inf=True)
+    assert not s["converged"] and s["itnewton"] == 2 and len(s["residuals"]) == 3
