@@ -832,9 +832,16 @@ def test_error_and_nonconvergence_behaviour(ctx):
     with pytest.raises(BkHipError, match="max_iterations"):
         hip.newton_native(prob, prob.vec(u), 0.1, hip.GMRESKrylovKit(dim=10, rtol=1e-8, atol=1e-12, maxiter=3), tol=1e-9,
                           max_iterations=1000)
+    with pytest.raises(AssertionError, match="positive"):             # `@assert k > 0`, src/LinearBorderSolver.jl:69-71
+        hip.BorderingBLS(hip.GMRESKrylovKit(dim=10, rtol=1e-8, atol=1e-12, maxiter=3), k=0)
+    bo = hip.L.BorderingOpts(1e-12, 1, 0)                               # ... and the same guard behind the C ABI
+    lo = hip.GMRESKrylovKit(dim=10, rtol=1e-8, atol=1e-12, maxiter=3)._opts()
+    dl, cv, itb = C.c_double(), C.c_int(), (C.c_int * 2)()
+    dX = rhs.similar()
     with pytest.raises(BkHipError, match="positive"):
-        hip.BorderingBLS(hip.GMRESKrylovKit(dim=10, rtol=1e-8, atol=1e-12, maxiter=3), k=0)(J, rhs, rhs, 0.1, rhs, 0.2,
-                                                                                               dotscale=1.0)
+        ctx.check(ctx.lib.bk_bls_bordering(ctx.h, J.h, C.c_void_p(rhs.t.data_ptr()), C.c_void_p(rhs.t.data_ptr()), 0.1,
+                                           C.c_void_p(rhs.t.data_ptr()), 0.2, 1.0, 1.0, 0, 0.0, 1.0, C.byref(bo), C.byref(lo),
+                                           None, C.c_void_p(dX.t.data_ptr()), C.byref(dl), C.byref(cv), itb), "bk_bls_bordering")
     # Newton that cannot converge within its budget reports converged = false and keeps the residual history
     s = hip.newton_native(prob, prob.vec(5.0 * u), 0.1,
                           hip.GMRESKrylovKit(dim=30, rtol=1e-9, atol=1e-12, maxiter=50, Pl=hip.DCTPreconditioner(prob, 1.0)),
