@@ -1,1 +1,4 @@
-cd "${GRAFT_REPO_ROOT:-/root/repo}"; export PYTHONPATH="$PWD"; timeout 600 python -m pytest tests -m gpu -q -x -k "error_and" 2>&1 | tail -8
+#!/bin/bash
+# one-off GPU command runner: bash scripts/gpu_one.sh '<command>' (output also lands in gpurun_out/one.log)
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; export PYTHONPATH="$PWD"; mkdir -p gpurun_out
+bash -c "$1" 2>&1 | tee gpurun_out/one.log | tail -${TAILN:-40}
