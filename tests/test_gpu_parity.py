@@ -206,7 +206,8 @@ def test_dct_preconditioner_is_exact_inverse(ctx, grid, shift):
     assert np.abs(got - ref).max() <= 1e-7 * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("dims", [(64, 64, 64), (128, 32, 16), (256, 8, 8), (16, 16, 512), (1024, 4), (8, 1024)])
+@pytest.mark.parametrize("dims", [(64, 64, 64), (128, 32, 16), (256, 8, 8), (16, 16, 512), (1024, 4), (8, 1024),
+                                  (48, 128, 64), (256, 512), (64, 64, 2), (512, 64), (32, 256, 128)])
 def test_dct_fast_path_matches_direct_and_scipy(ctx, dims):
     """LDS-FFT axis passes (dct_fast.hip) vs the O(N^2) direct kernels vs scipy's DCT on the CPU."""
     hip = _hip()
