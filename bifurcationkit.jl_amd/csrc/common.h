@@ -44,6 +44,7 @@ struct bk_ctx {
     int rank = 0, nranks = 1;
     bk::CommKind comm = bk::COMM_NONE;
     ncclComm_t nccl = nullptr;
+    void* blas = nullptr;          // rocblas_handle, created on first use by the dense transform passes (dct.hip)
     bk_allreduce_fn h_allreduce = nullptr;
     bk_sendrecv_fn h_sendrecv = nullptr;
     void* h_user = nullptr;
@@ -126,6 +127,7 @@ int reduce_finish(bk_ctx* ctx, int nblocks, int nvals, int op);
 int comm_allreduce_host(bk_ctx* ctx, double* buf, int n, int op);   // small host-side all-reduce
 
 // ---- BLAS-1 launchers (vecops.hip) ---------------------------------------------------------
+void blas_release(bk_ctx* ctx);    // dct.hip
 int v_copy(bk_ctx* ctx, size_t n, const double* x, double* y);
 int v_zero(bk_ctx* ctx, size_t n, double* x);
 int v_scale(bk_ctx* ctx, size_t n, double a, double* x);

@@ -325,6 +325,7 @@ int bk_ctx_destroy(bk_ctx* ctx) {
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->d_red) (void)hipFree(ctx->d_red);
     if (ctx->h_red) (void)hipHostFree(ctx->h_red);
+    blas_release(ctx);
     if (ctx->nccl) (void)ncclCommDestroy(ctx->nccl);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

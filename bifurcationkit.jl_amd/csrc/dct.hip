@@ -20,6 +20,8 @@
 #include <cmath>
 #include <vector>
 
+#include <rocblas/rocblas.h>
+
 #include "ops.h"
 
 namespace bk {
@@ -126,6 +128,52 @@ __global__ void __launch_bounds__(256) slab_blocks_kernel(int nx, int ny, int nz
 
 }  // namespace
 
+void blas_release(bk_ctx* ctx) {
+    if (ctx->blas) (void)rocblas_destroy_handle(static_cast<rocblas_handle>(ctx->blas));
+    ctx->blas = nullptr;
+}
+
+// Dense transform along one axis, out[.., o, ..] = sum_q M[q*N + o] in[.., q, ..]: sizes without a fast transform
+// (non-powers of two such as the reference's 22^3, the DST-I of the cGL Laplacian, N = 1024).  This IS a plain GEMM
+// -- along x: Out(rows x N) = X(rows x N) M; along y / z: Out_plane = M' X_plane, batched over the planes -- so from
+// N = 32 on it goes to rocBLAS' fp64 MFMA dgemm (the library call the design rules reserve for plain GEMMs); the
+// one-thread-per-output kernel stays for tiny extents and as a cross-check (option dct_gemm = 0).
+static int dense_axis_pass(bk_ctx* ctx, int n0, int n1, int n2, int axis, const double* M, const double* in, double* out) {
+    const int N = axis == 0 ? n0 : (axis == 1 ? n1 : n2);
+    const size_t total = (size_t)n0 * n1 * n2;
+    if (N < 32 || ctx->opt("dct_gemm", 1.0) == 0.0) {
+        hipLaunchKernelGGL(dct_axis_direct, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, n0, n1, n2, axis,
+                           M, in, out);
+        BK_HIP(ctx, hipGetLastError());
+        return 0;
+    }
+    if (!ctx->blas) {
+        rocblas_handle h = nullptr;
+        if (rocblas_create_handle(&h) != rocblas_status_success) return set_error(ctx, "rocblas_create_handle failed");
+        ctx->blas = h;
+    }
+    rocblas_handle h = static_cast<rocblas_handle>(ctx->blas);
+    if (rocblas_set_stream(h, ctx->stream) != rocblas_status_success) return set_error(ctx, "rocblas_set_stream failed");
+    const double one = 1.0, zero = 0.0;
+    rocblas_status st;
+    if (axis == 0) {
+        // row-major Out(rows x N) = X M  <=>  column-major Out'(N x rows) = M' X', and the row-major M pointer read
+        // column-major IS M'
+        const size_t rows = total / N;
+        st = rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, N, (rocblas_int)rows, N, &one, M, N, in, N, &zero,
+                           out, N);
+    } else {
+        // per plane (row-major [N][inner]): Out = M' X  <=>  column-major Out'(inner x N) = X'(inner x N) M
+        const size_t inner = axis == 1 ? (size_t)n0 : (size_t)n0 * n1;
+        const size_t batch = axis == 1 ? (size_t)n2 : 1;
+        st = rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, (rocblas_int)inner, N, N,
+                                           &one, in, (rocblas_int)inner, (rocblas_stride)(inner * N), M, N, 0, &zero, out,
+                                           (rocblas_int)inner, (rocblas_stride)(inner * N), (rocblas_int)batch);
+    }
+    if (st != rocblas_status_success) return set_error(ctx, "rocblas dgemm failed (%d)", (int)st);
+    return 0;
+}
+
 int dct_plan_create(bk_ctx* ctx, int ndim, const int n[3], const double ainv[3], double shift, DctPlan** out) {
     DctPlan* p = new DctPlan();
     p->ndim = ndim;
@@ -227,9 +275,7 @@ static int dst_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out) {
     const unsigned grid = (unsigned)((p->total + 255) / 256);
     auto pass = [&](int a, const double* in, double* o) -> int {
         ProfScope ps(ctx, "dct_pass", 16.0 * p->total);
-        hipLaunchKernelGGL(dct_axis_direct, dim3(grid), dim3(256), 0, ctx->stream, n0, n1, nb, a, p->T[a], in, o);
-        BK_HIP(ctx, hipGetLastError());
-        return 0;
+        return dense_axis_pass(ctx, n0, n1, nb, a, p->T[a], in, o);
     };
     BK_TRY(pass(0, v, p->t1));
     BK_TRY(pass(1, p->t1, p->t2));
@@ -270,10 +316,7 @@ int dct_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out) {
                                 p->ndim == 3 ? p->lam[2] : nullptr, p->shift, fuse);
         }
         // forward: out[k] = sum_n T[k][n] in[n]  -> M[q=n][o=k] = TT ; inverse: out[n] = sum_k T[k][n] in[k] -> M = T
-        hipLaunchKernelGGL(dct_axis_direct, dim3(grid), dim3(256), 0, ctx->stream, n0, n1, n2, a,
-                           inverse ? p->T[a] : p->TT[a], in, o);
-        BK_HIP(ctx, hipGetLastError());
-        return 0;
+        return dense_axis_pass(ctx, n0, n1, n2, a, inverse ? p->T[a] : p->TT[a], in, o);
     };
     // the last forward pass applies the inverse symbol while storing when it runs on the fast path
     const int last = p->ndim - 1;
@@ -393,11 +436,7 @@ static int dct_apply_dist(bk_ctx* ctx, DctPlan* p, const double* v, double* out)
         ProfScope ps(ctx, "dct_pass", 16.0 * (double)n0 * n1 * n2);
         if (use_fft && p->twid[which])
             return dct_axis_fft(ctx, n0, n1, n2, axis, inverse, p->twid[which], in, o, l0, l1, l2, p->shift, fuse, split);
-        const size_t tot = (size_t)n0 * n1 * n2;
-        hipLaunchKernelGGL(dct_axis_direct, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, n0, n1, n2, axis,
-                           inverse ? p->T[which] : p->TT[which], in, o);
-        BK_HIP(ctx, hipGetLastError());
-        return 0;
+        return dense_axis_pass(ctx, n0, n1, n2, axis, inverse ? p->T[which] : p->TT[which], in, o);
     };
     double *a = p->t1, *b = p->t2;
     const bool direct = p->kmap && use_fft && p->twid[1] && ctx->opt("dct_dist_direct", 1.0) != 0.0 &&
