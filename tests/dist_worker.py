@@ -150,6 +150,27 @@ def main_gpu(rank, world):
     ctx.set_option("dct_dist_direct", 0)
     out["Pv2_packed"] = gather_slabs(P2.ldiv(prob2.vec(v2)).numpy(), rank, world)
     ctx.set_option("dct_dist_direct", 1)
+    # a short PALC branch with every step one native call (bk_cont_step: corrector, eigenvalues, Bordered tangent) and a
+    # deflated Newton solve, on slabs
+    from bk_amd import continuation as Cn
+
+    def branch(ctx_, hip_):
+        d3, l3 = (12, 12, 12), (np.pi,) * 3
+        pr = hip_.SwiftHohenberg(ctx_, d3, l3)
+        sh3 = operators.SwiftHohenberg(d3, l3)
+        lsb = hip_.GMRESKrylovKit(dim=30, rtol=1e-10, atol=1e-13, maxiter=150, Pl=hip_.DCTPreconditioner(pr, 0.0))
+        eg = hip_.ShiftInvert(0.1, lsb, tol=1e-9, maxiter=20, hermitian=True, save_vectors=False)
+        nopt = Cn.NewtonPar(tol=1e-9, max_iterations=15, linsolver=lsb, eigsolver=eg)
+        cp = Cn.ContinuationPar(ds=-0.001, dsmin=1e-4, dsmax=0.005, p_min=-0.1, p_max=0.15, max_steps=2, nev=4,
+                                detect_bifurcation=3, newton_options=nopt)
+        alg = Cn.PALC(tangent="bordered", theta=0.5, bls=hip_.BorderingBLS(None, check_precision=False))
+        br = Cn.continuation_native(pr, pr.vec(sh3.guess()), 0.1, alg, cp, normC=Cn.norminf)
+        dfl = hip_.DeflationOperator(2, 1.0, [pr.vec(np.zeros(sh3.N))])
+        sd = hip_.newton_deflated_native(pr, dfl, pr.vec(0.4 * sh3.guess()), 0.1, lsb, tol=1e-9, max_iterations=60, norm_inf=True)
+        return dict(param=br.param, itnewton=br.itnewton, eig=[e.real for e in br.eig], n_unstable=br.n_unstable,
+                    defl=(sd["converged"], sd["itnewton"], sd["residuals"][:3]))
+
+    out["branch"] = branch(ctx, hip)
     ctx.close()
     if rank == 0:
         c1 = hip.Context(0)
@@ -158,6 +179,14 @@ def main_gpu(rank, world):
         assert np.array_equal(out["Pv2"], out["Pv2_packed"])
         assert np.allclose(out["Pv2"], ref2, rtol=1e-12, atol=1e-14), np.abs(out["Pv2"] - ref2).max()
         assert np.allclose(ref2, operators.dct_preconditioner(dims2, ls2, 1.0)(v2), rtol=1e-10, atol=1e-13)
+        b1 = branch(c1, hip)
+        assert len(out["branch"]["param"]) == len(b1["param"]) == 3
+        assert np.allclose(out["branch"]["param"], b1["param"], rtol=0, atol=1e-10), (out["branch"]["param"], b1["param"])
+        assert out["branch"]["itnewton"] == b1["itnewton"] and out["branch"]["n_unstable"] == b1["n_unstable"]
+        for ea, eb in zip(out["branch"]["eig"], b1["eig"]):
+            assert np.allclose(ea, eb, rtol=0, atol=1e-7, equal_nan=True)
+        # deflated Newton: the first iterates agree (later ones amplify the 1e-8 finite-difference noise of dM differently)
+        assert np.allclose(out["branch"]["defl"][2], b1["defl"][2], rtol=1e-5), (out["branch"]["defl"], b1["defl"])
         p1 = hip.SwiftHohenberg(c1, dims, ls)
         U1, V1, R1 = p1.vec(u), p1.vec(v), p1.vec(r)
         assert np.isclose(out["dot"], U1.inner(V1), rtol=1e-13)
