@@ -44,6 +44,8 @@ struct bk_ctx {
     int rank = 0, nranks = 1;
     bk::CommKind comm = bk::COMM_NONE;
     ncclComm_t nccl = nullptr;
+    hipStream_t comm_stream = nullptr;   // halo exchange runs here, overlapped with the interior z-chunks of the JVP
+    hipEvent_t ev_ready = nullptr, ev_halo = nullptr;
     void* blas = nullptr;          // rocblas_handle, created on first use by the dense transform passes (dct.hip)
     bk_allreduce_fn h_allreduce = nullptr;
     bk_sendrecv_fn h_sendrecv = nullptr;

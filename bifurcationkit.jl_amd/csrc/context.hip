@@ -147,7 +147,7 @@ int reduce_finish(bk_ctx* ctx, int nblocks, int nvals, int op) {
 // ------------------------------------------------------------------ halo exchange
 // Exchange `width` boundary planes (plane = `plane` doubles) of the local slab `v` (nplanes planes)
 // with the neighbour ranks: halo_lo <- last planes of rank-1, halo_hi <- first planes of rank+1.
-int halo_exchange(bk_ctx* ctx, const double* v, size_t plane, int nplanes, int width, double* halo_lo,
+int halo_exchange(bk_ctx* ctx, hipStream_t stream, const double* v, size_t plane, int nplanes, int width, double* halo_lo,
                   double* halo_hi) {
     if (ctx->nranks == 1) return 0;
     const int lo = ctx->rank - 1, hi = ctx->rank + 1;
@@ -159,21 +159,21 @@ int halo_exchange(bk_ctx* ctx, const double* v, size_t plane, int nplanes, int w
     if (ctx->comm == COMM_RCCL) {
         BK_NCCL(ctx, ncclGroupStart());
         if (has_lo) {
-            BK_NCCL(ctx, ncclSend(send_lo, cnt, ncclDouble, lo, ctx->nccl, ctx->stream));
-            BK_NCCL(ctx, ncclRecv(halo_lo, cnt, ncclDouble, lo, ctx->nccl, ctx->stream));
+            BK_NCCL(ctx, ncclSend(send_lo, cnt, ncclDouble, lo, ctx->nccl, stream));
+            BK_NCCL(ctx, ncclRecv(halo_lo, cnt, ncclDouble, lo, ctx->nccl, stream));
         }
         if (has_hi) {
-            BK_NCCL(ctx, ncclSend(send_hi, cnt, ncclDouble, hi, ctx->nccl, ctx->stream));
-            BK_NCCL(ctx, ncclRecv(halo_hi, cnt, ncclDouble, hi, ctx->nccl, ctx->stream));
+            BK_NCCL(ctx, ncclSend(send_hi, cnt, ncclDouble, hi, ctx->nccl, stream));
+            BK_NCCL(ctx, ncclRecv(halo_hi, cnt, ncclDouble, hi, ctx->nccl, stream));
         }
         BK_NCCL(ctx, ncclGroupEnd());
         return 0;
     }
     // host-staged (test communicator)
     std::vector<double> s_lo(has_lo ? cnt : 0), s_hi(has_hi ? cnt : 0), r_lo(has_lo ? cnt : 0), r_hi(has_hi ? cnt : 0);
-    if (has_lo) BK_HIP(ctx, hipMemcpyAsync(s_lo.data(), send_lo, cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (has_hi) BK_HIP(ctx, hipMemcpyAsync(s_hi.data(), send_hi, cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
-    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (has_lo) BK_HIP(ctx, hipMemcpyAsync(s_lo.data(), send_lo, cnt * 8, hipMemcpyDeviceToHost, stream));
+    if (has_hi) BK_HIP(ctx, hipMemcpyAsync(s_hi.data(), send_hi, cnt * 8, hipMemcpyDeviceToHost, stream));
+    BK_HIP(ctx, hipStreamSynchronize(stream));
     // even ranks talk to the upper neighbour first, odd ranks to the lower one (deadlock-free pairing)
     for (int phase = 0; phase < 2; ++phase) {
         const bool up = ((ctx->rank & 1) == 0) ? (phase == 0) : (phase == 1);
@@ -185,9 +185,9 @@ int halo_exchange(bk_ctx* ctx, const double* v, size_t plane, int nplanes, int w
                 return set_error(ctx, "host sendrecv callback failed");
         }
     }
-    if (has_lo) BK_HIP(ctx, hipMemcpyAsync(halo_lo, r_lo.data(), cnt * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (has_hi) BK_HIP(ctx, hipMemcpyAsync(halo_hi, r_hi.data(), cnt * 8, hipMemcpyHostToDevice, ctx->stream));
-    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (has_lo) BK_HIP(ctx, hipMemcpyAsync(halo_lo, r_lo.data(), cnt * 8, hipMemcpyHostToDevice, stream));
+    if (has_hi) BK_HIP(ctx, hipMemcpyAsync(halo_hi, r_hi.data(), cnt * 8, hipMemcpyHostToDevice, stream));
+    BK_HIP(ctx, hipStreamSynchronize(stream));
     return 0;
 }
 
@@ -326,6 +326,9 @@ int bk_ctx_destroy(bk_ctx* ctx) {
     if (ctx->d_red) (void)hipFree(ctx->d_red);
     if (ctx->h_red) (void)hipHostFree(ctx->h_red);
     blas_release(ctx);
+    if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
+    if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);
+    if (ctx->ev_halo) (void)hipEventDestroy(ctx->ev_halo);
     if (ctx->nccl) (void)ncclCommDestroy(ctx->nccl);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -6,7 +6,7 @@
 
 namespace bk {
 
-int halo_exchange(bk_ctx* ctx, const double* v, size_t plane, int nplanes, int width, double* halo_lo,
+int halo_exchange(bk_ctx* ctx, hipStream_t stream, const double* v, size_t plane, int nplanes, int width, double* halo_lo,
                   double* halo_hi);
 
 int comm_alltoallv(bk_ctx* ctx, const double* sendbuf, const size_t* scount, const size_t* sdispl, double* recvbuf,
@@ -25,6 +25,7 @@ struct ShArgs {             // Swift-Hohenberg 2-D/3-D, Neumann-ghost (mirror) b
     double* out;
     const double* halo_lo;  // 2 planes below local plane 0 (multi-GPU interior boundary) or NULL
     const double* halo_hi;  // 2 planes above local plane nz-1 or NULL
+    int part = 0;           // 0: all z-chunks; 1: the chunks that read no halo plane; 2: the two face chunks (halo overlap)
 };
 int sh_apply(bk_ctx* ctx, const ShArgs& a);
 

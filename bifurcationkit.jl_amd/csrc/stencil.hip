@@ -48,6 +48,7 @@ struct ShK {                // kernel-side copy of ShArgs (+ derived constants)
     const double* halo_lo;
     const double* halo_hi;
     int zchunk, ntx, nty, nzc, nblocks, grid8;
+    int zc0;                // first z-chunk of this launch (multi-GPU: interior and face chunks go in separate launches)
     int vec_ok;
 };
 
@@ -122,7 +123,7 @@ __global__ void __launch_bounds__(256) sh_stream_kernel(ShK P) {
     if (L >= P.nblocks) return;
     const int tix = L % P.ntx;
     const int tiy = (L / P.ntx) % P.nty;
-    const int zc = L / (P.ntx * P.nty);
+    const int zc = P.zc0 + L / (P.ntx * P.nty);
     const int x0 = tix * TX, y0 = tiy * TY;
     const int zs = zc * P.zchunk;
     const int ze = min(zs + P.zchunk, P.nz);
@@ -396,8 +397,10 @@ int sh_apply(bk_ctx* ctx, const ShArgs& a) {
     const size_t n = (size_t)a.nx * a.ny * a.nz;
     const bool dim3d = a.az != 0.0;
     const int variant = (int)ctx->opt("sh_kernel", 1.0);
-    ProfScope ps(ctx, a.mode == 0 ? "jvp" : "residual", (a.mode == 0 ? 24.0 : 16.0) * n);
+    P.zc0 = 0;
     if (variant == 0) {
+        if (a.part == 1) return 0;                            // the gather cross-check runs whole once the halos are in
+        ProfScope ps(ctx, a.mode == 0 ? "jvp" : "residual", (a.mode == 0 ? 24.0 : 16.0) * n);
         P.zchunk = 0; P.ntx = P.nty = P.nzc = P.nblocks = P.grid8 = 0; P.vec_ok = 0;
         const size_t grid = (n + 255) / 256;
         hipLaunchKernelGGL(sh_gather_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, P);
@@ -416,12 +419,30 @@ int sh_apply(bk_ctx* ctx, const ShArgs& a) {
         if (zchunk > a.nz) zchunk = a.nz;
         P.zchunk = zchunk;
         P.nzc = (a.nz + zchunk - 1) / zchunk;
-        P.nblocks = P.ntx * P.nty * P.nzc;
-        P.grid8 = (P.nblocks + 7) / 8 * 8;
         P.vec_ok = ((a.nx & 1) == 0) && (((uintptr_t)a.out & 15) == 0) &&
                    (a.mode != 0 || ((uintptr_t)a.u & 15) == 0);
-        if (dim3d) hipLaunchKernelGGL((sh_stream_kernel<true>), dim3(P.grid8), dim3(256), 0, ctx->stream, P);
-        else hipLaunchKernelGGL((sh_stream_kernel<false>), dim3(P.grid8), dim3(256), 0, ctx->stream, P);
+        // part 0: everything; part 1: the chunks that touch no halo plane (1 .. nzc-2); part 2: the two face chunks
+        auto launch = [&](int zc0, int count) {
+            if (count <= 0) return;
+            P.zc0 = zc0;
+            P.nblocks = P.ntx * P.nty * count;
+            P.grid8 = (P.nblocks + 7) / 8 * 8;
+            ProfScope ps(ctx, a.mode == 0 ? "jvp" : "residual", (a.mode == 0 ? 24.0 : 16.0) * n * count / P.nzc);
+            if (dim3d) hipLaunchKernelGGL((sh_stream_kernel<true>), dim3(P.grid8), dim3(256), 0, ctx->stream, P);
+            else hipLaunchKernelGGL((sh_stream_kernel<false>), dim3(P.grid8), dim3(256), 0, ctx->stream, P);
+        };
+        // face chunks: the first one (reads planes -2, -1) and the last one -- the last two when the last chunk is a
+        // single plane, because its lower neighbour then reads plane nz
+        const int tail = (a.nz - (P.nzc - 1) * zchunk < 2) ? 2 : 1;
+        const int inner = (zchunk >= 2) ? P.nzc - 1 - tail : 0;
+        if (a.part == 0 || inner <= 0) {
+            if (a.part != 1) launch(0, P.nzc);                // nothing can be split off: everything waits for the halos
+        } else if (a.part == 1) {
+            launch(1, inner);
+        } else {
+            launch(0, 1);
+            launch(1 + inner, tail);
+        }
     }
     BK_HIP(ctx, hipGetLastError());
     return 0;

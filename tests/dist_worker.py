@@ -129,6 +129,15 @@ def main_gpu(rank, world):
     ctx.set_option("sh_kernel", 0)
     out["Jv_gather"] = gather_slabs(J(V, 0.2, 0.8).numpy(), rank, world)
     ctx.set_option("sh_kernel", 1)
+    # split launches of the halo overlap: interior z-chunks first, the face chunks after the exchange (chunk lengths 2, 3
+    # and a single-plane last chunk), and the unsplit launch
+    for zc in (2, 3, 9):
+        ctx.set_option("sh_zchunk", zc)
+        out[f"Jv_zc{zc}"] = gather_slabs(J(V, 0.2, 0.8).numpy(), rank, world)
+    ctx.set_option("halo_split", 0)
+    out["Jv_nosplit"] = gather_slabs(J(V, 0.2, 0.8).numpy(), rank, world)
+    ctx.set_option("halo_split", 1)
+    ctx.set_option("sh_zchunk", 0)
     P = hip.DCTPreconditioner(prob, 1.0)
     out["Pv"] = gather_slabs(P.ldiv(V).numpy(), rank, world)
     lsol = hip.GMRESKrylovKit(dim=30, rtol=1e-10, atol=1e-13, maxiter=100, Pl=P)
@@ -196,6 +205,8 @@ def main_gpu(rank, world):
         ref = J1(V1, 0.2, 0.8).numpy()
         assert np.allclose(out["Jv"], ref, rtol=1e-14, atol=1e-11), np.abs(out["Jv"] - ref).max()
         assert np.allclose(out["Jv_gather"], ref, rtol=1e-13, atol=1e-10)
+        for key in ("Jv_zc2", "Jv_zc3", "Jv_zc9", "Jv_nosplit"):
+            assert np.array_equal(out[key], out["Jv"]), key
         P1 = hip.DCTPreconditioner(p1, 1.0)
         assert np.allclose(out["Pv"], P1.ldiv(V1).numpy(), rtol=1e-12, atol=1e-14)
         l1 = hip.GMRESKrylovKit(dim=30, rtol=1e-10, atol=1e-13, maxiter=100, Pl=P1)
