@@ -803,6 +803,15 @@ def test_cgl_hopf_detection_along_trivial_branch(ctx):
         for lam in ev_[~np.isnan(ev_.real)]:
             assert np.abs(dense - lam).min() <= 1e-6, (r_, lam)
     assert br.n_unstable[0] == 0 and br.n_unstable[-1] >= 2 and len(br.specialpoint) >= 1     # Hopf crossings detected
+    # the same branch with every step one native call (non-Hermitian eigensolver, complex pairs, IterativeSolvers flavor)
+    bn = Cn.continuation_native(prob, prob.vec(np.zeros(n2)), 0.5, alg, cp, normC=Cn.norminf)
+    assert len(bn.param) == len(br.param) and np.allclose(bn.param, br.param, rtol=0, atol=1e-12)
+    assert bn.n_unstable == br.n_unstable and bn.n_imag == br.n_imag
+    assert [d["step"] for d in bn.specialpoint] == [d["step"] for d in br.specialpoint]
+    for a_, b_ in zip(bn.eig, br.eig):
+        assert len(a_) == len(b_)
+        ok_ = ~np.isnan(b_.real)
+        assert np.array_equal(np.isnan(a_.real), np.isnan(b_.real)) and np.allclose(a_[ok_], b_[ok_], rtol=0, atol=1e-8)
 
 
 # --------------------------------------------------------------------------------------------- error behaviour
