@@ -132,6 +132,7 @@ SIGNATURES = {
                                     VP, VP, VP, c_double_p, c_int_p, c_int_p]),
     "bk_eig_shiftinvert": (I, [VP, VP, I, C.POINTER(EigOpts), C.POINTER(GmresOpts), VP, c_double_p, c_double_p,
                                VP, VP, SZ, c_int_p, c_int_p, c_int_p]),
+    "bk_eig_krylovkit": (I, [VP, VP, I, C.POINTER(EigOpts), c_double_p, c_double_p, VP, VP, SZ, c_int_p, c_int_p, c_int_p]),
     "bk_newton": (I, [VP, VP, VP, c_double_p, I, C.POINTER(NewtonOpts), C.POINTER(GmresOpts), VP,
                       C.POINTER(NewtonResult)]),
     "bk_cont_create": (I, [VP, VP, c_double_p, I, I, VP, D, VP, D, C.POINTER(ContOpts), C.POINTER(NewtonOpts),

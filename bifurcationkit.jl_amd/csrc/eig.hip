@@ -54,18 +54,15 @@ struct ShiftInvertOp : bk_op {
 using namespace bk;
 using dense::cplx;
 
-extern "C" int bk_eig_shiftinvert(bk_ctx* ctx, bk_op* J, int nev, const bk_eig_opts* eo, const bk_gmres_opts* lsopts,
-                                  bk_precond* pl, double* vals_re, double* vals_im, double* vecs, double* vecs_im,
-                                  size_t ldvecs, int* nvals_out, int* nconv_out, int* numops_out) {
-    if (!ctx || !J || !eo || !lsopts || !vals_re || !vals_im || nev < 1) return -1;
-    if (J->ntail != 0) return set_error(ctx, "bk_eig_shiftinvert: operator must be unbordered");
-    const size_t n = J->n;
+// Krylov-Schur core on an operator `Aop`.  invert: Aop = (J - sigma)^-1, Ritz values are ordered by magnitude (:LM) and
+// mapped back by 1/mu + sigma; otherwise Aop = J itself and the order is by real part (:LR, EigKrylovKit's default use).
+static int eig_core(bk_ctx* ctx, bk_op* Aop, bool invert, int nev, const bk_eig_opts* eo, double* vals_re, double* vals_im,
+                    double* vecs, double* vecs_im, size_t ldvecs, int* nvals_out, int* nconv_out, int* napplied) {
+    bk_op& A = *Aop;
+    const size_t n = A.n;
     int m = eo->krylovdim;
     if (m > kMaxBasis - 1) m = kMaxBasis - 1;
-    if (nev > m) return set_error(ctx, "bk_eig_shiftinvert: nev=%d exceeds the Krylov dimension %d", nev, m);
-    ShiftInvertOp A;
-    A.ctx = ctx; A.n = n; A.ntail = 0; A.ls = *lsopts; A.pl = pl;
-    A.Js.ctx = ctx; A.Js.n = n; A.Js.ntail = 0; A.Js.J = J; A.Js.sigma = eo->sigma;
+    if (nev > m) return set_error(ctx, "eigensolver: nev=%d exceeds the Krylov dimension %d", nev, m);
 
     WsGuard ws(ctx);
     const size_t ld = (n + 31) / 32 * 32;
@@ -94,7 +91,7 @@ extern "C" int bk_eig_shiftinvert(bk_ctx* ctx, bk_op* J, int nev, const bk_eig_o
     BK_TRY(v_scale(ctx, n, 1.0 / nrm, V));
 
     dense::Mat H(m + 1, m);
-    int k = 0, numiter = 0, nconv = 0;
+    int k = 0, numiter = 0, nconv = 0, applied = 0;
     std::vector<cplx> mu;
     dense::CMat Y;
     std::vector<int> order;
@@ -107,6 +104,7 @@ extern "C" int bk_eig_shiftinvert(bk_ctx* ctx, bk_op* J, int nev, const bk_eig_o
         while (k < meff) {
             double beta = 0.0;
             BK_TRY(arnoldi_step_public(ctx, &A, V, ld, tails, k, w, h.data(), &beta));
+            applied += 1;
             for (int i = 0; i <= k; ++i) H(i, k) = h[i];
             H(k + 1, k) = beta;
             k += 1;
@@ -134,7 +132,8 @@ extern "C" int bk_eig_shiftinvert(bk_ctx* ctx, bk_op* J, int nev, const bk_eig_o
         }
         order.resize(meff);
         for (int i = 0; i < meff; ++i) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return std::abs(mu[x]) > std::abs(mu[y]); });  // :LM
+        if (invert) std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return std::abs(mu[x]) > std::abs(mu[y]); });  // :LM
+        else std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return mu[x].real() > mu[y].real(); });              // :LR
         resid.assign(meff, 0.0);
         for (int jj = 0; jj < meff; ++jj) {
             const int j = order[jj];
@@ -205,7 +204,7 @@ extern "C" int bk_eig_shiftinvert(bk_ctx* ctx, bk_op* J, int nev, const bk_eig_o
         // "usable": Ritz residual below tol, or below sqrt(eps)|mu| -- the level inexact inner solves (rtol 1e-9 in
         // examples/SH3d.jl:115 against tol 1e-12) leave behind; the eigenvalue is then accurate to that level
         okv[jj] = (breakdown || resid[jj] < std::max(eo->tol, 1.4901161193847656e-08 * std::abs(mu[order[jj]]))) ? 1 : 0;
-        lam[jj] = okv[jj] ? cplx(1.0, 0.0) / mu[order[jj]] + eo->sigma : cplx(NAN, NAN);
+        lam[jj] = okv[jj] ? (invert ? cplx(1.0, 0.0) / mu[order[jj]] + eo->sigma : mu[order[jj]]) : cplx(NAN, NAN);
     }
     std::vector<int> perm(nout);
     for (int i = 0; i < nout; ++i) perm[i] = i;
@@ -231,6 +230,30 @@ extern "C" int bk_eig_shiftinvert(bk_ctx* ctx, bk_op* J, int nev, const bk_eig_o
         if (vecs_im) BK_TRY(v_basis_combine(ctx, n, V, ld, meff, Qi.data(), nout, vecs_im, ldvecs));
     }
     if (nconv_out) *nconv_out = std::min(nconv, nout);      // strictly converged (resid < tol), as info.converged
+    if (napplied) *napplied = applied;
+    return 0;
+}
+
+extern "C" int bk_eig_shiftinvert(bk_ctx* ctx, bk_op* J, int nev, const bk_eig_opts* eo, const bk_gmres_opts* lsopts,
+                                  bk_precond* pl, double* vals_re, double* vals_im, double* vecs, double* vecs_im,
+                                  size_t ldvecs, int* nvals_out, int* nconv_out, int* numops_out) {
+    if (!ctx || !J || !eo || !lsopts || !vals_re || !vals_im || nev < 1) return -1;
+    if (J->ntail != 0) return set_error(ctx, "bk_eig_shiftinvert: operator must be unbordered");
+    ShiftInvertOp A;
+    A.ctx = ctx; A.n = J->n; A.ntail = 0; A.ls = *lsopts; A.pl = pl;
+    A.Js.ctx = ctx; A.Js.n = J->n; A.Js.ntail = 0; A.Js.J = J; A.Js.sigma = eo->sigma;
+    BK_TRY(eig_core(ctx, &A, true, nev, eo, vals_re, vals_im, vecs, vecs_im, ldvecs, nvals_out, nconv_out, nullptr));
     if (numops_out) *numops_out = A.solves;
     return 0;
+}
+
+// (eig::EigKrylovKit)(J, nev) with which = :LR (src/EigSolver.jl:117-166): KrylovKit.eigsolve on J itself -- the
+// rightmost eigenvalues without a shift-invert solve (only practical on mildly stiff operators; the PDE examples use
+// ShiftInvert).  eo->sigma is ignored.
+extern "C" int bk_eig_krylovkit(bk_ctx* ctx, bk_op* J, int nev, const bk_eig_opts* eo, double* vals_re, double* vals_im,
+                                double* vecs, double* vecs_im, size_t ldvecs, int* nvals_out, int* nconv_out,
+                                int* numops_out) {
+    if (!ctx || !J || !eo || !vals_re || !vals_im || nev < 1) return -1;
+    if (J->ntail != 0) return set_error(ctx, "bk_eig_krylovkit: operator must be unbordered");
+    return eig_core(ctx, J, false, nev, eo, vals_re, vals_im, vecs, vecs_im, ldvecs, nvals_out, nconv_out, numops_out);
 }

@@ -673,6 +673,45 @@ class ShiftInvert:
         return vecs[n]
 
 
+@dataclass
+class EigKrylovKit:
+    """EigKrylovKit (src/EigSolver.jl:117-166) with ``which = :LR``: KrylovKit.eigsolve on the Jacobian itself, no inner
+    solves.  ``(eig)(J, nev) -> (vals, vecs, converged, numops)`` sorted by decreasing real part."""
+    tol: float = 1e-6
+    maxiter: int = 100
+    krylovdim: int = 30
+    hermitian: bool = False
+    seed: int = 1234
+    save_vectors: bool = False
+
+    def __call__(self, J: HipJacobian, nev: int, **kwargs):
+        ctx = J.ctx
+        kd = min(self.krylovdim, 63, J.prob.nglobal - 1)
+        nev = min(nev, kd)
+        eo = L.EigOpts(0.0, int(kd), int(self.maxiter), float(self.tol), 1 if self.hermitian else 0, int(self.seed))
+        re = (C.c_double * (nev + 1))()
+        im = (C.c_double * (nev + 1))()
+        n = J.prob.nlocal
+        ld = (n + 31) // 32 * 32
+        vr = ctx.empty(ld * (nev + 1)) if self.save_vectors else None
+        vi = ctx.empty(ld * (nev + 1)) if (self.save_vectors and not self.hermitian) else None
+        nvals, nconv, nops = C.c_int(), C.c_int(), C.c_int()
+        ctx.check(ctx.lib.bk_eig_krylovkit(ctx.h, J.h, nev, C.byref(eo), re, im, _ptr(vr) if vr is not None else None,
+                                           _ptr(vi) if vi is not None else None, ld, C.byref(nvals), C.byref(nconv),
+                                           C.byref(nops)), "bk_eig_krylovkit")
+        m = nvals.value
+        vals = np.array([complex(re[i], im[i]) for i in range(m)])
+        vecs = None
+        if vr is not None:
+            vecs = [(HipVec(ctx, vr[i * ld:i * ld + n], J.prob.nglobal),
+                     HipVec(ctx, vi[i * ld:i * ld + n], J.prob.nglobal) if vi is not None else None) for i in range(m)]
+        return vals, vecs, nconv.value >= nev, nops.value
+
+    @staticmethod
+    def geteigenvector(vecs, n):
+        return vecs[n]
+
+
 # ------------------------------------------------------------------------------------------ native correctors
 def newton_native(prob: _PdeProblem, x0: HipVec, p: float, ls: _GMRES, tol=1e-12, max_iterations=25, norm_inf=False):
     """_newton (src/Newton.jl:66-114) as one library call."""

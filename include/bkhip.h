@@ -238,6 +238,10 @@ int bk_eig_shiftinvert(bk_ctx* ctx, bk_op* J, int nev, const bk_eig_opts* eopts,
                        const bk_gmres_opts* lsopts, bk_precond* pl, double* vals_re,
                        double* vals_im, double* vecs, double* vecs_im, size_t ldvecs, int* nvals,
                        int* nconv, int* numops);
+/* (eig::EigKrylovKit)(J, nev), which = :LR (src/EigSolver.jl:117-166): Krylov-Schur on J itself, rightmost eigenvalues,
+ * no inner solves (sigma ignored); same output conventions as bk_eig_shiftinvert; *numops = operator applications.   */
+int bk_eig_krylovkit(bk_ctx* ctx, bk_op* J, int nev, const bk_eig_opts* eopts, double* vals_re, double* vals_im,
+                     double* vecs, double* vecs_im, size_t ldvecs, int* nvals, int* nconv, int* numops);
 
 /* ------------------------------------------------------------------ Newton correctors ------ */
 typedef struct {

@@ -18,7 +18,7 @@ def _declared():
 
 def test_header_declares_the_boundary():
     names = _declared()
-    for must in ["bk_gmres", "bk_gmres2", "bk_bls_bordering", "bk_bls_matrixfree", "bk_bls_block_bordering", "bk_gmres_cshift", "bk_jacobian_adjoint", "bk_bls_bordering_cshift", "bk_bls_block_matrixfree", "bk_newton_deflated", "bk_cont_create", "bk_cont_step", "bk_eig_shiftinvert",
+    for must in ["bk_gmres", "bk_gmres2", "bk_bls_bordering", "bk_bls_matrixfree", "bk_bls_block_bordering", "bk_gmres_cshift", "bk_jacobian_adjoint", "bk_bls_bordering_cshift", "bk_bls_block_matrixfree", "bk_newton_deflated", "bk_cont_create", "bk_cont_step", "bk_eig_shiftinvert", "bk_eig_krylovkit",
                  "bk_newton_palc", "bk_newton", "bk_residual", "bk_jacobian", "bk_op_apply", "bk_vec_dot",
                  "bk_precond_sh_create", "bk_ctx_create_dist"]:
         assert must in names

@@ -577,6 +577,33 @@ def _native_corrector(hip, Cn, prob, z, tau, zp, ds, theta, bls, nopt, pmin, pma
     return Cn.NonLinearSolution(r["u"], r["residuals"], r["converged"], r["itnewton"], r["itlineartot"])
 
 
+def test_eig_krylovkit_rightmost_vs_dense(ctx):
+    """EigKrylovKit(which = :LR) (src/EigSolver.jl:117-166): rightmost eigenvalues from Krylov-Schur on J itself, against
+    the dense spectrum (test_linear.jl:616-663 pattern: sorted by decreasing real part, complex pairs kept together)."""
+    hip = _hip()
+    dims, ls_ = (12, 7), (6.0, 3.5)                         # coarse grid: |Lap| ~ 10, the rightmost end is reachable
+    c = operators.CGL2d(dims, ls_)
+    prob = hip.CGL2d(ctx, dims, ls_)
+    n2 = 2 * c.n
+    pars = c.default_params()
+    pars["r"] = 1.2
+    dense = np.linalg.eigvals(c.J(np.zeros(n2), **pars).toarray())
+    dense = dense[np.argsort(-dense.real, kind="stable")]
+    J = prob.jacobian(prob.vec(np.zeros(n2)), 1.2)
+    eig = hip.EigKrylovKit(tol=1e-9, maxiter=200, krylovdim=40, hermitian=False, save_vectors=True)
+    vals, vecs, cv, nops = eig(J, 4)
+    assert cv and nops > 0 and len(vals) in (4, 5)
+    assert np.all(np.diff(vals.real) <= 1e-9)                                   # decreasing real part
+    for lam in vals:
+        assert np.abs(dense - lam).min() <= 1e-7, lam
+    assert abs(vals[0].real - dense[0].real) <= 1e-7                           # and it IS the rightmost one
+    # eigenvector residual |J v - lam v| for the first pair
+    vr, vi = vecs[0]
+    Jm = c.J(np.zeros(n2), **pars).toarray()
+    v = vr.numpy() + 1j * vi.numpy()
+    assert np.linalg.norm(Jm @ v - vals[0] * v) <= 1e-6 * np.linalg.norm(v)
+
+
 # --------------------------------------------------------------------------------------------- complex shifts (Hopf)
 def test_complex_shift_linear_solve_vs_dense(ctx):
     """ls(L, rhs; a0 = Complex(0, 2w), a1 = -1) (src/NormalForms.jl:1053) on a complex right-hand side: (re, im) pairs,
