@@ -220,6 +220,34 @@ function (l::HipGMRES)(J::HipJacobian, rhs::HipVec; a₀ = 0.0, a₁ = 1.0, kwar
 end
 # (ls)(J, rhs1, rhs2) keeps the default of src/LinearSolver.jl:15-19 (two calls of the method above).
 
+# Complex device vectors of the Hopf machinery: (re, im) pairs of HipVec.
+struct HipCVec
+    re::HipVec
+    im::HipVec
+end
+# ls(L, rhs; a₀ = Complex(0, 2ω), a₁ = -1), src/NormalForms.jl:1053
+function (l::HipGMRES)(J::HipJacobian, rhs::HipCVec; a₀ = 0.0, a₁ = 1.0, kwargs...)
+    ctx = rhs.re.ctx
+    x = HipCVec(similar(rhs.re), similar(rhs.re))
+    cv, it, rn = Ref{Cint}(0), Ref{Cint}(0), Ref{Cdouble}(0)
+    a0 = a₀ isa Number ? ComplexF64(a₀) : ComplexF64(0)
+    check(ctx, ccall((:bk_gmres_cshift, libbkhip[]), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Cdouble, Ref{GmresOpts},
+         Ptr{Cvoid}, Ref{Cint}, Ref{Cint}, Ref{Cdouble}),
+        ctx.h, J.h, rhs.re.p, rhs.im.p, x.re.p, x.im.p, real(a0), imag(a0), _num(a₁, 1.0), Ref(_opts(l)), _plh(l.Pl), cv, it, rn),
+        "bk_gmres_cshift")
+    return x, cv[] == 1, Int(it[])
+end
+# the adjoint Jacobian JAd of src/codim2/MinAugHopf.jl:66-80 (transposed pointwise block for cGL, J itself for SH)
+function jacobian_adjoint(prob::HipProblem, u::HipVec, par)
+    pv = Cdouble[Float64(x) for x in Tuple(par)][1:prob.nparams]
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    check(prob.ctx, ccall((:bk_jacobian_adjoint, libbkhip[]), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ref{Ptr{Cvoid}}),
+                          prob.h, u.p, pv, length(pv), r), "bk_jacobian_adjoint")
+    J = HipJacobian(prob, r[], u)
+    finalizer(j -> ccall((:bk_op_destroy, libbkhip[]), Cint, (Ptr{Cvoid},), j.h), J)
+end
+
 # ------------------------------------------------------------------------------------------------ bordered solvers
 """
     HipBorderingBLS(solver; tol = 1e-12, check_precision = true, k = 1)
@@ -250,6 +278,24 @@ function (lbs::HipBorderingBLS)(J::HipJacobian, dR::HipVec, dzu::HipVec, dzp::T,
         ctx.h, J.h, dR.p, dzu.p, dzp, R.p, n, ξu, ξp, isnothing(shift) ? 0 : 1, isnothing(shift) ? 0.0 : shift, _dotscale(dotp, R),
         Ref(bo), Ref(_opts(lbs.solver)), _plh(lbs.solver.Pl), dX.p, dl, cv, it), "bk_bls_bordering")
     return dX, dl[], cv[] == 1, (Int(it[1]), Int(it[2]))
+end
+
+# bls(J, a, b, 0, 0, 1; shift = Complex(0, -ω)) of src/codim2/MinAugHopf.jl:17, 72-76: complex border, one BEC pass
+function (lbs::HipBorderingBLS)(J::HipJacobian, dR::HipCVec, dzu::HipCVec, dzp, R::HipCVec, n, ξu = 1.0, ξp = 1.0;
+                                shift = nothing, dotp = nothing, applyξu! = nothing)
+    ctx = R.re.ctx
+    dX = HipCVec(similar(R.re), similar(R.re))
+    dl, cv, it = zeros(Cdouble, 2), Ref{Cint}(0), zeros(Cint, 2)
+    sh = isnothing(shift) ? ComplexF64(0) : ComplexF64(shift)
+    zp, nn = ComplexF64(dzp), ComplexF64(n)
+    check(ctx, ccall((:bk_bls_bordering_cshift, libbkhip[]), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Ptr{Cdouble}, Ptr{Cdouble},
+         Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Ref{GmresOpts}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble},
+         Ptr{Cdouble}, Ref{Cint}, Ptr{Cint}),
+        ctx.h, J.h, dR.re.p, dR.im.p, dzu.re.p, dzu.im.p, real(zp), imag(zp), R.re.p, R.im.p, real(nn), imag(nn), ξu, ξp,
+        real(sh), imag(sh), _dotscale(dotp, R.re), Ref(_opts(lbs.solver)), _plh(lbs.solver.Pl), dX.re.p, dX.im.p, dl, cv, it),
+        "bk_bls_bordering_cshift")
+    return dX, complex(dl[1], dl[2]), cv[] == 1, (Int(it[1]), Int(it[2]))
 end
 
 # m-column border (normal forms / Bogdanov-Takens), src/LinearBorderSolver.jl:173-206
