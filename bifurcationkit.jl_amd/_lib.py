@@ -18,6 +18,7 @@ BK_MAX_NEWTON_ITER = 64
 
 BK_PDE_SH, BK_PDE_SH1D, BK_PDE_CGL2D = 1, 2, 3
 BK_GMRES_KRYLOVKIT, BK_GMRES_ITERATIVESOLVERS, BK_GMRES_KRYLOVJL = 0, 1, 2
+BK_KRYLOV_MINRES, BK_KRYLOV_CG = 3, 4
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)

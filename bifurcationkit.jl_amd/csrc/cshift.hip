@@ -51,6 +51,7 @@ struct ComplexShiftOp : bk_op {
 // (a0 + a1 J) x = rhs on stacked vectors [re; im] of length 2N; x must not alias rhs
 int csolve(bk_ctx* ctx, bk_op* J, const double* rhs2, double* x2, double a0r, double a0i, double a1,
            const bk_gmres_opts& o, bk_precond* pl, GmresResult* res) {
+    if (o.flavor >= BK_KRYLOV_MINRES) return set_error(ctx, "complex-shift solves need a GMRES flavor (the real-equivalent operator is not symmetric)");
     const size_t N = J->n;
     WsGuard ws(ctx);
     ComplexShiftOp W;

@@ -325,10 +325,121 @@ struct ShiftPrecOp : bk_op {
 
 }  // namespace
 
+// ================================================================== symmetric Krylov.jl solvers (KrylovLS :minres / :cg)
+// Paige-Saunders MINRES for the symmetric operator v -> a0 v + a1 J v with the SPD preconditioner M^-1 = Pl^-1
+// (src/LinearSolver.jl:336-341 passes Pl as Krylov.jl's centered preconditioner M); restated in oracle/krylov.py
+// (minres_krylovjl).  Short recurrences: 8 vectors, no restarts.
+static int minres_core(bk_ctx* ctx, bk_op* J, const double* b, double* x, double a0, double a1, const bk_gmres_opts& o,
+                       bk_precond* pl, GmresResult* res) {
+    const size_t n = J->n;
+    WsGuard ws(ctx);
+    double *r1 = nullptr, *r2 = nullptr, *y = nullptr, *v = nullptr, *w = nullptr, *w1 = nullptr, *w2 = nullptr, *t = nullptr;
+    BK_TRY(ws.get(n, &r1)); BK_TRY(ws.get(n, &r2)); BK_TRY(ws.get(n, &y)); BK_TRY(ws.get(n, &v));
+    BK_TRY(ws.get(n, &w)); BK_TRY(ws.get(n, &w1)); BK_TRY(ws.get(n, &w2)); BK_TRY(ws.get(n, &t));
+    auto prec = [&](const double* in, double* out) -> int { return pl ? pl->apply(in, out) : v_copy(ctx, n, in, out); };
+    BK_TRY(v_zero(ctx, n, x));
+    BK_TRY(v_copy(ctx, n, b, r1));
+    BK_TRY(prec(r1, y));
+    double beta1;
+    BK_TRY(v_dot(ctx, n, r1, y, &beta1));
+    res->converged = 0; res->niter = 0; res->resnorm = 0.0;
+    if (beta1 < 0.0) return set_error(ctx, "minres: the preconditioner is not positive definite");
+    if (beta1 == 0.0) { res->converged = 1; return 0; }
+    beta1 = std::sqrt(beta1);
+    const double eps = 2.220446049250313e-16;
+    const double tol = o.atol + o.rtol * beta1;
+    const int itmax = o.maxiter > 0 ? o.maxiter : 2 * (int)std::min<size_t>(n, 1u << 30);
+    double oldb = 0.0, beta = beta1, dbar = 0.0, epsln = 0.0, phibar = beta1, cs = -1.0, sn = 0.0;
+    BK_TRY(v_zero(ctx, n, w)); BK_TRY(v_zero(ctx, n, w2));
+    BK_TRY(v_copy(ctx, n, r1, r2));
+    int it = 0;
+    bool solved = phibar <= tol;
+    while (!solved && it < itmax) {
+        it += 1;
+        BK_TRY(v_axpbyz(ctx, n, 1.0 / beta, y, 0.0, nullptr, v));                    // v = y / beta
+        BK_TRY(J->apply(v, nullptr, a0, a1, y, nullptr));                            // y = (a0 + a1 J) v
+        if (it >= 2) BK_TRY(v_axpby(ctx, n, -beta / oldb, r1, 1.0, y));
+        double alfa;
+        BK_TRY(v_dot(ctx, n, v, y, &alfa));
+        BK_TRY(v_axpby(ctx, n, -alfa / beta, r2, 1.0, y));
+        { double* tmp = r1; r1 = r2; r2 = y; y = tmp; }                             // r1 <- r2, r2 <- y (buffers rotate)
+        BK_TRY(prec(r2, y));
+        oldb = beta;
+        double b2;
+        BK_TRY(v_dot(ctx, n, r2, y, &b2));
+        if (b2 < 0.0) return set_error(ctx, "minres: the preconditioner is not positive definite");
+        beta = std::sqrt(b2);
+        const double oldeps = epsln;
+        const double delta = cs * dbar + sn * alfa;
+        const double gbar = sn * dbar - cs * alfa;
+        epsln = sn * beta;
+        dbar = -cs * beta;
+        const double gamma = std::max(std::hypot(gbar, beta), eps);
+        cs = gbar / gamma; sn = beta / gamma;
+        const double phi = cs * phibar;
+        phibar = sn * phibar;
+        { double* tmp = w1; w1 = w2; w2 = w; w = tmp; }                             // w1 <- w2, w2 <- w
+        BK_TRY(v_axpbyz(ctx, n, 1.0, v, -oldeps, w1, t));                            // w = (v - oldeps w1 - delta w2) / gamma
+        BK_TRY(v_axpbyz(ctx, n, 1.0 / gamma, t, -delta / gamma, w2, w));
+        BK_TRY(v_axpby(ctx, n, phi, w, 1.0, x));
+        solved = phibar <= tol;
+    }
+    res->converged = solved ? 1 : 0;
+    res->niter = it;
+    res->resnorm = phibar;
+    return 0;
+}
+
+// Preconditioned conjugate gradients (Krylov.jl `cg` semantics: sqrt(r' M^-1 r) <= atol + rtol * its initial value).
+static int cg_core(bk_ctx* ctx, bk_op* J, const double* b, double* x, double a0, double a1, const bk_gmres_opts& o,
+                   bk_precond* pl, GmresResult* res) {
+    const size_t n = J->n;
+    WsGuard ws(ctx);
+    double *r = nullptr, *z = nullptr, *p = nullptr, *Ap = nullptr;
+    BK_TRY(ws.get(n, &r)); BK_TRY(ws.get(n, &z)); BK_TRY(ws.get(n, &p)); BK_TRY(ws.get(n, &Ap));
+    auto prec = [&](const double* in, double* out) -> int { return pl ? pl->apply(in, out) : v_copy(ctx, n, in, out); };
+    BK_TRY(v_zero(ctx, n, x));
+    BK_TRY(v_copy(ctx, n, b, r));
+    BK_TRY(prec(r, z));
+    BK_TRY(v_copy(ctx, n, z, p));
+    double gamma;
+    BK_TRY(v_dot(ctx, n, r, z, &gamma));
+    res->converged = 0; res->niter = 0; res->resnorm = 0.0;
+    if (gamma == 0.0) { res->converged = 1; return 0; }
+    double rnorm = std::sqrt(std::max(gamma, 0.0));
+    const double tol = o.atol + o.rtol * rnorm;
+    const int itmax = o.maxiter > 0 ? o.maxiter : 2 * (int)std::min<size_t>(n, 1u << 30);
+    int it = 0;
+    bool solved = rnorm <= tol;
+    while (!solved && it < itmax) {
+        BK_TRY(J->apply(p, nullptr, a0, a1, Ap, nullptr));
+        double pAp;
+        BK_TRY(v_dot(ctx, n, p, Ap, &pAp));
+        if (!(pAp > 0.0)) break;                                                     // not positive definite along p
+        const double alpha = gamma / pAp;
+        BK_TRY(v_axpby(ctx, n, alpha, p, 1.0, x));
+        BK_TRY(v_axpby(ctx, n, -alpha, Ap, 1.0, r));
+        BK_TRY(prec(r, z));
+        double gnext;
+        BK_TRY(v_dot(ctx, n, r, z, &gnext));
+        rnorm = std::sqrt(std::max(gnext, 0.0));
+        BK_TRY(v_axpby(ctx, n, 1.0, z, gnext / gamma, p));                           // p = z + beta p
+        gamma = gnext;
+        it += 1;
+        solved = rnorm <= tol;
+    }
+    res->converged = solved ? 1 : 0;
+    res->niter = it;
+    res->resnorm = rnorm;
+    return 0;
+}
+
 int linsolve(bk_ctx* ctx, bk_op* J, const double* rhs, double* x, double a0, double a1, const bk_gmres_opts& o,
              bk_precond* pl, GmresResult* res) {
     if (J->ntail != 0) return set_error(ctx, "linsolve: operator must be unbordered");
     if (x == rhs) return set_error(ctx, "linsolve: x must not alias rhs");
+    if (o.flavor == BK_KRYLOV_MINRES) return minres_core(ctx, J, rhs, x, a0, a1, o, pl, res);
+    if (o.flavor == BK_KRYLOV_CG) return cg_core(ctx, J, rhs, x, a0, a1, o, pl, res);
     const bool kk = (o.flavor == BK_GMRES_KRYLOVKIT);
     if (!pl && kk) return gmres_core(ctx, J, rhs, nullptr, x, nullptr, a0, a1, o, res);
     WsGuard ws(ctx);
@@ -356,7 +467,9 @@ extern "C" {
 void bk_gmres_default_opts(bk_gmres_opts* o, int flavor) {
     if (!o) return;
     o->flavor = flavor;
-    if (flavor == BK_GMRES_KRYLOVJL) {              // Krylov.jl gmres defaults: memory 20, atol = rtol = sqrt(eps)
+    if (flavor == BK_KRYLOV_MINRES || flavor == BK_KRYLOV_CG) {   // Krylov.jl: atol = rtol = sqrt(eps), itmax = 0 -> 2n
+        o->dim = 0; o->maxiter = 0; o->atol = 1.4901161193847656e-08; o->rtol = 1.4901161193847656e-08;
+    } else if (flavor == BK_GMRES_KRYLOVJL) {       // Krylov.jl gmres defaults: memory 20, atol = rtol = sqrt(eps)
         o->dim = 20; o->maxiter = 2000; o->atol = 1.4901161193847656e-08; o->rtol = 1.4901161193847656e-08;
     } else if (flavor == BK_GMRES_ITERATIVESOLVERS) {      // src/LinearSolver.jl:151-160
         o->dim = 200 > kMaxBasis - 1 ? kMaxBasis - 1 : 200;
@@ -508,6 +621,7 @@ int bk_bls_matrixfree(bk_ctx* ctx, bk_op* J, const double* dR, const double* dzu
                       const bk_gmres_opts* lsopts, double* dX, double* dl, int* converged, int* itlinear) {
     if (!ctx || !J || !dR || !dzu || !R || !lsopts || !dX || !dl) return -1;
     if (dX == R || dX == dR || dX == dzu) return set_error(ctx, "bk_bls_matrixfree: dX must be a fresh buffer");
+    if (lsopts->flavor >= BK_KRYLOV_MINRES) return set_error(ctx, "bk_bls_matrixfree: the bordered operator is not symmetric (use a GMRES flavor)");
     BorderedMapOp M;
     M.ctx = ctx; M.n = J->n; M.ntail = 1;
     M.J = J; M.a[0] = dR; M.bvec[0] = dzu; M.bscale = xiu * dotscale; M.c[0] = dzp * xip;
@@ -584,6 +698,7 @@ int bk_bls_block_matrixfree(bk_ctx* ctx, bk_op* J, int m, const double* const* a
     if (!ctx || !J || !a || !b || !c || !rhst || !rhsb || !lsopts || !u1 || !u2) return -1;
     if (m < 1 || m > BK_MAX_BORDER) return set_error(ctx, "Linear bordered solver, wrong sizes! (1 <= m <= %d)", BK_MAX_BORDER);
     if (u1 == rhst) return set_error(ctx, "bk_bls_block_matrixfree: u1 must be a fresh buffer");
+    if (lsopts->flavor >= BK_KRYLOV_MINRES) return set_error(ctx, "bk_bls_block_matrixfree: the bordered operator is not symmetric (use a GMRES flavor)");
     BorderedMapOp M;
     M.ctx = ctx; M.n = J->n; M.ntail = m;
     M.J = J; M.bscale = dotscale;

@@ -433,6 +433,29 @@ class KrylovLS(_GMRES):
         return self.itmax
 
 
+@dataclass
+class KrylovLSSymmetric(_GMRES):
+    """KrylovLS(KrylovAlg = :minres | :cg) (src/LinearSolver.jl:336-341): Krylov.jl's symmetric solvers on the shifted
+    operator with the "centered" SPD preconditioner ``M = Pl``; stopping rule atol + rtol * (initial M^-1-norm of the
+    residual); ``itmax = 0`` means 2n.  Short recurrences: 8 (MINRES) / 4 (CG) work vectors instead of a Krylov basis."""
+    KrylovAlg: str = "minres"
+    atol: float = 1.4901161193847656e-08
+    rtol: float = 1.4901161193847656e-08
+    itmax: int = 0
+    Pl: DCTPreconditioner | None = None
+    dim = 0
+
+    @property
+    def flavor(self):
+        if self.KrylovAlg not in ("minres", "cg"):
+            raise ValueError("KrylovLSSymmetric: KrylovAlg must be 'minres' or 'cg'")
+        return L.BK_KRYLOV_MINRES if self.KrylovAlg == "minres" else L.BK_KRYLOV_CG
+
+    @property
+    def maxiter(self):
+        return self.itmax
+
+
 # ------------------------------------------------------------------------------------------ bordered solvers
 @dataclass
 class BorderedArray:

@@ -155,6 +155,12 @@ enum {
                                       niter = numops (operator applications)                       */
     BK_GMRES_ITERATIVESOLVERS = 1, /* GMRESIterativeSolvers semantics, :149-206: maxiter = inner
                                       iterations, tol = max(rtol*||r0||, atol), niter = iterations */
+    BK_KRYLOV_MINRES = 3,          /* KrylovLS(KrylovAlg = :minres), :336-341 (symmetric solvers, "centered" SPD
+                                      preconditioner M = Pl): Paige-Saunders MINRES on a0 + a1 J, stop on the
+                                      estimated M^-1-norm of the residual <= atol + rtol*beta1; dim unused;
+                                      maxiter = itmax; 8 vectors instead of a Krylov basis                        */
+    BK_KRYLOV_CG = 4,              /* KrylovLS(KrylovAlg = :cg): preconditioned CG for SPD a0 + a1 J; stops without
+                                      success on non-positive curvature                                            */
     BK_GMRES_KRYLOVJL = 2          /* KrylovLS / KrylovLSInplace with :gmres, :316-414: Krylov.jl stopping rule
                                       ||r|| <= atol + rtol*||r0||, dim = `memory` used as restart length,
                                       maxiter = itmax (inner iterations), niter = iterations; Pl = `M`      */

@@ -157,6 +157,106 @@ def gmres_krylovkit(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-
     return x, False, numops, beta
 
 
+def minres_krylovjl(A, b, a0=0.0, a1=1.0, *, atol=None, rtol=None, itmax=0, M=None):
+    """Krylov.jl `minres` (KrylovLS(KrylovAlg = :minres), src/LinearSolver.jl:339-341: symmetric operator v -> a0 v + a1 A v,
+    "centered" SPD preconditioner M = Pl passed as a callable applying Pl^-1): Paige-Saunders MINRES, x0 = 0, stop when
+    the estimated residual norm (in the M^-1 inner product) <= atol + rtol * beta1.  Returns (x, solved, niter)."""
+    b = np.asarray(b, dtype=float)
+    n = b.shape[0]
+    eps = np.finfo(float).eps
+    atol = np.sqrt(eps) if atol is None else atol
+    rtol = np.sqrt(eps) if rtol is None else rtol
+    itmax = 2 * n if itmax == 0 else itmax
+    op = lambda v: axpy_op(A, v, a0, a1)
+    prec = (lambda v: v) if M is None else M
+    x = np.zeros(n)
+    r1 = b.copy()
+    y = prec(r1)
+    beta1 = float(np.dot(r1, y))
+    if beta1 < 0:
+        raise ValueError("minres: the preconditioner is not positive definite")
+    if beta1 == 0.0:
+        return x, True, 0
+    beta1 = np.sqrt(beta1)
+    tol = atol + rtol * beta1
+    oldb, beta, dbar, epsln, phibar = 0.0, beta1, 0.0, 0.0, beta1
+    cs, sn = -1.0, 0.0
+    w = np.zeros(n); w2 = np.zeros(n)
+    r2 = r1.copy()
+    it = 0
+    solved = phibar <= tol
+    while not solved and it < itmax:
+        it += 1
+        v = y / beta
+        y = op(v)
+        if it >= 2:
+            y = y - (beta / oldb) * r1
+        alfa = float(np.dot(v, y))
+        y = y - (alfa / beta) * r2
+        r1, r2 = r2, y
+        y = prec(r2)
+        oldb = beta
+        b2 = float(np.dot(r2, y))
+        if b2 < 0:
+            raise ValueError("minres: the preconditioner is not positive definite")
+        beta = np.sqrt(b2)
+        oldeps = epsln
+        delta = cs * dbar + sn * alfa
+        gbar = sn * dbar - cs * alfa
+        epsln = sn * beta
+        dbar = -cs * beta
+        gamma = max(np.hypot(gbar, beta), eps)
+        cs, sn = gbar / gamma, beta / gamma
+        phi = cs * phibar
+        phibar = sn * phibar
+        w1, w2 = w2, w
+        w = (v - oldeps * w1 - delta * w2) / gamma
+        x = x + phi * w
+        solved = phibar <= tol
+    return x, bool(solved), it
+
+
+def cg_krylovjl(A, b, a0=0.0, a1=1.0, *, atol=None, rtol=None, itmax=0, M=None):
+    """Krylov.jl `cg` (KrylovLS(KrylovAlg = :cg)): preconditioned conjugate gradients for an SPD operator, x0 = 0,
+    residual norm sqrt(r' M^-1 r) <= atol + rtol * its initial value.  Returns (x, solved, niter)."""
+    b = np.asarray(b, dtype=float)
+    n = b.shape[0]
+    eps = np.finfo(float).eps
+    atol = np.sqrt(eps) if atol is None else atol
+    rtol = np.sqrt(eps) if rtol is None else rtol
+    itmax = 2 * n if itmax == 0 else itmax
+    op = lambda v: axpy_op(A, v, a0, a1)
+    prec = (lambda v: v) if M is None else M
+    x = np.zeros(n)
+    r = b.copy()
+    z = prec(r)
+    p = z.copy()
+    gamma = float(np.dot(r, z))
+    rnorm = np.sqrt(max(gamma, 0.0))
+    if gamma == 0.0:
+        return x, True, 0
+    tol = atol + rtol * rnorm
+    it = 0
+    solved = rnorm <= tol
+    while not solved and it < itmax:
+        Ap = op(p)
+        pAp = float(np.dot(p, Ap))
+        if pAp <= 0.0:                      # not positive definite along p: Krylov.jl stops (zero / negative curvature)
+            break
+        alpha = gamma / pAp
+        x = x + alpha * p
+        r = r - alpha * Ap
+        z = prec(r)
+        gnext = float(np.dot(r, z))
+        rnorm = np.sqrt(max(gnext, 0.0))
+        beta = gnext / gamma
+        gamma = gnext
+        p = z + beta * p
+        it += 1
+        solved = rnorm <= tol
+    return x, bool(solved), it
+
+
 def gmres_iterativesolvers(A, b, a0=0.0, a1=1.0, *, restart=200, maxiter=100, reltol=1e-8, abstol=0.0,
                            Pl=None):
     """IterativeSolvers.gmres on v -> a0 v + a1 A v (src/LinearSolver.jl:195-201), x0 = 0.

@@ -299,6 +299,53 @@ def test_gmres_nonconvergence_is_a_flag_not_an_error(ctx):
     assert ok is False and it > 0
 
 
+def test_symmetric_krylov_solvers_match_oracle(ctx):
+    """KrylovLS(KrylovAlg = :minres / :cg) (src/LinearSolver.jl:336-341) on the symmetric SH Jacobian with the SPD DCT
+    preconditioner as centered M: same iterates as the oracle's restatement (iteration counts, solution), solution ==
+    sparse direct solve; usable wherever a linear solver is (bordered solve, shift-invert eigensolver)."""
+    hip = _hip()
+    sh, prob, rng, u = _sh_setup(ctx, (12, 10, 8), (np.pi, 2.5, 2.0), seed=51)
+    n = sh.N
+    Jm = sh.J(u, 0.1, 1.2)
+    J = prob.jacobian(prob.vec(u), 0.1)
+    rhs = rng.standard_normal(n)
+    Plo = operators.dct_preconditioner((12, 10, 8), (np.pi, 2.5, 2.0), 1.0)
+    P = hip.DCTPreconditioner(prob, 1.0)
+    for a0, a1 in ((0.0, 1.0), (-0.1, 1.0)):
+        ref = spla.spsolve((a0 * sp.identity(n) + a1 * Jm).tocsc(), rhs)
+        xo, oko, ito = krylov.minres_krylovjl(Jm, rhs, a0, a1, atol=1e-13, rtol=1e-11, M=Plo)
+        ls = hip.KrylovLSSymmetric("minres", atol=1e-13, rtol=1e-11, Pl=P)
+        x, ok, it = ls(J, prob.vec(rhs), a0, a1)
+        assert ok and oko and abs(it - ito) <= max(2, ito // 20), (it, ito)
+        assert np.abs(x.numpy() - ref).max() <= 1e-7 * np.abs(ref).max()
+        assert np.abs(x.numpy() - xo).max() <= 1e-7 * np.abs(xo).max()
+    # CG on the SPD operator -(J - 2 I) = L1 + (2 - l) - 2 nu u + 3 u^2  (a0 = 2, a1 = -1)
+    spd = (2.0 * sp.identity(n) - Jm).tocsc()
+    assert np.linalg.eigvalsh(spd.toarray()).min() > 0
+    ref = spla.spsolve(spd, rhs)
+    xo, oko, ito = krylov.cg_krylovjl(Jm, rhs, 2.0, -1.0, atol=1e-13, rtol=1e-11, M=Plo)
+    x, ok, it = hip.KrylovLSSymmetric("cg", atol=1e-13, rtol=1e-11, Pl=P)(J, prob.vec(rhs), 2.0, -1.0)
+    assert ok and oko and abs(it - ito) <= max(2, ito // 20) and np.abs(x.numpy() - ref).max() <= 1e-7 * np.abs(ref).max()
+    # CG on the indefinite J itself stops without success; MINRES budget exhaustion is success = false, not an error
+    _, okc, _ = hip.KrylovLSSymmetric("cg", atol=1e-13, rtol=1e-11, itmax=500)(J, prob.vec(rhs))
+    _, okm, itm = hip.KrylovLSSymmetric("minres", atol=1e-15, rtol=1e-15, itmax=3, Pl=P)(J, prob.vec(rhs))
+    assert not okc and not okm and itm == 3
+    # as the inner solver of the shift-invert eigensolver and of the bordered solve
+    mn = hip.KrylovLSSymmetric("minres", atol=1e-13, rtol=1e-10, Pl=P)
+    vals, _, cv, _ = hip.ShiftInvert(0.1, mn, tol=1e-9, maxiter=20, hermitian=True, save_vectors=False)(J, 4)
+    dense = np.linalg.eigvalsh(Jm.toarray())
+    near = dense[np.argsort(np.abs(dense - 0.1))[:4]]                  # shift-invert (:LM of the inverse): closest to sigma
+    assert cv and np.allclose(np.sort(vals.real[:4]), np.sort(near), rtol=0, atol=1e-7), (vals, near)
+    dR, dzu, R = (rng.standard_normal(n) for _ in range(3))
+    A = np.block([[Jm.toarray(), dR[:, None]], [dzu[None, :] / n, np.array([[0.4]])]])
+    refb = np.linalg.solve(A, np.concatenate([R, [0.3]]))
+    dX, dl, okb, _ = hip.BorderingBLS(mn, check_precision=False)(J, prob.vec(dR), prob.vec(dzu), 0.4, prob.vec(R), 0.3,
+                                                                 dotscale=1.0 / n)
+    assert okb and np.abs(dX.numpy() - refb[:-1]).max() <= 1e-6 * np.abs(refb).max() and np.isclose(dl, refb[-1], rtol=1e-6)
+    with pytest.raises(Exception, match="not symmetric"):
+        hip.MatrixFreeBLS(mn)(J, prob.vec(dR), prob.vec(dzu), 0.4, prob.vec(R), 0.3, dotscale=1.0 / n)
+
+
 # --------------------------------------------------------------------------------------------- bordered solvers
 @pytest.mark.parametrize("shift", [None, 0.3])
 @pytest.mark.parametrize("xi", [(1.0, 1.0), (0.4, 0.6)])

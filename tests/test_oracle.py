@@ -345,3 +345,36 @@ def test_bordered_solver_complex_shift():
     rhs = rng.random(n) + 1j * rng.random(n)
     x, _, _ = bordered.default_ls(J0, rhs, a0=2j * w, a1=-1.0)
     assert np.allclose((2j * w * np.eye(n) - J0) @ x, rhs)
+
+
+def test_symmetric_krylovjl_solvers_vs_dense():
+    """KrylovLS(KrylovAlg = :minres / :cg) (src/LinearSolver.jl:336-341: symmetric solvers, centered preconditioner M = Pl,
+    shifted operator a0 + a1 J): solution == dense solve (test_linear.jl:106-169 identity), and MINRES agrees with SciPy's
+    implementation of the same Paige-Saunders recurrences."""
+    import scipy.sparse.linalg as spla
+    rng = np.random.default_rng(12)
+    n = 60
+    Q = np.linalg.qr(rng.standard_normal((n, n)))[0]
+    S = Q @ np.diag(np.concatenate([-np.linspace(0.5, 3, 10), np.linspace(0.2, 5, n - 10)])) @ Q.T    # symmetric indefinite
+    S = 0.5 * (S + S.T)
+    Mspd = Q @ np.diag(np.linspace(0.5, 2, n)) @ Q.T
+    Minv = np.linalg.inv(0.5 * (Mspd + Mspd.T))
+    b = rng.standard_normal(n)
+    for a0, a1 in ((0.0, 1.0), (0.3, 0.9)):
+        ref = np.linalg.solve(a0 * np.eye(n) + a1 * S, b)
+        x, ok, it = krylov.minres_krylovjl(S, b, a0, a1, atol=1e-13, rtol=1e-12)
+        assert ok and 0 < it <= 2 * n and np.allclose(x, ref, rtol=1e-8, atol=1e-10)
+        xp, okp, itp = krylov.minres_krylovjl(S, b, a0, a1, atol=1e-13, rtol=1e-12, M=lambda v: Minv @ v)
+        assert okp and np.allclose(xp, ref, rtol=1e-8, atol=1e-10)
+    xs, info = spla.minres(S, b, rtol=1e-12, maxiter=4 * n)
+    x, ok, it = krylov.minres_krylovjl(S, b, atol=0.0, rtol=1e-12)
+    assert info == 0 and np.allclose(x, xs, rtol=1e-7, atol=1e-9)
+    # CG on an SPD operator, with and without preconditioner
+    P = S @ S + np.eye(n)
+    ref = np.linalg.solve(P, b)
+    for Mfun in (None, lambda v: Minv @ v):
+        x, ok, it = krylov.cg_krylovjl(P, b, atol=1e-13, rtol=1e-12, M=Mfun)
+        assert ok and np.allclose(x, ref, rtol=1e-8, atol=1e-10)
+    # CG on an indefinite operator stops without claiming success
+    x, ok, it = krylov.cg_krylovjl(S, b, atol=1e-13, rtol=1e-12)
+    assert not ok
