@@ -139,6 +139,9 @@ int v_axpbyz(bk_ctx* ctx, size_t n, double a, const double* x, double b, const d
 int v_dot(bk_ctx* ctx, size_t n, const double* x, const double* y, double* out);
 int v_dot2(bk_ctx* ctx, size_t n, const double* x, const double* y1, const double* y2, double* out2);
 int v_nrm2(bk_ctx* ctx, size_t n, const double* x, double* out);
+int v_axpy_dot(bk_ctx* ctx, size_t n, double c, const double* r, double* y, const double* z, double* out);
+int v_minres_update(bk_ctx* ctx, size_t n, double cz, const double* z, double c1, const double* w1, double c2, const double* w2,
+                    double* w, double phi, double* x);
 int v_nrminf(bk_ctx* ctx, size_t n, const double* x, double* out);
 // out[i] = <V_i, w> for i < k, out[k] = <w, w>;  V_i = V + i*ldv
 int v_multidot(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const double* w, double* out);

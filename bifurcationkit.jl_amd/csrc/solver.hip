@@ -331,17 +331,20 @@ struct ShiftPrecOp : bk_op {
 // (minres_krylovjl).  Short recurrences: 8 vectors, no restarts.
 static int minres_core(bk_ctx* ctx, bk_op* J, const double* b, double* x, double a0, double a1, const bk_gmres_opts& o,
                        bk_precond* pl, GmresResult* res) {
+    // Per iteration: operator, preconditioner, and three streaming passes -- (y += c r1; alfa = z.y), (y += c r2),
+    // (beta^2 = r2.z), (w = .., x += phi w) -- the Lanczos vector v = z / beta is never materialised: its scale goes
+    // into the operator call and into the update coefficients.  Buffers r1, r2, y and w, w1, w2 rotate.
     const size_t n = J->n;
     WsGuard ws(ctx);
-    double *r1 = nullptr, *r2 = nullptr, *y = nullptr, *v = nullptr, *w = nullptr, *w1 = nullptr, *w2 = nullptr, *t = nullptr;
-    BK_TRY(ws.get(n, &r1)); BK_TRY(ws.get(n, &r2)); BK_TRY(ws.get(n, &y)); BK_TRY(ws.get(n, &v));
-    BK_TRY(ws.get(n, &w)); BK_TRY(ws.get(n, &w1)); BK_TRY(ws.get(n, &w2)); BK_TRY(ws.get(n, &t));
+    double *r1 = nullptr, *r2 = nullptr, *y = nullptr, *z = nullptr, *w = nullptr, *w1 = nullptr, *w2 = nullptr;
+    BK_TRY(ws.get(n, &r1)); BK_TRY(ws.get(n, &r2)); BK_TRY(ws.get(n, &y)); BK_TRY(ws.get(n, &z));
+    BK_TRY(ws.get(n, &w)); BK_TRY(ws.get(n, &w1)); BK_TRY(ws.get(n, &w2));
     auto prec = [&](const double* in, double* out) -> int { return pl ? pl->apply(in, out) : v_copy(ctx, n, in, out); };
     BK_TRY(v_zero(ctx, n, x));
-    BK_TRY(v_copy(ctx, n, b, r1));
-    BK_TRY(prec(r1, y));
+    BK_TRY(v_copy(ctx, n, b, r2));
+    BK_TRY(prec(r2, z));
     double beta1;
-    BK_TRY(v_dot(ctx, n, r1, y, &beta1));
+    BK_TRY(v_dot(ctx, n, r2, z, &beta1));
     res->converged = 0; res->niter = 0; res->resnorm = 0.0;
     if (beta1 < 0.0) return set_error(ctx, "minres: the preconditioner is not positive definite");
     if (beta1 == 0.0) { res->converged = 1; return 0; }
@@ -351,27 +354,30 @@ static int minres_core(bk_ctx* ctx, bk_op* J, const double* b, double* x, double
     const int itmax = o.maxiter > 0 ? o.maxiter : 2 * (int)std::min<size_t>(n, 1u << 30);
     double oldb = 0.0, beta = beta1, dbar = 0.0, epsln = 0.0, phibar = beta1, cs = -1.0, sn = 0.0;
     BK_TRY(v_zero(ctx, n, w)); BK_TRY(v_zero(ctx, n, w2));
-    BK_TRY(v_copy(ctx, n, r1, r2));
     int it = 0;
     bool solved = phibar <= tol;
     while (!solved && it < itmax) {
         it += 1;
-        BK_TRY(v_axpbyz(ctx, n, 1.0 / beta, y, 0.0, nullptr, v));                    // v = y / beta
-        BK_TRY(J->apply(v, nullptr, a0, a1, y, nullptr));                            // y = (a0 + a1 J) v
-        if (it >= 2) BK_TRY(v_axpby(ctx, n, -beta / oldb, r1, 1.0, y));
-        double alfa;
-        BK_TRY(v_dot(ctx, n, v, y, &alfa));
+        // y = (a0 + a1 J) v with v = z / beta
+        BK_TRY(J->apply(z, nullptr, a0 / beta, a1 / beta, y, nullptr));
+        double zy;                                                                   // y -= (beta/oldb) r1 ; alfa = v.y
+        BK_TRY(v_axpy_dot(ctx, n, it >= 2 ? -beta / oldb : 0.0, it >= 2 ? r1 : nullptr, y, z, &zy));
+        const double alfa = zy / beta;
         BK_TRY(v_axpby(ctx, n, -alfa / beta, r2, 1.0, y));
-        { double* tmp = r1; r1 = r2; r2 = y; y = tmp; }                             // r1 <- r2, r2 <- y (buffers rotate)
-        BK_TRY(prec(r2, y));
-        oldb = beta;
-        double b2;
-        BK_TRY(v_dot(ctx, n, r2, y, &b2));
-        if (b2 < 0.0) return set_error(ctx, "minres: the preconditioner is not positive definite");
-        beta = std::sqrt(b2);
+        // direction / solution update need v = z / beta of THIS iteration: do it before z is overwritten
         const double oldeps = epsln;
         const double delta = cs * dbar + sn * alfa;
         const double gbar = sn * dbar - cs * alfa;
+        { double* tmp = r1; r1 = r2; r2 = y; y = tmp; }                             // r1 <- r2, r2 <- y
+        // the rotation needs the NEXT beta = sqrt(r2 . M^-1 r2): keep v's vector alive in `y` (free now) meanwhile
+        { double* tmp = y; y = z; z = tmp; }                                         // y holds the old z (v * beta), z is free
+        BK_TRY(prec(r2, z));
+        const double vbeta = beta;                                                   // scale of the vector kept in y
+        oldb = beta;
+        double b2;
+        BK_TRY(v_dot(ctx, n, r2, z, &b2));
+        if (b2 < 0.0) return set_error(ctx, "minres: the preconditioner is not positive definite");
+        beta = std::sqrt(b2);
         epsln = sn * beta;
         dbar = -cs * beta;
         const double gamma = std::max(std::hypot(gbar, beta), eps);
@@ -379,9 +385,8 @@ static int minres_core(bk_ctx* ctx, bk_op* J, const double* b, double* x, double
         const double phi = cs * phibar;
         phibar = sn * phibar;
         { double* tmp = w1; w1 = w2; w2 = w; w = tmp; }                             // w1 <- w2, w2 <- w
-        BK_TRY(v_axpbyz(ctx, n, 1.0, v, -oldeps, w1, t));                            // w = (v - oldeps w1 - delta w2) / gamma
-        BK_TRY(v_axpbyz(ctx, n, 1.0 / gamma, t, -delta / gamma, w2, w));
-        BK_TRY(v_axpby(ctx, n, phi, w, 1.0, x));
+        // w = (v - oldeps w1 - delta w2) / gamma ; x += phi w
+        BK_TRY(v_minres_update(ctx, n, 1.0 / (vbeta * gamma), y, -oldeps / gamma, w1, -delta / gamma, w2, w, phi, x));
         solved = phibar <= tol;
     }
     res->converged = solved ? 1 : 0;

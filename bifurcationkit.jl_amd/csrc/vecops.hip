@@ -117,6 +117,81 @@ __global__ void __launch_bounds__(kThreads) dot_kernel(size_t n, const double* _
     }
 }
 
+// ------------------------------------------------------------------ fused MINRES passes (solver.hip: minres_core)
+// y <- y + c r (has_r), partial of z . y (after the update): the Lanczos three-term update and its alpha in one pass.
+template <int VEC>
+__global__ void __launch_bounds__(kThreads) axpy_dot_kernel(size_t n, double c, const double* __restrict__ r, int has_r,
+                                                            double* y, const double* __restrict__ z,
+                                                            double* __restrict__ partials) {
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    double s = 0.0;
+    if (VEC == 2) {
+        const size_t n2 = n >> 1;
+        for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += stride) {
+            double2 yv = reinterpret_cast<double2*>(y)[i];
+            if (has_r) {
+                const double2 rv = reinterpret_cast<const double2*>(r)[i];
+                yv.x = fma(c, rv.x, yv.x); yv.y = fma(c, rv.y, yv.y);
+                reinterpret_cast<double2*>(y)[i] = yv;
+            }
+            const double2 zv = reinterpret_cast<const double2*>(z)[i];
+            s = fma(zv.x, yv.x, s); s = fma(zv.y, yv.y, s);
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+            double yv = y[n - 1];
+            if (has_r) { yv = fma(c, r[n - 1], yv); y[n - 1] = yv; }
+            s = fma(z[n - 1], yv, s);
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+            double yv = y[i];
+            if (has_r) { yv = fma(c, r[i], yv); y[i] = yv; }
+            s = fma(z[i], yv, s);
+        }
+    }
+    __shared__ double sm[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+// w <- cz z + c1 w1 + c2 w2 ;  x <- x + phi w : the MINRES direction and solution updates in one pass
+template <int VEC>
+__global__ void __launch_bounds__(kThreads) minres_update_kernel(size_t n, double cz, const double* __restrict__ z, double c1,
+                                                                 const double* __restrict__ w1, double c2,
+                                                                 const double* __restrict__ w2, double* __restrict__ w,
+                                                                 double phi, double* __restrict__ x) {
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    if (VEC == 2) {
+        const size_t n2 = n >> 1;
+        for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += stride) {
+            const double2 zv = reinterpret_cast<const double2*>(z)[i];
+            const double2 a = reinterpret_cast<const double2*>(w1)[i];
+            const double2 b = reinterpret_cast<const double2*>(w2)[i];
+            double2 xv = reinterpret_cast<double2*>(x)[i];
+            double2 wv;
+            wv.x = fma(c2, b.x, fma(c1, a.x, cz * zv.x));
+            wv.y = fma(c2, b.y, fma(c1, a.y, cz * zv.y));
+            xv.x = fma(phi, wv.x, xv.x); xv.y = fma(phi, wv.y, xv.y);
+            reinterpret_cast<double2*>(w)[i] = wv;
+            reinterpret_cast<double2*>(x)[i] = xv;
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+            const size_t i = n - 1;
+            const double wv = fma(c2, w2[i], fma(c1, w1[i], cz * z[i]));
+            w[i] = wv;
+            x[i] = fma(phi, wv, x[i]);
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+            const double wv = fma(c2, w2[i], fma(c1, w1[i], cz * z[i]));
+            w[i] = wv;
+            x[i] = fma(phi, wv, x[i]);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(kThreads) absmax_kernel(size_t n, const double* __restrict__ x,
                                                           double* __restrict__ partials) {
     const size_t stride = (size_t)gridDim.x * kThreads;
@@ -349,6 +424,34 @@ int v_nrm2(bk_ctx* ctx, size_t n, const double* x, double* out) {
     double s = 0.0;
     BK_TRY(dot_launch(ctx, n, x, x, nullptr, 1, &s));
     *out = sqrt(s);
+    return 0;
+}
+
+// y <- y + c r (r may be NULL);  *out = z . y
+int v_axpy_dot(bk_ctx* ctx, size_t n, double c, const double* r, double* y, const double* z, double* out) {
+    const int has_r = (r != nullptr && c != 0.0) ? 1 : 0;
+    const bool vec = aligned16(y) && aligned16(z) && (!has_r || aligned16(r));
+    const int grid = grid_for(n, vec ? 2 : 1, kRedBlocks);
+    {
+        ProfScope ps(ctx, "blas1", 8.0 * n * (2 + 2 * has_r));
+        if (vec) hipLaunchKernelGGL((axpy_dot_kernel<2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, c, r, has_r, y, z, ctx->d_partials);
+        else hipLaunchKernelGGL((axpy_dot_kernel<1>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, c, r, has_r, y, z, ctx->d_partials);
+        BK_HIP(ctx, hipGetLastError());
+    }
+    BK_TRY(reduce_finish(ctx, grid, 1, 0));
+    *out = ctx->h_red[0];
+    return 0;
+}
+
+// w <- cz z + c1 w1 + c2 w2 ;  x <- x + phi w   (w must not alias z, w1, w2)
+int v_minres_update(bk_ctx* ctx, size_t n, double cz, const double* z, double c1, const double* w1, double c2, const double* w2,
+                    double* w, double phi, double* x) {
+    const bool vec = aligned16(z) && aligned16(w1) && aligned16(w2) && aligned16(w) && aligned16(x);
+    const int grid = grid_for(n, vec ? 2 : 1, 4096);
+    ProfScope ps(ctx, "blas1", 8.0 * n * 6);
+    if (vec) hipLaunchKernelGGL((minres_update_kernel<2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, cz, z, c1, w1, c2, w2, w, phi, x);
+    else hipLaunchKernelGGL((minres_update_kernel<1>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, cz, z, c1, w1, c2, w2, w, phi, x);
+    BK_HIP(ctx, hipGetLastError());
     return 0;
 }
 
