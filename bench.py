@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--sh-kernel", type=int, default=1)
     ap.add_argument("--dgks-eta", type=float, default=None)
     ap.add_argument("--opt", action="append", default=[], help="library tuning option key=value (experiments)")
+    ap.add_argument("--linsolver", default="gmres", choices=["gmres", "minres"],
+                    help="gmres: GMRESKrylovKit(30), the reference example's solver (the headline workload); minres: "
+                         "KrylovLS(KrylovAlg = :minres), valid because the SH Jacobian is symmetric (experiment)")
     return ap.parse_args()
 
 
@@ -269,6 +272,8 @@ def main():
     prob = hip.SwiftHohenberg(ctx, (n, n, n), big_l, l=0.1, nu=1.2)
     P = None if args.no_precond else hip.DCTPreconditioner(prob, args.shift)
     ls = hip.GMRESKrylovKit(dim=30, rtol=1e-9, atol=1e-12, maxiter=150, Pl=P)       # SH3d.jl:93
+    if args.linsolver == "minres":
+        ls = hip.KrylovLSSymmetric("minres", rtol=1e-9, atol=1e-12, itmax=4000, Pl=P)
     bls = hip.BorderingBLS(ls, check_precision=False)                               # SH3d.jl:163
     B = hip.BorderedArray
 
@@ -364,7 +369,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"SH3d {n}^3 PALC corrector (Palc.jl:237-295 pass), GMRES(30) rtol 1e-9, "
+            "config": {"workload": f"SH3d {n}^3 PALC corrector (Palc.jl:237-295 pass), "
+                                   f"{'GMRES(30)' if args.linsolver == 'gmres' else 'KrylovLS(:minres)'} rtol 1e-9, "
                                    f"Pl = (L1+shift)^-1 (DCT), BorderingBLS",
                        "grid": [n, n, n], "unknowns": prob.nglobal, "parallelism": f"z-slabs x{world}",
                        "itlinear_per_step": last["itlineartot"], "residual_after_step": last["residuals"][-1],
@@ -380,7 +386,7 @@ def main():
                        "cell_corrector": {"converged": cfull["converged"], "itnewton": cfull["itnewton"],
                                           "itlinear": cfull["itlineartot"], "residuals": cfull["residuals"],
                                           "p": cfull["u"].p},
-                       "setup_seconds": t_setup, "sh_kernel": args.sh_kernel,
+                       "setup_seconds": t_setup, "sh_kernel": args.sh_kernel, "linsolver": args.linsolver,
                        "preconditioner": "none" if P is None else "dct"},
             "roofline": roofline, "inner_loop": inner, "kernels": kernels,
         }
