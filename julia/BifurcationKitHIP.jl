@@ -220,6 +220,33 @@ function (l::HipGMRES)(J::HipJacobian, rhs::HipVec; a₀ = 0.0, a₁ = 1.0, kwar
 end
 # (ls)(J, rhs1, rhs2) keeps the default of src/LinearSolver.jl:15-19 (two calls of the method above).
 
+"""
+    HipKrylovLS(KrylovAlg = :gmres | :minres | :cg; atol, rtol, memory, itmax, Pl)
+
+`KrylovLS` (src/LinearSolver.jl:316-345): Krylov.jl semantics; `:minres` / `:cg` are the symmetric solvers with the
+centered preconditioner `M = Pl` (8 / 4 work vectors instead of a Krylov basis).
+"""
+Base.@kwdef mutable struct HipKrylovLS{Tl} <: AbstractIterativeLinearSolver
+    KrylovAlg::Symbol = :gmres
+    atol::Float64 = sqrt(eps())
+    rtol::Float64 = sqrt(eps())
+    memory::Int = 20
+    itmax::Int = 0
+    Pl::Tl = nothing
+end
+_flavor(l::HipKrylovLS) = l.KrylovAlg == :gmres ? Cint(2) : l.KrylovAlg == :minres ? Cint(3) : l.KrylovAlg == :cg ? Cint(4) :
+                          error("HipKrylovLS: KrylovAlg must be :gmres, :minres or :cg")
+_opts(l::HipKrylovLS) = GmresOpts(_flavor(l), l.memory, l.KrylovAlg == :gmres && l.itmax == 0 ? 2000 : l.itmax, l.atol, l.rtol)
+function (l::HipKrylovLS)(J::HipJacobian, rhs::HipVec; a₀ = 0.0, a₁ = 1.0, kwargs...)
+    ctx = rhs.ctx
+    x = similar(rhs)
+    cv, it, rn = Ref{Cint}(0), Ref{Cint}(0), Ref{Cdouble}(0)
+    check(ctx, ccall((:bk_gmres, libbkhip[]), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Ref{GmresOpts}, Ptr{Cvoid}, Ref{Cint}, Ref{Cint}, Ref{Cdouble}),
+        ctx.h, J.h, rhs.p, x.p, _num(a₀, 0.0), _num(a₁, 1.0), Ref(_opts(l)), _plh(l.Pl), cv, it, rn), "bk_gmres")
+    return x, cv[] == 1, Int(it[])
+end
+
 # Complex device vectors of the Hopf machinery: (re, im) pairs of HipVec.
 struct HipCVec
     re::HipVec
