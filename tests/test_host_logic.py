@@ -4,6 +4,7 @@ continuation run.  This is the plugin contract of test/continuation/test-cont-no
 a state type that is not an array, an opaque Jacobian, custom solvers returning (out, true, 1).
 The NumPy vector type lives HERE (test infrastructure); the product has no CPU backend."""
 import numpy as np
+import pytest
 import scipy.sparse.linalg as spla
 
 from bk_amd import continuation as C
@@ -98,3 +99,33 @@ def test_step_size_control_and_stability():
     ds, stop = C.step_size_control(-0.09, True, 0, cp)
     assert np.isclose(ds, -0.1)
     assert C.is_stable(np.array([0.5 + 1j, 0.5 - 1j, 1e-11, -0.2]), 1e-10) == (2, 2)
+
+
+def test_bench_tiling_helpers_agree():
+    """bench.py: the device tiling (tile_cell, torch) and the CPU baseline's NumPy tiling produce the same even-reflection
+    layout, on the whole grid and on a z-slab; thread selection honours the affinity mask."""
+    import os
+    import sys
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    cx, cy, cz = bench.CELL
+    rng = np.random.default_rng(0)
+    cell = rng.standard_normal(cx * cy * cz)
+    tiles = (2, 3, 2)
+    idx = [np.concatenate([np.arange(nc) if c % 2 == 0 else np.arange(nc)[::-1] for c in range(T)])
+           for nc, T in zip(bench.CELL, tiles)]
+    ref = np.ascontiguousarray(cell.reshape(cz, cy, cx)[np.ix_(idx[2], idx[1], idx[0])])
+    full = bench.tile_cell(torch.from_numpy(cell), tiles, (0, cz * tiles[2]), "cpu").numpy()
+    assert np.array_equal(full, ref.reshape(-1))
+    lo, hi = 7, 41                                                       # a slab that crosses the reflection plane
+    part = bench.tile_cell(torch.from_numpy(cell), tiles, (lo, hi), "cpu").numpy()
+    assert np.array_equal(part, ref[lo:hi].reshape(-1))
+    # the tiled field continues the cell evenly: plane cz-1 == plane cz (reflection), so a Neumann-ghost stencil sees no seam
+    assert np.array_equal(ref[cz - 1], ref[cz])
+    assert bench.tiles_for(512) == (8, 16, 16)
+    with pytest.raises(SystemExit):
+        bench.tiles_for(100)
+    n = bench.available_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1) and max(bench.thread_counts()) == n
