@@ -87,7 +87,8 @@ def test_krylov_multidot_multiaxpy(ctx, k, n):
 # --------------------------------------------------------------------------------------------- stencils
 SH_GRIDS = [((22, 22, 22), (np.pi,) * 3), ((20, 17, 13), (np.pi, 2.0, 1.3)), ((64, 48, 40), (5.0, 4.0, 3.0)),
             ((130, 37, 21), (9.0, 3.0, 2.0)), ((66, 18, 5), (3.0, 2.0, 1.0)), ((5, 4, 3), (1.0, 1.0, 1.0)),
-            ((151, 100), (8 * np.pi, 4 * np.pi / np.sqrt(3))), ((64, 64), (6.0, 6.0)), ((7, 5), (1.0, 2.0))]
+            ((151, 100), (8 * np.pi, 4 * np.pi / np.sqrt(3))), ((64, 64), (6.0, 6.0)), ((7, 5), (1.0, 2.0)),
+            ((2, 2, 2), (1.0, 1.0, 1.0)), ((3, 2), (1.0, 1.0)), ((2, 3, 4), (1.0, 1.0, 1.0))]      # minimum extents
 
 
 @pytest.mark.parametrize("grid", SH_GRIDS)
