@@ -18,7 +18,7 @@
  *     synchronise that stream before returning, the others are asynchronous.
  *   - state layout: flat index = i + Nx*(j + Ny*k), x fastest -- the order the reference's
  *     `kron` assembly and `vec` of an [x,y,z] comprehension produce (examples/SH3d.jl:38-39,77).
- *     Multi-GPU: z-slabs (3-D) / y-slabs (2-D) of contiguous planes, one slab per rank.
+ *     Multi-GPU (3-D Swift-Hohenberg): z-slabs of contiguous planes, one slab per rank.
  */
 #ifndef BKHIP_H
 #define BKHIP_H
@@ -60,11 +60,13 @@ int bk_ctx_create_hostcomm(bk_ctx** ctx, int device, void* stream, int rank, int
 int bk_ctx_destroy(bk_ctx* ctx);
 const char* bk_last_error(bk_ctx* ctx);
 int bk_ctx_sync(bk_ctx* ctx);
-/* Tuning knobs ("sh_kernel": 0 gather / 1 streaming; "sh_zchunk"; "dgks_eta_ppm"; ...).         */
+/* Tuning knobs ("sh_kernel": 0 gather / 1 streaming; "sh_zchunk"; "dgks_eta"; "dct_fft"; "dct_roundtrip";
+ * "dct_gemm"; "halo_overlap"; ...): experiments and cross-checks, the defaults are the measured optimum.        */
 int bk_ctx_set_option(bk_ctx* ctx, const char* key, double value);
 int bk_ctx_get_option(bk_ctx* ctx, const char* key, double* value);
 /* Per-kernel timing with HIP events on the context's stream (bench.py's roofline leg):
- * names: "jvp", "residual", "multidot", "multiaxpy", "precond", "blas1".                        */
+ * names: "jvp", "residual", "multidot", "multiaxpy", "dct_pass", "blas1", "combine"; multi-GPU also "halo",
+ * "alltoall", "transpose".                                                                       */
 int bk_prof_enable(bk_ctx* ctx, int on);
 int bk_prof_reset(bk_ctx* ctx);
 int bk_prof_get(bk_ctx* ctx, const char* name, double* total_ms, long long* calls,
