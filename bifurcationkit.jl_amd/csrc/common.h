@@ -54,6 +54,7 @@ struct bk_ctx {
     double* d_partials = nullptr;   // [kRedBlocks * kMaxBasis+2]
     double* d_red = nullptr;        // [kRedSlots]
     double* h_red = nullptr;        // pinned [kRedSlots]
+    double* h_red_dev = nullptr;    // its device-side address (mapped): single-rank reductions land in it directly
     // workspace pool (device buffers keyed by size in doubles)
     std::multimap<size_t, double*> pool_free;
     std::map<double*, size_t> pool_all;

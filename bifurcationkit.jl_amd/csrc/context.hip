@@ -128,6 +128,15 @@ int comm_allreduce_host(bk_ctx* ctx, double* buf, int n, int op) {
 
 int reduce_finish(bk_ctx* ctx, int nblocks, int nvals, int op) {
     if (nvals > kRedSlots) return set_error(ctx, "reduce_finish: too many values");
+    if (ctx->nranks == 1 && ctx->h_red_dev) {
+        // single rank: the second stage writes straight into the pinned, device-mapped host buffer -- no copy
+        // operation, the host only waits for the stream
+        hipLaunchKernelGGL(reduce_stage2_kernel, dim3(nvals), dim3(256), 0, ctx->stream, ctx->d_partials, nblocks,
+                           nvals, op, ctx->h_red_dev);
+        BK_HIP(ctx, hipGetLastError());
+        BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return 0;
+    }
     hipLaunchKernelGGL(reduce_stage2_kernel, dim3(nvals), dim3(256), 0, ctx->stream, ctx->d_partials, nblocks,
                        nvals, op, ctx->d_red);
     BK_HIP(ctx, hipGetLastError());
@@ -235,7 +244,12 @@ static int ctx_init_common(bk_ctx* ctx, int device, void* stream) {
     ctx->own_stream = false;
     BK_HIP(ctx, hipMalloc(&ctx->d_partials, sizeof(double) * kRedBlocks * (kMaxBasis + 2)));
     BK_HIP(ctx, hipMalloc(&ctx->d_red, sizeof(double) * kRedSlots));
-    BK_HIP(ctx, hipHostMalloc(&ctx->h_red, sizeof(double) * kRedSlots, hipHostMallocDefault));
+    BK_HIP(ctx, hipHostMalloc(&ctx->h_red, sizeof(double) * kRedSlots, hipHostMallocMapped));
+    {
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, ctx->h_red, 0) == hipSuccess) ctx->h_red_dev = static_cast<double*>(dp);
+        (void)hipGetLastError();
+    }
     return 0;
 }
 
