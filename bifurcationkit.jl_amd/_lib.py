@@ -69,6 +69,16 @@ class ContStepResult(C.Structure):
                 ("vals_im", C.c_double * (BK_MAX_NEV + 1)), ("tangent_converged", C.c_int)]
 
 
+class BisectionOpts(C.Structure):
+    _fields_ = [("dsmin_bisection", C.c_double), ("n_inversion", C.c_int), ("max_bisection_steps", C.c_int),
+                ("tol_bisection_eigenvalue", C.c_double), ("max_steps", C.c_int)]
+
+
+class BisectionResult(C.Structure):
+    _fields_ = [("status", C.c_int), ("type", C.c_int), ("interval", C.c_double * 2), ("p", C.c_double),
+                ("n_unstable", C.c_int * 2), ("n_imag", C.c_int * 2), ("steps", C.c_int)]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, c_double_p, C.c_int, C.c_int)
 SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, c_double_p, C.c_size_t, C.c_int, c_double_p, C.c_size_t, C.c_int)
 
@@ -142,6 +152,8 @@ SIGNATURES = {
     "bk_cont_step": (I, [VP, C.POINTER(ContStepResult)]),
     "bk_cont_get": (I, [VP, VP, c_double_p, VP, c_double_p, c_double_p]),
     "bk_cont_destroy": (I, [VP]),
+    "bk_cont_clone": (I, [VP, C.POINTER(VP)]),
+    "bk_cont_locate_bifurcation": (I, [VP, C.POINTER(BisectionOpts), C.POINTER(BisectionResult)]),
     "bk_newton_deflated": (I, [VP, VP, VP, c_double_p, I, C.POINTER(VP), I, D, D, I, D, C.POINTER(NewtonOpts),
                                C.POINTER(GmresOpts), VP, C.POINTER(NewtonResult)]),
     "bk_newton_palc": (I, [VP, VP, VP, c_double_p, VP, D, VP, D, D, D, c_double_p, I, I, D, D,

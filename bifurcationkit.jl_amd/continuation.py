@@ -60,6 +60,10 @@ class ContinuationPar:
     nev: int = 3
     tol_stability: float = 1e-10
     detect_bifurcation: int = 3
+    dsmin_bisection: float = 1e-16           # bisection of detected bifurcations (detect_bifurcation = 3),
+    n_inversion: int = 2                     # src/ContParameters.jl:78-81
+    max_bisection_steps: int = 25
+    tol_bisection_eigenvalue: float = 1e-16
     newton_options: NewtonPar = field(default_factory=NewtonPar)
 
 
@@ -282,11 +286,14 @@ def continuation(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm2, verb
     return br
 
 
-def continuation_native(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm2, verbosity=0, save_sol=False) -> ContResult:
+def continuation_native(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm2, verbosity=0, save_sol=False,
+                        bisection=False) -> ContResult:
     """The same branch with every step issued as ONE library call (``bk_cont_step``: corrector, eigenvalues, step-size
     control, tangent and predictor -- the body of ``iterate``, src/Continuation.jl:458-504) and the two initial Newton
     solves as ``bk_newton``.  Needs the native solver types (GMRES* + BorderingBLS + ShiftInvert); ``normC`` must be
-    ``norm2`` or ``norminf``.  Returns the same record as :func:`continuation`."""
+    ``norm2`` or ``norminf``.  Returns the same record as :func:`continuation`.  ``bisection=True`` (the reference's
+    ``detect_bifurcation = 3``): every detected change of stability is located by ``bk_cont_locate_bifurcation``
+    (locate_bifurcation!, src/Bifurcations.jl:159-349) and the special point carries its interval, status and type."""
     import ctypes as C
 
     from . import _lib as L
@@ -356,7 +363,18 @@ def continuation_native(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm
                       f"itnewton={r.itnewton} itlinear={r.itlinear}")
             if r.converged:
                 if r.bifurcation:
-                    br.specialpoint.append(dict(step=step + 1, param=r.p, n_unstable=(prev_unst, r.n_unstable)))
+                    sp = dict(step=step + 1, param=r.p, n_unstable=(prev_unst, r.n_unstable))
+                    on_boundary = r.p in (cp.p_min, cp.p_max)
+                    if bisection and not on_boundary:                          # Continuation.jl:537-541
+                        bo = L.BisectionOpts(cp.dsmin_bisection, cp.n_inversion, cp.max_bisection_steps,
+                                             cp.tol_bisection_eigenvalue, cp.max_steps)
+                        res = L.BisectionResult()
+                        ctx.check(ctx.lib.bk_cont_locate_bifurcation(h, C.byref(bo), C.byref(res)), "bk_cont_locate_bifurcation")
+                        sp.update(status=("none", "guess", "converged", "guessL")[res.status],
+                                  type=("none", "bp", "hopf", "nd")[res.type], interval=(res.interval[0], res.interval[1]),
+                                  param=res.p, n_unstable=(res.n_unstable[1], res.n_unstable[0]), bisection_steps=res.steps)
+                        r.p, r.n_unstable, r.n_imag = res.p, res.n_unstable[0], res.n_imag[0]
+                    br.specialpoint.append(sp)
                 step += 1
                 record(r, r.itnewton, r.itlinear, [r.residuals[i] for i in range(r.itnewton + 1)])
             if r.stop:

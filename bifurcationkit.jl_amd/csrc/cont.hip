@@ -32,6 +32,11 @@ struct bk_cont {
     double *zu = nullptr, *zoldu = nullptr, *tauu = nullptr, *predu = nullptr, *work = nullptr, *work2 = nullptr;
     double zp = 0, zoldp = 0, taup = 0, predp = 0, ds = 0;
     int n_unstable = -1, n_imag = -1, step = 0;
+    // the rest of ContState that the bisection of locate_bifurcation! steers (src/Bifurcations.jl:159-349)
+    int n_unstable_prev = -1, n_imag_prev = -1;       // n_unstable / n_imag are (current, previous) pairs in the reference
+    bool stepsizecontrol = true, converged = true;
+    int nvals = 0;
+    double vals_re[BK_MAX_NEV + 1], vals_im[BK_MAX_NEV + 1];
 };
 
 namespace {
@@ -126,8 +131,12 @@ int eigen(bk_cont* c, bk_cont_step_result* r) {
     r->nvals = nvals;
     r->eig_converged = nconv >= nev;
     r->eig_numops = nops;
+    c->n_unstable_prev = c->n_unstable;                     // update_stability!, src/Continuation.jl:274-278
+    c->n_imag_prev = c->n_imag;
     c->n_unstable = nu;
     c->n_imag = ni;
+    c->nvals = nvals;
+    for (int i = 0; i < nvals; ++i) { c->vals_re[i] = r->vals_re[i]; c->vals_im[i] = r->vals_im[i]; }
     return 0;
 }
 
@@ -202,6 +211,7 @@ int bk_cont_step(bk_cont* c, bk_cont_step_result* r) {
     BK_TRY(bk_newton_palc(ctx, c->prob, x, &p, c->zu, c->zp, c->tauu, c->taup, c->ds, c->co.theta, c->params, c->nparams,
                           c->ipar, c->co.p_min, c->co.p_max, &c->no, &c->bo, &c->lo, c->pl, &nr));
     r->converged = nr.converged; r->itnewton = nr.itnewton; r->itlinear = nr.itlinear;
+    c->converged = nr.converged != 0;
     for (int i = 0; i <= nr.itnewton && i <= BK_MAX_NEWTON_ITER; ++i) r->residuals[i] = nr.residuals[i];
     const int prev_unst = c->n_unstable;
     if (nr.converged) {
@@ -218,9 +228,11 @@ int bk_cont_step(bk_cont* c, bk_cont_step_result* r) {
     r->p = c->zp;
     r->n_unstable = c->n_unstable; r->n_imag = c->n_imag;
     r->step = c->step;
-    // _step_size_control!, Contbase.jl:77-102
+    // _step_size_control!, Contbase.jl:77-102 (skipped while a bisection drives ds itself: stepsizecontrol = false)
     double ds = c->ds;
-    if (!nr.converged) {
+    if (!c->stepsizecontrol) {
+        // keep ds
+    } else if (!nr.converged) {
         if (std::fabs(ds) <= c->co.dsmin) {
             r->stop = 1;
             return 0;
@@ -231,7 +243,8 @@ int bk_cont_step(bk_cont* c, bk_cont_step_result* r) {
         const double factor = (Nmax - nr.itnewton) / Nmax;
         ds = ds * (1.0 + c->co.a * factor * factor);
     }
-    ds = std::copysign(std::min(std::max(std::fabs(ds), c->co.dsmin), c->co.dsmax), ds);          // clamp_ds
+    if (c->stepsizecontrol)
+        ds = std::copysign(std::min(std::max(std::fabs(ds), c->co.dsmin), c->co.dsmax), ds);      // clamp_ds
     c->ds = ds;
     r->ds_next = ds;
     if (nr.converged) {                                                 // Palc.jl:140-143
@@ -244,6 +257,123 @@ int bk_cont_step(bk_cont* c, bk_cont_step_result* r) {
     }
     BK_TRY(predictor(c));
     return 0;
+}
+
+static int cont_copy_state(bk_cont* dst, const bk_cont* src) {      // copyto!(dst, src) on ContState
+    double* d[] = {dst->zu, dst->zoldu, dst->tauu, dst->predu};
+    const double* from[] = {src->zu, src->zoldu, src->tauu, src->predu};
+    for (int i = 0; i < 4; ++i) BK_TRY(v_copy(src->ctx, src->n, from[i], d[i]));
+    dst->zp = src->zp; dst->zoldp = src->zoldp; dst->taup = src->taup; dst->predp = src->predp; dst->ds = src->ds;
+    dst->n_unstable = src->n_unstable; dst->n_imag = src->n_imag; dst->step = src->step;
+    dst->n_unstable_prev = src->n_unstable_prev; dst->n_imag_prev = src->n_imag_prev;
+    dst->stepsizecontrol = src->stepsizecontrol; dst->converged = src->converged;
+    dst->nvals = src->nvals;
+    for (int i = 0; i < src->nvals; ++i) { dst->vals_re[i] = src->vals_re[i]; dst->vals_im[i] = src->vals_im[i]; }
+    return 0;
+}
+
+int bk_cont_clone(bk_cont* src, bk_cont** out) {
+    if (!src || !out) return -1;
+    bk_cont* c = new bk_cont(*src);                           // options, solver settings, scalars
+    c->zu = c->zoldu = c->tauu = c->predu = c->work = c->work2 = nullptr;
+    double** bufs[] = {&c->zu, &c->zoldu, &c->tauu, &c->predu, &c->work, &c->work2};
+    for (double** b : bufs)
+        if (hipMalloc(b, c->n * sizeof(double)) != hipSuccess) {
+            bk_cont_destroy(c);
+            return set_error(src->ctx, "bk_cont_clone: device allocation failed");
+        }
+    const int s = cont_copy_state(c, src);
+    if (s != 0) { bk_cont_destroy(c); return s; }
+    *out = c;
+    return 0;
+}
+
+// locate_bifurcation!(iter, state), src/Bifurcations.jl:159-349: bisection with the continuation step itself.  `c` is the
+// state right after the step that changed n_unstable; on return it sits right after (status guess / converged) or right
+// before (guessL) the bifurcation point, its (n_unstable, n_imag) pairs bracket the crossing, and the predictor is rebuilt.
+int bk_cont_locate_bifurcation(bk_cont* c, const bk_bisection_opts* bo, bk_bisection_result* res) {
+    if (!c || !bo || !res) return -1;
+    *res = bk_bisection_result{};
+    const int n2 = c->n_unstable, n1 = c->n_unstable_prev;
+    if (n1 == -1 || n2 == -1 || std::fabs(c->ds) < c->co.dsmin) return 0;                 // status none
+    bk_cont *after = nullptr, *state = nullptr, *before = nullptr;
+    int s = bk_cont_clone(c, &after);
+    if (!s) s = bk_cont_clone(c, &state);
+    if (!s) s = bk_cont_clone(c, &before);
+    auto cleanup = [&]() { bk_cont_destroy(after); bk_cont_destroy(state); bk_cont_destroy(before); };
+    if (s) { cleanup(); return s; }
+    std::swap(before->n_unstable, before->n_unstable_prev);
+    std::swap(before->n_imag, before->n_imag_prev);
+    std::swap(before->zp, before->zoldp);
+    state->ds *= -1.0;
+    state->step = 0;
+    state->stepsizecontrol = false;
+    int last_unst = n2;
+    double interval[2] = {std::min(state->zp, state->zoldp), std::max(state->zp, state->zoldp)};
+    int ind = interval[0] == state->zp ? 0 : 1;
+    int n_inv = 0, steps = 0;
+    bool have_next = true, first = true;
+    while (true) {
+        if (!state->converged) break;
+        if (!have_next) break;
+        // (the first pass looks at the initial state itself: same count -> ds is halved before the first backward step)
+        (void)first;
+        if (state->n_unstable == last_unst) state->ds /= 2.0;
+        else { state->ds /= -2.0; n_inv += 1; ind = 1 - ind; }
+        last_unst = state->n_unstable;
+        if ((s = predictor(state))) break;                                                 // update_predictor!, Palc.jl:148-151
+        if ((s = cont_copy_state(n_inv % 2 == 0 ? after : before, state))) break;
+        if (state->step > 0) interval[ind] = state->zp;
+        double rm = INFINITY;                                                               // rightmost: smallest |Re|
+        for (int i = 0; i < state->nvals; ++i)
+            if (!std::isnan(state->vals_re[i])) rm = std::min(rm, std::fabs(state->vals_re[i]));
+        const bool located = rm < bo->tol_bisection_eigenvalue;
+        if (!(std::fabs(state->ds) >= bo->dsmin_bisection && state->step < bo->max_bisection_steps &&
+              n_inv < bo->n_inversion && !located))
+            break;
+        if (state->step > bo->max_steps) { have_next = false; continue; }                  // done(it, state), Continuation.jl:254
+        bk_cont_step_result r;
+        if ((s = bk_cont_step(state, &r))) break;
+        steps += 1;
+        have_next = r.stop == 0;
+        first = false;
+    }
+    if (s) { cleanup(); return s; }
+    const bk_cont* src;
+    if (n_inv % 2 == 0) {
+        res->status = n_inv >= bo->n_inversion ? 2 : 1;
+        src = state;
+        res->n_unstable[0] = state->n_unstable; res->n_unstable[1] = before->n_unstable;
+        res->n_imag[0] = state->n_imag; res->n_imag[1] = before->n_imag;
+        interval[0] = state->zp; interval[1] = before->zp;
+    } else {
+        res->status = 3;
+        src = after;
+        res->n_unstable[0] = after->n_unstable; res->n_unstable[1] = state->n_unstable;
+        res->n_imag[0] = after->n_imag; res->n_imag[1] = state->n_imag;
+        interval[0] = state->zp; interval[1] = after->zp;
+    }
+    // _copyto! of z_old, z_pred, z, tau and the eigenvalues; ds, step and the solver state of `c` stay
+    {
+        const double keep_ds = c->ds;
+        const int keep_step = c->step;
+        const bool keep_ssc = c->stepsizecontrol;
+        s = cont_copy_state(c, src);
+        c->ds = keep_ds; c->step = keep_step; c->stepsizecontrol = keep_ssc; c->converged = true;
+    }
+    c->n_unstable = res->n_unstable[0]; c->n_unstable_prev = res->n_unstable[1];
+    c->n_imag = res->n_imag[0]; c->n_imag_prev = res->n_imag[1];
+    if (!s) s = predictor(c);                                                               // update_predictor!(_state, iter)
+    res->interval[0] = std::min(interval[0], interval[1]);
+    res->interval[1] = std::max(interval[0], interval[1]);
+    res->steps = steps;
+    res->p = c->zp;
+    {   // _get_bifurcation_type, codim-1 cases (Bifurcations.jl:95-130): 1 bp, 2 hopf, 3 nd
+        const int dn = std::abs(res->n_unstable[0] - res->n_unstable[1]), di = std::abs(res->n_imag[0] - res->n_imag[1]);
+        res->type = dn == 1 ? (di == 0 ? 1 : (di == 1 ? 2 : 3)) : (dn == 2 ? (di == 2 ? 2 : 3) : (dn > 2 ? 3 : 0));
+    }
+    cleanup();
+    return s;
 }
 
 int bk_cont_get(bk_cont* c, double* u, double* p, double* tauu, double* taup, double* ds) {

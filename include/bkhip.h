@@ -334,6 +334,28 @@ int bk_cont_step(bk_cont* c, bk_cont_step_result* res);
 /* copies of the current point / tangent (device buffers of the local length, any may be NULL) */
 int bk_cont_get(bk_cont* c, double* u, double* p, double* tauu, double* taup, double* ds);
 int bk_cont_destroy(bk_cont* c);
+/* copy(state), src/Continuation.jl (ContState copies used by the bisection and by the engine's own bookkeeping)        */
+int bk_cont_clone(bk_cont* src, bk_cont** out);
+/* locate_bifurcation!(iter, state), src/Bifurcations.jl:159-349: call right after a bk_cont_step whose result has
+ * bifurcation = 1.  Bisects with the continuation step itself (step-size control off, ds halved / reversed at every
+ * crossing) until n_inversion crossings, max_bisection_steps steps or |ds| < dsmin_bisection; leaves the state next to the
+ * bifurcation point with the predictor rebuilt.  status: 0 none, 1 guess, 2 converged, 3 guessL; type: 0 none, 1 bp,
+ * 2 hopf, 3 nd (the codim-1 classification of _get_bifurcation_type, :80-130).                                        */
+typedef struct {
+    double dsmin_bisection;          /* ContinuationPar.dsmin_bisection           (1e-16)                             */
+    int n_inversion;                 /* ContinuationPar.n_inversion               (2, must be even)                   */
+    int max_bisection_steps;         /* ContinuationPar.max_bisection_steps       (25)                                */
+    double tol_bisection_eigenvalue; /* ContinuationPar.tol_bisection_eigenvalue  (1e-16)                             */
+    int max_steps;                   /* ContinuationPar.max_steps: `done` also bounds the bisection's own step counter */
+} bk_bisection_opts;
+typedef struct {
+    int status, type;
+    double interval[2];              /* parameter interval that contains the bifurcation point                        */
+    double p;                        /* parameter of the state on return                                             */
+    int n_unstable[2], n_imag[2];    /* (current, previous) pairs of the state on return                              */
+    int steps;                       /* continuation steps spent                                                      */
+} bk_bisection_result;
+int bk_cont_locate_bifurcation(bk_cont* c, const bk_bisection_opts* opts, bk_bisection_result* res);
 
 /* ------------------------------------------------------------------ deflated Newton --------------
  * solve(prob, defOp, options, DeflatedProblemCustomLS()) (src/DeflationOperator.jl:340-355): Newton on M(u) F(u) with

@@ -889,6 +889,59 @@ def test_cgl_hopf_detection_along_trivial_branch(ctx):
         assert np.array_equal(np.isnan(a_.real), np.isnan(b_.real)) and np.allclose(a_[ok_], b_[ok_], rtol=0, atol=1e-8)
 
 
+# --------------------------------------------------------------------------------------------- bisection
+def test_native_bisection_locates_hopf_points(ctx):
+    """bk_cont_locate_bifurcation (locate_bifurcation!, src/Bifurcations.jl:159-349) along the trivial branch of cGL2d
+    (examples/cGL2d.jl:96-100): the Jacobian at u = 0 has the eigenvalues r + lam_Lap +- i nu, so the Hopf points are
+    r* = -lam_Lap, known in closed form.  The native bisection brackets them, ends right after each crossing, classifies
+    them as Hopf, and walks the same states as the oracle's restatement of the algorithm (dense eigenvalues, direct solves)."""
+    hip = _hip()
+    from bk_amd import continuation as Cn
+    from oracle import bifurcations as B
+    dims, ls_ = (16, 9), (np.pi, np.pi / 2)
+    c = operators.CGL2d(dims, ls_)
+    prob = hip.CGL2d(ctx, dims, ls_, r=0.5)
+    n2 = 2 * c.n
+    lam = []
+    for n_, l_ in zip(dims, ls_):
+        h = 2 * l_ / n_
+        lam.append(-(4 / h ** 2) * np.sin(np.pi * np.arange(1, n_ + 1) / (2 * (n_ + 1))) ** 2)
+    hopf = np.sort(-(lam[0][:, None] + lam[1][None, :]).ravel())               # r* of every mode, ascending
+    # oracle run
+    pars = c.default_params()
+    oprob = palc.Problem(lambda x, p: c.F(x, **dict(pars, r=p)), lambda x, p: c.J(x, **dict(pars, r=p)))
+
+    def oeig(Jm, nev):                       # what shift-invert at sigma = 1 sees: the nev eigenvalues closest to sigma
+        v = np.linalg.eigvals(Jm.toarray())
+        v = v[np.argsort(np.abs(v - 1.0), kind="stable")][:nev + (nev % 2)]          # (conjugate pairs stay together)
+        return v[np.argsort(-v.real, kind="stable")], None, True, 1
+
+    # (both runs end on the step budget, well inside [p_min, p_max]: the boundary handling -- Natural corrector at the clamped
+    # parameter, Palc.jl:157-160 -- is not part of this comparison)
+    ocp = B.ContPar(ds=0.2, dsmin=1e-3, dsmax=0.3, p_min=0.0, p_max=4.0, max_steps=5, nev=9, tol=1e-9, max_iterations=20,
+                    n_inversion=4, max_bisection_steps=30, dsmin_bisection=1e-7)
+    obls = lambda *a, **k: bordered.bordering_bls(bordered.default_ls, *a, check_precision=False, **k)
+    oo = B.continuation(oprob, np.zeros(n2), 0.5, ls=bordered.default_ls, bls=obls, eig=oeig, cp=ocp, normC=palc.norminf)
+    assert len(oo["specialpoint"]) >= 2
+    # native run
+    P = hip.LaplacePreconditioner(prob, 1.0)
+    ls = hip.GMRESIterativeSolvers(reltol=1e-11, restart=60, maxiter=600, Pl=P)
+    eig = hip.ShiftInvert(1.0, ls, tol=1e-9, maxiter=40, hermitian=False, save_vectors=False)
+    nopt = Cn.NewtonPar(tol=1e-9, max_iterations=20, linsolver=ls, eigsolver=eig)
+    cp = Cn.ContinuationPar(ds=0.2, dsmin=1e-3, dsmax=0.3, p_min=0.0, p_max=4.0, max_steps=5, nev=9, newton_options=nopt,
+                            n_inversion=4, max_bisection_steps=30, dsmin_bisection=1e-7)
+    alg = Cn.PALC(tangent="secant", theta=0.5, bls=hip.BorderingBLS(None, check_precision=False))
+    bn = Cn.continuation_native(prob, prob.vec(np.zeros(n2)), 0.5, alg, cp, normC=Cn.norminf, bisection=True)
+    assert len(bn.specialpoint) == len(oo["specialpoint"])
+    for sp, so, rstar in zip(bn.specialpoint, oo["specialpoint"], hopf):
+        lo, hi = sp["interval"]
+        assert sp["type"] == so["type"] == "hopf" and sp["status"] == so["status"], (bn.specialpoint, oo["specialpoint"])
+        assert lo - 1e-9 <= rstar <= hi + 1e-9 and hi - lo < 2e-2, (sp, rstar)       # continuation steps are ~0.25 wide
+        assert abs(sp["param"] - so["param"]) <= 1e-6 and np.allclose(sp["interval"], so["interval"], rtol=0, atol=1e-6)
+        assert tuple(sp["n_unstable"]) == (so["n_unstable"][1], so["n_unstable"][0])
+    assert len(bn.param) == len(oo["param"]) and np.allclose(bn.param, oo["param"], rtol=0, atol=1e-6)
+
+
 # --------------------------------------------------------------------------------------------- error behaviour
 def test_error_and_nonconvergence_behaviour(ctx):
     """The contract of SURVEY 8(b): misuse -> negative status + message (raised by the binding); non-convergence is NOT an

@@ -378,3 +378,31 @@ def test_symmetric_krylovjl_solvers_vs_dense():
     # CG on an indefinite operator stops without claiming success
     x, ok, it = krylov.cg_krylovjl(S, b, atol=1e-13, rtol=1e-12)
     assert not ok
+
+
+def test_locate_bifurcation_by_bisection():
+    """locate_bifurcation! (src/Bifurcations.jl:159-349) on a decoupled pitchfork family F_i = (p - a_i) x_i - x_i^3: along the
+    trivial branch the Jacobian is diag(p - a_i), so stability changes exactly at p = a_i; the bisection must bracket every
+    a_i tightly, end right after the crossing (status converged after n_inversion crossings) and classify branch points."""
+    from oracle import bifurcations as B
+    a = np.array([0.3, 0.62, 1.1, 1.5])
+    prob = palc.Problem(lambda x, p: (p - a) * x - x ** 3, lambda x, p: np.diag((p - a) - 3 * x ** 2))
+
+    def eig(Jm, nev):
+        v = np.linalg.eigvals(Jm)
+        return v[np.argsort(-v.real)][:nev].astype(complex), None, True, 1
+
+    cp = B.ContPar(ds=0.05, dsmin=1e-4, dsmax=0.08, p_min=-0.5, p_max=2.0, max_steps=60, nev=4, tol=1e-11, n_inversion=6,
+                   max_bisection_steps=40, dsmin_bisection=1e-9)
+    bls = lambda *args, **k: bordered.bordering_bls(bordered.default_ls, *args, **k)
+    out = B.continuation(prob, np.zeros(4), 0.0, ls=bordered.default_ls, bls=bls, eig=eig, cp=cp)
+    sps = out["specialpoint"]
+    assert [sp["type"] for sp in sps] == ["bp"] * 4 and all(sp["status"] == "converged" for sp in sps)
+    for sp, ai in zip(sps, a):
+        lo, hi = sp["interval"]
+        assert lo - 1e-12 <= ai <= hi + 1e-12 and hi - lo < 2e-3, (sp, ai)
+        assert sp["n_unstable"][0] == sp["n_unstable"][1] + 1 and sp["param"] >= ai       # the state sits right after
+    assert out["n_unstable"][-1] == 4 and np.all(np.diff(out["param"]) > 0)
+    # without bisection (detect_bifurcation = 2) the special points are only bracketed by the continuation steps
+    out2 = B.continuation(prob, np.zeros(4), 0.0, ls=bordered.default_ls, bls=bls, eig=eig, cp=cp, detect_bifurcation_level=2)
+    assert len(out2["specialpoint"]) == 4 and all(sp["interval"][1] - sp["interval"][0] > 1e-2 for sp in out2["specialpoint"])
