@@ -58,6 +58,14 @@ def parse():
     ap.add_argument("--sh-kernel", type=int, default=1)
     ap.add_argument("--dgks-eta", type=float, default=None)
     ap.add_argument("--opt", action="append", default=[], help="library tuning option key=value (experiments)")
+    ap.add_argument("--workload", default="corrector", choices=["corrector", "branch"],
+                    help="corrector: the BASELINE metric (PALC corrector steps/s); branch: BASELINE config 5 -- --steps native "
+                         "continuation steps (corrector + 15 eigenvalues + Bordered tangent + predictor per step)")
+    ap.add_argument("--no-steady", action="store_true", help="skip the steady-state record (corrector of a running branch)")
+    ap.add_argument("--nev", type=int, default=15)
+    ap.add_argument("--eig-tol", type=float, default=1e-8)
+    ap.add_argument("--eig-thick", type=int, default=1, help="branch workload: eigensolve starts from the previous step's Ritz vectors")
+    ap.add_argument("--eig-inner", default="minres", choices=["gmres", "minres"], help="branch workload: inner solver of the shift-invert eigensolver")
     ap.add_argument("--linsolver", default="gmres", choices=["gmres", "minres"],
                     help="gmres: GMRESKrylovKit(30), the reference example's solver (the headline workload); minres: "
                          "KrylovLS(KrylovAlg = :minres), valid because the SH Jacobian is symmetric (experiment)")
@@ -306,6 +314,22 @@ def main():
     barrier()
     t_setup = time.perf_counter() - t_setup
 
+    from bk_amd import continuation as Cn
+
+    def branch_setup(eig):
+        nopt = Cn.NewtonPar(tol=1e-9, max_iterations=15, linsolver=ls, eigsolver=eig)                # SH3d.jl:160
+        cp = Cn.ContinuationPar(ds=ds, dsmin=1e-4, dsmax=0.005, p_min=-0.1, p_max=0.15, max_steps=1, nev=args.nev,
+                                detect_bifurcation=3 if eig is not None else 0, newton_options=nopt)
+        alg = Cn.PALC(tangent="bordered", theta=theta, bls=hip.BorderingBLS(None, check_precision=False))   # SH3d.jl:163
+        return cp, alg
+
+    if args.workload == "branch":
+        run_branch_workload(args, ctx, hip, Cn, prob, P, ls, u0, branch_setup, barrier, rank, world, n, tiles, t_setup)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        ctx.close()
+        return
+
     def one_step():
         return hip.newton_palc_native(prob, z0, tau, z_pred, ds, theta, bls, tol=0.0, max_iterations=1,
                                       p_min=-0.1, p_max=0.15, norm_inf=True)
@@ -325,6 +349,33 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if hostcomm_mode else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # ---- steady state: the corrector of a RUNNING branch (state, Bordered tangent and step size after two native
+    # continuation steps), run to convergence -- next to the first-corrector headline (Weak 2)
+    steady = None
+    if not args.no_steady:
+        cp, alg = branch_setup(None)
+        cp.max_steps = 2
+        grab = {}
+        Cn.continuation_native(prob, u0, p0, alg, cp, normC=Cn.norminf,
+                               finalise_solution=lambda get, r: grab.update(get(), step=r.step, itlinear=r.itlinear) or True)
+        zs, ts, dss = grab["z"], grab["tau"], grab["ds"]
+        zps = zs.copy().add_(ts, dss)
+        run_s = lambda: hip.newton_palc_native(prob, zs, ts, zps, dss, theta, bls, tol=1e-9, max_iterations=15,
+                                               p_min=-0.1, p_max=0.15, norm_inf=True)
+        run_s()
+        barrier()
+        ts0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            ss = run_s()
+        barrier()
+        dts = (time.perf_counter() - ts0) / reps
+        steady = {"what": "corrector of continuation step 3 (state / Bordered tangent / ds after two native bk_cont_step calls), "
+                          "run to convergence (tol 1e-9)", "ms_per_corrector": dts * 1e3, "steps_per_s": 1.0 / dts,
+                  "converged": ss["converged"], "itnewton": ss["itnewton"], "itlinear": ss["itlineartot"],
+                  "ms_per_operator_application": dts * 1e3 / max(ss["itlineartot"], 1), "ds": dss, "p": zs.p,
+                  "itlinear_of_native_step_2": grab["itlinear"], "residuals": ss["residuals"]}
 
     kernels = {}
     for name in ("jvp", "residual", "multidot", "multiaxpy", "dct_pass", "blas1", "combine", "transpose", "alltoall",
@@ -388,7 +439,7 @@ def main():
                                           "p": cfull["u"].p},
                        "setup_seconds": t_setup, "sh_kernel": args.sh_kernel, "linsolver": args.linsolver,
                        "preconditioner": "none" if P is None else "dct"},
-            "roofline": roofline, "inner_loop": inner, "kernels": kernels,
+            "roofline": roofline, "inner_loop": inner, "steady_state": steady, "kernels": kernels,
         }
         cb = None
         if world == 1 and args.cpu_sample > 0:
@@ -420,6 +471,52 @@ def main():
     if dist.is_initialized():
         dist.destroy_process_group()
     ctx.close()
+
+
+def run_branch_workload(args, ctx, hip, Cn, prob, P, ls, u0, branch_setup, barrier, rank, world, n, tiles, t_setup):
+    """BASELINE config 5: a PALC branch with the reference example's settings (examples/SH3d.jl:160-166: Bordered tangent,
+    BorderingBLS(check_precision = false), ds = -0.001, dsmax = 0.005, Newton tol 1e-9, normC = norminf, detect_bifurcation 3,
+    nev = 15: shift-invert eigensolve sigma = 0.1, Krylov dimension 45 after every step), every step ONE bk_cont_step call."""
+    import torch
+    els = hip.KrylovLSSymmetric("minres", rtol=1e-9, atol=1e-12, itmax=4000, Pl=P) if args.eig_inner == "minres" else ls
+    eig = hip.ShiftInvert(0.1, els, tol=args.eig_tol, maxiter=20, hermitian=True, save_vectors=False)
+    cp, alg = branch_setup(eig)
+    cp.max_steps = args.steps
+    ctx.set_option("eig_thick_start", args.eig_thick)
+    per = []
+    last_t = [time.perf_counter()]
+
+    def fin(get, r):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        per.append(dict(step=r.step, seconds=t - last_t[0], p=r.p, ds=r.ds_used, itnewton=r.itnewton, itlinear=r.itlinear,
+                        eig_solves=r.eig_numops, eig_converged=bool(r.eig_converged), n_unstable=r.n_unstable,
+                        rightmost=[r.vals_re[i] for i in range(min(4, r.nvals))]))
+        last_t[0] = t
+        return True
+
+    barrier()
+    t0 = time.perf_counter()
+    last_t[0] = t0
+    br = Cn.continuation_native(prob, u0, 0.1, alg, cp, normC=Cn.norminf, finalise_solution=fin)
+    barrier()
+    dt = time.perf_counter() - t0
+    nst = len(br.param) - 1
+    t_init = dt - sum(p_["seconds"] for p_ in per)            # two Newton solves + the eigensolve at the first point
+    if per:
+        per[0]["seconds"] -= t_init
+    t_steps = sum(p_["seconds"] for p_ in per)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "palc_continuation_steps_per_s", "value": nst / max(t_steps, 1e-9), "unit": "steps/s", "n_gpus": world,
+            "steps": nst, "warmup": 0, "ms_per_step": t_steps / max(nst, 1) * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"SH3d {n}^3 PALC branch (BASELINE config 5): corrector + {args.nev} eigenvalues "
+                                   f"(ShiftInvert sigma 0.1, Krylov-Schur dim {max(30, args.nev + 30)}, tol {args.eig_tol:g}, inner "
+                                   f"{args.eig_inner}, thick start {args.eig_thick}) + Bordered tangent + predictor per step",
+                       "grid": [n, n, n], "tiles": list(tiles), "parallelism": f"z-slabs x{world}",
+                       "initialisation_seconds": t_init, "setup_seconds": t_setup},
+            "per_step": per, "param": br.param, "n_unstable": br.n_unstable}))
 
 
 if __name__ == "__main__":

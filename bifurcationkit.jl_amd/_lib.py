@@ -42,8 +42,14 @@ class EigOpts(C.Structure):
                 ("hermitian", C.c_int), ("seed", C.c_ulonglong)]
 
 
+NEWTON_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_double,
+                              C.c_void_p, C.c_double, C.c_int)
+
+
 class NewtonOpts(C.Structure):
-    _fields_ = [("tol", C.c_double), ("max_iterations", C.c_int), ("norm_inf", C.c_int)]
+    _fields_ = [("tol", C.c_double), ("max_iterations", C.c_int), ("norm_inf", C.c_int), ("linesearch", C.c_int),
+                ("alpha", C.c_double), ("alpha_min", C.c_double), ("max_residual", C.c_double),
+                ("callback", NEWTON_CALLBACK), ("callback_user", C.c_void_p)]
 
 
 class NewtonResult(C.Structure):
@@ -66,7 +72,7 @@ class ContStepResult(C.Structure):
                 ("ds_next", C.c_double), ("step", C.c_int), ("stop", C.c_int), ("n_unstable", C.c_int),
                 ("n_imag", C.c_int), ("bifurcation", C.c_int), ("nvals", C.c_int), ("eig_converged", C.c_int),
                 ("eig_numops", C.c_int), ("vals_re", C.c_double * (BK_MAX_NEV + 1)),
-                ("vals_im", C.c_double * (BK_MAX_NEV + 1)), ("tangent_converged", C.c_int)]
+                ("vals_im", C.c_double * (BK_MAX_NEV + 1)), ("tangent_converged", C.c_int), ("natural", C.c_int)]
 
 
 class BisectionOpts(C.Structure):
@@ -76,7 +82,8 @@ class BisectionOpts(C.Structure):
 
 class BisectionResult(C.Structure):
     _fields_ = [("status", C.c_int), ("type", C.c_int), ("interval", C.c_double * 2), ("p", C.c_double),
-                ("n_unstable", C.c_int * 2), ("n_imag", C.c_int * 2), ("steps", C.c_int)]
+                ("n_unstable", C.c_int * 2), ("n_imag", C.c_int * 2), ("steps", C.c_int), ("nvals", C.c_int),
+                ("vals_re", C.c_double * (BK_MAX_NEV + 1)), ("vals_im", C.c_double * (BK_MAX_NEV + 1))]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, c_double_p, C.c_int, C.c_int)
@@ -102,6 +109,7 @@ SIGNATURES = {
     "bk_prof_enable": (I, [VP, I]),
     "bk_prof_reset": (I, [VP]),
     "bk_prof_get": (I, [VP, C.c_char_p, c_double_p, C.POINTER(C.c_longlong), c_double_p]),
+    "bk_solver_history": (I, [VP, c_double_p, SZ, C.POINTER(SZ), I]),
     "bk_malloc": (I, [VP, SZ, C.POINTER(VP)]),
     "bk_free": (I, [VP, VP]),
     "bk_upload": (I, [VP, VP, c_double_p, SZ]),
@@ -119,6 +127,7 @@ SIGNATURES = {
     "bk_problem_destroy": (I, [VP]),
     "bk_problem_nlocal": (I, [VP, C.POINTER(SZ), c_int_p, c_int_p]),
     "bk_residual": (I, [VP, VP, c_double_p, I, VP]),
+    "bk_residual_dparam": (I, [VP, VP, c_double_p, I, I, D, VP]),
     "bk_jacobian": (I, [VP, VP, c_double_p, I, C.POINTER(VP)]),
     "bk_op_destroy": (I, [VP]),
     "bk_jacobian_adjoint": (I, [VP, VP, c_double_p, I, C.POINTER(VP)]),
@@ -143,6 +152,7 @@ SIGNATURES = {
                                     VP, VP, VP, c_double_p, c_int_p, c_int_p]),
     "bk_eig_shiftinvert": (I, [VP, VP, I, C.POINTER(EigOpts), C.POINTER(GmresOpts), VP, c_double_p, c_double_p,
                                VP, VP, SZ, c_int_p, c_int_p, c_int_p]),
+    "bk_eig_set_start_vector": (I, [VP, VP]),
     "bk_eig_krylovkit": (I, [VP, VP, I, C.POINTER(EigOpts), c_double_p, c_double_p, VP, VP, SZ, c_int_p, c_int_p, c_int_p]),
     "bk_newton": (I, [VP, VP, VP, c_double_p, I, C.POINTER(NewtonOpts), C.POINTER(GmresOpts), VP,
                       C.POINTER(NewtonResult)]),

@@ -44,6 +44,23 @@ class NewtonPar:
     verbose: bool = False
     linsolver: object = None
     eigsolver: object = None
+    linesearch: bool = False         # :27, used by newton_palc only (Palc.jl:254-281)
+    alpha: float = 1.0               # :29
+    alphamin: float = 1e-3           # :31
+
+
+def cb_default(state, **kw):         # src/Newton.jl:151
+    return True
+
+
+@dataclass
+class cbMaxNorm:
+    """src/Newton.jl:156-159: reject iterates whose residual exceeds ``maxres``.  The native correctors evaluate it inside
+    the library (bk_newton_opts.max_residual); any other callable becomes a host callback (bk_newton_callback)."""
+    maxres: float
+
+    def __call__(self, state, **kw):
+        return state["residual"] < self.maxres
 
 
 @dataclass
@@ -90,14 +107,15 @@ class NonLinearSolution:
     itlineartot: int
 
 
-def newton(prob, x0, p, options: NewtonPar, normN=norm2) -> NonLinearSolution:
+def newton(prob, x0, p, options: NewtonPar, normN=norm2, callback=cb_default) -> NonLinearSolution:
     """_newton, src/Newton.jl:66-114."""
     x = x0.copy()
     fx = prob.residual(x, p)
     res = normN(fx)
     residuals = [res]
     step, itlin = 0, 0
-    while step < options.max_iterations and res > options.tol:
+    compute = callback(dict(x=x, fx=fx, residual=res, step=step, residuals=residuals), fromNewton=True)
+    while step < options.max_iterations and res > options.tol and compute:
         J = prob.jacobian(x, p)
         u, cv, it = options.linsolver(J, fx)
         itlin += int(np.sum(it))
@@ -108,7 +126,10 @@ def newton(prob, x0, p, options: NewtonPar, normN=norm2) -> NonLinearSolution:
         step += 1
         if options.verbose:
             print(f"  newton {step:3d}  res = {res:.4e}  itlinear = {it}")
-    return NonLinearSolution(x, residuals, residuals[-1] < options.tol, step, itlin)
+        compute = callback(dict(x=x, fx=fx, residual=res, step=step, itlinear=it, residuals=residuals), fromNewton=True)
+    flag = residuals[-1] < options.tol and bool(callback(dict(x=x, fx=fx, residual=res, step=step, residuals=residuals),
+                                                         fromNewton=True))
+    return NonLinearSolution(x, residuals, flag, step, itlin)
 
 
 def dot_theta(u1, u2, p1, p2, theta):
@@ -123,9 +144,19 @@ def solve_bls_palc(bls, theta, tau, J, dR, R, n, shift=None):
                dotp=lambda x, y: x.inner(y) / N, dotscale=1.0 / N)
 
 
+def _dFdp(prob, x, p, eps, res_f=None):
+    """dFdp = (F(x, p + eps) - F(x, p)) / eps (Palc.jl:239-240, Tangents.jl:77-82).  Device problems evaluate the
+    quotient cancellation-free in one pass (bk_residual_dparam), like the native corrector."""
+    if hasattr(prob, "residual_dparam"):
+        return prob.residual_dparam(x, p, eps)
+    dFdp = prob.residual(x, p + eps)
+    dFdp.add_(res_f if res_f is not None else prob.residual(x, p), -1.0)
+    return dFdp.scale_(1.0 / eps)
+
+
 def newton_palc(prob, z0, tau0, z_pred, ds, theta, bls, options: NewtonPar, p_min=-math.inf, p_max=math.inf,
-                normN=norm2) -> NonLinearSolution:
-    """newton_palc, Palc.jl:187-305 (linesearch = false)."""
+                normN=norm2, callback=cb_default) -> NonLinearSolution:
+    """newton_palc, Palc.jl:187-305 (plain update :282-285, line search :254-281, callback :235,294-297)."""
     eps = prob.delta
 
     def Nfun(u, p):                            # arc_length_eq, Palc.jl:44-56 (two dots, as written)
@@ -138,23 +169,45 @@ def newton_palc(prob, z0, tau0, z_pred, ds, theta, bls, options: NewtonPar, p_mi
     res = max(normN(res_f), abs(res_n))
     residuals = [res]
     step, itlin = 0, 0
-    while step < options.max_iterations and res > options.tol:
-        dFdp = prob.residual(x, p + eps)
-        dFdp.add_(res_f, -1.0)
-        dFdp.scale_(1.0 / eps)
+    alpha, line_step = options.alpha, True
+    compute = callback(dict(x=x, res_f=res_f, residual=res, step=step, z0=z0, p=p, residuals=residuals), fromNewton=False)
+    while step < options.max_iterations and res > options.tol and line_step and compute:
+        dFdp = _dFdp(prob, x, p, eps, res_f)
         J = prob.jacobian(x, p)
         u, up, flag, it = solve_bls_palc(bls, theta, tau0, J, dFdp, res_f, res_n)
         itlin += int(np.sum(it))
-        x.add_(u, -1.0)
-        p = min(max(p - up, p_min), p_max)
-        res_f = prob.residual(x, p)
-        res_n = Nfun(x, p)
-        res = max(normN(res_f), abs(res_n))
+        if options.linesearch:
+            line_step = False
+            while not line_step and alpha > options.alphamin:
+                x_pred = x.copy().add_(u, -alpha)
+                p_pred = p - alpha * up
+                res_f = prob.residual(x_pred, p_pred)
+                res_n = Nfun(x_pred, p_pred)
+                res = max(normN(res_f), abs(res_n))
+                if res < residuals[-1]:
+                    if res < residuals[-1] / 4 and alpha < 1:
+                        alpha *= 2
+                    line_step = True
+                    x.copyto_(x_pred)
+                    p = min(max(p_pred, p_min), p_max)
+                else:
+                    alpha /= 2
+            alpha = options.alpha
+        else:
+            x.add_(u, -1.0)
+            p = min(max(p - up, p_min), p_max)
+            res_f = prob.residual(x, p)
+            res_n = Nfun(x, p)
+            res = max(normN(res_f), abs(res_n))
         residuals.append(res)
         step += 1
         if options.verbose:
             print(f"  newton_palc {step:3d}  res = {res:.4e}  itlinear = {it}")
-    return NonLinearSolution(BorderedArray(x, p), residuals, residuals[-1] < options.tol, step, itlin)
+        compute = callback(dict(x=x, res_f=res_f, residual=res, step=step, itlinear=it, z0=z0, p=p, residuals=residuals),
+                           fromNewton=False)
+    flag = residuals[-1] < options.tol and bool(callback(dict(x=x, res_f=res_f, residual=res, step=step, p=p,
+                                                              residuals=residuals), fromNewton=False))
+    return NonLinearSolution(BorderedArray(x, p), residuals, flag, step, itlin)
 
 
 def secant_tangent(z1, z0, ds, theta):
@@ -168,9 +221,7 @@ def secant_tangent(z1, z0, ds, theta):
 def bordered_tangent(prob, z, tau, theta, bls):
     """gettangent!(::Bordered), Tangents.jl:71-104."""
     eps = prob.delta
-    dFdl = prob.residual(z.u, z.p + eps)
-    dFdl.add_(prob.residual(z.u, z.p), -1.0)
-    dFdl.scale_(1.0 / eps)
+    dFdl = _dFdp(prob, z.u, z.p, eps)
     J = prob.jacobian(z.u, z.p)
     tu, tp, flag, _ = solve_bls_palc(bls, theta, tau, J, dFdl, z.u.zerovector(), 1.0)
     a = 1.0 / math.sqrt(dot_theta(tu, tu, tp, tp, theta))
@@ -215,17 +266,17 @@ class ContResult:
 
 
 def continuation(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm2, verbosity=0, save_sol=False,
-                 corrector=newton_palc) -> ContResult:
+                 corrector=newton_palc, callback_newton=cb_default) -> ContResult:
     """PALC branch.  Continuation.jl:349-456 (two Newton solves + secant tangent), :458-504 (one step:
     corrector!, compute_eigenvalues!, step_size_control!, getpredictor!)."""
     alg = alg.update(cp)
     nopt = cp.newton_options
     eig = nopt.eigsolver if cp.detect_bifurcation > 0 else None
-    sol0 = newton(prob, x0, p0, nopt, normC)
+    sol0 = newton(prob, x0, p0, nopt, normC, callback_newton)
     if not sol0.converged:
         raise RuntimeError("Newton failed to converge for the initial guess on the branch")
     p1 = p0 + cp.ds / cp.eta
-    sol1 = newton(prob, sol0.u, p1, nopt, normC)
+    sol1 = newton(prob, sol0.u, p1, nopt, normC, callback_newton)
     if not sol1.converged:
         raise RuntimeError("Newton failed to converge. Required for the computation of the initial tangent")
     z0 = BorderedArray(sol0.u, p0)
@@ -234,7 +285,7 @@ def continuation(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm2, verb
     n_unst, n_imag = -1, -1
 
     def eigen(z, n_prev):
-        nev_ = max(max(n_prev, 0) + 5, cp.nev)                          # Utils.jl:78-79
+        nev_ = max(n_prev + 5, cp.nev)                                  # n = state.n_unstable[2], Utils.jl:78-79
         vals, _, cv, it = eig(prob.jacobian(z.u, z.p), nev_)
         nu, ni = is_stable(vals, cp.tol_stability)
         return vals, nu, ni
@@ -247,6 +298,7 @@ def continuation(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm2, verb
             br.sol.append(z.u.copy())
 
     vals = None
+    n_unst_prev = -1
     if eig is not None:
         vals, n_unst, n_imag = eigen(z0, -1)
     ds = cp.ds
@@ -256,10 +308,16 @@ def continuation(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm2, verb
     z_pred = z.copy().add_(tau, ds)                                     # addtangent!
     record(z, sol0, ds, vals)
     step = 0
-    while step < cp.max_steps:
+    while step < cp.max_steps and (cp.p_min < z.p < cp.p_max or step == 0):        # done, Continuation.jl:254-257
         if z_pred.p <= cp.p_min or z_pred.p >= cp.p_max:
-            break              # the reference switches to a Natural corrector at the clamped p (Palc.jl:157-160)
-        sol = corrector(prob, z, tau, z_pred, ds, alg.theta, alg.bls, nopt, cp.p_min, cp.p_max, normC)
+            # corrector!(::PALC) hands over to Natural at the clamped parameter (Palc.jl:157-160, Natural.jl:38-58)
+            z_pred.p = min(max(z_pred.p, cp.p_min), cp.p_max)
+            sn = newton(prob, z_pred.u, z_pred.p, nopt, normC, callback_newton)
+            sol = NonLinearSolution(BorderedArray(sn.u, z_pred.p), sn.residuals, sn.converged, sn.itnewton, sn.itlineartot)
+        elif corrector is newton_palc:
+            sol = corrector(prob, z, tau, z_pred, ds, alg.theta, alg.bls, nopt, cp.p_min, cp.p_max, normC, callback_newton)
+        else:
+            sol = corrector(prob, z, tau, z_pred, ds, alg.theta, alg.bls, nopt, cp.p_min, cp.p_max, normC)
         conv = sol.converged
         if verbosity:
             print(f"step {step:3d} ds={ds:+.3e} p={z.p:+.6f} -> {sol.u.p:+.6f} conv={conv} "
@@ -269,7 +327,8 @@ def continuation(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm2, verb
             z.copyto_(sol.u)
             prev_unst = n_unst
             if eig is not None:
-                vals, n_unst, n_imag = eigen(z, n_unst)
+                vals, n_unst, n_imag = eigen(z, n_unst_prev)
+                n_unst_prev = prev_unst
                 if prev_unst != -1 and n_unst != prev_unst:             # detect_bifurcation, Bifurcations.jl:22-28
                     br.specialpoint.append(dict(step=step + 1, param=z.p, n_unstable=(prev_unst, n_unst)))
             step += 1
@@ -287,13 +346,15 @@ def continuation(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm2, verb
 
 
 def continuation_native(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm2, verbosity=0, save_sol=False,
-                        bisection=False) -> ContResult:
+                        bisection=False, finalise_solution=None, callback_newton=None) -> ContResult:
     """The same branch with every step issued as ONE library call (``bk_cont_step``: corrector, eigenvalues, step-size
     control, tangent and predictor -- the body of ``iterate``, src/Continuation.jl:458-504) and the two initial Newton
     solves as ``bk_newton``.  Needs the native solver types (GMRES* + BorderingBLS + ShiftInvert); ``normC`` must be
     ``norm2`` or ``norminf``.  Returns the same record as :func:`continuation`.  ``bisection=True`` (the reference's
     ``detect_bifurcation = 3``): every detected change of stability is located by ``bk_cont_locate_bifurcation``
-    (locate_bifurcation!, src/Bifurcations.jl:159-349) and the special point carries its interval, status and type."""
+    (locate_bifurcation!, src/Bifurcations.jl:159-349) and the special point carries its interval, status and type.
+    ``finalise_solution(state, r) -> bool`` (the reference's hook of the same name, src/Continuation.jl:296-310) is called
+    after every accepted step with a ``get()`` accessor of the device state; returning False stops the run."""
     import ctypes as C
 
     from . import _lib as L
@@ -307,17 +368,17 @@ def continuation_native(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm
     inf = normC is norminf
     ctx = prob.ctx
     eig = nopt.eigsolver if cp.detect_bifurcation > 0 else None
-    s0 = hip.newton_native(prob, x0, p0, ls, nopt.tol, nopt.max_iterations, inf)
+    s0 = hip.newton_native(prob, x0, p0, ls, nopt.tol, nopt.max_iterations, inf, callback=callback_newton)
     if not s0["converged"]:
         raise RuntimeError("Newton failed to converge for the initial guess on the branch")
     p1 = p0 + cp.ds / cp.eta
-    s1 = hip.newton_native(prob, s0["u"], p1, ls, nopt.tol, nopt.max_iterations, inf)
+    s1 = hip.newton_native(prob, s0["u"], p1, ls, nopt.tol, nopt.max_iterations, inf, callback=callback_newton)
     if not s1["converged"]:
         raise RuntimeError("Newton failed to converge. Required for the computation of the initial tangent")
     big = 1.7e308
     co = L.ContOpts(cp.ds, cp.dsmin, cp.dsmax, cp.a, alg.theta, max(cp.p_min, -big), min(cp.p_max, big),
                     0 if alg.tangent == "secant" else 1, 1 if eig is not None else 0, cp.nev, cp.tol_stability)
-    no = L.NewtonOpts(float(nopt.tol), int(nopt.max_iterations), 1 if inf else 0)
+    no = hip.newton_opts(nopt.tol, nopt.max_iterations, inf, nopt.linesearch, nopt.alpha, nopt.alphamin, callback_newton)
     bo = L.BorderingOpts(bls.tol, 1 if bls.check_precision else 0, bls.k)
     lo = bls.solver._opts()
     eo = elo = None
@@ -365,18 +426,36 @@ def continuation_native(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm
                 if r.bifurcation:
                     sp = dict(step=step + 1, param=r.p, n_unstable=(prev_unst, r.n_unstable))
                     on_boundary = r.p in (cp.p_min, cp.p_max)
+                    keep = True
                     if bisection and not on_boundary:                          # Continuation.jl:537-541
                         bo = L.BisectionOpts(cp.dsmin_bisection, cp.n_inversion, cp.max_bisection_steps,
                                              cp.tol_bisection_eigenvalue, cp.max_steps)
                         res = L.BisectionResult()
                         ctx.check(ctx.lib.bk_cont_locate_bifurcation(h, C.byref(bo), C.byref(res)), "bk_cont_locate_bifurcation")
-                        sp.update(status=("none", "guess", "converged", "guessL")[res.status],
-                                  type=("none", "bp", "hopf", "nd")[res.type], interval=(res.interval[0], res.interval[1]),
-                                  param=res.p, n_unstable=(res.n_unstable[1], res.n_unstable[0]), bisection_steps=res.steps)
-                        r.p, r.n_unstable, r.n_imag = res.p, res.n_unstable[0], res.n_imag[0]
-                    br.specialpoint.append(sp)
+                        if res.status != 0:                                    # status none: the state was left untouched
+                            sp.update(status=("none", "guess", "converged", "guessL")[res.status],
+                                      type=("none", "bp", "hopf", "nd")[res.type], interval=(res.interval[0], res.interval[1]),
+                                      param=res.p, n_unstable=(res.n_unstable[1], res.n_unstable[0]), bisection_steps=res.steps)
+                            # the record takes the bisected state: p, counts AND its eigenvalues (_state.eigvals = state.eigvals)
+                            r.p, r.n_unstable, r.n_imag = res.p, res.n_unstable[0], res.n_imag[0]
+                            r.nvals = res.nvals
+                            for i in range(res.nvals):
+                                r.vals_re[i], r.vals_im[i] = res.vals_re[i], res.vals_im[i]
+                            # "double-check that the bisection did not remove the bifurcation point" (Continuation.jl:543-546)
+                            keep = res.n_unstable[0] != res.n_unstable[1] and res.type != 0
+                    if keep:
+                        br.specialpoint.append(sp)
                 step += 1
                 record(r, r.itnewton, r.itlinear, [r.residuals[i] for i in range(r.itnewton + 1)])
+                if finalise_solution is not None:
+                    def get():
+                        u, tu = s0["u"].similar(), s0["u"].similar()
+                        pp, tp, dd = C.c_double(), C.c_double(), C.c_double()
+                        ctx.check(ctx.lib.bk_cont_get(h, hip._ptr(u.t), C.byref(pp), hip._ptr(tu.t), C.byref(tp), C.byref(dd)),
+                                  "bk_cont_get")
+                        return dict(z=BorderedArray(u, pp.value), tau=BorderedArray(tu, tp.value), ds=dd.value)
+                    if finalise_solution(get, r) is False:
+                        break
             if r.stop:
                 break
     finally:

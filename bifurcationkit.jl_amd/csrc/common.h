@@ -65,6 +65,11 @@ struct bk_ctx {
     std::map<std::string, bk::ProfEntry> prof_entries;
     std::vector<hipEvent_t> event_pool;
     std::string err;
+    // residual history of the linear solves since the last bk_solver_history_reset (option "solver_trace" != 0):
+    // one entry per Krylov iteration (the solver's own residual estimate); a negative entry -(k+1) opens solve k
+    std::vector<double> hist;
+    int hist_solves = 0;
+    const double* eig_x0 = nullptr;   // one-shot start vector of the next eigensolve (bk_eig_set_start_vector)
 
     double opt(const char* key, double dflt) const {
         auto it = opts.find(key);

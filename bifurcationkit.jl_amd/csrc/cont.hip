@@ -37,6 +37,11 @@ struct bk_cont {
     bool stepsizecontrol = true, converged = true;
     int nvals = 0;
     double vals_re[BK_MAX_NEV + 1], vals_im[BK_MAX_NEV + 1];
+    // context option "eig_thick_start" != 0 at bk_cont_create: the eigensolve of a step starts from the sum of the
+    // previous step's Ritz vectors (the x0 of KrylovKit.eigsolve, EigKrylovKit.x0 src/EigSolver.jl:143,160) instead of
+    // rand(N); the eigenvectors move slowly along the branch, so the Krylov-Schur iteration restarts (almost) converged
+    bool thick = false, have_x0 = false;
+    double* eigx0 = nullptr;
 };
 
 namespace {
@@ -70,11 +75,8 @@ int bordered_tangent(bk_cont* c, int* converged) {
     for (int i = 0; i < c->nparams; ++i) par[i] = c->params[i];
     double* dFdl = c->work;
     double* f0 = c->work2;
-    par[c->ipar] = c->zp + eps;
-    BK_TRY(bk_residual(c->prob, c->zu, par, c->nparams, dFdl));
     par[c->ipar] = c->zp;
-    BK_TRY(bk_residual(c->prob, c->zu, par, c->nparams, f0));
-    BK_TRY(v_axpby(c->ctx, c->n, -1.0 / eps, f0, 1.0 / eps, dFdl));
+    BK_TRY(c->prob->dparam(c->zu, par, c->nparams, c->ipar, eps, nullptr, dFdl));      // Tangents.jl:77-82
     BK_TRY(v_zero(c->ctx, c->n, f0));                      // rhs (0, 1), Tangents.jl:90-94
     bk_op* J = nullptr;
     BK_TRY(bk_jacobian(c->prob, c->zu, par, c->nparams, &J));
@@ -108,19 +110,33 @@ int eigen(bk_cont* c, bk_cont_step_result* r) {
     double par[BK_MAX_PARAMS];
     for (int i = 0; i < c->nparams; ++i) par[i] = c->params[i];
     par[c->ipar] = c->zp;
-    int nev = std::max(std::max(c->n_unstable, 0) + 5, c->co.nev);
+    // n = state.n_unstable[2]: the count BEFORE the last update (Utils.jl:78-79); -1 at the first two calls
+    int nev = std::max(c->n_unstable_prev + 5, c->co.nev);
     nev = std::min(nev, BK_MAX_NEV);
     bk_eig_opts eo = c->eo;
     if (eo.krylovdim <= 0) eo.krylovdim = std::max(30, nev + 30);      // examples/SH3d.jl:109
     eo.krylovdim = std::min(eo.krylovdim, 63);
-    nev = std::min(nev, eo.krylovdim);
+    nev = std::max(1, std::min(nev, eo.krylovdim - 2));                // room for a restart that keeps a conjugate pair
     bk_op* J = nullptr;
     BK_TRY(bk_jacobian(c->prob, c->zu, par, c->nparams, &J));
     int nvals = 0, nconv = 0, nops = 0;
-    const int s = bk_eig_shiftinvert(c->ctx, J, nev, &eo, &c->elo, c->epl, r->vals_re, r->vals_im, nullptr, nullptr, 0,
+    WsGuard ws(c->ctx);
+    double* vecs = nullptr;
+    const size_t ld = (c->n + 31) / 32 * 32;
+    if (c->thick) {
+        BK_TRY(ws.get(ld * (size_t)(nev + 1), &vecs));
+        if (c->have_x0) BK_TRY(bk_eig_set_start_vector(c->ctx, c->eigx0));
+    }
+    const int s = bk_eig_shiftinvert(c->ctx, J, nev, &eo, &c->elo, c->epl, r->vals_re, r->vals_im, vecs, nullptr, ld,
                                      &nvals, &nconv, &nops);
     bk_op_destroy(J);
     if (s != 0) return s;
+    if (c->thick && nvals > 0) {                                        // x0 of the next eigensolve: sum of the Ritz vectors
+        double ones[BK_MAX_NEV + 1];
+        for (int i = 0; i < nvals; ++i) ones[i] = 1.0;
+        BK_TRY(v_multiaxpy(c->ctx, c->n, vecs, ld, nvals, ones, nullptr, 1.0, c->eigx0, nullptr));
+        c->have_x0 = true;
+    }
     int nu = 0, ni = 0;
     for (int i = 0; i < nvals; ++i) {                       // NaN (unconverged) compares false, as in the mirror
         if (r->vals_re[i] > c->co.tol_stability) {
@@ -162,12 +178,15 @@ int bk_cont_create(bk_ctx* ctx, bk_problem* prob, const double* params, int npar
     c->co = *copts; c->no = *nopts; c->bo = *bopts; c->lo = *lsopts; c->pl = pl;
     c->has_eig = copts->detect != 0;
     if (c->has_eig) { c->eo = *eopts; c->elo = *eig_lsopts; c->epl = eig_pl; }
-    double** bufs[] = {&c->zu, &c->zoldu, &c->tauu, &c->predu, &c->work, &c->work2};
-    for (double** b : bufs)
+    c->thick = c->has_eig && ctx->opt("eig_thick_start", 0.0) != 0.0;
+    double** bufs[] = {&c->zu, &c->zoldu, &c->tauu, &c->predu, &c->work, &c->work2, &c->eigx0};
+    for (double** b : bufs) {
+        if (b == &c->eigx0 && !c->thick) continue;
         if (hipMalloc(b, c->n * sizeof(double)) != hipSuccess) {
             bk_cont_destroy(c);
             return set_error(ctx, "bk_cont_create: device allocation failed");
         }
+    }
     // initialize!, Palc.jl:112-123 after the two Newton solves of Continuation.jl:349-456
     int s = 0;
     c->ds = copts->ds;
@@ -186,7 +205,7 @@ int bk_cont_create(bk_ctx* ctx, bk_problem* prob, const double* params, int npar
 
 int bk_cont_destroy(bk_cont* c) {
     if (!c) return 0;
-    double* bufs[] = {c->zu, c->zoldu, c->tauu, c->predu, c->work, c->work2};
+    double* bufs[] = {c->zu, c->zoldu, c->tauu, c->predu, c->work, c->work2, c->eigx0};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     delete c;
@@ -199,17 +218,29 @@ int bk_cont_step(bk_cont* c, bk_cont_step_result* r) {
     *r = bk_cont_step_result{};
     r->n_unstable = c->n_unstable; r->n_imag = c->n_imag;
     r->p = c->zp; r->ds_used = c->ds; r->ds_next = c->ds;
-    if (c->predp <= c->co.p_min || c->predp >= c->co.p_max) {          // the mirror stops here (Palc.jl:157-160 switches
-        r->stop = 2;                                                    // to a Natural corrector at the clamped p)
+    // done(it, state), src/Continuation.jl:254-257: the point that reached the boundary of [p_min, p_max] was the last one
+    if (c->step > 0 && !(c->zp > c->co.p_min && c->zp < c->co.p_max)) {
+        r->stop = 2;
         return 0;
     }
-    // corrector!: newton_palc from the predictor; z (the last point) and tau are inputs
     double* x = c->work;
     BK_TRY(v_copy(ctx, c->n, c->predu, x));
     double p = c->predp;
     bk_newton_result nr = {};
-    BK_TRY(bk_newton_palc(ctx, c->prob, x, &p, c->zu, c->zp, c->tauu, c->taup, c->ds, c->co.theta, c->params, c->nparams,
-                          c->ipar, c->co.p_min, c->co.p_max, &c->no, &c->bo, &c->lo, c->pl, &nr));
+    if (c->predp <= c->co.p_min || c->predp >= c->co.p_max) {
+        // corrector!(::PALC) hands over to the Natural corrector at the clamped parameter (Palc.jl:157-160,
+        // Natural.jl:38-58): plain Newton from z_pred.u at p = clamp(z_pred.p); the point lands ON the boundary
+        c->predp = p = std::min(std::max(c->predp, c->co.p_min), c->co.p_max);
+        double par[BK_MAX_PARAMS];
+        for (int i = 0; i < c->nparams; ++i) par[i] = c->params[i];
+        par[c->ipar] = p;
+        BK_TRY(bk_newton(ctx, c->prob, x, par, c->nparams, &c->no, &c->lo, c->pl, &nr));
+        r->natural = 1;
+    } else {
+        // corrector!: newton_palc from the predictor; z (the last point) and tau are inputs
+        BK_TRY(bk_newton_palc(ctx, c->prob, x, &p, c->zu, c->zp, c->tauu, c->taup, c->ds, c->co.theta, c->params,
+                              c->nparams, c->ipar, c->co.p_min, c->co.p_max, &c->no, &c->bo, &c->lo, c->pl, &nr));
+    }
     r->converged = nr.converged; r->itnewton = nr.itnewton; r->itlinear = nr.itlinear;
     c->converged = nr.converged != 0;
     for (int i = 0; i <= nr.itnewton && i <= BK_MAX_NEWTON_ITER; ++i) r->residuals[i] = nr.residuals[i];
@@ -269,19 +300,23 @@ static int cont_copy_state(bk_cont* dst, const bk_cont* src) {      // copyto!(d
     dst->stepsizecontrol = src->stepsizecontrol; dst->converged = src->converged;
     dst->nvals = src->nvals;
     for (int i = 0; i < src->nvals; ++i) { dst->vals_re[i] = src->vals_re[i]; dst->vals_im[i] = src->vals_im[i]; }
+    if (src->thick && dst->thick && src->have_x0) BK_TRY(v_copy(src->ctx, src->n, src->eigx0, dst->eigx0));
+    dst->have_x0 = src->thick && dst->thick && src->have_x0;
     return 0;
 }
 
 int bk_cont_clone(bk_cont* src, bk_cont** out) {
     if (!src || !out) return -1;
     bk_cont* c = new bk_cont(*src);                           // options, solver settings, scalars
-    c->zu = c->zoldu = c->tauu = c->predu = c->work = c->work2 = nullptr;
-    double** bufs[] = {&c->zu, &c->zoldu, &c->tauu, &c->predu, &c->work, &c->work2};
-    for (double** b : bufs)
+    c->zu = c->zoldu = c->tauu = c->predu = c->work = c->work2 = c->eigx0 = nullptr;
+    double** bufs[] = {&c->zu, &c->zoldu, &c->tauu, &c->predu, &c->work, &c->work2, &c->eigx0};
+    for (double** b : bufs) {
+        if (b == &c->eigx0 && !c->thick) continue;
         if (hipMalloc(b, c->n * sizeof(double)) != hipSuccess) {
             bk_cont_destroy(c);
             return set_error(src->ctx, "bk_cont_clone: device allocation failed");
         }
+    }
     const int s = cont_copy_state(c, src);
     if (s != 0) { bk_cont_destroy(c); return s; }
     *out = c;
@@ -368,6 +403,8 @@ int bk_cont_locate_bifurcation(bk_cont* c, const bk_bisection_opts* bo, bk_bisec
     res->interval[1] = std::max(interval[0], interval[1]);
     res->steps = steps;
     res->p = c->zp;
+    res->nvals = c->nvals;
+    for (int i = 0; i < c->nvals; ++i) { res->vals_re[i] = c->vals_re[i]; res->vals_im[i] = c->vals_im[i]; }
     {   // _get_bifurcation_type, codim-1 cases (Bifurcations.jl:95-130): 1 bp, 2 hopf, 3 nd
         const int dn = std::abs(res->n_unstable[0] - res->n_unstable[1]), di = std::abs(res->n_imag[0] - res->n_imag[1]);
         res->type = dn == 1 ? (di == 0 ? 1 : (di == 1 ? 2 : 3)) : (dn == 2 ? (di == 2 ? 2 : 3) : (dn > 2 ? 3 : 0));

@@ -384,6 +384,15 @@ int bk_prof_reset(bk_ctx* ctx) {
     return 0;
 }
 
+int bk_solver_history(bk_ctx* ctx, double* buf, size_t cap, size_t* n, int reset) {
+    if (!ctx) return -1;
+    if (n) *n = ctx->hist.size();
+    if (buf)
+        for (size_t i = 0; i < ctx->hist.size() && i < cap; ++i) buf[i] = ctx->hist[i];
+    if (reset) { ctx->hist.clear(); ctx->hist_solves = 0; }
+    return 0;
+}
+
 int bk_prof_get(bk_ctx* ctx, const char* name, double* total_ms, long long* calls, double* alg_bytes) {
     if (!ctx || !name) return -1;
     prof_resolve(ctx);

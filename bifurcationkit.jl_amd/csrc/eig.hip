@@ -58,6 +58,10 @@ using dense::cplx;
 // mapped back by 1/mu + sigma; otherwise Aop = J itself and the order is by real part (:LR, EigKrylovKit's default use).
 static int eig_core(bk_ctx* ctx, bk_op* Aop, bool invert, int nev, const bk_eig_opts* eo, double* vals_re, double* vals_im,
                     double* vecs, double* vecs_im, size_t ldvecs, int* nvals_out, int* nconv_out, int* napplied) {
+    // one-shot start vector (bk_eig_set_start_vector): the x0 of KrylovKit.eigsolve(A, x0, ...) -- EigKrylovKit.x0,
+    // src/EigSolver.jl:143,160; the reference's SH3dEig passes rand(N) (examples/SH3d.jl:109), which stays the default
+    const double* x0 = ctx->eig_x0;
+    ctx->eig_x0 = nullptr;
     bk_op& A = *Aop;
     const size_t n = A.n;
     int m = eo->krylovdim;
@@ -85,9 +89,11 @@ static int eig_core(bk_ctx* ctx, bk_op* Aop, bool invert, int nev, const bk_eig_
         }
         goff = (size_t)offs[0];
     }
-    BK_TRY(v_fill_random(ctx, n, goff, eo->seed, V));
+    if (x0) BK_TRY(v_copy(ctx, n, x0, V));
+    else BK_TRY(v_fill_random(ctx, n, goff, eo->seed, V));
     double nrm;
     BK_TRY(v_nrm2(ctx, n, V, &nrm));
+    if (!(nrm > 0.0)) return set_error(ctx, "eigensolver: the start vector is zero");
     BK_TRY(v_scale(ctx, n, 1.0 / nrm, V));
 
     dense::Mat H(m + 1, m);
@@ -231,6 +237,12 @@ static int eig_core(bk_ctx* ctx, bk_op* Aop, bool invert, int nev, const bk_eig_
     }
     if (nconv_out) *nconv_out = std::min(nconv, nout);      // strictly converged (resid < tol), as info.converged
     if (napplied) *napplied = applied;
+    return 0;
+}
+
+extern "C" int bk_eig_set_start_vector(bk_ctx* ctx, const double* x0) {
+    if (!ctx) return -1;
+    ctx->eig_x0 = x0;
     return 0;
 }
 

@@ -52,6 +52,8 @@ struct Sh1dArgs {           // 1-D cubic-quintic SH, Dirichlet, L1 = -(I + D)^2
     double* out;
 };
 int sh1d_apply(bk_ctx* ctx, const Sh1dArgs& a);
+// out = c * phi_ipar(u): the parameter derivative of the pointwise part (npts = grid points per field)
+int pde_dparam(bk_ctx* ctx, int pde, int ipar, size_t npts, double c, const double* u, double* out);
 
 // ---- DCT preconditioner launchers (dct.hip) -------------------------------------------------
 struct DctPlan;
@@ -86,6 +88,9 @@ struct bk_problem {
     double* halo_lo = nullptr;
     double* halo_hi = nullptr;
     int apply(int mode, const double* v, const double* u, const double* params, double a0, double a1, double* out);
+    // dFdp = (F(u, p + eps) - F(u, p)) / eps for the parameter `ipar`; `f0` = F(u, p) when the caller already has it
+    // (only read by the literal two-residual form, option "fd_dparam" = 0), `out` must not alias u or f0
+    int dparam(const double* u, const double* params, int nparams, int ipar, double eps, const double* f0, double* out);
 };
 
 struct bk_op {              // a linear operator on (device vector [+ one host tail scalar])

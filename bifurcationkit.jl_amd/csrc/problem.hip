@@ -72,6 +72,28 @@ int bk_problem::apply(int mode, const double* v, const double* u, const double* 
     return set_error(ctx, "unknown pde kind %d", d.pde);
 }
 
+int bk_problem::dparam(const double* u, const double* params, int nparams, int ipar, double eps, const double* f0,
+                       double* out) {
+    if (ctx->opt("fd_dparam", 1.0) != 0.0) {
+        // the scalar keeps the quotient's own rounding: ((p + eps) - p) / eps
+        const volatile double pe = params[ipar] + eps;
+        const double c = (pe - params[ipar]) / eps;
+        const size_t npts = desc.pde == BK_PDE_CGL2D ? nloc / 2 : nloc;
+        return pde_dparam(ctx, desc.pde, ipar, npts, c, u, out);
+    }
+    // literal form: two residual evaluations and a scaled difference (Palc.jl:239-240)
+    double par[BK_MAX_PARAMS];
+    for (int i = 0; i < nparams; ++i) par[i] = params[i];
+    par[ipar] = params[ipar] + eps;
+    BK_TRY(apply(1, u, u, par, 0.0, 1.0, out));
+    if (f0) return v_axpby(ctx, nloc, -1.0 / eps, f0, 1.0 / eps, out);
+    WsGuard ws(ctx);
+    double* tmp = nullptr;
+    BK_TRY(ws.get(nloc, &tmp));
+    BK_TRY(apply(1, u, u, params, 0.0, 1.0, tmp));
+    return v_axpby(ctx, nloc, -1.0 / eps, tmp, 1.0 / eps, out);
+}
+
 int PdeJacobian::apply(const double* x, const double*, double a0, double a1, double* out, double*) {
     // the SH Jacobians are symmetric (issymmetric = true, examples/SH3d.jl:123): only cGL has a distinct adjoint
     return prob->apply(adjoint && prob->desc.pde == BK_PDE_CGL2D ? 2 : 0, x, u, params, a0, a1, out);
@@ -149,6 +171,17 @@ int bk_residual(bk_problem* p, const double* u, const double* params, int nparam
     if (nparams < nparams_of(p->desc.pde)) return set_error(p->ctx, "bk_residual: expected %d parameters", nparams_of(p->desc.pde));
     if (u == out) return set_error(p->ctx, "bk_residual: out must not alias u");
     return p->apply(1, u, u, params, 0.0, 1.0, out);
+}
+
+int bk_residual_dparam(bk_problem* p, const double* u, const double* params, int nparams, int ipar, double eps,
+                       double* out) {
+    if (!p || !u || !params || !out) return -1;
+    if (nparams < nparams_of(p->desc.pde) || nparams > BK_MAX_PARAMS)
+        return set_error(p->ctx, "bk_residual_dparam: expected %d parameters", nparams_of(p->desc.pde));
+    if (ipar < 0 || ipar >= nparams_of(p->desc.pde)) return set_error(p->ctx, "bk_residual_dparam: bad parameter index");
+    if (!(eps > 0.0)) return set_error(p->ctx, "bk_residual_dparam: eps must be positive");
+    if (u == out) return set_error(p->ctx, "bk_residual_dparam: out must not alias u");
+    return p->dparam(u, params, nparams, ipar, eps, nullptr, out);
 }
 
 int bk_jacobian(bk_problem* p, const double* u, const double* params, int nparams, bk_op** out) {

@@ -190,6 +190,8 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     auto Rat = [&](int i, int j) -> double& { return R[(size_t)i + (size_t)j * m]; };
     int numiter = 0;
     double hnext = 0.0;
+    const bool trace = ctx->opt("solver_trace", 0.0) != 0.0;
+    if (trace) { ctx->hist_solves += 1; ctx->hist.push_back(-(double)ctx->hist_solves); ctx->hist.push_back(beta); }
 
     auto start_cycle = [&]() -> int {        // V[0] = r / beta ; first Arnoldi column
         BK_TRY(v_axpbyz(ctx, n, 1.0 / beta, rsrc, 0.0, nullptr, B.vec(0)));
@@ -226,6 +228,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
             y[k] = -sn[k - 1] * y[k - 1];
             y[k - 1] = cs[k - 1] * y[k - 1];
             beta = std::fabs(y[k]);
+            if (trace) ctx->hist.push_back(beta);
             const bool conv = kk ? !(beta > tol) : (beta <= tol);
             if (conv || k >= m || hnext == 0.0) break;
             if (!kk && iters >= o.maxiter) { stop = true; break; }
@@ -356,6 +359,8 @@ static int minres_core(bk_ctx* ctx, bk_op* J, const double* b, double* x, double
     BK_TRY(v_zero(ctx, n, w)); BK_TRY(v_zero(ctx, n, w2));
     int it = 0;
     bool solved = phibar <= tol;
+    const bool trace = ctx->opt("solver_trace", 0.0) != 0.0;
+    if (trace) { ctx->hist_solves += 1; ctx->hist.push_back(-(double)ctx->hist_solves); ctx->hist.push_back(phibar); }
     while (!solved && it < itmax) {
         it += 1;
         // y = (a0 + a1 J) v with v = z / beta
@@ -387,6 +392,7 @@ static int minres_core(bk_ctx* ctx, bk_op* J, const double* b, double* x, double
         { double* tmp = w1; w1 = w2; w2 = w; w = tmp; }                             // w1 <- w2, w2 <- w
         // w = (v - oldeps w1 - delta w2) / gamma ; x += phi w
         BK_TRY(v_minres_update(ctx, n, 1.0 / (vbeta * gamma), y, -oldeps / gamma, w1, -delta / gamma, w2, w, phi, x));
+        if (trace) ctx->hist.push_back(phibar);
         solved = phibar <= tol;
     }
     res->converged = solved ? 1 : 0;
@@ -733,6 +739,14 @@ static int norm_of(bk_ctx* ctx, size_t n, const double* x, bool inf, double* out
 
 extern "C" {
 
+// callback(state; fromNewton): the built-in cbMaxNorm veto first, then the user's function pointer
+static int newton_cb(const bk_newton_opts* no, const double* x, const double* fx, double residual, int step, int itlinear,
+                     double p, const double* z0u, double z0p, int from_newton) {
+    if (no->max_residual > 0.0 && !(residual < no->max_residual)) return 0;      // cbMaxNorm, src/Newton.jl:156-159
+    if (no->callback) return no->callback(no->callback_user, x, fx, residual, step, itlinear, p, z0u, z0p, from_newton) != 0;
+    return 1;
+}
+
 int bk_newton(bk_ctx* ctx, bk_problem* prob, double* x, const double* params, int nparams, const bk_newton_opts* no,
               const bk_gmres_opts* lsopts, bk_precond* pl, bk_newton_result* res) {
     if (!ctx || !prob || !x || !params || !no || !lsopts || !res) return -1;
@@ -747,7 +761,8 @@ int bk_newton(bk_ctx* ctx, bk_problem* prob, double* x, const double* params, in
     BK_TRY(norm_of(ctx, n, fx, no->norm_inf != 0, &r));
     int step = 0, itlin = 0;
     res->residuals[0] = r;
-    while (step < no->max_iterations && r > no->tol) {
+    int compute = newton_cb(no, x, fx, r, 0, 0, NAN, nullptr, NAN, 1);               // src/Newton.jl:88
+    while (step < no->max_iterations && r > no->tol && compute) {
         bk_op* J = nullptr;
         BK_TRY(bk_jacobian(prob, x, params, nparams, &J));
         GmresResult g;
@@ -760,8 +775,9 @@ int bk_newton(bk_ctx* ctx, bk_problem* prob, double* x, const double* params, in
         BK_TRY(norm_of(ctx, n, fx, no->norm_inf != 0, &r));
         step += 1;
         res->residuals[step] = r;
+        compute = newton_cb(no, x, fx, r, step, g.niter, NAN, nullptr, NAN, 1);     // :111
     }
-    res->converged = res->residuals[step] < no->tol;
+    res->converged = (res->residuals[step] < no->tol) & newton_cb(no, x, fx, r, step, 0, NAN, nullptr, NAN, 1);   // :114
     res->itnewton = step;
     res->itlinear = itlin;
     return 0;
@@ -782,18 +798,23 @@ int bk_newton_palc(bk_ctx* ctx, bk_problem* prob, double* x, double* p, const do
     const double dotscale = 1.0 / Nglob;
     const double eps = 1.4901161193847656e-08;             // sqrt(eps(Float64)): src/Problems.jl:69-70
     WsGuard ws(ctx);
-    double *res_f = nullptr, *dFdp = nullptr, *u = nullptr;
+    double *res_f = nullptr, *dFdp = nullptr, *u = nullptr, *x_pred = nullptr;
     BK_TRY(ws.get(n, &res_f));
     BK_TRY(ws.get(n, &dFdp));
     BK_TRY(ws.get(n, &u));
+    const bool linesearch = no->linesearch != 0;
+    if (linesearch) BK_TRY(ws.get(n, &x_pred));
+    const double alpha0 = no->alpha > 0.0 ? no->alpha : 1.0;                        // NewtonPar defaults, src/Newton.jl:29-31
+    const double alpha_min = no->alpha_min > 0.0 ? no->alpha_min : 1e-3;
+    double alpha = alpha0;
     double par[BK_MAX_PARAMS];
     for (int i = 0; i < nparams; ++i) par[i] = params[i];
     const bool inf = no->norm_inf != 0;
     double dz0;                                            // <z0.u, tau.u>: second term of arc_length_eq, Palc.jl:51-55
     BK_TRY(v_dot(ctx, n, z0u, tauu, &dz0));
-    auto Nfun = [&](double pp, double* out) -> int {       // Palc.jl:212
+    auto Nfun = [&](const double* xx, double pp, double* out) -> int {       // Palc.jl:212
         double d;
-        BK_TRY(v_dot(ctx, n, x, tauu, &d));
+        BK_TRY(v_dot(ctx, n, xx, tauu, &d));
         *out = (d * dotscale * theta + (pp - z0p) * taup * (1.0 - theta) - ds) - (dz0 * dotscale * theta);
         return 0;
     };
@@ -801,16 +822,16 @@ int bk_newton_palc(bk_ctx* ctx, bk_problem* prob, double* x, double* p, const do
     par[ipar] = pc;
     BK_TRY(bk_residual(prob, x, par, nparams, res_f));
     double res_n, rf;
-    BK_TRY(Nfun(pc, &res_n));
+    BK_TRY(Nfun(x, pc, &res_n));
     BK_TRY(norm_of(ctx, n, res_f, inf, &rf));
     double r = std::max(rf, std::fabs(res_n));
     int step = 0, itlin = 0;
     res->residuals[0] = r;
-    while (step < no->max_iterations && r > no->tol) {
-        par[ipar] = pc + eps;                              // dFdp = (F(x, p + eps) - res_f)/eps, Palc.jl:239-240
-        BK_TRY(bk_residual(prob, x, par, nparams, dFdp));
-        BK_TRY(v_axpby(ctx, n, -1.0 / eps, res_f, 1.0 / eps, dFdp));
-        par[ipar] = pc;
+    bool line_step = true;
+    int compute = newton_cb(no, x, res_f, r, 0, 0, pc, z0u, z0p, 0);                // Palc.jl:235
+    while (step < no->max_iterations && r > no->tol && line_step && compute) {
+        par[ipar] = pc;                                    // dFdp = (F(x, p + eps) - res_f)/eps, Palc.jl:239-240
+        BK_TRY(prob->dparam(x, par, nparams, ipar, eps, res_f, dFdp));
         bk_op* J = nullptr;
         BK_TRY(bk_jacobian(prob, x, par, nparams, &J));
         double up = 0.0;
@@ -820,18 +841,42 @@ int bk_newton_palc(bk_ctx* ctx, bk_problem* prob, double* x, double* p, const do
         bk_op_destroy(J);
         if (s != 0) return s;
         itlin += it[0] + it[1];
-        BK_TRY(v_axpby(ctx, n, -1.0, u, 1.0, x));            // x = minus!!(x, u), Palc.jl:282
-        pc = std::min(std::max(pc - up, p_min), p_max);      // clamp, :283
-        par[ipar] = pc;
-        BK_TRY(bk_residual(prob, x, par, nparams, res_f));
-        BK_TRY(Nfun(pc, &res_n));
-        BK_TRY(norm_of(ctx, n, res_f, inf, &rf));
-        r = std::max(rf, std::fabs(res_n));
+        if (linesearch) {                                    // Palc.jl:254-281
+            line_step = false;
+            while (!line_step && alpha > alpha_min) {
+                BK_TRY(v_axpbyz(ctx, n, 1.0, x, -alpha, u, x_pred));                // x_pred = x - alpha u
+                const double p_pred = pc - alpha * up;
+                par[ipar] = p_pred;
+                BK_TRY(bk_residual(prob, x_pred, par, nparams, res_f));
+                BK_TRY(Nfun(x_pred, p_pred, &res_n));
+                BK_TRY(norm_of(ctx, n, res_f, inf, &rf));
+                r = std::max(rf, std::fabs(res_n));
+                if (r < res->residuals[step]) {
+                    if (r < res->residuals[step] / 4.0 && alpha < 1.0) alpha *= 2.0;
+                    line_step = true;
+                    BK_TRY(v_copy(ctx, n, x_pred, x));
+                    pc = std::min(std::max(p_pred, p_min), p_max);
+                } else {
+                    alpha /= 2.0;
+                }
+            }
+            alpha = alpha0;                                  // "we put back the initial value"
+            par[ipar] = pc;
+        } else {
+            BK_TRY(v_axpby(ctx, n, -1.0, u, 1.0, x));        // x = minus!!(x, u), Palc.jl:282
+            pc = std::min(std::max(pc - up, p_min), p_max);  // clamp, :283
+            par[ipar] = pc;
+            BK_TRY(bk_residual(prob, x, par, nparams, res_f));
+            BK_TRY(Nfun(x, pc, &res_n));
+            BK_TRY(norm_of(ctx, n, res_f, inf, &rf));
+            r = std::max(rf, std::fabs(res_n));
+        }
         step += 1;
         res->residuals[step] = r;
+        compute = newton_cb(no, x, res_f, r, step, it[0] + it[1], pc, z0u, z0p, 0);   // Palc.jl:294
     }
     *p = pc;
-    res->converged = res->residuals[step] < no->tol;
+    res->converged = (res->residuals[step] < no->tol) & newton_cb(no, x, res_f, r, step, 0, pc, z0u, z0p, 0);   // :297
     res->itnewton = step;
     res->itlinear = itlin;
     return 0;

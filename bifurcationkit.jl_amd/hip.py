@@ -96,6 +96,21 @@ class Context:
         self.check(self.lib.bk_prof_get(self.h, name.encode(), C.byref(ms), C.byref(calls), C.byref(nbytes)))
         return dict(ms=ms.value, calls=calls.value, bytes=nbytes.value)
 
+    def solver_history(self, reset=True):
+        """Residual histories of the linear solves since the last reset (needs ``set_option("solver_trace", 1)``):
+        a list with one list per solve, [initial residual, estimate after iteration 1, ...]."""
+        n = C.c_size_t()
+        self.check(self.lib.bk_solver_history(self.h, None, 0, C.byref(n), 0))
+        buf = (C.c_double * max(n.value, 1))()
+        self.check(self.lib.bk_solver_history(self.h, buf, n.value, C.byref(n), 1 if reset else 0))
+        out = []
+        for v in buf[:n.value]:
+            if v < 0:
+                out.append([])
+            else:
+                out[-1].append(v)
+        return out
+
     def empty(self, n: int) -> torch.Tensor:
         return torch.empty(int(n), dtype=torch.float64, device=self.torch_device)
 
@@ -246,6 +261,16 @@ class _PdeProblem:
         pv = self._pvec(p)
         arr = (C.c_double * len(pv))(*pv)
         self.ctx.check(self.ctx.lib.bk_residual(self.h, _ptr(x.t), arr, len(pv), _ptr(out.t)), "bk_residual")
+        return out
+
+    def residual_dparam(self, x: HipVec, p: float, eps: float | None = None) -> HipVec:
+        """(F(x, p + eps) - F(x, p)) / eps for the continuation parameter, cancellation-free (bk_residual_dparam)."""
+        out = x.similar()
+        pv = self._pvec(p)
+        arr = (C.c_double * len(pv))(*pv)
+        self.ctx.check(self.ctx.lib.bk_residual_dparam(self.h, _ptr(x.t), arr, len(pv), self.ipar,
+                                                       float(self.delta if eps is None else eps), _ptr(out.t)),
+                       "bk_residual_dparam")
         return out
 
     def jacobian(self, x: HipVec, p: float) -> HipJacobian:
@@ -662,9 +687,12 @@ class ShiftInvert:
     hermitian: bool = False
     seed: int = 1234
     save_vectors: bool = True
+    x0: object = None                    # start vector (HipVec); None -> rand(N), examples/SH3d.jl:109
 
     def __call__(self, J: HipJacobian, nev: int, **kwargs):
         ctx = J.ctx
+        if self.x0 is not None:
+            ctx.check(ctx.lib.bk_eig_set_start_vector(ctx.h, _ptr(self.x0.t)), "bk_eig_set_start_vector")
         kd = self.krylovdim if self.krylovdim is not None else max(30, nev + 30)
         kd = min(kd, 63, J.prob.nglobal - 1)
         nev = min(nev, kd)
@@ -706,9 +734,12 @@ class EigKrylovKit:
     hermitian: bool = False
     seed: int = 1234
     save_vectors: bool = False
+    x0: object = None                    # EigKrylovKit.x0, src/EigSolver.jl:143
 
     def __call__(self, J: HipJacobian, nev: int, **kwargs):
         ctx = J.ctx
+        if self.x0 is not None:
+            ctx.check(ctx.lib.bk_eig_set_start_vector(ctx.h, _ptr(self.x0.t)), "bk_eig_set_start_vector")
         kd = min(self.krylovdim, 63, J.prob.nglobal - 1)
         nev = min(nev, kd)
         eo = L.EigOpts(0.0, int(kd), int(self.maxiter), float(self.tol), 1 if self.hermitian else 0, int(self.seed))
@@ -736,13 +767,40 @@ class EigKrylovKit:
 
 
 # ------------------------------------------------------------------------------------------ native correctors
-def newton_native(prob: _PdeProblem, x0: HipVec, p: float, ls: _GMRES, tol=1e-12, max_iterations=25, norm_inf=False):
+def newton_opts(tol, max_iterations, norm_inf, linesearch=False, alpha=1.0, alphamin=1e-3, callback=None):
+    """``bk_newton_opts`` from the NewtonPar fields (src/Newton.jl:17-33) and a reference-style callback
+    ``callback(state; fromNewton) -> Bool`` (src/Newton.jl:88): a ``cbMaxNorm``-like object (attribute ``maxres``) is
+    evaluated inside the library; any other callable becomes a host callback receiving
+    ``dict(x, fx | res_f, residual, step, itlinear, p, z0)`` where ``x``, ``fx`` / ``res_f`` and ``z0[0]`` are raw device
+    addresses (ints; None for a plain Newton's ``z0``) of vectors of the problem's local length."""
+    no = L.NewtonOpts()
+    no.tol, no.max_iterations, no.norm_inf = float(tol), int(max_iterations), 1 if norm_inf else 0
+    no.linesearch, no.alpha, no.alpha_min = 1 if linesearch else 0, float(alpha), float(alphamin)
+    if callback is not None and hasattr(callback, "maxres"):
+        no.max_residual = float(callback.maxres)
+    elif callback is not None:
+        def tramp(user, x, fx, residual, step, itlinear, p, z0u, z0p, from_newton):
+            st = dict(x=x, residual=residual, step=step, itlinear=itlinear, p=p, z0=(z0u, z0p))
+            st["fx" if from_newton else "res_f"] = fx
+            try:
+                return 1 if callback(st, fromNewton=bool(from_newton)) else 0
+            except Exception:      # an exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 0
+        no.callback = L.NEWTON_CALLBACK(tramp)
+        no._keepalive = (tramp, no.callback)
+    return no
+
+
+def newton_native(prob: _PdeProblem, x0: HipVec, p: float, ls: _GMRES, tol=1e-12, max_iterations=25, norm_inf=False,
+                  callback=None):
     """_newton (src/Newton.jl:66-114) as one library call."""
     ctx = prob.ctx
     x = x0.copy()
     pv = prob._pvec(p)
     arr = (C.c_double * len(pv))(*pv)
-    no = L.NewtonOpts(float(tol), int(max_iterations), 1 if norm_inf else 0)
+    no = newton_opts(tol, max_iterations, norm_inf, callback=callback)
     lo = ls._opts()
     res = L.NewtonResult()
     ctx.check(ctx.lib.bk_newton(ctx.h, prob.h, _ptr(x.t), arr, len(pv), C.byref(no), C.byref(lo), ls._pl(),
@@ -753,14 +811,14 @@ def newton_native(prob: _PdeProblem, x0: HipVec, p: float, ls: _GMRES, tol=1e-12
 
 def newton_palc_native(prob: _PdeProblem, z0: BorderedArray, tau: BorderedArray, z_pred: BorderedArray, ds, theta,
                        bls: BorderingBLS, tol=1e-12, max_iterations=25, p_min=-math.inf, p_max=math.inf,
-                       norm_inf=False):
-    """newton_palc (src/continuation/Palc.jl:187-305, linesearch=false) with BorderingBLS as one library call."""
+                       norm_inf=False, linesearch=False, alpha=1.0, alphamin=1e-3, callback=None):
+    """newton_palc (src/continuation/Palc.jl:187-305) with BorderingBLS as one library call."""
     ctx = prob.ctx
     x = z_pred.u.copy()
     p = C.c_double(z_pred.p)
     pv = prob._pvec(z_pred.p)
     arr = (C.c_double * len(pv))(*pv)
-    no = L.NewtonOpts(float(tol), int(max_iterations), 1 if norm_inf else 0)
+    no = newton_opts(tol, max_iterations, norm_inf, linesearch, alpha, alphamin, callback)
     bo = L.BorderingOpts(bls.tol, 1 if bls.check_precision else 0, bls.k)
     lo = bls.solver._opts()
     res = L.NewtonResult()
@@ -847,7 +905,7 @@ def newton_deflated_native(prob: _PdeProblem, defop: DeflationOperator, x0: HipV
     x = x0.copy()
     pv = prob._pvec(p)
     arr = (C.c_double * len(pv))(*pv)
-    no = L.NewtonOpts(float(tol), int(max_iterations), 1 if norm_inf else 0)
+    no = newton_opts(tol, max_iterations, norm_inf)
     lo = ls._opts()
     res = L.NewtonResult()
     m = len(defop)

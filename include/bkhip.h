@@ -72,6 +72,13 @@ int bk_prof_reset(bk_ctx* ctx);
 int bk_prof_get(bk_ctx* ctx, const char* name, double* total_ms, long long* calls,
                 double* alg_bytes);
 
+/* Diagnostics: with option "solver_trace" != 0 every Krylov linear solve appends its residual-estimate history (one
+ * value per iteration: GMRES |y_k+1|, MINRES phibar) to a per-context log; a negative entry -(k) opens the k-th solve
+ * and is followed by the initial residual norm.  Copies up to cap entries into buf (may be NULL), *n = entries
+ * available; reset != 0 clears the log.  The reference's counterpart is the `verbose` / `log = true` switch of the
+ * Krylov packages (src/LinearSolver.jl:169,202,244).                                                              */
+int bk_solver_history(bk_ctx* ctx, double* buf, size_t cap, size_t* n, int reset);
+
 /* ------------------------------------------------------------------ memory ----------------- */
 
 int bk_malloc(bk_ctx* ctx, size_t n, double** out);
@@ -125,6 +132,13 @@ int bk_problem_nlocal(bk_problem* prob, size_t* nlocal, int* slab_lo, int* slab_
 /* out = F(u, params): F_sh examples/SH3d.jl:44-47, R_SH SHpde_snaking.jl:19-23,
  * Fcgl! examples/cGL2d.jl:44-47                                                                  */
 int bk_residual(bk_problem* prob, const double* u, const double* params, int nparams, double* out);
+/* out = (F(u, p + eps) - F(u, p)) / eps for params[ipar] -- the finite-difference dF/dp of newton_palc and the Bordered
+ * tangent (src/continuation/Palc.jl:239-240, src/continuation/Tangents.jl:77-82).  Every parameter of these problems
+ * multiplies a pointwise term and the stencil part cancels identically, so the quotient is evaluated as
+ * ((p + eps) - p)/eps * phi_p(u) in one pass without the ~1e-8 white rounding noise of the two-residual form (context
+ * option "fd_dparam" = 0 selects the literal two-residual form).  out must not alias u.                            */
+int bk_residual_dparam(bk_problem* prob, const double* u, const double* params, int nparams, int ipar, double eps,
+                       double* out);
 /* J(u, params) as an operator handle: the closure `dx -> dF_sh(x, p, dx)` of
  * examples/SH3d.jl:119 / the opaque Jacobian object of src/Problems.jl:98-101.  Like the Julia
  * closure it REFERENCES u (no copy): u must stay alive and unchanged while the handle is used. */
@@ -246,16 +260,35 @@ int bk_eig_shiftinvert(bk_ctx* ctx, bk_op* J, int nev, const bk_eig_opts* eopts,
                        const bk_gmres_opts* lsopts, bk_precond* pl, double* vals_re,
                        double* vals_im, double* vecs, double* vecs_im, size_t ldvecs, int* nvals,
                        int* nconv, int* numops);
+/* Start vector of the NEXT bk_eig_shiftinvert / bk_eig_krylovkit call on this context (one-shot; NULL restores the
+ * default rand(N) of examples/SH3d.jl:109): the x0 argument of KrylovKit.eigsolve, EigKrylovKit.x0 (src/EigSolver.jl:
+ * 143,160).  x0 (device, local length) must stay valid until that call returns.                                    */
+int bk_eig_set_start_vector(bk_ctx* ctx, const double* x0);
 /* (eig::EigKrylovKit)(J, nev), which = :LR (src/EigSolver.jl:117-166): Krylov-Schur on J itself, rightmost eigenvalues,
  * no inner solves (sigma ignored); same output conventions as bk_eig_shiftinvert; *numops = operator applications.   */
 int bk_eig_krylovkit(bk_ctx* ctx, bk_op* J, int nev, const bk_eig_opts* eopts, double* vals_re, double* vals_im,
                      double* vecs, double* vecs_im, size_t ldvecs, int* nvals, int* nconv, int* numops);
 
 /* ------------------------------------------------------------------ Newton correctors ------ */
+/* Newton callback, the reference's `callback(state; fromNewton, kwargs...) -> Bool` (src/Newton.jl:88,111-113,
+ * src/continuation/Palc.jl:235,294-297; e.g. cbMaxNorm src/Newton.jl:156-159): called before the first iteration
+ * (step = 0, itlinear = 0), after every iteration, and once more when the loop has ended (its value is AND-ed into
+ * `converged`).  x / fx are device vectors of the current iterate and residual; p the current continuation parameter
+ * (newton_palc) or NaN (_newton); z0u / z0p the previous point of the branch (newton_palc) or NULL / NaN.
+ * Return 0 to stop the iteration (a veto), non-zero to go on.                                                        */
+typedef int (*bk_newton_callback)(void* user, const double* x, const double* fx, double residual, int step,
+                                  int itlinear, double p, const double* z0u, double z0p, int from_newton);
 typedef struct {
     double tol;           /* NewtonPar.tol            src/Newton.jl:19                            */
     int max_iterations;   /* NewtonPar.max_iterations :21                                         */
     int norm_inf;         /* normN: 1 = norminf (examples/SH3d.jl:166), 0 = 2-norm                */
+    /* the remaining fields may be left zero (= the reference defaults)                                              */
+    int linesearch;       /* NewtonPar.linesearch (:27): Armijo-type damping in newton_palc, Palc.jl:254-281        */
+    double alpha;         /* NewtonPar.alpha  (:29), <= 0 -> 1                                                       */
+    double alpha_min;     /* NewtonPar.alphamin (:31), <= 0 -> 1e-3                                                  */
+    double max_residual;  /* > 0: built-in cbMaxNorm(max_residual) veto (src/Newton.jl:156-159), no host round trip  */
+    bk_newton_callback callback;   /* may be NULL                                                                    */
+    void* callback_user;
 } bk_newton_opts;
 #define BK_MAX_NEWTON_ITER 64
 typedef struct {
@@ -318,11 +351,14 @@ typedef struct {
     double p;                                    /* parameter of the current point z after the step                  */
     double ds_used, ds_next;                     /* arclength step of this corrector / of the next predictor         */
     int step;                                    /* number of accepted steps so far                                  */
-    int stop;                                    /* 0 continue, 1 |ds| <= dsmin after a failed corrector, 2 predictor left [p_min, p_max] */
+    int stop;                                    /* 0 continue, 1 |ds| <= dsmin after a failed corrector, 2 the previous point reached
+                                                    the boundary of [p_min, p_max]: nothing was done (`done`, Continuation.jl:254) */
     int n_unstable, n_imag, bifurcation;         /* is_stable counts; bifurcation = 1 when n_unstable changed        */
     int nvals, eig_converged, eig_numops;        /* eigensolver return values; vals sorted by decreasing real part   */
     double vals_re[BK_MAX_NEV + 1], vals_im[BK_MAX_NEV + 1];
     int tangent_converged;                       /* Bordered(): convergence flag of the tangent's bordered solve     */
+    int natural;                                 /* 1: the predictor left [p_min, p_max] and the step was corrected by the Natural
+                                                    corrector at the clamped parameter (Palc.jl:157-160, Natural.jl:38-58)      */
 } bk_cont_step_result;
 typedef struct bk_cont bk_cont;
 int bk_cont_create(bk_ctx* ctx, bk_problem* prob, const double* params, int nparams, int ipar,
@@ -354,6 +390,8 @@ typedef struct {
     double p;                        /* parameter of the state on return                                             */
     int n_unstable[2], n_imag[2];    /* (current, previous) pairs of the state on return                              */
     int steps;                       /* continuation steps spent                                                      */
+    int nvals;                       /* eigenvalues of the state on return (`_state.eigvals = state.eigvals`, :341)   */
+    double vals_re[BK_MAX_NEV + 1], vals_im[BK_MAX_NEV + 1];
 } bk_bisection_result;
 int bk_cont_locate_bifurcation(bk_cont* c, const bk_bisection_opts* opts, bk_bisection_result* res);
 

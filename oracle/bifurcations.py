@@ -74,7 +74,7 @@ def detect_bifurcation(st: ContState) -> bool:
 
 
 def _eigen(prob, st, eig, cp):
-    nev_ = max(max(st.n_unstable[0], 0) + 5, cp.nev)                      # src/Utils.jl:78-79
+    nev_ = max(st.n_unstable[1] + 5, cp.nev)                              # n = state.n_unstable[2], src/Utils.jl:78-79
     vals = np.asarray(eig(prob.J(st.z[0], st.z[1]), nev_)[0])
     nu, ni = palc.is_stable(vals, cp.tol_stability)
     st.n_unstable = (nu, st.n_unstable[0])                                # update_stability!, Continuation.jl:274-278
@@ -86,8 +86,13 @@ def iterate(prob, st: ContState, *, ls, bls, eig, cp: ContPar, normC=palc.norm2)
     """One pass of Base.iterate (Continuation.jl:458-504); returns the state, or None when `done` says stop (:254-257)."""
     if not (st.step <= cp.max_steps and (cp.p_min < st.z[1] < cp.p_max or st.step == 0) and not st.stop):
         return None
-    sol = palc.newton_palc(prob, st.z, st.tau, st.z_pred, st.ds, cp.theta, bls, tol=cp.tol, max_iterations=cp.max_iterations,
-                           p_min=cp.p_min, p_max=cp.p_max, normN=normC)
+    if st.z_pred[1] <= cp.p_min or st.z_pred[1] >= cp.p_max:              # corrector!(::PALC) -> Natural, Palc.jl:157-160
+        st.z_pred = (st.z_pred[0], float(np.clip(st.z_pred[1], cp.p_min, cp.p_max)))
+        sol = palc.natural_corrector(prob, st.z_pred, ls, p_min=cp.p_min, p_max=cp.p_max, tol=cp.tol,
+                                     max_iterations=cp.max_iterations, normN=normC)
+    else:
+        sol = palc.newton_palc(prob, st.z, st.tau, st.z_pred, st.ds, cp.theta, bls, tol=cp.tol,
+                               max_iterations=cp.max_iterations, p_min=cp.p_min, p_max=cp.p_max, normN=normC)
     st.converged, st.itnewton, st.itlinear, st.residuals = sol["converged"], sol["itnewton"], sol["itlineartot"], sol["residuals"]
     if st.converged:
         st.z_old = (st.z[0].copy(), st.z[1])

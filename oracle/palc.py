@@ -36,15 +36,27 @@ def norm2(x):
     return float(np.linalg.norm(x))
 
 
-def newton(prob, x0, p, ls, *, tol=1e-12, max_iterations=25, normN=norm2):
-    """_newton, src/Newton.jl:66-114.  Returns dict(u, residuals, converged, itnewton, itlineartot)."""
+def cb_default(state, **kw):
+    """cb_default, src/Newton.jl:151."""
+    return True
+
+
+def cb_max_norm(maxres):
+    """cbMaxNorm, src/Newton.jl:156-159: veto iterates whose residual exceeds ``maxres``."""
+    return lambda state, **kw: state["residual"] < maxres
+
+
+def newton(prob, x0, p, ls, *, tol=1e-12, max_iterations=25, normN=norm2, callback=cb_default):
+    """_newton, src/Newton.jl:66-114.  Returns dict(u, residuals, converged, itnewton, itlineartot).
+    ``callback(state; fromNewton)`` is consulted before the loop, after every iteration and for the final flag (:88,111,114)."""
     x = x0.copy()
     fx = prob.F(x, p)
     res = normN(fx)
     residuals = [res]
     step = 0
     itlin = 0
-    while step < max_iterations and res > tol:
+    compute = callback(dict(x=x, fx=fx, residual=res, step=step, residuals=residuals), fromNewton=True)
+    while step < max_iterations and res > tol and compute:
         J = prob.J(x, p)
         u, cv, it = ls(J, fx)
         itlin += int(np.sum(it))
@@ -53,7 +65,9 @@ def newton(prob, x0, p, ls, *, tol=1e-12, max_iterations=25, normN=norm2):
         res = normN(fx)
         residuals.append(res)
         step += 1
-    return dict(u=x, residuals=residuals, converged=residuals[-1] < tol, itnewton=step, itlineartot=itlin)
+        compute = callback(dict(x=x, fx=fx, residual=res, step=step, itlinear=it, residuals=residuals), fromNewton=True)
+    flag = (residuals[-1] < tol) and bool(callback(dict(x=x, fx=fx, residual=res, step=step, residuals=residuals), fromNewton=True))
+    return dict(u=x, residuals=residuals, converged=flag, itnewton=step, itlineartot=itlin)
 
 
 def dot_theta(u1, u2, p1, p2, theta):
@@ -71,9 +85,11 @@ def arc_length_eq(u1, u2, p, du, dp, theta, ds):
 
 
 def newton_palc(prob, z0, tau0, z_pred, ds, theta, bls, *, tol=1e-12, max_iterations=25,
-                p_min=-np.inf, p_max=np.inf, normN=norm2):
-    """newton_palc, Palc.jl:187-305 (linesearch=false branch).
-    z0, tau0, z_pred are (u, p) pairs.  Returns dict(u, p, residuals, converged, itnewton, itlineartot)."""
+                p_min=-np.inf, p_max=np.inf, normN=norm2, linesearch=False, alpha=1.0, alpha_min=1e-3,
+                callback=cb_default):
+    """newton_palc, Palc.jl:187-305, both the plain update (:282-285) and the line search (:254-281), with the
+    callback veto (:235, 294-297).  z0, tau0, z_pred are (u, p) pairs.
+    Returns dict(u, p, residuals, converged, itnewton, itlineartot)."""
     eps = prob.delta
     N = lambda u, p: arc_length_eq(u, z0[0], p - z0[1], tau0[0], tau0[1], theta, ds)
     x = z_pred[0].copy()
@@ -84,20 +100,53 @@ def newton_palc(prob, z0, tau0, z_pred, ds, theta, bls, *, tol=1e-12, max_iterat
     residuals = [res]
     step = 0
     itlin = 0
-    while step < max_iterations and res > tol:
+    alpha0 = alpha
+    line_step = True
+    compute = callback(dict(x=x, res_f=res_f, residual=res, step=step, z0=z0, p=p, residuals=residuals), fromNewton=False)
+    while step < max_iterations and res > tol and line_step and compute:
         dFdp = (prob.F(x, p + eps) - res_f) * (1.0 / eps)
         J = prob.J(x, p)
         u, up, flag, it = solve_bls_palc(bls, theta, tau0[0], tau0[1], J, dFdp, res_f, res_n)
         itlin += int(np.sum(it))
-        x = x - u
-        p = float(np.clip(p - up, p_min, p_max))
-        res_f = prob.F(x, p)
-        res_n = N(x, p)
-        res = max(normN(res_f), abs(res_n))
+        if linesearch:
+            line_step = False
+            while not line_step and alpha > alpha_min:
+                x_pred = x - alpha * u
+                p_pred = p - alpha * up
+                res_f = prob.F(x_pred, p_pred)
+                res_n = N(x_pred, p_pred)
+                res = max(normN(res_f), abs(res_n))
+                if res < residuals[-1]:
+                    if res < residuals[-1] / 4 and alpha < 1:
+                        alpha *= 2
+                    line_step = True
+                    x = x_pred
+                    p = float(np.clip(p_pred, p_min, p_max))
+                else:
+                    alpha /= 2
+            alpha = alpha0
+        else:
+            x = x - u
+            p = float(np.clip(p - up, p_min, p_max))
+            res_f = prob.F(x, p)
+            res_n = N(x, p)
+            res = max(normN(res_f), abs(res_n))
         residuals.append(res)
         step += 1
-    return dict(u=x, p=p, residuals=residuals, converged=residuals[-1] < tol, itnewton=step,
-                itlineartot=itlin)
+        compute = callback(dict(x=x, res_f=res_f, residual=res, step=step, itlinear=it, z0=z0, p=p, residuals=residuals),
+                           fromNewton=False)
+    flag = (residuals[-1] < tol) and bool(callback(dict(x=x, res_f=res_f, residual=res, step=step, p=p, residuals=residuals),
+                                                   fromNewton=False))
+    return dict(u=x, p=p, residuals=residuals, converged=flag, itnewton=step, itlineartot=itlin)
+
+
+def natural_corrector(prob, z_pred, ls, *, p_min, p_max, **newton_kw):
+    """corrector!(state, it, ::Natural), src/continuation/Natural.jl:38-58: plain Newton from z_pred.u at the clamped
+    parameter; the new point takes p = z_pred.p (already clamped by the caller, Palc.jl:157-160)."""
+    pc = float(np.clip(z_pred[1], p_min, p_max))
+    sol = newton(prob, z_pred[0], pc, ls, **newton_kw)
+    sol["p"] = pc
+    return sol
 
 
 def secant_tangent(z1, z0, ds, theta):
@@ -186,16 +235,22 @@ def continuation(prob, x0, p0, *, ls, bls, ds=1e-2, dsmin=1e-4, dsmax=1e-1, thet
         br.sol.append(z[0].copy())
     step = 0
     z_old = (z[0].copy(), z[1])
-    while step < max_steps and p_min < z[1] < p_max:
-        sol = newton_palc(prob, z, tau, z_pred, ds, theta, bls, tol=tol, max_iterations=max_iterations,
-                          p_min=p_min, p_max=p_max, normN=normC)
+    n_prev = -1                                                            # state.n_unstable[2]
+    while step < max_steps and (p_min < z[1] < p_max or step == 0):        # done(it, state), Continuation.jl:254-257
+        if z_pred[1] <= p_min or z_pred[1] >= p_max:                       # corrector!(::PALC), Palc.jl:157-160
+            z_pred = (z_pred[0], float(np.clip(z_pred[1], p_min, p_max)))
+            sol = natural_corrector(prob, z_pred, ls, p_min=p_min, p_max=p_max, **newton_kw)
+        else:
+            sol = newton_palc(prob, z, tau, z_pred, ds, theta, bls, tol=tol, max_iterations=max_iterations,
+                              p_min=p_min, p_max=p_max, normN=normC)
         conv = sol["converged"]
         if conv:
             z_old = (z[0].copy(), z[1])
             z = (sol["u"], sol["p"])
             if eig is not None:
-                nev_ = max(max(n_unst, 0) + 5, nev)                       # Utils.jl:78-79
+                nev_ = max(n_prev + 5, nev)                                # n = state.n_unstable[2], Utils.jl:78-79
                 vals, _, _, _ = eig(prob.J(z[0], z[1]), nev_)
+                n_prev = n_unst
                 n_unst = is_stable(vals, tol_stability)[0]
                 br.eig.append(np.asarray(vals))
             step += 1

@@ -183,6 +183,57 @@ def test_sh1d_residual_and_jvp(ctx):
     assert np.abs(prob.jacobian(prob.vec(u), -0.1)(prob.vec(du)).numpy() - s1.dF(u, -0.1, 2.0, du)).max() <= tol
 
 
+def test_residual_dparam_is_the_finite_difference_without_its_noise(ctx):
+    """bk_residual_dparam = (F(u, p + eps) - F(u, p)) / eps (Palc.jl:239-240) for every parameter of the three PDEs:
+    equal to the oracle's two-residual quotient up to that quotient's own rounding noise eps_mach*|L1 u|/eps, equal to
+    ((p + eps) - p)/eps * phi_p(u) to 1 ulp, and option fd_dparam = 0 reproduces the two-residual form on the device."""
+    hip = _hip()
+    eps = np.sqrt(EPS)
+    rng = np.random.default_rng(11)
+    cases = []
+    sh = operators.SwiftHohenberg((20, 17, 13), (np.pi, 2.0, 1.3))
+    u = 0.8 * rng.standard_normal(sh.N)
+    for lens, phi in (("l", u), ("nu", u * u)):
+        prob = hip.SwiftHohenberg(ctx, sh.dims, sh.ls, l=0.1, nu=1.2, lens=lens)
+        p0 = dict(l=0.1, nu=1.2)
+        F = lambda p, lens=lens, p0=p0: sh.F(u, **dict(p0, **{lens: p}))
+        cases.append((prob, u, p0[lens], phi, F, abs(sh.L1).sum(axis=1).max()))
+    s1 = operators.SwiftHohenberg1D(200, 6.0)
+    u1 = s1.guess() + 0.05 * rng.standard_normal(200)
+    for lens, phi in (("lam", u1), ("nu", u1 ** 3)):
+        prob = hip.SwiftHohenberg1D(ctx, 200, 6.0, lam=-0.1, nu=2.0, lens=lens)
+        p0 = dict(lam=-0.1, nu=2.0)
+        F = lambda p, lens=lens, p0=p0: s1.F(u1, *[p if k == lens else p0[k] for k in ("lam", "nu")])
+        cases.append((prob, u1, p0[lens], phi, F, abs(s1.L1).sum(axis=1).max()))
+    c = operators.CGL2d((41, 21), (np.pi, np.pi / 2))
+    uc = 0.4 * rng.standard_normal(2 * c.n)
+    a, b = uc[:c.n], uc[c.n:]
+    ua = a * a + b * b
+    phis = dict(r=(a, b), mu=(ua * b, -ua * a), nu=(-b, a), c3=(-ua * a, -ua * b), c5=(-ua * ua * a, -ua * ua * b),
+                gamma=(np.ones(c.n), np.zeros(c.n)))
+    for lens, phi in phis.items():
+        prob = hip.CGL2d(ctx, (41, 21), (np.pi, np.pi / 2), r=1.2, gamma=0.3, lens=lens)
+        pd = dict(c.default_params(), r=1.2, gamma=0.3)
+        F = lambda p, lens=lens, pd=pd: c.F(uc, **dict(pd, **{lens: p}))
+        cases.append((prob, uc, pd[lens], np.concatenate(phi), F, abs(c.Delta).sum(axis=1).max()))
+    for prob, uu, p, phi, F, l1 in cases:
+        U = prob.vec(uu)
+        d = prob.residual_dparam(U, p).numpy()
+        cfac = ((p + eps) - p) / eps
+        assert np.abs(d - cfac * phi).max() <= 4 * EPS * np.abs(phi).max()
+        fd = (F(p + eps) - F(p)) / eps
+        noise = 64 * EPS * (l1 + 10.0) * max(1.0, np.abs(uu).max()) ** 5 / eps
+        assert np.abs(d - fd).max() <= noise
+        # the literal form on the device
+        ctx.set_option("fd_dparam", 0)
+        try:
+            d0 = prob.residual_dparam(U, p).numpy()
+        finally:
+            ctx.set_option("fd_dparam", 1)
+        lit = prob.residual(U, p + eps).add_(prob.residual(U, p), -1.0).scale_(1.0 / eps).numpy()
+        assert np.abs(d0 - lit).max() <= noise and np.abs(d0 - fd).max() <= noise
+
+
 # --------------------------------------------------------------------------------------------- preconditioner
 @pytest.mark.parametrize("grid", [((22, 22, 22), (np.pi,) * 3), ((16, 8, 32), (2.0, 1.0, 3.0)),
                                   ((12, 10, 9), (2.0, 2.0, 2.0)), ((24, 18), (3.0, 2.0)), ((64, 32), (6.0, 3.0)),
@@ -602,21 +653,161 @@ def test_native_continuation_step_matches_mirror(ctx, tangent):
         assert np.abs(sh.F(u_.numpy(), p_, 1.2)).max() < 1e-8
 
 
-def test_native_continuation_stops_at_parameter_bound(ctx):
-    """p_max reached: the native loop reports stop = 2 where the mirror breaks (predictor outside [p_min, p_max])."""
+def test_continuation_reaches_the_parameter_bound_with_the_natural_corrector(ctx):
+    """Palc.jl:157-160 + Natural.jl:38-58: when the predictor leaves [p_min, p_max] its parameter is clamped and the step
+    is corrected by a plain Newton at the boundary; that point is recorded and `done` (Continuation.jl:254-257) ends the
+    run.  Oracle (restated engine), Python mirror and the native one-call step agree and all end ON p_max."""
     hip = _hip()
     from bk_amd import continuation as Cn
     dims, ls_ = (12, 12, 12), (np.pi,) * 3
     sh, prob, rng, u = _sh_setup(ctx, dims, ls_)
+    oprob = palc.Problem(lambda x, p: sh.F(x, p, 1.2), lambda x, p: (lambda dx: sh.dF(x, p, 1.2, dx)))
+    ols = _oracle_ls(sh)
+    obls = lambda *a, **k: bordered.bordering_bls(ols, *a, check_precision=False, **k)
+    s0 = palc.newton(oprob, u, 0.1, ols, tol=1e-9, max_iterations=30, normN=palc.norminf)
+    bo = palc.continuation(oprob, s0["u"], 0.1, ls=ols, bls=obls, tangent="secant", normC=palc.norminf, ds=0.004,
+                           dsmin=1e-4, dsmax=0.005, p_min=-0.1, p_max=0.108, max_steps=50, tol=1e-9, max_iterations=15)
     ls = hip.GMRESKrylovKit(dim=30, rtol=1e-9, atol=1e-12, maxiter=150, Pl=hip.DCTPreconditioner(prob, 0.0))
     nopt = Cn.NewtonPar(tol=1e-9, max_iterations=15, linsolver=ls)
     cp = Cn.ContinuationPar(ds=0.004, dsmin=1e-4, dsmax=0.005, p_min=-0.1, p_max=0.108, max_steps=50,
                             detect_bifurcation=0, newton_options=nopt)
     alg = Cn.PALC(tangent="secant", theta=0.5, bls=hip.BorderingBLS(None, check_precision=False))
-    bm = Cn.continuation(prob, prob.vec(u), 0.1, alg, cp, normC=Cn.norminf)
-    bn = Cn.continuation_native(prob, prob.vec(u), 0.1, alg, cp, normC=Cn.norminf)
-    assert 2 <= len(bn.param) < 50 and len(bn.param) == len(bm.param)
-    assert np.allclose(bn.param, bm.param, rtol=0, atol=1e-10) and max(bn.param) < 0.108
+    x0 = prob.vec(s0["u"])
+    bm = Cn.continuation(prob, x0, 0.1, alg, cp, normC=Cn.norminf)
+    bn = Cn.continuation_native(prob, x0, 0.1, alg, cp, normC=Cn.norminf, save_sol=True)
+    assert 3 <= len(bo.param) < 50 and len(bn.param) == len(bm.param) == len(bo.param)
+    assert bo.param[-1] == bm.param[-1] == bn.param[-1] == 0.108                  # the clamp is exact
+    assert np.allclose(bn.param, bo.param, rtol=0, atol=1e-8) and np.allclose(bm.param, bo.param, rtol=0, atol=1e-8)
+    assert bn.itnewton[-1] == bm.itnewton[-1] == bo.itnewton[-1] >= 1
+    assert np.abs(sh.F(bn.sol[-1].numpy(), 0.108, 1.2)).max() < 1e-9              # a solution AT the boundary
+
+
+def test_newton_palc_linesearch_and_callbacks_match_oracle(ctx):
+    """newton_palc with linesearch = true (Palc.jl:254-281) and the callback veto (Palc.jl:235,294-297; cbMaxNorm
+    src/Newton.jl:156-159): the native one-call corrector, the Python mirror and the oracle take the same accept / halve /
+    veto decisions.  Predictors: the PALC predictor plus a multiple of the solution itself (amp = 1: every full step is
+    accepted; alpha = 1/2: damped, linear convergence, never doubles because the residual is not quartered; amp = -0.7:
+    the full Newton step increases the residual tenfold, so the first iteration must halve)."""
+    hip = _hip()
+    from bk_amd import continuation as Cn
+    dims, ls_ = (12, 12, 12), (np.pi,) * 3
+    sh, prob, rng, u = _sh_setup(ctx, dims, ls_)
+    oprob = palc.Problem(lambda x, p: sh.F(x, p, 1.2), lambda x, p: (lambda dx: sh.dF(x, p, 1.2, dx)))
+    ols = _oracle_ls(sh)
+    obls = lambda *a, **k: bordered.bordering_bls(ols, *a, check_precision=False, **k)
+    s0 = palc.newton(oprob, u, 0.1, ols, tol=1e-10, max_iterations=30, normN=palc.norminf)
+    s1 = palc.newton(oprob, s0["u"], 0.1 - 0.01 / 150, ols, tol=1e-10, max_iterations=30, normN=palc.norminf)
+    z0, z1 = (s0["u"], 0.1), (s1["u"], 0.1 - 0.01 / 150)
+    ds = -0.01
+    tau = palc.secant_tangent(z1, z0, ds, 0.5)
+    zp0 = palc.add_tangent(z0, tau, ds)
+    P = hip.DCTPreconditioner(prob, 0.0)
+    ls = hip.GMRESKrylovKit(dim=30, rtol=1e-9, atol=1e-12, maxiter=150, Pl=P)
+    B = hip.BorderedArray
+    gz0, gtau = B(prob.vec(z0[0]), z0[1]), B(prob.vec(tau[0]), tau[1])
+    bls = hip.BorderingBLS(ls, check_precision=False)
+    okw = dict(tol=1e-9, max_iterations=14, normN=palc.norminf)
+
+    def three(amp, alpha, linesearch=True, ocb=None, gcb=None):
+        zp = (zp0[0] + amp * s0["u"], zp0[1])
+        gzp = B(prob.vec(zp[0]), zp[1])
+        so = palc.newton_palc(oprob, z0, tau, zp, ds, 0.5, obls, linesearch=linesearch, alpha=alpha, alpha_min=1e-3,
+                              **({} if ocb is None else dict(callback=ocb)), **okw)
+        sn = hip.newton_palc_native(prob, gz0, gtau, gzp, ds, 0.5, bls, tol=1e-9, max_iterations=14, norm_inf=True,
+                                    linesearch=linesearch, alpha=alpha, alphamin=1e-3, callback=gcb)
+        sm = Cn.newton_palc(prob, gz0, gtau, gzp, ds, 0.5, bls,
+                            Cn.NewtonPar(tol=1e-9, max_iterations=14, linsolver=ls, linesearch=linesearch, alpha=alpha),
+                            normN=Cn.norminf, **({} if gcb is None else dict(callback=gcb)))
+        return so, sn, sm, zp, gzp
+
+    for amp, alpha in ((1.0, 1.0), (1.0, 0.5)):
+        so, sn, sm, _, _ = three(amp, alpha)
+        assert sn["itnewton"] == so["itnewton"] == sm.itnewton and sn["converged"] == so["converged"] == sm.converged
+        for a, b, c in zip(sn["residuals"], so["residuals"], sm.residuals):
+            assert abs(a - b) <= 1e-6 * max(b, 1e-4) and abs(c - b) <= 1e-6 * max(b, 1e-4), (sn["residuals"], so["residuals"])
+        assert abs(sn["u"].p - so["p"]) <= 1e-8 and abs(sm.u.p - so["p"]) <= 1e-8
+    assert so["itnewton"] == 14 and not so["converged"]                      # alpha = 1/2: damped all the way
+    assert all(0.5 < b / a < 0.6 for a, b in zip(so["residuals"][:-1], so["residuals"][1:]))
+    so, sn, sm, _, _ = three(-0.7, 1.0)
+    plain = palc.newton_palc(oprob, z0, tau, (zp0[0] - 0.7 * s0["u"], zp0[1]), ds, 0.5, obls, **okw)
+    assert plain["residuals"][1] > 5 * plain["residuals"][0]                 # the full step is rejected ...
+    for r in (so["residuals"], sn["residuals"], sm.residuals):               # ... and the damped one decreases
+        assert r[1] < r[0]
+    assert np.allclose(sn["residuals"][:3], so["residuals"][:3], rtol=1e-5) and np.allclose(sm.residuals[:3], so["residuals"][:3], rtol=1e-5)
+
+    # ---- callbacks.  cbMaxNorm (evaluated inside the library): the exploding plain iteration is cut after one step
+    cb = 1.0
+    so, sn, sm, zp, gzp = three(-0.7, 1.0, linesearch=False, ocb=palc.cb_max_norm(cb), gcb=Cn.cbMaxNorm(cb))
+    assert sn["itnewton"] == so["itnewton"] == sm.itnewton == 1 and not (sn["converged"] or so["converged"] or sm.converged)
+    assert np.allclose(sn["residuals"], so["residuals"], rtol=1e-6)
+    # a host callback that vetoes after two iterations: call protocol (before the loop, after every iteration, final flag)
+    seen = []
+
+    def veto_after_two(state, **kw):
+        seen.append((state["step"], state["residual"], kw.get("fromNewton")))
+        return state["step"] < 2
+
+    zp = (zp0[0] + s0["u"], zp0[1])
+    gzp = B(prob.vec(zp[0]), zp[1])
+    so = palc.newton_palc(oprob, z0, tau, zp, ds, 0.5, obls, callback=lambda st, **kw: st["step"] < 2, **okw)
+    sn = hip.newton_palc_native(prob, gz0, gtau, gzp, ds, 0.5, bls, tol=1e-9, max_iterations=14, norm_inf=True,
+                                callback=veto_after_two)
+    assert sn["itnewton"] == so["itnewton"] == 2 and not sn["converged"] and not so["converged"]
+    assert [s_[0] for s_ in seen] == [0, 1, 2, 2] and all(s_[2] is False for s_ in seen)
+    assert np.allclose([s_[1] for s_ in seen[:3]], so["residuals"], rtol=1e-6)
+    seen.clear()                                                              # plain Newton: fromNewton = true
+    on = palc.newton(oprob, zp[0], 0.1, ols, tol=1e-9, max_iterations=12, normN=palc.norminf,
+                     callback=lambda st, **kw: st["step"] < 2)
+    gn = hip.newton_native(prob, gzp.u, 0.1, ls, tol=1e-9, max_iterations=12, norm_inf=True, callback=veto_after_two)
+    assert gn["itnewton"] == on["itnewton"] == 2 and not gn["converged"] and all(s_[2] is True for s_ in seen)
+    assert np.allclose(gn["residuals"], on["residuals"], rtol=1e-6)
+
+
+def test_eigensolver_start_vector_and_thick_start(ctx):
+    """x0 of KrylovKit.eigsolve (EigKrylovKit.x0, src/EigSolver.jl:143,160): (i) started from the sum of the wanted
+    eigenvectors the Krylov-Schur iteration converges at once to the same eigenvalues as from rand(N); (ii) a native
+    branch with the context option eig_thick_start reports the same eigenvalues / stability counts as the default
+    (fresh random start every step, examples/SH3d.jl:109) with fewer inner solves."""
+    hip = _hip()
+    from bk_amd import continuation as Cn
+    dims, ls_ = (12, 12, 12), (np.pi,) * 3
+    sh, prob, rng, u = _sh_setup(ctx, dims, ls_)
+    P = hip.DCTPreconditioner(prob, 0.0)
+    ls = hip.GMRESKrylovKit(dim=30, rtol=1e-10, atol=1e-13, maxiter=150, Pl=P)
+    s0 = hip.newton_native(prob, prob.vec(u), 0.1, ls, tol=1e-10, max_iterations=30, norm_inf=True)
+    J = prob.jacobian(s0["u"], 0.1)
+    eig = hip.ShiftInvert(0.1, ls, tol=1e-9, maxiter=30, hermitian=True, save_vectors=True)
+    vals, vecs, ok, nops = eig(J, 6)
+    assert ok
+    x0 = vecs[0][0].copy()
+    for v in vecs[1:]:
+        x0.add_(v[0], 1.0)
+    eig2 = hip.ShiftInvert(0.1, ls, tol=1e-9, maxiter=30, hermitian=True, save_vectors=False, x0=x0)
+    vals2, _, ok2, nops2 = eig2(J, 6)
+    assert ok2 and np.allclose(vals2.real, vals.real, rtol=0, atol=1e-8) and nops2 < nops
+    dense = np.sort(np.linalg.eigvalsh(sh.J(s0["u"].numpy(), 0.1, 1.2).toarray()))[::-1][:6]
+    assert np.allclose(np.sort(vals.real)[::-1], dense, rtol=0, atol=1e-8)
+    # (ii)
+    eigc = hip.ShiftInvert(0.1, ls, tol=1e-9, maxiter=30, hermitian=True, save_vectors=False)
+    nopt = Cn.NewtonPar(tol=1e-9, max_iterations=15, linsolver=ls, eigsolver=eigc)
+    cp = Cn.ContinuationPar(ds=-0.001, dsmin=1e-4, dsmax=0.005, p_min=-0.1, p_max=0.15, max_steps=4, nev=6,
+                            detect_bifurcation=3, newton_options=nopt)
+    alg = Cn.PALC(tangent="bordered", theta=0.5, bls=hip.BorderingBLS(None, check_precision=False))
+    numops = {}
+    for thick in (0, 1):
+        ctx.set_option("eig_thick_start", thick)
+        ops = []
+        try:
+            br = Cn.continuation_native(prob, prob.vec(u), 0.1, alg, cp, normC=Cn.norminf,
+                                        finalise_solution=lambda get, r: ops.append(r.eig_numops) or True)
+        finally:
+            ctx.set_option("eig_thick_start", 0)
+        numops[thick] = (br, ops)
+    b0, b1 = numops[0][0], numops[1][0]
+    assert np.allclose(b0.param, b1.param, rtol=0, atol=1e-12) and b0.n_unstable == b1.n_unstable
+    for a, b in zip(b0.eig, b1.eig):
+        assert np.allclose(a.real, b.real, rtol=0, atol=1e-8)
+    assert sum(numops[1][1][1:]) < sum(numops[0][1][1:]), numops            # steps >= 2 start from the previous Ritz vectors
 
 
 def _native_corrector(hip, Cn, prob, z, tau, zp, ds, theta, bls, nopt, pmin, pmax):
