@@ -346,7 +346,7 @@ def continuation(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm2, verb
 
 
 def continuation_native(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm2, verbosity=0, save_sol=False,
-                        bisection=False, finalise_solution=None, callback_newton=None) -> ContResult:
+                        bisection=False, finalise_solution=None, callback_newton=None, on_init=None) -> ContResult:
     """The same branch with every step issued as ONE library call (``bk_cont_step``: corrector, eigenvalues, step-size
     control, tangent and predictor -- the body of ``iterate``, src/Continuation.jl:458-504) and the two initial Newton
     solves as ``bk_newton``.  Needs the native solver types (GMRES* + BorderingBLS + ShiftInvert); ``normC`` must be
@@ -413,6 +413,8 @@ def continuation_native(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm
 
     try:
         record(r, s0["itnewton"], s0["itlineartot"], list(s0["residuals"]))
+        if on_init is not None:
+            on_init(r)
         step = 0
         while step < cp.max_steps:
             prev_unst = r.n_unstable

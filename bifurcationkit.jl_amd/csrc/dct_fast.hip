@@ -48,6 +48,7 @@ struct FftK {
     int split;
     long long* trace;         // debug (option dct_trace): per-tile phase timestamps, 8 per workgroup, or NULL
     int fast;                 // full tiles, power-of-two shapes, < 2^31 elements: incremental addressing (host-checked)
+    int nr_steps;             // Newton steps after v_rcp_f64 in the fused symbol (option dct_rcp_steps, default 2)
 };
 
 template <int NT>
@@ -310,10 +311,11 @@ __global__ void __launch_bounds__(NT) dct_fft_kernel(FftK P) {
 // 1/d for d > 0 in the normal range: hardware reciprocal + two Newton steps (<= 1 ulp), a third of the cost of the
 // IEEE division sequence; the symbol is evaluated twice per grid point and pass, which made the divisions the largest
 // single VALU item of the roundtrip pass.
-__device__ __forceinline__ double rcp_nr(double d) {
+__device__ __forceinline__ double rcp_nr(double d, int steps = 2) {
     double y = __builtin_amdgcn_rcp(d);
     double e = __builtin_fma(-d, y, 1.0);
     y = __builtin_fma(y, e, y);
+    if (steps < 2) return y;
     e = __builtin_fma(-d, y, 1.0);
     return __builtin_fma(y, e, y);
 }
@@ -434,7 +436,7 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
                 double sa, sb;
                 if (P.axis == 1) { sa = 1.0 + la + lk + lo_; sb = 1.0 + lb + lk + lo_; }
                 else { sa = 1.0 + la + lo_ + lk; sb = 1.0 + lb + lo_ + lk; }
-                c2 r; r.x = rcp_nr(sa * sa + P.shift); r.y = rcp_nr(sb * sb + P.shift); return r;
+                c2 r; r.x = rcp_nr(sa * sa + P.shift, P.nr_steps); r.y = rcp_nr(sb * sb + P.shift, P.nr_steps); return r;
             };
             dctc::fused_mid<2>(zp, N, t, tw, ew, s0, s2, nold, nost, sym);
         } else if (MODE == 0) {
@@ -550,6 +552,7 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
     }
     P.pairvec = (axis != 0 && (n0 % 2 == 0) && (((uintptr_t)in | (uintptr_t)out) & 15) == 0) ? 1 : 0;
     P.fast = 0;            // decided after the thread count is known
+    P.nr_steps = (int)ctx->opt("dct_rcp_steps", 2.0);
     P.trace = nullptr;
     const size_t lds = ((size_t)(P.LT / 2) * (P.N + 1) + (size_t)(P.N / 2)) * sizeof(c2);
     static bool attr_set = false;

@@ -167,7 +167,16 @@ static int eig_core(bk_ctx* ctx, bk_op* Aop, bool invert, int nev, const bk_eig_
             }
         }
         dense::Mat Q;
-        const int kq = dense::orthonormalize_columns(C, 1e-8, Q);
+        int kq = dense::orthonormalize_columns(C, 1e-8, Q);
+        if (kq >= meff && keep > 1) {
+            // the kept directions fill the whole basis (nev close to the Krylov dimension and a conjugate pair at the
+            // cut): drop the trailing one(s) instead of failing
+            const int cols = eo->hermitian ? keep - 1 : 2 * (keep - 2 > 0 ? keep - 2 : 1);
+            dense::Mat C2(meff, cols);
+            for (int c = 0; c < cols; ++c)
+                for (int i = 0; i < meff; ++i) C2(i, c) = C(i, c);
+            kq = dense::orthonormalize_columns(C2, 1e-8, Q);
+        }
         if (kq < 1 || kq >= meff) return set_error(ctx, "eig: restart basis has rank %d of %d", kq, meff);
         // V[0..kq) <- V[0..meff) Q  (in place), V[kq] <- V[meff]
         BK_TRY(v_basis_combine(ctx, n, V, ld, meff, Q.a.data(), kq, V, ld));
@@ -256,6 +265,7 @@ extern "C" int bk_eig_shiftinvert(bk_ctx* ctx, bk_op* J, int nev, const bk_eig_o
     A.Js.ctx = ctx; A.Js.n = J->n; A.Js.ntail = 0; A.Js.J = J; A.Js.sigma = eo->sigma;
     BK_TRY(eig_core(ctx, &A, true, nev, eo, vals_re, vals_im, vecs, vecs_im, ldvecs, nvals_out, nconv_out, nullptr));
     if (numops_out) *numops_out = A.solves;
+    ctx->opts["eig_last_inner_ops"] = (double)A.inner_ops;     // diagnostics: bk_ctx_get_option
     return 0;
 }
 

@@ -208,7 +208,8 @@ __global__ void __launch_bounds__(kThreads) absmax_kernel(size_t n, const double
 // partials[block][j] = sum_chunk V_j . w  (j < k), partials[block][k] = sum_chunk w . w.
 // KB = compile-time bucket >= k: accumulators stay in registers, loads of absent vectors are skipped
 // by a wave-uniform predicate.  Every thread keeps KB+1 independent load streams in flight.
-template <int KB, int VEC>
+typedef double nt_d2_ __attribute__((ext_vector_type(2)));
+template <int KB, int VEC, bool LDNT = false>
 __global__ void __launch_bounds__(kThreads) multidot_kernel(size_t n, const double* __restrict__ V, size_t ldv, int k,
                                                             const double* __restrict__ w,
                                                             double* __restrict__ partials) {
@@ -225,7 +226,11 @@ __global__ void __launch_bounds__(kThreads) multidot_kernel(size_t n, const doub
 #pragma unroll
             for (int j = 0; j < KB; ++j) {
                 if (j < k) {
-                    const double2 vv = reinterpret_cast<const double2*>(V + (size_t)j * ldv)[i];
+                    double2 vv;
+                    if (LDNT) {
+                        const nt_d2_ t = __builtin_nontemporal_load(reinterpret_cast<const nt_d2_*>(V + (size_t)j * ldv) + i);
+                        vv = make_double2(t.x, t.y);
+                    } else vv = reinterpret_cast<const double2*>(V + (size_t)j * ldv)[i];
                     acc[j] = fma(vv.x, wv.x, acc[j]);
                     acc[j] = fma(vv.y, wv.y, acc[j]);
                 }
@@ -267,7 +272,17 @@ __global__ void __launch_bounds__(kThreads) multidot_kernel(size_t n, const doub
 
 // ------------------------------------------------------------------ fused multi-axpy (+scale, +norm)
 // dst = scale * (src + sum_{j<k} c[j] V_j);  partials[block] = sum_chunk dst^2 (if want_norm).
-template <int KB, int VEC, bool NT = false>
+typedef double nt_d2 __attribute__((ext_vector_type(2)));
+template <bool LDNT>
+__device__ __forceinline__ double2 ld2(const double* p, size_t i) {
+    if (LDNT) {
+        const nt_d2 t = __builtin_nontemporal_load(reinterpret_cast<const nt_d2*>(p) + i);
+        return make_double2(t.x, t.y);
+    }
+    return reinterpret_cast<const double2*>(p)[i];
+}
+
+template <int KB, int VEC, bool NT = false, bool LDNT = false, int U = 1>
 __global__ void __launch_bounds__(kThreads) multiaxpy_kernel(size_t n, const double* __restrict__ V, size_t ldv, int k,
                                                              Coefs cf, const double* src, double scale, double* dst,
                                                              int want_norm, double* __restrict__ partials) {
@@ -275,24 +290,39 @@ __global__ void __launch_bounds__(kThreads) multiaxpy_kernel(size_t n, const dou
     double nn = 0.0;
     if (VEC == 2) {
         const size_t n2 = n >> 1;
-        for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += stride) {
-            double2 r = src ? reinterpret_cast<const double2*>(src)[i] : make_double2(0.0, 0.0);
+        for (size_t i0 = (size_t)blockIdx.x * kThreads + threadIdx.x; i0 < n2; i0 += stride * U) {
+            double2 r[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t i = i0 + u * stride;
+                r[u] = (src && i < n2) ? ld2<LDNT>(src, i) : make_double2(0.0, 0.0);
+            }
 #pragma unroll
             for (int j = 0; j < KB; ++j) {
                 if (j < k) {
-                    const double2 vv = reinterpret_cast<const double2*>(V + (size_t)j * ldv)[i];
-                    r.x = fma(cf.c[j], vv.x, r.x);
-                    r.y = fma(cf.c[j], vv.y, r.y);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const size_t i = i0 + u * stride;
+                        if (U == 1 || i < n2) {
+                            const double2 vv = ld2<LDNT>(V + (size_t)j * ldv, i);
+                            r[u].x = fma(cf.c[j], vv.x, r[u].x);
+                            r[u].y = fma(cf.c[j], vv.y, r[u].y);
+                        }
+                    }
                 }
             }
-            r.x *= scale; r.y *= scale;
-            if (NT) {
-                typedef double nt_d2 __attribute__((ext_vector_type(2)));
-                nt_d2 rr; rr.x = r.x; rr.y = r.y;
-                __builtin_nontemporal_store(rr, reinterpret_cast<nt_d2*>(dst) + i);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t i = i0 + u * stride;
+                if (U > 1 && i >= n2) break;
+                r[u].x *= scale; r[u].y *= scale;
+                if (NT) {
+                    nt_d2 rr; rr.x = r[u].x; rr.y = r[u].y;
+                    __builtin_nontemporal_store(rr, reinterpret_cast<nt_d2*>(dst) + i);
+                }
+                else reinterpret_cast<double2*>(dst)[i] = r[u];
+                nn = fma(r[u].x, r[u].x, nn); nn = fma(r[u].y, r[u].y, nn);
             }
-            else reinterpret_cast<double2*>(dst)[i] = r;
-            nn = fma(r.x, r.x, nn); nn = fma(r.y, r.y, nn);
         }
         if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
             const size_t i = n - 1;
@@ -469,7 +499,8 @@ int v_nrminf(bk_ctx* ctx, size_t n, const double* x, double* out) {
 
 template <int KB>
 static void launch_multidot(bk_ctx* ctx, bool vec, int grid, size_t n, const double* V, size_t ldv, int k, const double* w) {
-    if (vec) hipLaunchKernelGGL((multidot_kernel<KB, 2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, w, ctx->d_partials);
+    if (vec && ctx->opt("dot_variant", 0.0) == 1.0) hipLaunchKernelGGL((multidot_kernel<KB, 2, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, w, ctx->d_partials);
+    else if (vec) hipLaunchKernelGGL((multidot_kernel<KB, 2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, w, ctx->d_partials);
     else hipLaunchKernelGGL((multidot_kernel<KB, 1>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, w, ctx->d_partials);
 }
 
@@ -497,7 +528,11 @@ template <int KB>
 static void launch_multiaxpy(bk_ctx* ctx, bool vec, int grid, size_t n, const double* V, size_t ldv, int k, const Coefs& cf,
                              const double* src, double scale, double* dst, int want_norm) {
     const bool nt = ctx->opt("axpy_nt", 1.0) != 0.0;       // non-temporal store of the one output stream: +1.5 % at 512^3
-    if (vec && nt) hipLaunchKernelGGL((multiaxpy_kernel<KB, 2, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials);
+    const int variant = (int)ctx->opt("axpy_variant", 0.0); // experiments: 1 non-temporal loads of the basis, 2 two elements per lane, 3 both
+    if (vec && variant == 1) hipLaunchKernelGGL((multiaxpy_kernel<KB, 2, true, true, 1>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials);
+    else if (vec && variant == 2) hipLaunchKernelGGL((multiaxpy_kernel<KB, 2, true, false, 2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials);
+    else if (vec && variant == 3) hipLaunchKernelGGL((multiaxpy_kernel<KB, 2, true, true, 2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials);
+    else if (vec && nt) hipLaunchKernelGGL((multiaxpy_kernel<KB, 2, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials);
     else if (vec) hipLaunchKernelGGL((multiaxpy_kernel<KB, 2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials);
     else hipLaunchKernelGGL((multiaxpy_kernel<KB, 1>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials);
 }

@@ -82,6 +82,11 @@ class Context:
     def set_option(self, key: str, value: float):
         self.check(self.lib.bk_ctx_set_option(self.h, key.encode(), float(value)), "bk_ctx_set_option")
 
+    def get_option(self, key: str) -> float:
+        v = C.c_double()
+        self.check(self.lib.bk_ctx_get_option(self.h, key.encode(), C.byref(v)), "bk_ctx_get_option")
+        return v.value
+
     def sync(self):
         self.check(self.lib.bk_ctx_sync(self.h), "bk_ctx_sync")
 
