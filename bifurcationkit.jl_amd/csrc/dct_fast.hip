@@ -49,6 +49,7 @@ struct FftK {
     long long* trace;         // debug (option dct_trace): per-tile phase timestamps, 8 per workgroup, or NULL
     int fast;                 // full tiles, power-of-two shapes, < 2^31 elements: incremental addressing (host-checked)
     int nr_steps;             // Newton steps after v_rcp_f64 in the fused symbol (option dct_rcp_steps, default 2)
+    int nt_load, nt_store;    // fused kernel: non-temporal hint on the tile loads / stores (every element is touched once)
 };
 
 template <int NT>
@@ -350,12 +351,22 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
     const size_t sbase = (size_t)x0 + (size_t)other * P.split_plane;
     const double* gin = P.in + (!AX0 && P.split == 2 ? sbase : base);
     double* gout = P.out + (!AX0 && P.split == 1 ? sbase : base);
+    typedef double nt_d2 __attribute__((ext_vector_type(2)));
+    auto ld16 = [&](const double* p) {
+        c2 r;
+        if (P.nt_load) { const nt_d2 t = __builtin_nontemporal_load(reinterpret_cast<const nt_d2*>(p)); r.x = t.x; r.y = t.y; }
+        else { const double2 t = *reinterpret_cast<const double2*>(p); r.x = t.x; r.y = t.y; }
+        return r;
+    };
+    auto st16 = [&](double* p, double a, double b) {
+        if (P.nt_store) { nt_d2 t; t.x = a; t.y = b; __builtin_nontemporal_store(t, reinterpret_cast<nt_d2*>(p)); }
+        else *reinterpret_cast<double2*>(p) = make_double2(a, b);
+    };
     auto ldg = [&](unsigned el) {
-        const double2 t = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(gin) + (size_t)(el * 8u));
-        c2 r; r.x = t.x; r.y = t.y; return r;
+        return ld16(reinterpret_cast<const double*>(reinterpret_cast<const char*>(gin) + (size_t)(el * 8u)));
     };
     auto stg = [&](unsigned el, c2 v) {
-        *reinterpret_cast<double2*>(reinterpret_cast<char*>(gout) + (size_t)(el * 8u)) = make_double2(v.x, v.y);
+        st16(reinterpret_cast<double*>(reinterpret_cast<char*>(gout) + (size_t)(el * 8u)), v.x, v.y);
     };
     // AX0 accessors: one double of line a / b (merged middle), or the adjacent samples (2j, 2j+1) of both lines
     auto ld1 = [&](unsigned el) {
@@ -401,8 +412,8 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
                 const double* row = gin + (size_t)(2 * pr) * lstride;
                 dctc::fused_first2(z + (size_t)pr * pstride, N, bits, w & ((1 << hbits) - 1),
                                    [&](int j, double& ea, double& oa, double& eb, double& ob) {
-                                       const double2 ta = *reinterpret_cast<const double2*>(row + 2 * j);
-                                       const double2 tb = *reinterpret_cast<const double2*>(row + lstride + 2 * j);
+                                       const c2 ta = ld16(row + 2 * j);
+                                       const c2 tb = ld16(row + lstride + 2 * j);
                                        ea = ta.x; oa = ta.y; eb = tb.x; ob = tb.y;
                                    });
             } else {
@@ -468,8 +479,8 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
             double* row = gout + (size_t)(2 * pr) * lstride;
             dctc::fused_last2(z + (size_t)pr * pstride, N, bits, w & ((1 << hbits) - 1),
                               [&](int j, double ea, double oa, double eb, double ob) {
-                                  *reinterpret_cast<double2*>(row + 2 * j) = make_double2(ea, oa);
-                                  *reinterpret_cast<double2*>(row + lstride + 2 * j) = make_double2(eb, ob);
+                                  st16(row + 2 * j, ea, oa);
+                                  st16(row + lstride + 2 * j, eb, ob);
                               });
         } else {
             const unsigned o = 2u * (w & (npairs - 1));
@@ -553,6 +564,11 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
     P.pairvec = (axis != 0 && (n0 % 2 == 0) && (((uintptr_t)in | (uintptr_t)out) & 15) == 0) ? 1 : 0;
     P.fast = 0;            // decided after the thread count is known
     P.nr_steps = (int)ctx->opt("dct_rcp_steps", 2.0);
+    {
+        const bool big = (size_t)n0 * n1 * n2 >= ((size_t)1 << 22);
+        P.nt_load = big && ctx->opt("dct_nt_load", 1.0) != 0.0;
+        P.nt_store = big && ctx->opt("dct_nt_store", 1.0) != 0.0;
+    }
     P.trace = nullptr;
     const size_t lds = ((size_t)(P.LT / 2) * (P.N + 1) + (size_t)(P.N / 2)) * sizeof(c2);
     static bool attr_set = false;

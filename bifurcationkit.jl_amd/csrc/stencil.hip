@@ -50,6 +50,8 @@ struct ShK {                // kernel-side copy of ShArgs (+ derived constants)
     int zchunk, ntx, nty, nzc, nblocks, grid8;
     int zc0;                // first z-chunk of this launch (multi-GPU: interior and face chunks go in separate launches)
     int vec_ok;
+    int vload;              // plane staging with 16-B loads (nx a multiple of the tile width, 16-B aligned planes)
+    int nt;                 // non-temporal hint on the u loads and the output stores (touched once)
 };
 
 // pointer to local plane lp in [-2, nz+2): halo buffers hold the two planes beyond each interior slab face
@@ -111,8 +113,13 @@ constexpr int NTX = TX / 2, NTY = 8;       // 32 x 8 threads, each owns 2 (x) x 
 constexpr int LW = TX + 4, LH = TY + 4;    // LDS plane with a 2-cell halo
 constexpr int LWP = LW;                    // row stride (68 doubles = 544 B: 16-B aligned rows)
 constexpr int NLOAD = (LW * LH + 255) / 256;
+constexpr int NPAIR = (LW / 2) * LH;       // plane staging as (x, x+1) pairs: 34 x 20 = 680 16-byte loads per plane
+constexpr int NLOADV = (NPAIR + 255) / 256;
+typedef double sh_nt_d2 __attribute__((ext_vector_type(2)));
 
-template <bool DIM3>
+// VL: plane staging with 16-byte loads (host-checked shapes), else 8-byte gathers.  162 VGPRs -> 3 waves / SIMD; capping the
+// registers for a 4th wave (__launch_bounds__(256, 4)) spills and halves the rate (measured)
+template <bool DIM3, bool VL>
 __global__ void __launch_bounds__(256) sh_stream_kernel(ShK P) {
     __shared__ __attribute__((aligned(16))) double lds[2][LH * LWP];
 
@@ -133,13 +140,15 @@ __global__ void __launch_bounds__(256) sh_stream_kernel(ShK P) {
     const size_t plane = (size_t)P.nx * P.ny;
 
     // plane-independent source offsets of the LDS cells this thread stages
-    int off[NLOAD];
+    int off[VL ? 1 : NLOAD];
+    if (!VL) {
 #pragma unroll
-    for (int r = 0; r < NLOAD; ++r) {
-        const int c = tid + r * 256;
-        const int ly = c / LW, lx = c - ly * LW;
-        const int gy = mirror_idx(y0 - 2 + ly, P.ny), gx = mirror_idx(x0 - 2 + lx, P.nx);
-        off[r] = (c < LW * LH) ? gy * P.nx + gx : -1;
+        for (int r = 0; r < NLOAD; ++r) {
+            const int c = tid + r * 256;
+            const int ly = c / LW, lx = c - ly * LW;
+            const int gy = mirror_idx(y0 - 2 + ly, P.ny), gx = mirror_idx(x0 - 2 + lx, P.nx);
+            off[r] = (c < LW * LH) ? gy * P.nx + gx : -1;
+        }
     }
     // own points
     const int ox = x0 + 2 * tx;
@@ -168,20 +177,49 @@ __global__ void __launch_bounds__(256) sh_stream_kernel(ShK P) {
         if (p_last + P.zoff > P.nzg - 1) p_last = P.nzg - 1 - P.zoff;
     }
 
-    double rv[NLOAD];
+    // 16-byte staging: the tile starts at an even x and the row has an even length, so the LDS cells (lx, lx+1) with lx
+    // even are the aligned pair (gx, gx+1) of the source row -- except at the domain faces, where the reflected cells
+    // (-2, -1) -> (1, 0) and (nx, nx+1) -> (nx-1, nx-2) are the SWAPPED pair at 0 / nx-2
+    int offv[VL ? NLOADV : 1];
+    unsigned swapmask = 0;
+    if (VL) {
+#pragma unroll
+        for (int r = 0; r < NLOADV; ++r) {
+            const int c = tid + r * 256;
+            const int ly = c / (LW / 2), lx = 2 * (c - ly * (LW / 2));
+            const int gy = mirror_idx(y0 - 2 + ly, P.ny);
+            int gx = x0 - 2 + lx;
+            if (gx < 0) { gx = 0; swapmask |= 1u << r; }
+            else if (gx >= P.nx) { gx = P.nx - 2; swapmask |= 1u << r; }
+            offv[r] = (c < NPAIR) ? gy * P.nx + gx : -1;
+        }
+    }
+    double rv[VL ? 1 : NLOAD];
+    double2 rvv[VL ? NLOADV : 1];
     double ru[2][2];
     auto load_plane = [&](int p) {
         const double* src = plane_ptr(P, p);
+        if (VL) {
 #pragma unroll
-        for (int r = 0; r < NLOAD; ++r) rv[r] = (off[r] >= 0) ? src[off[r]] : 0.0;
+            for (int r = 0; r < NLOADV; ++r)
+                rvv[r] = (offv[r] >= 0) ? *reinterpret_cast<const double2*>(src + offv[r]) : make_double2(0.0, 0.0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < NLOAD; ++r) rv[r] = (off[r] >= 0) ? src[off[r]] : 0.0;
+        }
         if (P.mode == 0 && p >= 0 && p < P.nz) {
             const double* us = P.u + (size_t)p * plane;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const size_t o = (size_t)oy[r] * P.nx + ox;
                 if (oky[r] && okx1 && P.vec_ok) {
-                    const double2 t = *reinterpret_cast<const double2*>(us + o);
-                    ru[r][0] = t.x; ru[r][1] = t.y;
+                    if (P.nt) {
+                        const sh_nt_d2 t = __builtin_nontemporal_load(reinterpret_cast<const sh_nt_d2*>(us + o));
+                        ru[r][0] = t.x; ru[r][1] = t.y;
+                    } else {
+                        const double2 t = *reinterpret_cast<const double2*>(us + o);
+                        ru[r][0] = t.x; ru[r][1] = t.y;
+                    }
                 } else {
                     ru[r][0] = (oky[r] && okx0) ? us[o] : 0.0;
                     ru[r][1] = (oky[r] && okx1) ? us[o + 1] : 0.0;
@@ -190,10 +228,21 @@ __global__ void __launch_bounds__(256) sh_stream_kernel(ShK P) {
         }
     };
     auto stage_plane = [&](int buf) {
+        if (VL) {
 #pragma unroll
-        for (int r = 0; r < NLOAD; ++r) {
-            const int c = tid + r * 256;
-            if (c < LW * LH) lds[buf][c] = rv[r];
+            for (int r = 0; r < NLOADV; ++r) {
+                const int c = tid + r * 256;
+                if (c < NPAIR) {
+                    const double2 t = rvv[r];
+                    reinterpret_cast<double2*>(lds[buf])[c] = (swapmask >> r) & 1u ? make_double2(t.y, t.x) : t;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < NLOAD; ++r) {
+                const int c = tid + r * 256;
+                if (c < LW * LH) lds[buf][c] = rv[r];
+            }
         }
     };
 
@@ -258,7 +307,10 @@ __global__ void __launch_bounds__(256) sh_stream_kernel(ShK P) {
                 double* dst = P.out + (size_t)k * plane + (size_t)oy[r] * P.nx + ox;
                 const double o0 = acc[r][0][DIM3 ? 0 : 2], o1 = acc[r][1][DIM3 ? 0 : 2];
                 if (okx1 && P.vec_ok) {
-                    *reinterpret_cast<double2*>(dst) = make_double2(o0, o1);
+                    if (P.nt) {
+                        sh_nt_d2 t; t.x = o0; t.y = o1;
+                        __builtin_nontemporal_store(t, reinterpret_cast<sh_nt_d2*>(dst));
+                    } else *reinterpret_cast<double2*>(dst) = make_double2(o0, o1);
                 } else {
                     if (okx0) dst[0] = o0;
                     if (okx1) dst[1] = o1;
@@ -452,7 +504,7 @@ int sh_apply(bk_ctx* ctx, const ShArgs& a) {
     if (variant == 0) {
         if (a.part == 1) return 0;                            // the gather cross-check runs whole once the halos are in
         ProfScope ps(ctx, a.mode == 0 ? "jvp" : "residual", (a.mode == 0 ? 24.0 : 16.0) * n);
-        P.zchunk = 0; P.ntx = P.nty = P.nzc = P.nblocks = P.grid8 = 0; P.vec_ok = 0;
+        P.zchunk = 0; P.ntx = P.nty = P.nzc = P.nblocks = P.grid8 = 0; P.vec_ok = 0; P.vload = 0; P.nt = 0;
         const size_t grid = (n + 255) / 256;
         hipLaunchKernelGGL(sh_gather_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, P);
     } else {
@@ -472,6 +524,11 @@ int sh_apply(bk_ctx* ctx, const ShArgs& a) {
         P.nzc = (a.nz + zchunk - 1) / zchunk;
         P.vec_ok = ((a.nx & 1) == 0) && (((uintptr_t)a.out & 15) == 0) &&
                    (a.mode != 0 || ((uintptr_t)a.u & 15) == 0);
+        // 16-byte plane staging: full tiles in x (no overhang), even plane size (every plane 16-B aligned), aligned bases
+        P.vload = ctx->opt("sh_vload", 1.0) != 0.0 && a.nx % TX == 0 && (((size_t)a.nx * a.ny) & 1) == 0 &&
+                  (((uintptr_t)a.v & 15) == 0) && (!a.halo_lo || ((uintptr_t)a.halo_lo & 15) == 0) &&
+                  (!a.halo_hi || ((uintptr_t)a.halo_hi & 15) == 0);
+        P.nt = n >= ((size_t)1 << 22) && ctx->opt("sh_nt", 1.0) != 0.0;
         // part 0: everything; part 1: the chunks that touch no halo plane (1 .. nzc-2); part 2: the two face chunks
         auto launch = [&](int zc0, int count) {
             if (count <= 0) return;
@@ -479,8 +536,10 @@ int sh_apply(bk_ctx* ctx, const ShArgs& a) {
             P.nblocks = P.ntx * P.nty * count;
             P.grid8 = (P.nblocks + 7) / 8 * 8;
             ProfScope ps(ctx, a.mode == 0 ? "jvp" : "residual", (a.mode == 0 ? 24.0 : 16.0) * n * count / P.nzc);
-            if (dim3d) hipLaunchKernelGGL((sh_stream_kernel<true>), dim3(P.grid8), dim3(256), 0, ctx->stream, P);
-            else hipLaunchKernelGGL((sh_stream_kernel<false>), dim3(P.grid8), dim3(256), 0, ctx->stream, P);
+            if (dim3d && P.vload) hipLaunchKernelGGL((sh_stream_kernel<true, true>), dim3(P.grid8), dim3(256), 0, ctx->stream, P);
+            else if (dim3d) hipLaunchKernelGGL((sh_stream_kernel<true, false>), dim3(P.grid8), dim3(256), 0, ctx->stream, P);
+            else if (P.vload) hipLaunchKernelGGL((sh_stream_kernel<false, true>), dim3(P.grid8), dim3(256), 0, ctx->stream, P);
+            else hipLaunchKernelGGL((sh_stream_kernel<false, false>), dim3(P.grid8), dim3(256), 0, ctx->stream, P);
         };
         // face chunks: the first one (reads planes -2, -1) and the last one -- the last two when the last chunk is a
         // single plane, because its lower neighbour then reads plane nz

@@ -22,6 +22,10 @@ inline int grid_for(size_t n, int per_thread, int max_blocks) {
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// non-temporal hint only for vectors that cannot live in the caches anyway (>= 32 MiB): the cache-resident 2-D configs keep
+// their operands in L2 / Infinity Cache between kernels
+inline bool nt_hint(bk_ctx* ctx, size_t n) { return n >= ((size_t)1 << 22) && ctx->opt("nt_hint", 1.0) != 0.0; }
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -33,8 +37,25 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 
+// Streams that are read exactly once per kernel (Krylov basis vectors, BLAS-1 operands) are loaded with the non-temporal
+// hint: measured at 512^3 (profiles/r2_kernel_variants_512_nt_loads.jsonl) multidot 6.3 -> 6.6-6.9 TB/s, multiaxpy
+// 5.1-5.3 -> 5.6 TB/s (with two elements per lane in flight).
+typedef double nt_d2 __attribute__((ext_vector_type(2)));
+template <bool LDNT>
+__device__ __forceinline__ double2 ld2(const double* p, size_t i) {
+    if (LDNT) {
+        const nt_d2 t = __builtin_nontemporal_load(reinterpret_cast<const nt_d2*>(p) + i);
+        return make_double2(t.x, t.y);
+    }
+    return reinterpret_cast<const double2*>(p)[i];
+}
+__device__ __forceinline__ void st2nt(double* p, size_t i, double2 v) {
+    nt_d2 r; r.x = v.x; r.y = v.y;
+    __builtin_nontemporal_store(r, reinterpret_cast<nt_d2*>(p) + i);
+}
+
 // ------------------------------------------------------------------ elementwise
-template <int VEC>
+template <int VEC, bool NTH = false>
 __global__ void __launch_bounds__(kThreads) axpbyz_kernel(size_t n, double a, const double* __restrict__ x, double b,
                                                           const double* y, double* z, int has_x, int has_y) {
     const size_t stride = (size_t)gridDim.x * kThreads;
@@ -42,9 +63,10 @@ __global__ void __launch_bounds__(kThreads) axpbyz_kernel(size_t n, double a, co
         const size_t n2 = n >> 1;
         for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += stride) {
             double2 r = make_double2(0.0, 0.0);
-            if (has_x) { const double2 xv = reinterpret_cast<const double2*>(x)[i]; r.x = a * xv.x; r.y = a * xv.y; }
-            if (has_y) { const double2 yv = reinterpret_cast<const double2*>(y)[i]; r.x += b * yv.x; r.y += b * yv.y; }
-            reinterpret_cast<double2*>(z)[i] = r;
+            if (has_x) { const double2 xv = ld2<NTH>(x, i); r.x = a * xv.x; r.y = a * xv.y; }
+            if (has_y) { const double2 yv = ld2<NTH>(y, i); r.x += b * yv.x; r.y += b * yv.y; }
+            if (NTH) st2nt(z, i, r);
+            else reinterpret_cast<double2*>(z)[i] = r;
         }
         if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
             const size_t i = n - 1;
@@ -78,7 +100,7 @@ __global__ void __launch_bounds__(kThreads) fill_random_kernel(size_t n, size_t 
 
 // ------------------------------------------------------------------ reductions, stage 1
 // NV outputs per block: out[block*NV + j].
-template <int VEC, int NY>   // dot of x with NY vectors y[0..NY) ; if y==x it is a squared norm
+template <int VEC, int NY, bool NTH = false>   // dot of x with NY vectors y[0..NY) ; if y==x it is a squared norm
 __global__ void __launch_bounds__(kThreads) dot_kernel(size_t n, const double* __restrict__ x,
                                                        const double* __restrict__ y0, const double* __restrict__ y1,
                                                        double* __restrict__ partials) {
@@ -87,11 +109,11 @@ __global__ void __launch_bounds__(kThreads) dot_kernel(size_t n, const double* _
     if (VEC == 2) {
         const size_t n2 = n >> 1;
         for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += stride) {
-            const double2 xv = reinterpret_cast<const double2*>(x)[i];
-            const double2 a = reinterpret_cast<const double2*>(y0)[i];
+            const double2 xv = ld2<NTH>(x, i);
+            const double2 a = ld2<NTH>(y0, i);
             s0 = fma(xv.x, a.x, s0); s0 = fma(xv.y, a.y, s0);
             if (NY == 2) {
-                const double2 b = reinterpret_cast<const double2*>(y1)[i];
+                const double2 b = ld2<NTH>(y1, i);
                 s1 = fma(xv.x, b.x, s1); s1 = fma(xv.y, b.y, s1);
             }
         }
@@ -119,7 +141,7 @@ __global__ void __launch_bounds__(kThreads) dot_kernel(size_t n, const double* _
 
 // ------------------------------------------------------------------ fused MINRES passes (solver.hip: minres_core)
 // y <- y + c r (has_r), partial of z . y (after the update): the Lanczos three-term update and its alpha in one pass.
-template <int VEC>
+template <int VEC, bool NTH = false>
 __global__ void __launch_bounds__(kThreads) axpy_dot_kernel(size_t n, double c, const double* __restrict__ r, int has_r,
                                                             double* y, const double* __restrict__ z,
                                                             double* __restrict__ partials) {
@@ -128,13 +150,14 @@ __global__ void __launch_bounds__(kThreads) axpy_dot_kernel(size_t n, double c, 
     if (VEC == 2) {
         const size_t n2 = n >> 1;
         for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += stride) {
-            double2 yv = reinterpret_cast<double2*>(y)[i];
+            double2 yv = ld2<NTH>(y, i);
             if (has_r) {
-                const double2 rv = reinterpret_cast<const double2*>(r)[i];
+                const double2 rv = ld2<NTH>(r, i);
                 yv.x = fma(c, rv.x, yv.x); yv.y = fma(c, rv.y, yv.y);
-                reinterpret_cast<double2*>(y)[i] = yv;
+                if (NTH) st2nt(y, i, yv);
+                else reinterpret_cast<double2*>(y)[i] = yv;
             }
-            const double2 zv = reinterpret_cast<const double2*>(z)[i];
+            const double2 zv = ld2<NTH>(z, i);
             s = fma(zv.x, yv.x, s); s = fma(zv.y, yv.y, s);
         }
         if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -157,7 +180,7 @@ __global__ void __launch_bounds__(kThreads) axpy_dot_kernel(size_t n, double c, 
 }
 
 // w <- cz z + c1 w1 + c2 w2 ;  x <- x + phi w : the MINRES direction and solution updates in one pass
-template <int VEC>
+template <int VEC, bool NTH = false>
 __global__ void __launch_bounds__(kThreads) minres_update_kernel(size_t n, double cz, const double* __restrict__ z, double c1,
                                                                  const double* __restrict__ w1, double c2,
                                                                  const double* __restrict__ w2, double* __restrict__ w,
@@ -166,16 +189,16 @@ __global__ void __launch_bounds__(kThreads) minres_update_kernel(size_t n, doubl
     if (VEC == 2) {
         const size_t n2 = n >> 1;
         for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += stride) {
-            const double2 zv = reinterpret_cast<const double2*>(z)[i];
-            const double2 a = reinterpret_cast<const double2*>(w1)[i];
-            const double2 b = reinterpret_cast<const double2*>(w2)[i];
-            double2 xv = reinterpret_cast<double2*>(x)[i];
+            const double2 zv = ld2<NTH>(z, i);
+            const double2 a = ld2<NTH>(w1, i);
+            const double2 b = ld2<NTH>(w2, i);
+            double2 xv = ld2<NTH>(x, i);
             double2 wv;
             wv.x = fma(c2, b.x, fma(c1, a.x, cz * zv.x));
             wv.y = fma(c2, b.y, fma(c1, a.y, cz * zv.y));
             xv.x = fma(phi, wv.x, xv.x); xv.y = fma(phi, wv.y, xv.y);
-            reinterpret_cast<double2*>(w)[i] = wv;
-            reinterpret_cast<double2*>(x)[i] = xv;
+            if (NTH) { st2nt(w, i, wv); st2nt(x, i, xv); }
+            else { reinterpret_cast<double2*>(w)[i] = wv; reinterpret_cast<double2*>(x)[i] = xv; }
         }
         if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
             const size_t i = n - 1;
@@ -208,7 +231,6 @@ __global__ void __launch_bounds__(kThreads) absmax_kernel(size_t n, const double
 // partials[block][j] = sum_chunk V_j . w  (j < k), partials[block][k] = sum_chunk w . w.
 // KB = compile-time bucket >= k: accumulators stay in registers, loads of absent vectors are skipped
 // by a wave-uniform predicate.  Every thread keeps KB+1 independent load streams in flight.
-typedef double nt_d2_ __attribute__((ext_vector_type(2)));
 template <int KB, int VEC, bool LDNT = false>
 __global__ void __launch_bounds__(kThreads) multidot_kernel(size_t n, const double* __restrict__ V, size_t ldv, int k,
                                                             const double* __restrict__ w,
@@ -221,16 +243,12 @@ __global__ void __launch_bounds__(kThreads) multidot_kernel(size_t n, const doub
     if (VEC == 2) {
         const size_t n2 = n >> 1;
         for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += stride) {
-            const double2 wv = reinterpret_cast<const double2*>(w)[i];
+            const double2 wv = ld2<LDNT>(w, i);
             ww = fma(wv.x, wv.x, ww); ww = fma(wv.y, wv.y, ww);
 #pragma unroll
             for (int j = 0; j < KB; ++j) {
                 if (j < k) {
-                    double2 vv;
-                    if (LDNT) {
-                        const nt_d2_ t = __builtin_nontemporal_load(reinterpret_cast<const nt_d2_*>(V + (size_t)j * ldv) + i);
-                        vv = make_double2(t.x, t.y);
-                    } else vv = reinterpret_cast<const double2*>(V + (size_t)j * ldv)[i];
+                    const double2 vv = ld2<LDNT>(V + (size_t)j * ldv, i);
                     acc[j] = fma(vv.x, wv.x, acc[j]);
                     acc[j] = fma(vv.y, wv.y, acc[j]);
                 }
@@ -272,16 +290,6 @@ __global__ void __launch_bounds__(kThreads) multidot_kernel(size_t n, const doub
 
 // ------------------------------------------------------------------ fused multi-axpy (+scale, +norm)
 // dst = scale * (src + sum_{j<k} c[j] V_j);  partials[block] = sum_chunk dst^2 (if want_norm).
-typedef double nt_d2 __attribute__((ext_vector_type(2)));
-template <bool LDNT>
-__device__ __forceinline__ double2 ld2(const double* p, size_t i) {
-    if (LDNT) {
-        const nt_d2 t = __builtin_nontemporal_load(reinterpret_cast<const nt_d2*>(p) + i);
-        return make_double2(t.x, t.y);
-    }
-    return reinterpret_cast<const double2*>(p)[i];
-}
-
 template <int KB, int VEC, bool NT = false, bool LDNT = false, int U = 1>
 __global__ void __launch_bounds__(kThreads) multiaxpy_kernel(size_t n, const double* __restrict__ V, size_t ldv, int k,
                                                              Coefs cf, const double* src, double scale, double* dst,
@@ -402,7 +410,9 @@ int v_axpbyz(bk_ctx* ctx, size_t n, double a, const double* x, double b, const d
     ProfScope ps(ctx, "blas1", 8.0 * n * (1 + hx + has_y));
     const bool vec = aligned16(z) && (!hx || aligned16(x)) && (!has_y || aligned16(y));
     const int grid = grid_for(n, vec ? 2 : 1, 4096);
-    if (vec)
+    if (vec && nt_hint(ctx, n))
+        hipLaunchKernelGGL((axpbyz_kernel<2, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, a, x, b, y, z, hx, has_y);
+    else if (vec)
         hipLaunchKernelGGL((axpbyz_kernel<2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, a, x, b, y, z, hx, has_y);
     else
         hipLaunchKernelGGL((axpbyz_kernel<1>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, a, x, b, y, z, hx, has_y);
@@ -428,7 +438,10 @@ static int dot_launch(bk_ctx* ctx, size_t n, const double* x, const double* y0, 
     const int grid = grid_for(n, vec ? 2 : 1, kRedBlocks);
     {
         ProfScope ps(ctx, "blas1", 8.0 * n * ((x == y0 ? 1 : 2) + (ny - 1)));
-        if (ny == 1) {
+        if (vec && nt_hint(ctx, n)) {
+            if (ny == 1) hipLaunchKernelGGL((dot_kernel<2, 1, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, x, y0, y1, ctx->d_partials);
+            else hipLaunchKernelGGL((dot_kernel<2, 2, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, x, y0, y1, ctx->d_partials);
+        } else if (ny == 1) {
             if (vec) hipLaunchKernelGGL((dot_kernel<2, 1>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, x, y0, y1, ctx->d_partials);
             else hipLaunchKernelGGL((dot_kernel<1, 1>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, x, y0, y1, ctx->d_partials);
         } else {
@@ -464,7 +477,8 @@ int v_axpy_dot(bk_ctx* ctx, size_t n, double c, const double* r, double* y, cons
     const int grid = grid_for(n, vec ? 2 : 1, kRedBlocks);
     {
         ProfScope ps(ctx, "blas1", 8.0 * n * (2 + 2 * has_r));
-        if (vec) hipLaunchKernelGGL((axpy_dot_kernel<2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, c, r, has_r, y, z, ctx->d_partials);
+        if (vec && nt_hint(ctx, n)) hipLaunchKernelGGL((axpy_dot_kernel<2, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, c, r, has_r, y, z, ctx->d_partials);
+        else if (vec) hipLaunchKernelGGL((axpy_dot_kernel<2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, c, r, has_r, y, z, ctx->d_partials);
         else hipLaunchKernelGGL((axpy_dot_kernel<1>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, c, r, has_r, y, z, ctx->d_partials);
         BK_HIP(ctx, hipGetLastError());
     }
@@ -479,7 +493,8 @@ int v_minres_update(bk_ctx* ctx, size_t n, double cz, const double* z, double c1
     const bool vec = aligned16(z) && aligned16(w1) && aligned16(w2) && aligned16(w) && aligned16(x);
     const int grid = grid_for(n, vec ? 2 : 1, 4096);
     ProfScope ps(ctx, "blas1", 8.0 * n * 6);
-    if (vec) hipLaunchKernelGGL((minres_update_kernel<2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, cz, z, c1, w1, c2, w2, w, phi, x);
+    if (vec && nt_hint(ctx, n)) hipLaunchKernelGGL((minres_update_kernel<2, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, cz, z, c1, w1, c2, w2, w, phi, x);
+    else if (vec) hipLaunchKernelGGL((minres_update_kernel<2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, cz, z, c1, w1, c2, w2, w, phi, x);
     else hipLaunchKernelGGL((minres_update_kernel<1>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, cz, z, c1, w1, c2, w2, w, phi, x);
     BK_HIP(ctx, hipGetLastError());
     return 0;
@@ -499,7 +514,7 @@ int v_nrminf(bk_ctx* ctx, size_t n, const double* x, double* out) {
 
 template <int KB>
 static void launch_multidot(bk_ctx* ctx, bool vec, int grid, size_t n, const double* V, size_t ldv, int k, const double* w) {
-    if (vec && ctx->opt("dot_variant", 0.0) == 1.0) hipLaunchKernelGGL((multidot_kernel<KB, 2, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, w, ctx->d_partials);
+    if (vec && nt_hint(ctx, n) && ctx->opt("dot_variant", 1.0) == 1.0) hipLaunchKernelGGL((multidot_kernel<KB, 2, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, w, ctx->d_partials);
     else if (vec) hipLaunchKernelGGL((multidot_kernel<KB, 2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, w, ctx->d_partials);
     else hipLaunchKernelGGL((multidot_kernel<KB, 1>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, w, ctx->d_partials);
 }
@@ -528,7 +543,7 @@ template <int KB>
 static void launch_multiaxpy(bk_ctx* ctx, bool vec, int grid, size_t n, const double* V, size_t ldv, int k, const Coefs& cf,
                              const double* src, double scale, double* dst, int want_norm) {
     const bool nt = ctx->opt("axpy_nt", 1.0) != 0.0;       // non-temporal store of the one output stream: +1.5 % at 512^3
-    const int variant = (int)ctx->opt("axpy_variant", 0.0); // experiments: 1 non-temporal loads of the basis, 2 two elements per lane, 3 both
+    const int variant = nt_hint(ctx, n) ? (int)ctx->opt("axpy_variant", 3.0) : 0; // 0 plain loads, 1 non-temporal loads of the basis, 2 two elements per lane, 3 both (default)
     if (vec && variant == 1) hipLaunchKernelGGL((multiaxpy_kernel<KB, 2, true, true, 1>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials);
     else if (vec && variant == 2) hipLaunchKernelGGL((multiaxpy_kernel<KB, 2, true, false, 2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials);
     else if (vec && variant == 3) hipLaunchKernelGGL((multiaxpy_kernel<KB, 2, true, true, 2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials);

@@ -98,6 +98,100 @@ if "axpy" in what:
     ctx.set_option("axpy_blocks", 4096)
     del V
 
+if "variants" in what:
+    # round-2 A/B variants behind context options, interleaved repetitions (same buffers, same clocks)
+    ld = (N + 31) // 32 * 32
+    V = torch.rand(ld * 16, dtype=torch.float64, device="cuda", generator=g)
+    hbuf = (C.c_double * 65)()
+    for k in (4, 8, 12, 16):
+        cc = (C.c_double * k)(*([0.01] * k))
+        fa = lambda: ctx.check(ctx.lib.bk_krylov_multiaxpy(ctx.h, N, C.c_void_p(V.data_ptr()), ld, k, cc, C.c_void_p(v.t.data_ptr()),
+                                                           1.0, C.c_void_p(out.t.data_ptr()), None))
+        fd = lambda: ctx.check(ctx.lib.bk_krylov_multidot(ctx.h, N, C.c_void_p(V.data_ptr()), ld, k, C.c_void_p(v.t.data_ptr()), hbuf))
+        for rep in range(2):
+            for var in (0, 1, 2, 3):
+                ctx.set_option("axpy_variant", var)
+                report("multiaxpy", timeit(fa, reps=5, warm=1), 8.0 * N * (k + 2), k=k, variant=var, rep=rep)
+            for var in (0, 1):
+                ctx.set_option("dot_variant", var)
+                report("multidot", timeit(fd, reps=5, warm=1), 8.0 * N * (k + 1), k=k, variant=var, rep=rep)
+        ctx.set_option("axpy_variant", 0)
+        ctx.set_option("dot_variant", 0)
+    for blocks in (512, 768, 1024, 1536, 2048):
+        ctx.set_option("axpy_blocks", blocks)
+        k = 8
+        cc = (C.c_double * k)(*([0.01] * k))
+        fa = lambda: ctx.check(ctx.lib.bk_krylov_multiaxpy(ctx.h, N, C.c_void_p(V.data_ptr()), ld, k, cc, C.c_void_p(v.t.data_ptr()),
+                                                           1.0, C.c_void_p(out.t.data_ptr()), None))
+        report("multiaxpy", timeit(fa, reps=5, warm=1), 8.0 * N * (k + 2), k=k, blocks=blocks)
+    ctx.set_option("axpy_blocks", 1024)
+    del V
+    P = hip.DCTPreconditioner(prob, 1.0)
+    o2 = v.similar()
+    f = lambda: ctx.check(ctx.lib.bk_precond_apply(P.h, C.c_void_p(v.t.data_ptr()), C.c_void_p(out.t.data_ptr())))
+    f()
+    ref = out.copy()
+    for rep in range(2):
+        for steps in (2, 1):
+            ctx.set_option("dct_rcp_steps", steps)
+            t = timeit(f, reps=5, warm=1)
+            err = out.copy().add_(ref, -1.0).norminf() / ref.norminf()
+            report("dct_precond", t, 80.0 * N, rcp_steps=steps, rel_diff_vs_2steps=err, rep=rep)
+    ctx.set_option("dct_rcp_steps", 2)
+
+if "jvp2" in what:
+    J = prob.jacobian(u, 0.1)
+    lib = ctx.lib
+    pv = (C.c_double * 2)(0.1, 1.2)
+    fj = lambda: ctx.check(lib.bk_op_apply(J.h, C.c_void_p(v.t.data_ptr()), 0.0, 1.0, C.c_void_p(out.t.data_ptr())))
+    fr = lambda: ctx.check(lib.bk_residual(prob.h, C.c_void_p(u.t.data_ptr()), pv, 2, C.c_void_p(out.t.data_ptr())))
+    for rep in range(2):
+        for vl, nt, mw in ((0, 0, 1), (0, 1, 1), (1, 0, 1), (1, 1, 1)):
+            ctx.set_option("sh_vload", vl)
+            ctx.set_option("sh_nt", nt)
+            ctx.set_option("sh_minw", mw)
+            report("sh3d_jvp", timeit(fj, reps=8, warm=2), 24.0 * N, vload=vl, nt=nt, minw=mw, rep=rep)
+            report("sh3d_residual", timeit(fr, reps=8, warm=2), 16.0 * N, vload=vl, nt=nt, minw=mw, rep=rep)
+    for zc in (16, 32, 64):
+        ctx.set_option("sh_zchunk", zc)
+        report("sh3d_jvp", timeit(fj, reps=8, warm=2), 24.0 * N, vload=1, nt=1, minw=mw, zchunk=zc)
+    ctx.set_option("sh_zchunk", 0)
+    ctx.set_option("sh_vload", 1)
+    ctx.set_option("sh_nt", 1)
+    ctx.set_option("sh_minw", 1)
+
+if "nt2" in what:
+    # second batch of round-2 variants: 16-byte plane staging / non-temporal hints in the JVP, DCT passes, BLAS-1
+    J = prob.jacobian(u, 0.1)
+    lib = ctx.lib
+    pv = (C.c_double * 2)(0.1, 1.2)
+    fj = lambda: ctx.check(lib.bk_op_apply(J.h, C.c_void_p(v.t.data_ptr()), 0.0, 1.0, C.c_void_p(out.t.data_ptr())))
+    fr = lambda: ctx.check(lib.bk_residual(prob.h, C.c_void_p(u.t.data_ptr()), pv, 2, C.c_void_p(out.t.data_ptr())))
+    for rep in range(2):
+        for vl, nt in ((0, 0), (1, 0), (0, 1), (1, 1)):
+            ctx.set_option("sh_vload", vl)
+            ctx.set_option("sh_nt", nt)
+            report("sh3d_jvp", timeit(fj, reps=8, warm=2), 24.0 * N, vload=vl, nt=nt, rep=rep)
+            report("sh3d_residual", timeit(fr, reps=8, warm=2), 16.0 * N, vload=vl, nt=nt, rep=rep)
+    ctx.set_option("sh_vload", 1)
+    ctx.set_option("sh_nt", 1)
+    P = hip.DCTPreconditioner(prob, 1.0)
+    f = lambda: ctx.check(ctx.lib.bk_precond_apply(P.h, C.c_void_p(v.t.data_ptr()), C.c_void_p(out.t.data_ptr())))
+    for rep in range(2):
+        for nl, ns in ((0, 0), (1, 0), (0, 1), (1, 1)):
+            ctx.set_option("dct_nt_load", nl)
+            ctx.set_option("dct_nt_store", ns)
+            report("dct_precond", timeit(f, reps=5, warm=1), 80.0 * N, nt_load=nl, nt_store=ns, rep=rep)
+    ctx.set_option("dct_nt_load", 1)
+    ctx.set_option("dct_nt_store", 1)
+    for rep in range(2):
+        for h in (0, 1):
+            ctx.set_option("nt_hint", h)
+            report("axpby", timeit(lambda: out.add_(v, 0.5, 2.0), reps=8, warm=2), 24.0 * N, nt_hint=h, rep=rep)
+            report("dot", timeit(lambda: u.inner(v), reps=8, warm=2), 16.0 * N, nt_hint=h, rep=rep)
+            report("scale", timeit(lambda: out.scale_(1.0000001), reps=8, warm=2), 16.0 * N, nt_hint=h, rep=rep)
+    ctx.set_option("nt_hint", 1)
+
 if "precond" in what:
     P = hip.DCTPreconditioner(prob, 1.0)
     f = lambda: ctx.check(ctx.lib.bk_precond_apply(P.h, C.c_void_p(v.t.data_ptr()), C.c_void_p(out.t.data_ptr())))
