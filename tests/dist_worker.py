@@ -49,12 +49,12 @@ def main_cpu(rank, world):
     assert hostcomm.allreduce(None, p, 2, 1) == 0 and np.all(buf == world - 1)
     s = np.full(5, float(rank))
     r = np.zeros(5)
-    peer = 1 - rank
-    assert hostcomm.sendrecv(None, s.ctypes.data_as(C.POINTER(C.c_double)), 5, peer,
-                             r.ctypes.data_as(C.POINTER(C.c_double)), 5, peer) == 0
-    assert np.all(r == peer)
+    dst, src = (rank + 1) % world, (rank - 1) % world                 # ring shift (world = 2: the pair exchange)
+    assert hostcomm.sendrecv(None, s.ctypes.data_as(C.POINTER(C.c_double)), 5, dst,
+                             r.ctypes.data_as(C.POINTER(C.c_double)), 5, src) == 0
+    assert np.all(r == src)
     # ---- slab-decomposed oracle JVP == serial oracle
-    dims, ls = (9, 8, 11), (2.0, 1.5, 2.5)
+    dims, ls = (9, 8, 11 if world <= 2 else 3 * world + 2), (2.0, 1.5, 2.5)      # ragged split for every world size
     sh = operators.SwiftHohenberg(dims, ls)
     rng = np.random.default_rng(0)
     u, v = rng.standard_normal(sh.N), rng.standard_normal(sh.N)
@@ -223,11 +223,84 @@ def main_gpu(rank, world):
     print(f"rank {rank}: gpu distributed checks OK", flush=True)
 
 
+def slab_checks(ctx, hip, rank, world, tag):
+    """The core of the distributed path against the 1-rank result, on grids whose z extent does not divide evenly
+    (ragged slabs), with slabs as thin as the 2-plane halo allows, and on a power-of-two grid (fused FFT passes + the
+    all-to-all block layout): JVP (all split-launch variants), preconditioner, GMRES, bordered solve."""
+    cases = [((16, 12, 4 * world + 2 if world > 2 else 20), (2.0, 1.5, 2.5)),      # ragged: some ranks own one plane more
+             ((8, 6, 2 * world + 1), (1.0, 1.5, 2.0)),                               # thin: 2 or 3 planes per rank
+             ((32, 64, 64), (2.0, 3.0, 2.5))]                                        # power of two: fused DCT passes
+    for ci, (dims, ls) in enumerate(cases):
+        N = int(np.prod(dims))
+        rng = np.random.default_rng(10 + ci)
+        u, v, r = 0.5 * rng.standard_normal(N), rng.standard_normal(N), rng.standard_normal(N)
+        prob = hip.SwiftHohenberg(ctx, dims, ls)
+        assert prob.slab == hostcomm.slab(dims[2], rank, world)
+        U, V, Rv = prob.vec(u), prob.vec(v), prob.vec(r)
+        J = prob.jacobian(U, 0.1)
+        out = dict(dot=U.inner(V), Jv=gather_slabs(J(V, 0.2, 0.8).numpy(), rank, world),
+                   F=gather_slabs(prob.residual(U, 0.1).numpy(), rank, world))
+        for zc in (1, 2, 3):
+            ctx.set_option("sh_zchunk", zc)
+            out[f"Jv_zc{zc}"] = gather_slabs(J(V, 0.2, 0.8).numpy(), rank, world)
+        ctx.set_option("sh_zchunk", 0)
+        P = hip.DCTPreconditioner(prob, 1.0)
+        out["Pv"] = gather_slabs(P.ldiv(V).numpy(), rank, world)
+        lsol = hip.GMRESKrylovKit(dim=30, rtol=1e-10, atol=1e-13, maxiter=100, Pl=P)
+        x, ok, it = lsol(J, Rv)
+        out["x"], out["ok"], out["it"] = gather_slabs(x.numpy(), rank, world), ok, it
+        dX, dl, okb, itb = hip.BorderingBLS(lsol, check_precision=False)(J, V, U, 0.3, Rv, 0.7, 0.5, 0.5, dotscale=1.0 / N)
+        out["dX"], out["dl"] = gather_slabs(dX.numpy(), rank, world), dl
+        if rank == 0:
+            c1 = hip.Context(0)
+            p1 = hip.SwiftHohenberg(c1, dims, ls)
+            U1, V1, R1 = p1.vec(u), p1.vec(v), p1.vec(r)
+            J1 = p1.jacobian(U1, 0.1)
+            ref = J1(V1, 0.2, 0.8).numpy()
+            assert np.isclose(out["dot"], U1.inner(V1), rtol=1e-13)
+            assert np.allclose(out["F"], p1.residual(U1, 0.1).numpy(), rtol=1e-14, atol=1e-12), (tag, dims)
+            assert np.allclose(out["Jv"], ref, rtol=1e-14, atol=1e-11), (tag, dims, np.abs(out["Jv"] - ref).max())
+            for zc in (1, 2, 3):
+                assert np.array_equal(out[f"Jv_zc{zc}"], out["Jv"]), (tag, dims, zc)
+            P1 = hip.DCTPreconditioner(p1, 1.0)
+            assert np.allclose(out["Pv"], P1.ldiv(V1).numpy(), rtol=1e-12, atol=1e-14), (tag, dims)
+            l1 = hip.GMRESKrylovKit(dim=30, rtol=1e-10, atol=1e-13, maxiter=100, Pl=P1)
+            x1, ok1, it1 = l1(J1, R1)
+            assert out["ok"] and ok1 and abs(out["it"] - it1) <= 1, (tag, dims, out["it"], it1)
+            assert np.allclose(out["x"], x1.numpy(), rtol=1e-7, atol=1e-9 * np.abs(x1.numpy()).max())
+            dX1, dl1, _, _ = hip.BorderingBLS(l1, check_precision=False)(J1, V1, U1, 0.3, R1, 0.7, 0.5, 0.5, dotscale=1.0 / N)
+            assert np.isclose(out["dl"], dl1, rtol=1e-7)
+            assert np.allclose(out["dX"], dX1.numpy(), rtol=1e-6, atol=1e-8 * np.abs(dX1.numpy()).max())
+            c1.close()
+
+
+def main_gpu_many(rank, world):
+    """world ranks on cuda:0 through the host-staged communicator (ragged and thin slabs)."""
+    from bk_amd import hip
+    ctx = hip.Context(0, hostcomm.comm_tuple())
+    slab_checks(ctx, hip, rank, world, f"hostcomm x{world}")
+    ctx.close()
+    print(f"rank {rank}: gpu distributed checks OK", flush=True)
+
+
+def main_rccl(rank, world):
+    """One rank per GPU over RCCL (needs >= world visible devices): ncclSend / ncclRecv halo exchange on the second stream,
+    ncclAllReduce of the batched dots, the all-to-all transposes of the preconditioner -- against the 1-rank result."""
+    from bk_amd import hip
+    torch.cuda.set_device(rank)
+    idt = [hip.Context.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(idt, src=0)
+    ctx = hip.Context(rank, ("rccl", rank, world, idt[0]))
+    slab_checks(ctx, hip, rank, world, f"rccl x{world}")
+    ctx.close()
+    print(f"rank {rank}: gpu distributed checks OK", flush=True)
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        (main_cpu if mode == "cpu" else main_gpu)(rank, world)
+        dict(cpu=main_cpu, gpu=main_gpu, gpu_many=main_gpu_many, rccl=main_rccl)[mode](rank, world)
     finally:
         dist.destroy_process_group()

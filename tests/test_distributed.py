@@ -40,10 +40,28 @@ def _run(mode, world=2, timeout=600):
         assert "checks OK" in o, o[-2000:]
 
 
-def test_two_rank_decomposition_gloo_cpu():
-    _run("cpu")
+@pytest.mark.parametrize("world", [2, 3])
+def test_decomposition_gloo_cpu(world):
+    _run("cpu", world)
 
 
 @pytest.mark.gpu
 def test_two_ranks_share_one_gpu_host_communicator():
     _run("gpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [3, 4])
+def test_ragged_and_thin_slabs_host_communicator(world):
+    """3 and 4 ranks on one GPU: z extents that do not divide evenly, slabs of 2-3 planes (every z-chunk is a face chunk)."""
+    _run("gpu_many", world)
+
+
+@pytest.mark.gpu
+def test_real_rccl_ranks_when_two_gpus_are_visible():
+    """The RCCL calls themselves (ncclSend / ncclRecv groups, ncclAllReduce) with one rank per GPU.  Skipped on a
+    single-GPU box -- there the same code paths run through the host-staged communicator above."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 visible GPUs")
+    _run("rccl", 2)

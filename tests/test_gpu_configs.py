@@ -138,3 +138,66 @@ def test_c3_cgl2d_1024_jvp_preconditioner_bordered_solve(ctx):
     assert top.norm() <= 1e-6 * R.norm(), (top.norm(), R.norm())
     bot = theta * dzu.inner(dX) / n2 + (1 - theta) * dzp * dl - nn
     assert abs(bot) <= 1e-9
+
+
+def _cgl_full():
+    n = 1024
+    dims, ls_ = (n, n), (np.pi * n / 41, (np.pi / 2) * n / 21)
+    lam = []
+    for n_, l_ in zip(dims, ls_):
+        h = 2 * l_ / n_
+        lam.append(-(4 / h ** 2) * np.sin(np.pi * np.arange(1, n_ + 1) / (2 * (n_ + 1))) ** 2)
+    lap = np.sort((lam[0][:, None] + lam[1][None, :]).ravel())[::-1]          # Dirichlet Laplacian eigenvalues, descending
+    return dims, ls_, lap
+
+
+def test_c3_cgl_1024_shift_invert_eigenvalues_match_closed_form(ctx):
+    """examples/cGL2d.jl:96,100 at full size: ShiftInvert(sigma = 1, nev = 9) (EigArpack(1.0, :LM)) on the trivial state at
+    r = 0.5.  The Jacobian at u = 0 is Lap (+) Lap + [[r, -nu], [nu, r]], so its eigenvalues are r + lam_Lap(i, j) +- i nu in
+    closed form; on this domain (25 x the example's) consecutive ones are 1e-3 apart, 1.118 away from the shift."""
+    hip = _hip()
+    dims, ls_, lap = _cgl_full()
+    prob = hip.CGL2d(ctx, dims, ls_, r=0.5)
+    n2 = 2 * dims[0] * dims[1]
+    P = hip.LaplacePreconditioner(prob, 1.0)
+    ls = hip.GMRESIterativeSolvers(reltol=1e-10, restart=60, maxiter=600, Pl=P)
+    eig = hip.ShiftInvert(1.0, ls, tol=1e-8, maxiter=300, hermitian=False, save_vectors=False)
+    vals, _, ok, nops = eig(prob.jacobian(prob.vec(np.zeros(n2)), 0.5), 9)
+    assert ok and len(vals) == 10 and not np.isnan(vals.real).any()            # 9 -> 10: the cut never splits a conjugate pair
+    exact = np.array([complex(0.5 + l, s) for l in lap[:5] for s in (1.0, -1.0)])
+    # the returned set IS the rightmost five pairs (nothing skipped, nothing spurious), to 1e-8
+    assert max(np.abs(exact - v).min() for v in vals) <= 1e-8
+    assert max(np.abs(vals - e).min() for e in exact) <= 1e-8
+    assert np.all(np.diff(vals.real) <= 1e-12)                                  # sorted by decreasing real part
+
+
+def test_c3_cgl_1024_first_hopf_point_is_detected_and_bracketed(ctx):
+    """Native PALC continuation in r along the trivial branch at full size across the first Hopf point r* = -lam_Lap(1, 1)
+    (closed form): n_unstable goes 0 -> 2 with a complex pair, the special point is classified `hopf`, and the bisection
+    (locate_bifurcation!, src/Bifurcations.jl:159-349; a few steps only, each is a full eigensolve) brackets r*."""
+    hip = _hip()
+    from bk_amd import continuation as Cn
+    dims, ls_, lap = _cgl_full()
+    prob = hip.CGL2d(ctx, dims, ls_, r=0.5)
+    n2 = 2 * dims[0] * dims[1]
+    P = hip.LaplacePreconditioner(prob, 1.0)
+    ls = hip.GMRESIterativeSolvers(reltol=1e-10, restart=60, maxiter=600, Pl=P)
+    eig = hip.ShiftInvert(1.0, ls, tol=1e-8, maxiter=300, hermitian=False, save_vectors=False)
+    rstar = -lap[:2]
+    width = float(rstar[1] - rstar[0])
+    nopt = Cn.NewtonPar(tol=1e-9, max_iterations=20, linsolver=ls, eigsolver=eig)
+    cp = Cn.ContinuationPar(ds=0.5 * width, dsmin=1e-3 * width, dsmax=0.6 * width, p_min=float(rstar[0] - 2 * width),
+                            p_max=float(rstar[1]), max_steps=2, nev=9, newton_options=nopt, n_inversion=2,
+                            max_bisection_steps=3, dsmin_bisection=1e-4 * width)
+    alg = Cn.PALC(tangent="secant", theta=0.5, bls=hip.BorderingBLS(None, check_precision=False))
+    ctx.set_option("eig_thick_start", 1)
+    try:
+        br = Cn.continuation_native(prob, prob.vec(np.zeros(n2)), float(rstar[0] - 0.7 * width), alg, cp, normC=Cn.norminf,
+                                    bisection=True)
+    finally:
+        ctx.set_option("eig_thick_start", 0)
+    assert br.n_unstable[0] == 0 and br.n_unstable[-1] == 2 and br.n_imag[-1] == 2
+    assert len(br.specialpoint) == 1
+    sp = br.specialpoint[0]
+    lo, hi = sp["interval"]
+    assert sp["type"] == "hopf" and lo - 1e-9 <= rstar[0] <= hi + 1e-9 and hi - lo <= 0.6 * width, (sp, rstar)

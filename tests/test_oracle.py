@@ -406,3 +406,21 @@ def test_locate_bifurcation_by_bisection():
     # without bisection (detect_bifurcation = 2) the special points are only bracketed by the continuation steps
     out2 = B.continuation(prob, np.zeros(4), 0.0, ls=bordered.default_ls, bls=bls, eig=eig, cp=cp, detect_bifurcation_level=2)
     assert len(out2["specialpoint"]) == 4 and all(sp["interval"][1] - sp["interval"][0] > 1e-2 for sp in out2["specialpoint"])
+
+
+@pytest.mark.parametrize("n,R", [(512, 8), (512, 2), (256, 8), (64, 4), (32, 8)])
+def test_slab_zsolve_woodbury_equals_the_global_dct_inverse(n, R):
+    """The communication-light distributed z-solve (oracle/slab_zsolve.py: local DCT solves + rank-2-per-face Woodbury
+    correction) equals the exact inverse ((c + D)^2 + s)^-1 over the whole range of c = 1 + lam_x + lam_y of a 512^3 grid
+    at h = 0.196, including the lines with c + lam_z ~ 0, to 1e-11 relative (shift s = 1, the bench's preconditioner)."""
+    from oracle import slab_zsolve as Z
+    a = 1.0 / 0.19634954084936207 ** 2
+    rng = np.random.default_rng(n + R)
+    lam = Z.lam_neumann(512, a)
+    cs = np.concatenate([np.linspace(1.0 - 8.0 * a, 1.0, 60), 1.0 + lam[rng.integers(0, 512, 30)] + lam[rng.integers(0, 512, 30)]])
+    worst = 0.0
+    for c in cs:
+        f = rng.standard_normal(n)
+        x, xe = Z.slab_zsolve(f, c, 1.0, R, a), Z.exact_zsolve(f, c, 1.0, a)
+        worst = max(worst, np.abs(x - xe).max() / np.abs(xe).max())
+    assert worst <= 1e-11, worst
