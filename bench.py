@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=512, help="grid points per axis (BASELINE metric: 512)")
+    ap.add_argument("--size-z", type=int, default=0, help="z extent if different from --size (cost-model runs: the z-slab one of "
+                                                          "8 ranks owns, e.g. --size 512 --size-z 64 --opt dct_slab_emulate=8)")
     ap.add_argument("--shift", type=float, default=1.0, help="preconditioner (L1 + shift I)^-1")
     ap.add_argument("--cpu-sample", type=int, default=3, help="CPU-baseline sample: tiles per axis of the cell (0: skip)")
     ap.add_argument("--no-precond", action="store_true")
@@ -78,10 +80,11 @@ CELL = (64, 32, 32)                                            # points per cell
 CELL_L = (2.0 * math.pi, 2.0 * math.pi / math.sqrt(3.0), math.pi)     # half-widths of the cell
 
 
-def tiles_for(n):
-    if any(n % c for c in CELL):
-        raise SystemExit(f"--size must be a multiple of {CELL}")
-    return tuple(n // c for c in CELL)
+def tiles_for(n, nz=0):
+    dims = (n, n, nz or n)
+    if any(d % c for d, c in zip(dims, CELL)):
+        raise SystemExit(f"--size / --size-z must be multiples of {CELL}")
+    return tuple(d // c for d, c in zip(dims, CELL))
 
 
 def tile_cell(cell_vec, tiles, slab, device):
@@ -272,14 +275,15 @@ def main():
         ctx.set_option(k_, float(v_))
 
     n = args.size
-    tiles = tiles_for(n)
+    nzz = args.size_z or n
+    tiles = tiles_for(n, nzz)
     big_l = tuple(l * t for l, t in zip(CELL_L, tiles))
     ds, theta = -0.001, 0.5
     # ---- setup (untimed)
     t_setup = time.perf_counter()
     ctx_cell = ctx if world == 1 else hip.Context(local)
     cprob, cls_, c0, c1 = cell_branch_points(ctx_cell, hip, args.shift, ds)
-    prob = hip.SwiftHohenberg(ctx, (n, n, n), big_l, l=0.1, nu=1.2)
+    prob = hip.SwiftHohenberg(ctx, (n, n, nzz), big_l, l=0.1, nu=1.2)
     P = None if args.no_precond else hip.DCTPreconditioner(prob, args.shift)
     ls = hip.GMRESKrylovKit(dim=30, rtol=1e-9, atol=1e-12, maxiter=150, Pl=P)       # SH3d.jl:93
     if args.linsolver == "minres":
@@ -425,7 +429,7 @@ def main():
             "config": {"workload": f"SH3d {n}^3 PALC corrector (Palc.jl:237-295 pass), "
                                    f"{'GMRES(30)' if args.linsolver == 'gmres' else 'KrylovLS(:minres)'} rtol 1e-9, "
                                    f"Pl = (L1+shift)^-1 (DCT), BorderingBLS",
-                       "grid": [n, n, n], "unknowns": prob.nglobal, "parallelism": f"z-slabs x{world}",
+                       "grid": [n, n, nzz], "unknowns": prob.nglobal, "parallelism": f"z-slabs x{world}",
                        "itlinear_per_step": last["itlineartot"], "residual_after_step": last["residuals"][-1],
                        "cell": list(CELL), "tiles": list(tiles), "h": [2 * l / c for l, c in zip(CELL_L, CELL)],
                        "precond_shift": args.shift, "state": "z-invariant hexagons (stable), l = 0.1, nu = 1.2",

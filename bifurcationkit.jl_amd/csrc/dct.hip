@@ -47,6 +47,30 @@ struct DctPlan {
     std::vector<int> zcut, ycut;              // slab boundaries per rank (R+1 entries)
     std::vector<size_t> cnt_f, dsp_f, cnt_b, dsp_b;   // forward: send counts (to y-owners) / recv counts (from z-owners)
     double* lam_yloc = nullptr;               // lam[1] + ylo (view)
+    // slab z-solve (dct_slab.hip): local DCT of length nl = nz / R + Woodbury correction over the slab faces
+    bool slab_ok = false;
+    int nl = 0;
+    double az = 0.0;
+    double* twid_loc = nullptr;               // twiddles of the length-nl transform
+    double* lam_loc = nullptr;                // eigenvalues of the slab-local Neumann second difference
+    double* phi_loc = nullptr;                // [2][nl] local DCT-II basis at planes 0, 1
+    double* fsend = nullptr;                  // face data: [R][4][Lr] each
+    double* frecv = nullptr;
+    std::vector<size_t> cnt_s, dsp_s;
+};
+
+struct SlabK;
+int slab_faces_gather(bk_ctx* ctx, const SlabK& P, const double* y, double* sbuf);
+int slab_faces_solve(bk_ctx* ctx, const SlabK& P, const double* rbuf, double* out);
+int slab_faces_correct(bk_ctx* ctx, const SlabK& P, const double* rbuf, double* f);
+struct SlabK {                                // kernel argument of dct_slab.hip (same definition there)
+    int nx, ny, nl, R, rank;
+    size_t L, Lr;
+    double a, shift;
+    const double* lam0;
+    const double* lam1;
+    const double* lam_loc;
+    const double* phi;
 };
 
 struct Cuts {                                 // slab boundaries by value (kernel argument), up to 64 ranks
@@ -298,10 +322,16 @@ void dct_plan_destroy(DctPlan* p) {
     }
     if (p->t1) (void)hipFree(p->t1);
     if (p->t2) (void)hipFree(p->t2);
+    double* extra[] = {p->twid_loc, p->lam_loc, p->phi_loc, p->fsend, p->frecv};
+    for (double* e : extra)
+        if (e) (void)hipFree(e);
     delete p;
 }
 
+static int dct_apply_slab(bk_ctx* ctx, DctPlan* p, const double* v, double* out);
+
 int dct_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out) {
+    if (p->slab_ok) return dct_apply_slab(ctx, p, v, out);      // cost-model emulation (option dct_slab_emulate), timing only
     const int n0 = p->n[0], n1 = p->n[1], n2 = p->n[2];
     const unsigned grid = (unsigned)((p->total + 255) / 256);
     const bool use_fft = ctx->opt("dct_fft", 1.0) != 0.0;
@@ -363,6 +393,8 @@ int dct_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out) {
     return 0;
 }
 
+static int slab_tables_create(bk_ctx* ctx, DctPlan* p, int nl, bool even, double az);
+
 int dct_plan_create_dist(bk_ctx* ctx, const int n[3], const double ainv[3], double shift, int zlo, int zhi, DctPlan** out) {
     if (ctx->nranks > 64) return set_error(ctx, "distributed DCT: at most 64 ranks");
     DctPlan* p = nullptr;
@@ -414,7 +446,93 @@ int dct_plan_create_dist(bk_ctx* ctx, const int n[3], const double ainv[3], doub
         }
         (void)hipMemcpy(p->kmap, km.data(), sizeof(unsigned) * km.size(), hipMemcpyHostToDevice);
     }
+    // slab z-solve: equal power-of-two slabs, lines divisible among the ranks, a positive shift (B_r SPD, well conditioned)
+    BK_TRY(slab_tables_create(ctx, p, n[2] / R, n[2] % R == 0, ainv[2]));
     *out = p;
+    return 0;
+}
+
+static int slab_tables_create(bk_ctx* ctx, DctPlan* p, int nl, bool even, double az) {
+    {
+        const int R = p->R;
+        const size_t nx = p->n[0];
+        const int* n = p->n;
+        const double shift = p->shift;
+        const double ainv[3] = {0.0, 0.0, az};
+        const size_t L = nx * (size_t)n[1];
+        if (even && nl >= 8 && dct_axis_fft_supported(nl) && L % R == 0 && shift > 0.0 && R - 1 <= 15) {
+            std::vector<double> tw(2 * (size_t)(nl / 2) + 2 * (size_t)nl), lam(nl), phi(2 * (size_t)nl);
+            for (int j = 0; j < nl / 2; ++j) { tw[2 * j] = std::cos(2.0 * M_PI * j / nl); tw[2 * j + 1] = -std::sin(2.0 * M_PI * j / nl); }
+            for (int k = 0; k < nl; ++k) {
+                tw[nl + 2 * k] = std::cos(M_PI * k / (2.0 * nl));
+                tw[nl + 2 * k + 1] = -std::sin(M_PI * k / (2.0 * nl));
+                const double sn = std::sin(M_PI * k / (2.0 * nl));
+                lam[k] = -4.0 * ainv[2] * sn * sn;
+                const double sk = k == 0 ? std::sqrt(1.0 / nl) : std::sqrt(2.0 / nl);
+                phi[k] = sk * std::cos(M_PI * (double)k / (2.0 * nl));                 // plane 0
+                phi[nl + k] = sk * std::cos(M_PI * 3.0 * (double)k / (2.0 * nl));      // plane 1
+            }
+            const size_t fb = 4 * L;
+            if (hipMalloc(&p->twid_loc, sizeof(double) * tw.size()) != hipSuccess ||
+                hipMalloc(&p->lam_loc, sizeof(double) * nl) != hipSuccess ||
+                hipMalloc(&p->phi_loc, sizeof(double) * 2 * nl) != hipSuccess ||
+                hipMalloc(&p->fsend, sizeof(double) * fb) != hipSuccess ||
+                hipMalloc(&p->frecv, sizeof(double) * fb) != hipSuccess) {
+                dct_plan_destroy(p);
+                return set_error(ctx, "distributed DCT: slab tables allocation failed");
+            }
+            (void)hipMemcpy(p->twid_loc, tw.data(), sizeof(double) * tw.size(), hipMemcpyHostToDevice);
+            (void)hipMemcpy(p->lam_loc, lam.data(), sizeof(double) * nl, hipMemcpyHostToDevice);
+            (void)hipMemcpy(p->phi_loc, phi.data(), sizeof(double) * 2 * nl, hipMemcpyHostToDevice);
+            p->nl = nl;
+            p->az = ainv[2];
+            p->cnt_s.assign(R, 4 * (L / R));
+            p->dsp_s.resize(R);
+            for (int r = 0; r < R; ++r) p->dsp_s[r] = (size_t)r * 4 * (L / R);
+            p->slab_ok = true;
+        }
+    }
+    return 0;
+}
+
+// Slab path of the distributed apply (dct_slab.hip): x, y passes on the z-slab; B^-1 = the fused z pass of length nl on the
+// slab; face data to the line owners, the capacitance solves, the corrections back; B^-1 again on the corrected right-hand
+// side; inverse y, x.  Two small all-to-alls (4 doubles per line each way) instead of two transposes of the array.
+static int dct_apply_slab(bk_ctx* ctx, DctPlan* p, const double* v, double* out) {
+    const int nx = p->n[0], ny = p->n[1], nl = p->nl;
+    const double n3 = (double)nx * ny * nl;
+    auto pass = [&](int axis, int inverse, const double* tw, const double* in, double* o, int fuse, const double* l2) -> int {
+        ProfScope ps(ctx, "dct_pass", 16.0 * n3);
+        return dct_axis_fft(ctx, nx, ny, nl, axis, inverse, tw, in, o, p->lam[0], p->lam[1], l2, p->shift, fuse, nullptr);
+    };
+    SlabK K;
+    K.nx = nx; K.ny = ny; K.nl = nl; K.R = p->R; K.rank = p->rank;
+    K.L = (size_t)nx * ny; K.Lr = K.L / p->R;
+    K.a = p->az; K.shift = p->shift;
+    K.lam0 = p->lam[0]; K.lam1 = p->lam[1]; K.lam_loc = p->lam_loc; K.phi = p->phi_loc;
+    double *a = p->t1, *b = p->t2;
+    BK_TRY(pass(0, 0, p->twid[0], v, a, 0, nullptr));
+    BK_TRY(pass(1, 0, p->twid[1], a, b, 0, nullptr));               // b = f (z-solve right-hand side, spectral in x, y)
+    BK_TRY(pass(2, 0, p->twid_loc, b, a, 2, p->lam_loc));          // a = B^-1 f
+    {
+        ProfScope ps(ctx, "blas1", 8.0 * 8.0 * K.L);
+        BK_TRY(slab_faces_gather(ctx, K, a, p->fsend));
+    }
+    { ProfScope ps(ctx, "alltoall", 8.0 * 4.0 * K.L);
+    BK_TRY(comm_alltoallv(ctx, p->fsend, p->cnt_s.data(), p->dsp_s.data(), p->frecv, p->cnt_s.data(), p->dsp_s.data())); }
+    {
+        ProfScope ps(ctx, "blas1", 8.0 * 8.0 * K.L);
+        BK_TRY(slab_faces_solve(ctx, K, p->frecv, p->fsend));
+    }
+    { ProfScope ps(ctx, "alltoall", 8.0 * 4.0 * K.L);
+    BK_TRY(comm_alltoallv(ctx, p->fsend, p->cnt_s.data(), p->dsp_s.data(), p->frecv, p->cnt_s.data(), p->dsp_s.data())); }
+    {
+        ProfScope ps(ctx, "blas1", 8.0 * 12.0 * K.L);
+        BK_TRY(slab_faces_correct(ctx, K, p->frecv, b));
+    }
+    BK_TRY(pass(2, 0, p->twid_loc, b, a, 2, p->lam_loc));          // a = B^-1 (f - U nu) = M^-1 f
+    BK_TRY(pass(1, 1, p->twid[1], a, b, 0, nullptr));
+    BK_TRY(pass(0, 1, p->twid[0], b, out, 0, nullptr));
     return 0;
 }
 
@@ -424,6 +542,8 @@ int dct_plan_create_dist(bk_ctx* ctx, const int n[3], const double ainv[3], doub
 // uniform y split and the fused y kernel the forward y pass writes the block layout itself and the inverse y pass reads
 // it (DctSplit), so no pack / unpack kernel runs at all; otherwise slab_blocks_kernel packs / unpacks.
 static int dct_apply_dist(bk_ctx* ctx, DctPlan* p, const double* v, double* out) {
+    if (p->slab_ok && ctx->opt("dct_fft", 1.0) != 0.0 && p->twid[0] && p->twid[1] && ctx->opt("dct_dist_slab", 1.0) != 0.0)
+        return dct_apply_slab(ctx, p, v, out);
     const int nx = p->n[0], ny = p->n[1], nz = p->n[2];
     const int nzl = p->zhi - p->zlo, nyl = p->yhi - p->ylo;
     const size_t loc_z = (size_t)nx * ny * nzl, loc_y = (size_t)nx * nyl * nz;
@@ -485,6 +605,8 @@ static int dct_apply_dist(bk_ctx* ctx, DctPlan* p, const double* v, double* out)
     return 0;
 }
 
+int dct_slab_emulate_tables(bk_ctx* ctx, DctPlan* p, double az) { return slab_tables_create(ctx, p, p->n[2], true, az); }
+
 namespace {
 struct ShDctPrecond : bk_precond {
     DctPlan* plan = nullptr;
@@ -513,6 +635,14 @@ int bk_precond_sh_create(bk_problem* prob, double shift, bk_precond** out) {
                 ? dct_plan_create_dist(ctx, prob->desc.n, prob->ainv, shift, prob->lo, prob->hi, &P->plan)
                 : dct_plan_create(ctx, prob->desc.ndim, prob->desc.n, prob->ainv, shift, &P->plan);
     if (s != 0) { delete P; return s; }
+    const int emu = (int)ctx->opt("dct_slab_emulate", 0.0);
+    if (ctx->nranks == 1 && emu > 1 && prob->desc.ndim == 3) {
+        // cost-model runs (bench.py --size-z): this single-rank grid plays the z-slab of rank 1 of `emu`; the local kernels of
+        // the slab z-solve run exactly as there, the two face all-to-alls degenerate to local copies.  The RESULT is not the
+        // preconditioner of this grid -- timing only.
+        P->plan->R = emu; P->plan->rank = 1;
+        if ((s = dct_slab_emulate_tables(ctx, P->plan, prob->ainv[2])) != 0) { delete P; return s; }
+    }
     *out = P;
     return 0;
 }

@@ -410,13 +410,23 @@ class _GMRES:
 
 @dataclass
 class GMRESKrylovKit(_GMRES):
-    """Fields of src/LinearSolver.jl:223-250 (defaults = KrylovDefaults, :225-234)."""
+    """Fields of src/LinearSolver.jl:223-250 (defaults = KrylovDefaults, :225-234).  ``issymmetric`` / ``ishermitian`` /
+    ``isposdef`` are the switches the reference forwards to ``KrylovKit.linsolve`` (:256-267): KrylovKit keeps GMRES unless
+    the map is declared symmetric AND positive definite, where it switches to CG -- here that combination selects the
+    library's preconditioned CG (BK_KRYLOV_CG, the ``KrylovLS(:cg)`` core, M = Pl), same stopping rule
+    max(atol, rtol*||b||) up to the M-norm; the symmetric-indefinite case stays GMRES exactly as in KrylovKit."""
     dim: int = 30
     atol: float = 1e-12
     rtol: float = 1e-12
     maxiter: int = 100
     Pl: DCTPreconditioner | None = None
-    flavor = L.BK_GMRES_KRYLOVKIT
+    issymmetric: bool = False
+    ishermitian: bool = False
+    isposdef: bool = False
+
+    @property
+    def flavor(self):
+        return L.BK_KRYLOV_CG if (self.isposdef and (self.issymmetric or self.ishermitian)) else L.BK_GMRES_KRYLOVKIT
 
 
 @dataclass
@@ -765,6 +775,78 @@ class EigKrylovKit:
             vecs = [(HipVec(ctx, vr[i * ld:i * ld + n], J.prob.nglobal),
                      HipVec(ctx, vi[i * ld:i * ld + n], J.prob.nglobal) if vi is not None else None) for i in range(m)]
         return vals, vecs, nconv.value >= nev, nops.value
+
+    @staticmethod
+    def geteigenvector(vecs, n):
+        return vecs[n]
+
+
+@dataclass
+class EigArpack:
+    """EigArpack(sigma = nothing, which = :LR; tol, maxiter, ncv, v0) (src/EigSolver.jl:67-102): the same
+    ``(eig)(J, nev) -> (vals, vecs, true, 1)`` contract on the library's Krylov-Schur cores.  With ``sigma`` ARPACK
+    factorises ``J - sigma I`` (matrix only); the matrix-free replacement solves with the iterative ``ls`` (required then),
+    ``which`` applying to 1/(lambda - sigma) as in ARPACK.  Without ``sigma`` only ``which = "LR"`` is offered.  ARPACK
+    defaults: ``ncv = max(20, 2 nev + 1)``, ``maxiter = 300``, ``tol = 0`` (-> machine precision; clamped to what the inner
+    solves can deliver, 10 x their rtol)."""
+    sigma: float | None = None
+    which: str = "LR"
+    ls: _GMRES | None = None
+    tol: float = 0.0
+    maxiter: int = 300
+    ncv: int | None = None
+    v0: object = None
+    hermitian: bool = False
+    save_vectors: bool = True
+
+    def __call__(self, J: HipJacobian, nev: int, **kwargs):
+        ncv = self.ncv if self.ncv is not None else max(20, 2 * nev + 1)
+        if self.sigma is None:
+            if self.which != "LR":
+                raise NotImplementedError("EigArpack (HIP): without sigma only which = :LR is available")
+            core = EigKrylovKit(tol=max(self.tol, 1e-10), maxiter=self.maxiter, krylovdim=ncv, hermitian=self.hermitian,
+                                save_vectors=self.save_vectors, x0=self.v0)
+        else:
+            if self.ls is None:
+                raise TypeError("EigArpack (HIP): the matrix-free shift-invert needs a linear solver `ls` for J - sigma I")
+            if self.which != "LM":
+                raise NotImplementedError("EigArpack (HIP): with sigma use which = :LM (eigenvalues closest to sigma)")
+            core = ShiftInvert(self.sigma, self.ls, tol=max(self.tol, 10.0 * self.ls.rtol), maxiter=self.maxiter,
+                               krylovdim=ncv, hermitian=self.hermitian, save_vectors=self.save_vectors, x0=self.v0)
+        vals, vecs, cv, it = core(J, nev)
+        return vals, vecs, True, 1                         # __sort_arpack returns (.., true, 1), src/EigSolver.jl:98-102
+
+    @staticmethod
+    def geteigenvector(vecs, n):
+        return vecs[n]
+
+
+@dataclass
+class EigArnoldiMethod:
+    """EigArnoldiMethod(; sigma = nothing, which = LR(), x0, tol, mindim, maxdim, restarts) (src/EigSolver.jl:182-235):
+    implicitly restarted Arnoldi (Krylov-Schur) for the rightmost eigenvalues of the operator; like the reference, the
+    shift-invert strategy is not available for maps (:218-220 warns and ignores ``sigma``).  ArnoldiMethod defaults:
+    ``tol = sqrt(eps)``, ``mindim = max(10, nev)``, ``maxdim = max(20, 2 nev)``, ``restarts = 200``."""
+    sigma: float | None = None
+    which: str = "LR"
+    x0: object = None
+    tol: float = 1.4901161193847656e-08
+    maxdim: int | None = None
+    restarts: int = 200
+    hermitian: bool = False
+    save_vectors: bool = True
+
+    def __call__(self, J: HipJacobian, nev: int, **kwargs):
+        if self.sigma is not None:
+            import warnings
+            warnings.warn("Shift-Invert strategy not implemented for maps")      # the reference's own message
+        if self.which != "LR":
+            raise NotImplementedError("EigArnoldiMethod (HIP): which = LR() only")
+        maxdim = self.maxdim if self.maxdim is not None else max(20, 2 * nev)
+        core = EigKrylovKit(tol=self.tol, maxiter=self.restarts, krylovdim=maxdim, hermitian=self.hermitian,
+                            save_vectors=self.save_vectors, x0=self.x0)
+        vals, vecs, cv, it = core(J, nev)
+        return vals, vecs, cv, 1
 
     @staticmethod
     def geteigenvector(vecs, n):

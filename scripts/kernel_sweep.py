@@ -16,6 +16,36 @@ from bk_amd import hip  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 what = sys.argv[2].split(",") if len(sys.argv) > 2 else ["jvp", "krylov", "blas", "precond"]
 ctx = hip.Context(0)
+
+if "slabemu" in what:
+    # local cost of one preconditioner application on the z-slab one of R ranks owns (512 x 512 x 512/R), transposed z pass
+    # replaced by the slab z-solve (two local round trips + the face kernels; the two small all-to-alls are local copies here)
+    for R in (8, 4, 2):
+        nzl = n // R
+        N_ = n * n * nzl
+        g_ = torch.Generator(device="cuda").manual_seed(0)
+        v_ = hip.HipVec(ctx, torch.rand(N_, dtype=torch.float64, device="cuda", generator=g_))
+        o_ = v_.similar()
+        for emu in (0, R):
+            ctx.set_option("dct_slab_emulate", emu)
+            pr = hip.SwiftHohenberg(ctx, (n, n, nzl), (math.pi * n / 32, math.pi * n / 32, math.pi * nzl / 32))
+            P_ = hip.DCTPreconditioner(pr, 1.0)
+            f_ = lambda: ctx.check(ctx.lib.bk_precond_apply(P_.h, C.c_void_p(v_.t.data_ptr()), C.c_void_p(o_.t.data_ptr())))
+            for _ in range(2):
+                f_()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                f_()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 10
+            print(json.dumps(dict(kernel="precond_apply_on_slab", n=n, R=R, nzl=nzl, slab_zsolve=bool(emu), ms=dt * 1e3,
+                                  passes=6 if emu else 5, gbs=16.0 * N_ * (6 if emu else 5) / dt / 1e9)), flush=True)
+            del P_, pr
+        ctx.set_option("dct_slab_emulate", 0)
+        del v_, o_
+    sys.exit(0)
+
 import os
 for kv in os.environ.get("BK_OPTS", "").split(","):
     if "=" in kv:

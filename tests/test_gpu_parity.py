@@ -1087,6 +1087,39 @@ def test_cgl_hopf_detection_along_trivial_branch(ctx):
         assert np.array_equal(np.isnan(a_.real), np.isnan(b_.real)) and np.allclose(a_[ok_], b_[ok_], rtol=0, atol=1e-8)
 
 
+def test_eigarpack_and_eigarnoldimethod_surfaces(ctx):
+    """EigArpack(sigma, :LM) / EigArpack(which = :LR) / EigArnoldiMethod (src/EigSolver.jl:67-102, 182-235): same contract,
+    same eigenvalues as the dense spectrum; and GMRESKrylovKit's isposdef switch (src/LinearSolver.jl:256-267)."""
+    hip = _hip()
+    dims, ls_ = (12, 10), (3.0, 2.5)
+    sh, prob, rng, u = _sh_setup(ctx, dims, ls_)
+    Jm = sh.J(u, 0.1, 1.2).toarray()
+    dense = np.sort(np.linalg.eigvalsh(Jm))[::-1]
+    J = prob.jacobian(prob.vec(u), 0.1)
+    ls = hip.GMRESKrylovKit(dim=40, rtol=1e-11, atol=1e-13, maxiter=100, Pl=hip.DCTPreconditioner(prob, 1.0))
+    vals, vecs, ok, it = hip.EigArpack(0.3, "LM", ls=ls, tol=1e-9, hermitian=True)(J, 5)
+    near = dense[np.argsort(np.abs(dense - 0.3))][:5]
+    assert ok is True and it == 1 and np.allclose(np.sort(vals.real), np.sort(near), atol=1e-7)
+    assert np.all(np.diff(vals.real) <= 1e-12) and len(vecs) >= 5
+    v0 = hip.EigArpack.geteigenvector(vecs, 0)[0]
+    lam0 = vals[0].real
+    assert J(v0).add_(v0, -lam0).norm() <= 1e-6 * v0.norm()                       # an eigenpair of J
+    vals2, _, ok2, _ = hip.EigArpack(None, "LR", tol=1e-9, maxiter=300, ncv=40, hermitian=True, save_vectors=False)(J, 3)
+    assert np.allclose(vals2.real, dense[:3], atol=1e-6)
+    vals3, _, ok3, it3 = hip.EigArnoldiMethod(tol=1e-9, maxdim=40, hermitian=True, save_vectors=False)(J, 3)
+    assert ok3 and it3 == 1 and np.allclose(vals3.real, dense[:3], atol=1e-6)
+    with pytest.raises(TypeError):
+        hip.EigArpack(0.3, "LM")(J, 3)
+    # isposdef + issymmetric -> CG: -J + 40 I is SPD here
+    rhs = rng.standard_normal(sh.N)
+    lcg = hip.GMRESKrylovKit(rtol=1e-10, atol=1e-13, maxiter=400, issymmetric=True, isposdef=True)
+    x, okc, itc = lcg(J, prob.vec(rhs), 40.0, -1.0)
+    ref = np.linalg.solve(40.0 * np.eye(sh.N) - Jm, rhs)
+    assert okc and np.abs(x.numpy() - ref).max() <= 1e-7 * np.abs(ref).max()
+    lg = hip.GMRESKrylovKit(rtol=1e-10, atol=1e-13, maxiter=400, dim=60, issymmetric=True)       # indefinite: stays GMRES
+    assert lg.flavor == 0 and lcg.flavor == 4
+
+
 # --------------------------------------------------------------------------------------------- bisection
 def test_native_bisection_locates_hopf_points(ctx):
     """bk_cont_locate_bifurcation (locate_bifurcation!, src/Bifurcations.jl:159-349) along the trivial branch of cGL2d
