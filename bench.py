@@ -404,17 +404,27 @@ def main():
     roofline = None
     if dom:
         k = kernels[dom]
+        # PMC traffic comes from a separate rocprofv3 pass (scripts/gpu_profile.sh -> profiles/rN_pmc_hbm_traffic.json); it is
+        # only reported when that pass was taken on EXACTLY the kernel sources running now (fingerprint), else null
         traffic, tsrc = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")
-        pmc_name = {"dct_pass": "dct_pass (all dct_f* kernels)", "jvp": "sh_stream_kernel<true>", "blas1": "axpbyz_kernel<2>"}.get(dom)
-        if world == 1 and n == 512 and os.path.exists(pmc_file):
+        import glob
+        import hashlib
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+        pmc_file = cands[-1] if cands else None
+        pmc_name = {"dct_pass": "dct_pass (all dct_f* kernels)", "jvp": "sh_stream_kernel<true, true>", "blas1": "axpbyz_kernel<2, true>"}.get(dom)
+        if world == 1 and n == 512 and nzz == 512 and pmc_file:
             pmc = json.load(open(pmc_file))
-            if pmc_name in pmc:
+            hsh = hashlib.sha256()
+            cdir = os.path.join(ROOT, "bifurcationkit.jl_amd", "csrc")
+            for f_ in sorted(os.listdir(cdir)):
+                if f_.endswith((".hip", ".h")):
+                    hsh.update(open(os.path.join(cdir, f_), "rb").read())
+            rel = os.path.relpath(pmc_file, ROOT)
+            if pmc.get("_meta", {}).get("sources_sha") != hsh.hexdigest()[:16]:
+                tsrc = f"{rel} is stale (taken on other kernel sources): re-run scripts/gpu_profile.sh"
+            elif pmc_name in pmc:
                 traffic = pmc[pmc_name]["read_bytes"] + pmc[pmc_name]["write_bytes"]
-                tsrc = "profiles/r1_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 on gfx950)"
-            elif dom in ("multidot", "multiaxpy"):
-                traffic = k["alg_gb_per_call"] * 1e9          # measured == algorithmic for these kernels
-                tsrc = "profiles/r1_pmc_hbm_traffic.txt: FETCH/WRITE == algorithmic bytes for every multidot/multiaxpy launch"
+                tsrc = f"{rel} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 on gfx950; same kernel sources)"
         roofline = dict(kernel=dom, bound="hbm", achieved=k["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=k["gbs"] / HBM_PEAK_GBS, traffic=traffic, traffic_source=tsrc, avg_ms=k["avg_ms"],
                         calls=k["calls"], alg_bytes_per_launch=k["alg_gb_per_call"] * 1e9)

@@ -156,6 +156,18 @@ function residual(prob::HipProblem, u::HipVec, par)
     out
 end
 
+# (F(u, p + eps) - F(u, p)) / eps for the parameter number `ipar` (0-based kernel order), evaluated without the ~1e-8 white
+# rounding noise of the two-residual quotient (every parameter multiplies a pointwise term; bk_residual_dparam).  The
+# reference's newton_palc forms the quotient itself from two `residual` calls (src/continuation/Palc.jl:239-240); a problem
+# can hand this out through a custom `BK.residual` method or use the one-call native corrector.
+function residual_dparam(prob::HipProblem, u::HipVec, par, ipar::Integer; eps = sqrt(Base.eps(Float64)))
+    out = similar(u)
+    pv = Cdouble[Float64(x) for x in Tuple(par)][1:prob.nparams]
+    check(prob.ctx, ccall((:bk_residual_dparam, libbkhip[]), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cdouble, Ptr{Cdouble}),
+                          prob.h, u.p, pv, length(pv), ipar, eps, out.p), "bk_residual_dparam")
+    out
+end
+
 mutable struct HipJacobian
     prob::HipProblem
     h::Ptr{Cvoid}
@@ -377,6 +389,7 @@ Base.@kwdef struct HipShiftInvert <: AbstractEigenSolver
     maxiter::Int = 20
     hermitian::Bool = false
     seed::UInt64 = 1234
+    x₀::Union{Nothing, HipVec} = nothing      # start vector (EigKrylovKit.x₀, src/EigSolver.jl:143); nothing -> rand(N), SH3d.jl:109
 end
 BK.geteigenvector(::HipShiftInvert, vecs, n::Union{Int, AbstractVector{Int64}}) = vecs[n]     # like SH3dEig, SH3d.jl:101
 
@@ -389,6 +402,7 @@ function (e::HipShiftInvert)(J::HipJacobian, nev::Int; kwargs...)
     buf = HipVec(ctx, ld * (nev + 1))
     nvals, nconv, nops = Ref{Cint}(0), Ref{Cint}(0), Ref{Cint}(0)
     eo = EigOpts(e.σ, kd, e.maxiter, e.tol, e.hermitian, e.seed)
+    isnothing(e.x₀) || check(ctx, ccall((:bk_eig_set_start_vector, libbkhip[]), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), ctx.h, e.x₀.p), "bk_eig_set_start_vector")
     check(ctx, ccall((:bk_eig_shiftinvert, libbkhip[]), Cint,
         (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ref{EigOpts}, Ref{GmresOpts}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
          Csize_t, Ref{Cint}, Ref{Cint}, Ref{Cint}),

@@ -3,12 +3,26 @@ profiles/<tag>_pmc_hbm_traffic.{txt,json}: measured HBM bytes per launch of ever
 Usage: python scripts/pmc_summary.py gpurun_out/pmc_fetch_<tag> gpurun_out/pmc_write_<tag> profiles/<tag>"""
 import collections
 import glob
+import hashlib
 import json
+import os
 import sqlite3
 import statistics
 import sys
 
 fetch_dir, write_dir, out_prefix = sys.argv[1:4]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def sources_sha():
+    """Fingerprint of the kernel sources the counters belong to (bench.py refuses a traffic file whose fingerprint differs
+    from the sources it runs: a PMC pass must be regenerated whenever a kernel changes)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "bifurcationkit.jl_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def clean(k):
@@ -46,11 +60,12 @@ for k in sorted(med):
     lines.append(f"{k[:40]:40s} {f_[0]:4d} {f_[1]:15.1f} {2 * f_[1] / 1048576:13.3f} {w_[1]:15.1f} {w_[1] / 1048576:10.3f}")
     out[k] = dict(n=f_[0], read_bytes=2 * f_[1] * 1024, write_bytes=w_[1] * 1024, read_bytes_min=2 * f_[2] * 1024,
                   read_bytes_max=2 * f_[3] * 1024)
-lines += ["", "# sh_stream_kernel<true>: the JVP launches read ~2.5 GiB against 2 GiB algorithmic (v + u): +25 % = the 2-cell halo of",
-          "#   the 64x16 tile and the z-chunk priming planes, which miss L2; writes 1.00 GiB; total 1.17x algorithmic.",
-          "# multidot<KB> / multiaxpy<KB>: the median launch has k+1 = read_GiB vectors; traffic == algorithmic bytes.",
-          "# axpbyz, dct_fused_kernel<NT, MODE, AX0> / dct_fft_kernel, copyBuffer: traffic == algorithmic bytes (1 GiB read,",
-          "#   1 GiB written; MODE 2 = forward + symbol + inverse of the last axis in one pass)."]
+lines += ["", "# multidot<KB> / multiaxpy<KB>: the median launch has k+1 (k+2) = read_GiB vectors; compare with the algorithmic bytes.",
+          "# dct_fused_kernel<NT, MODE, AX0>: algorithmic 1 GiB read + 1 GiB written per pass (MODE 2 = forward + symbol +",
+          "#   inverse of the last axis in one pass).  sh_stream_kernel<true, VL>: algorithmic 2 GiB read (v, u) + 1 GiB written."]
+out["_meta"] = dict(sources_sha=sources_sha(), command="rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py "
+                    "--steps 1 --warmup 0 --cpu-sample 0 --no-steady")
+lines.append(f"# kernel sources fingerprint (bifurcationkit.jl_amd/csrc/*.hip, *.h): {out['_meta']['sources_sha']}")
 open(out_prefix + "_pmc_hbm_traffic.txt", "w").write("\n".join(lines) + "\n")
 json.dump(out, open(out_prefix + "_pmc_hbm_traffic.json", "w"), indent=1)
 print("\n".join(lines))

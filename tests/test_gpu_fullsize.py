@@ -117,8 +117,15 @@ def test_fullsize_tiled_corrector_matches_cpu_oracle_cell(ctx, big):
                                 max_iterations=15, p_min=-0.1, p_max=0.15, norm_inf=True)
     assert sg["converged"] and sg["itnewton"] == so["itnewton"]
     r0 = so["residuals"][0]
-    # same predictor => same residual up to the rounding of one stencil evaluation (eps * |L1| * |u| ~ 1e-12)
-    assert abs(sg["residuals"][0] - r0) <= 1e-10 * (1.0 + r0), (sg["residuals"], so["residuals"])
+    # same predictor => same residual up to the rounding of ONE stencil evaluation.  The predictor residual is O(ds^2) ~
+    # 5.6e-6 while every evaluation of F carries the absolute rounding floor ~ eps |L1|_inf |u|_inf of a cancelling 25-term
+    # sum, so the honest statement is an ABSOLUTE bound (measured difference: 1.1e-13, i.e. 2e-8 of r0); "1e-10 relative"
+    # (BASELINE.json) is asserted where the residual is O(1..10): tests/test_gpu_parity.py::test_newton_matches_oracle
+    h = [2.0 * l / c for l, c in zip(bench.CELL_L, bench.CELL)]
+    l1_inf = (1.0 + 4.0 / h[0] ** 2 + 4.0 / h[1] ** 2 + 4.0 / h[2] ** 2) ** 2          # |I + Lap|_inf^2 >= |L1|_inf
+    floor = 4 * np.finfo(float).eps * l1_inf * float(np.abs(c0["u"]).max())             # ~1e-10 absolute
+    assert floor < 1e-9                                                                  # well below the Newton tolerance
+    assert abs(sg["residuals"][0] - r0) <= floor, (sg["residuals"], so["residuals"], floor)
     assert abs(sg["u"].p - so["p"]) <= 1e-9
     # a stable state: the big GMRES needs about as many operator applications as the one-cell run
     assert sg["itlineartot"] <= 2 * so["itlineartot"] + 4, (sg["itlineartot"], so["itlineartot"])
