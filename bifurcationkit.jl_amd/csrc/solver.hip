@@ -164,6 +164,48 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     BK_TRY(ws.get(B.ld, &w));
     BK_TRY(ws.get(B.ld, &r));
 
+    // Device-resident Arnoldi chunks (option gmres_chunk; default: 4 steps for vectors that live in the caches, 1 = the
+    // host-driven step for HBM-sized vectors): `chunk` steps are enqueued back to back -- operator, V'w, coefficients,
+    // V_k = (w - V h)/beta all in the stream, coefficients never leaving the device -- and the host picks the Hessenberg
+    // columns up after ONE synchronisation, replaying its Givens / convergence logic on them.  Steps past convergence are
+    // discarded (they cost launch-bound microseconds at these sizes); a step whose classical Gram-Schmidt pass needs the
+    // DGKS second pass (or broke down) is flagged by the device and repeated on the host path.  Counters (numops / iters)
+    // count consumed steps only, so they equal the host-driven run.
+    int chunk = (int)ctx->opt("gmres_chunk", n <= ((size_t)1 << 22) ? 4.0 : 1.0);
+    if (nt != 0 || (ctx->comm == COMM_HOST && ctx->nranks > 1) || chunk < 2) chunk = 1;
+    double *d_rec = nullptr, *d_coef = nullptr;
+    std::vector<double> h_rec;
+    int q_first = 0, q_count = 0;              // columns q_first .. q_first + q_count - 1 of this cycle wait in h_rec
+    if (chunk > 1) {
+        BK_TRY(ws.get((size_t)chunk * (kMaxBasis + 2), &d_rec));
+        BK_TRY(ws.get((size_t)kMaxBasis + 2, &d_coef));
+        h_rec.resize((size_t)chunk * (kMaxBasis + 2));
+    }
+    // next Hessenberg column (Arnoldi step from V[j]): from the queue of device-computed columns, else computed now
+    auto next_column = [&](int j, double* hcol, double* hnext_out) -> int {
+        if (chunk > 1) {
+            if (!(q_count > 0 && j >= q_first && j < q_first + q_count)) {
+                const int steps = std::min(chunk, m - j);
+                for (int s2 = 0; s2 < steps; ++s2) {
+                    BK_TRY(A->apply(B.vec(j + s2), nullptr, op_a0, op_a1, w, nullptr));
+                    BK_TRY(v_arnoldi_step_dev(ctx, n, B.V, B.ld, j + s2 + 1, w, eta, d_rec + (size_t)s2 * (kMaxBasis + 2), d_coef));
+                }
+                BK_HIP(ctx, hipMemcpyAsync(h_rec.data(), d_rec, sizeof(double) * (size_t)steps * (kMaxBasis + 2),
+                                           hipMemcpyDeviceToHost, ctx->stream));
+                BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                q_first = j; q_count = steps;
+            }
+            const double* rec = h_rec.data() + (size_t)(j - q_first) * (kMaxBasis + 2);
+            if (rec[kMaxBasis + 1] == 0.0) {
+                for (int i = 0; i <= j; ++i) hcol[i] = rec[i];
+                *hnext_out = rec[kMaxBasis];
+                return 0;
+            }
+            q_count = j - q_first;             // flagged: this and the later speculative steps are void; redo on the host path
+        }
+        return arnoldi_step(ctx, A, B, j, w, hcol, hnext_out, op_a0, op_a1, eta);
+    };
+
     bool x_zero = true;                        // x0 = 0 is never materialised: the first update writes x = V y
     double xtail[BK_MAX_BORDER] = {0.0};
     double bnorm = 0.0;
@@ -197,7 +239,8 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
         BK_TRY(v_axpbyz(ctx, n, 1.0 / beta, rsrc, 0.0, nullptr, B.vec(0)));
         rsrc = r;
         for (int q = 0; q < nt; ++q) B.tail(0)[q] = rt[q] / beta;
-        BK_TRY(arnoldi_step(ctx, A, B, 0, w, h.data(), &hnext, op_a0, op_a1, eta));
+        q_count = 0;                           // a new cycle: nothing speculative carries over
+        BK_TRY(next_column(0, h.data(), &hnext));
         numops += 1;
         return 0;
     };
@@ -232,7 +275,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
             const bool conv = kk ? !(beta > tol) : (beta <= tol);
             if (conv || k >= m || hnext == 0.0) break;
             if (!kk && iters >= o.maxiter) { stop = true; break; }
-            BK_TRY(arnoldi_step(ctx, A, B, k, w, h.data(), &hnext, op_a0, op_a1, eta));
+            BK_TRY(next_column(k, h.data(), &hnext));
             numops += 1;
         }
         // solve R yk = y[0..k) and update x += V[0..k) yk

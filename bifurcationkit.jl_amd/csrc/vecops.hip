@@ -362,6 +362,87 @@ __global__ void __launch_bounds__(kThreads) multiaxpy_kernel(size_t n, const dou
     }
 }
 
+// second reduction stage into a DEVICE buffer: the same fixed summation order as reduce_stage2_kernel (context.hip), so the
+// device-resident and the host-driven Arnoldi steps produce bitwise identical projections
+__global__ void __launch_bounds__(256) reduce_stage2_dev(const double* __restrict__ partials, int nblocks, int nvals,
+                                                         double* __restrict__ out) {
+    const int v = blockIdx.x;
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) acc += partials[(size_t)b * nvals + v];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    __shared__ double sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = sm[0];
+        for (int w = 1; w < 4; ++w) r += sm[w];
+        out[v] = r;
+    }
+}
+
+// ------------------------------------------------------------------ device-resident Arnoldi step (no host round trip)
+// One record per speculative Arnoldi step: rec[0..k) = h = V'w, rec[kMaxBasis] = beta, rec[kMaxBasis + 1] = flag
+// (0: the classical Gram-Schmidt pass with the Pythagorean norm is trustworthy; 1: cancellation below the DGKS threshold
+// or breakdown -- the host repeats that step on its own path).  coef[0..k) = -h, coef[kMaxBasis] = 1 / beta feed the
+// multiaxpy that follows in the stream.
+__global__ void arnoldi_coef_kernel(const double* __restrict__ hw, int k, double eta2, double* __restrict__ rec,
+                                    double* __restrict__ coef) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double ww = hw[k];
+    double hsq = 0.0;
+    for (int i = 0; i < k; ++i) { const double h = hw[i]; hsq += h * h; rec[i] = h; coef[i] = -h; }
+    const double b2 = ww - hsq;
+    const bool ok = ww > 0.0 && b2 > 1e-8 * ww && b2 >= eta2 * ww;
+    const double be = ok ? sqrt(b2) : 1.0;
+    rec[kMaxBasis] = ok ? be : 0.0;
+    rec[kMaxBasis + 1] = ok ? 0.0 : 1.0;
+    coef[kMaxBasis] = 1.0 / be;
+}
+
+// dst = scale * (src + sum_j c[j] V_j) with c and scale read from device memory (written by arnoldi_coef_kernel)
+template <int KB, int VEC>
+__global__ void __launch_bounds__(kThreads) multiaxpy_dev_kernel(size_t n, const double* __restrict__ V, size_t ldv, int k,
+                                                                 const double* __restrict__ coef, const double* src,
+                                                                 double* dst) {
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    const double scale = coef[kMaxBasis];
+    double c[KB];
+#pragma unroll
+    for (int j = 0; j < KB; ++j) c[j] = j < k ? coef[j] : 0.0;
+    if (VEC == 2) {
+        const size_t n2 = n >> 1;
+        for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += stride) {
+            double2 r = reinterpret_cast<const double2*>(src)[i];
+#pragma unroll
+            for (int j = 0; j < KB; ++j) {
+                if (j < k) {
+                    const double2 vv = reinterpret_cast<const double2*>(V + (size_t)j * ldv)[i];
+                    r.x = fma(c[j], vv.x, r.x);
+                    r.y = fma(c[j], vv.y, r.y);
+                }
+            }
+            r.x *= scale; r.y *= scale;
+            reinterpret_cast<double2*>(dst)[i] = r;
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+            const size_t i = n - 1;
+            double r = src[i];
+#pragma unroll
+            for (int j = 0; j < KB; ++j)
+                if (j < k) r = fma(c[j], V[(size_t)j * ldv + i], r);
+            dst[i] = r * scale;
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+            double r = src[i];
+#pragma unroll
+            for (int j = 0; j < KB; ++j)
+                if (j < k) r = fma(c[j], V[(size_t)j * ldv + i], r);
+            dst[i] = r * scale;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ basis rotation  dst_j = sum_i Q(i,j) V_i
 // One thread owns element(s) e: it loads V_i[e] for all i < m into registers, then forms the kout outputs
 // one at a time -- so dst may alias V (Krylov-Schur restart rotates the basis in place).  Q (m x kout,
@@ -582,6 +663,52 @@ int v_multiaxpy(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const
     return 0;
 }
 
+
+// One speculative Arnoldi orthogonalisation step entirely in the stream: hw = [V'w ; w'w] (all-reduced over RCCL ranks),
+// coefficients, V_k = (w - V h) / beta.  Nothing is copied to the host; `rec` (kRecLen doubles, device) receives h, beta and
+// the trust flag for the host to pick up after a later synchronisation.
+int v_arnoldi_step_dev(bk_ctx* ctx, size_t n, double* V, size_t ldv, int k, const double* w, double eta, double* rec,
+                       double* coef) {
+    if (k < 1 || k > kMaxBasis - 1) return set_error(ctx, "v_arnoldi_step_dev: k=%d out of range", k);
+    if (ctx->comm == COMM_HOST && ctx->nranks > 1) return set_error(ctx, "v_arnoldi_step_dev: needs a device-side all-reduce");
+    const bool vec = aligned16(V) && aligned16(w) && (ldv % 2 == 0);
+    const int grid = grid_for(n, vec ? 2 : 1, kRedBlocks);
+    {
+        ProfScope ps(ctx, "multidot", 8.0 * n * (k + 1));
+        if (k <= 4) launch_multidot<4>(ctx, vec, grid, n, V, ldv, k, w);
+        else if (k <= 8) launch_multidot<8>(ctx, vec, grid, n, V, ldv, k, w);
+        else if (k <= 16) launch_multidot<16>(ctx, vec, grid, n, V, ldv, k, w);
+        else if (k <= 24) launch_multidot<24>(ctx, vec, grid, n, V, ldv, k, w);
+        else if (k <= 32) launch_multidot<32>(ctx, vec, grid, n, V, ldv, k, w);
+        else if (k <= 48) launch_multidot<48>(ctx, vec, grid, n, V, ldv, k, w);
+        else launch_multidot<64>(ctx, vec, grid, n, V, ldv, k, w);
+        hipLaunchKernelGGL(reduce_stage2_dev, dim3(k + 1), dim3(256), 0, ctx->stream, ctx->d_partials, grid, k + 1, ctx->d_red);
+        BK_HIP(ctx, hipGetLastError());
+    }
+    if (ctx->comm == COMM_RCCL && ctx->nranks > 1)
+        BK_NCCL(ctx, ncclAllReduce(ctx->d_red, ctx->d_red, k + 1, ncclDouble, ncclSum, ctx->nccl, ctx->stream));
+    hipLaunchKernelGGL(arnoldi_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_red, k, eta * eta, rec, coef);
+    {
+        ProfScope ps(ctx, "multiaxpy", 8.0 * n * (k + 2));
+        const int g2 = grid_for(n, vec ? 2 : 1, kRedBlocks);
+        double* dst = V + (size_t)k * ldv;
+#define BK_MA_DEV(KB)                                                                                                         \
+    do {                                                                                                                      \
+        if (vec) hipLaunchKernelGGL((multiaxpy_dev_kernel<KB, 2>), dim3(g2), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, coef, w, dst); \
+        else hipLaunchKernelGGL((multiaxpy_dev_kernel<KB, 1>), dim3(g2), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, coef, w, dst);     \
+    } while (0)
+        if (k <= 4) BK_MA_DEV(4);
+        else if (k <= 8) BK_MA_DEV(8);
+        else if (k <= 16) BK_MA_DEV(16);
+        else if (k <= 24) BK_MA_DEV(24);
+        else if (k <= 32) BK_MA_DEV(32);
+        else if (k <= 48) BK_MA_DEV(48);
+        else BK_MA_DEV(64);
+#undef BK_MA_DEV
+        BK_HIP(ctx, hipGetLastError());
+    }
+    return 0;
+}
 
 int v_basis_combine(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int m, const double* Qhost, int kout,
                     double* dst, size_t lddst) {
