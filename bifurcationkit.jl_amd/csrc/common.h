@@ -20,6 +20,7 @@ namespace bk {
 constexpr int kMaxBasis = 64;      // largest Krylov dimension + 1 the fused kernels are built for
 constexpr int kRedSlots = 256;     // doubles in the reduction result buffers
 constexpr int kRedBlocks = 1024;   // blocks of a reduction kernel (stage 1); stage 2 is one block
+constexpr int kRecChunks = 16;     // most speculative Arnoldi steps per synchronisation (option gmres_chunk)
 
 struct Coefs {                     // by-value kernel argument: coefficients of a fused multi-axpy
     double c[kMaxBasis];
@@ -55,6 +56,8 @@ struct bk_ctx {
     double* d_red = nullptr;        // [kRedSlots]
     double* h_red = nullptr;        // pinned [kRedSlots]
     double* h_red_dev = nullptr;    // its device-side address (mapped): single-rank reductions land in it directly
+    double* h_rec = nullptr;        // pinned, mapped: records of the device-resident Arnoldi chunks (kRecChunks x (kMaxBasis+2))
+    double* h_rec_dev = nullptr;
     // workspace pool (device buffers keyed by size in doubles)
     std::multimap<size_t, double*> pool_free;
     std::map<double*, size_t> pool_all;

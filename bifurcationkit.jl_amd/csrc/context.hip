@@ -248,6 +248,10 @@ static int ctx_init_common(bk_ctx* ctx, int device, void* stream) {
     {
         void* dp = nullptr;
         if (hipHostGetDevicePointer(&dp, ctx->h_red, 0) == hipSuccess) ctx->h_red_dev = static_cast<double*>(dp);
+        if (hipHostMalloc(&ctx->h_rec, sizeof(double) * kRecChunks * (kMaxBasis + 2), hipHostMallocMapped) == hipSuccess) {
+            void* dr = nullptr;
+            if (hipHostGetDevicePointer(&dr, ctx->h_rec, 0) == hipSuccess) ctx->h_rec_dev = static_cast<double*>(dr);
+        }
         (void)hipGetLastError();
     }
     return 0;
@@ -339,6 +343,7 @@ int bk_ctx_destroy(bk_ctx* ctx) {
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->d_red) (void)hipFree(ctx->d_red);
     if (ctx->h_red) (void)hipHostFree(ctx->h_red);
+    if (ctx->h_rec) (void)hipHostFree(ctx->h_rec);
     blas_release(ctx);
     if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
     if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);

@@ -172,15 +172,12 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     // DGKS second pass (or broke down) is flagged by the device and repeated on the host path.  Counters (numops / iters)
     // count consumed steps only, so they equal the host-driven run.
     int chunk = (int)ctx->opt("gmres_chunk", n <= ((size_t)1 << 22) ? 4.0 : 1.0);
-    if (nt != 0 || (ctx->comm == COMM_HOST && ctx->nranks > 1) || chunk < 2) chunk = 1;
-    double *d_rec = nullptr, *d_coef = nullptr;
-    std::vector<double> h_rec;
+    if (nt != 0 || (ctx->comm == COMM_HOST && ctx->nranks > 1) || chunk < 2 || !ctx->h_rec_dev) chunk = 1;
+    if (chunk > kRecChunks) chunk = kRecChunks;
+    double* d_coef = nullptr;
+    const double* h_rec = ctx->h_rec;          // the records land in pinned, device-mapped host memory: no copy operation
     int q_first = 0, q_count = 0;              // columns q_first .. q_first + q_count - 1 of this cycle wait in h_rec
-    if (chunk > 1) {
-        BK_TRY(ws.get((size_t)chunk * (kMaxBasis + 2), &d_rec));
-        BK_TRY(ws.get((size_t)kMaxBasis + 2, &d_coef));
-        h_rec.resize((size_t)chunk * (kMaxBasis + 2));
-    }
+    if (chunk > 1) BK_TRY(ws.get((size_t)kMaxBasis + 4, &d_coef));
     // next Hessenberg column (Arnoldi step from V[j]): from the queue of device-computed columns, else computed now
     auto next_column = [&](int j, double* hcol, double* hnext_out) -> int {
         if (chunk > 1) {
@@ -188,14 +185,12 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
                 const int steps = std::min(chunk, m - j);
                 for (int s2 = 0; s2 < steps; ++s2) {
                     BK_TRY(A->apply(B.vec(j + s2), nullptr, op_a0, op_a1, w, nullptr));
-                    BK_TRY(v_arnoldi_step_dev(ctx, n, B.V, B.ld, j + s2 + 1, w, eta, d_rec + (size_t)s2 * (kMaxBasis + 2), d_coef));
+                    BK_TRY(v_arnoldi_step_dev(ctx, n, B.V, B.ld, j + s2 + 1, w, eta, ctx->h_rec_dev + (size_t)s2 * (kMaxBasis + 2), d_coef));
                 }
-                BK_HIP(ctx, hipMemcpyAsync(h_rec.data(), d_rec, sizeof(double) * (size_t)steps * (kMaxBasis + 2),
-                                           hipMemcpyDeviceToHost, ctx->stream));
                 BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 q_first = j; q_count = steps;
             }
-            const double* rec = h_rec.data() + (size_t)(j - q_first) * (kMaxBasis + 2);
+            const double* rec = h_rec + (size_t)(j - q_first) * (kMaxBasis + 2);
             if (rec[kMaxBasis + 1] == 0.0) {
                 for (int i = 0; i <= j; ++i) hcol[i] = rec[i];
                 *hnext_out = rec[kMaxBasis];

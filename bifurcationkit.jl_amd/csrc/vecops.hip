@@ -234,7 +234,8 @@ __global__ void __launch_bounds__(kThreads) absmax_kernel(size_t n, const double
 template <int KB, int VEC, bool LDNT = false>
 __global__ void __launch_bounds__(kThreads) multidot_kernel(size_t n, const double* __restrict__ V, size_t ldv, int k,
                                                             const double* __restrict__ w,
-                                                            double* __restrict__ partials) {
+                                                            double* __restrict__ partials, const double* gate = nullptr) {
+    if (gate && gate[0] == 0.0) return;        // device-resident Arnoldi: the DGKS second pass is not needed
     double acc[KB];
 #pragma unroll
     for (int j = 0; j < KB; ++j) acc[j] = 0.0;
@@ -365,7 +366,8 @@ __global__ void __launch_bounds__(kThreads) multiaxpy_kernel(size_t n, const dou
 // second reduction stage into a DEVICE buffer: the same fixed summation order as reduce_stage2_kernel (context.hip), so the
 // device-resident and the host-driven Arnoldi steps produce bitwise identical projections
 __global__ void __launch_bounds__(256) reduce_stage2_dev(const double* __restrict__ partials, int nblocks, int nvals,
-                                                         double* __restrict__ out) {
+                                                         double* __restrict__ out, const double* gate) {
+    if (gate && gate[0] == 0.0) return;
     const int v = blockIdx.x;
     double acc = 0.0;
     for (int b = threadIdx.x; b < nblocks; b += 256) acc += partials[(size_t)b * nvals + v];
@@ -381,10 +383,10 @@ __global__ void __launch_bounds__(256) reduce_stage2_dev(const double* __restric
 }
 
 // ------------------------------------------------------------------ device-resident Arnoldi step (no host round trip)
-// One record per speculative Arnoldi step: rec[0..k) = h = V'w, rec[kMaxBasis] = beta, rec[kMaxBasis + 1] = flag
-// (0: the classical Gram-Schmidt pass with the Pythagorean norm is trustworthy; 1: cancellation below the DGKS threshold
-// or breakdown -- the host repeats that step on its own path).  coef[0..k) = -h, coef[kMaxBasis] = 1 / beta feed the
-// multiaxpy that follows in the stream.
+// One record per speculative Arnoldi step: rec[0..k) = h = V'w, rec[kMaxBasis] = beta, rec[kMaxBasis + 1] = flag.
+// coef[0..k) = -h, coef[kMaxBasis] = 1 / beta feed the multiaxpy that follows in the stream.
+// (0: trustworthy; 1: severe cancellation or breakdown -- the host repeats that step on its own path).
+// coef[kMaxBasis + 1] is the gate of the DGKS second pass: 1 when the remainder kept less than eta of ||w||.
 __global__ void arnoldi_coef_kernel(const double* __restrict__ hw, int k, double eta2, double* __restrict__ rec,
                                     double* __restrict__ coef) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -392,18 +394,36 @@ __global__ void arnoldi_coef_kernel(const double* __restrict__ hw, int k, double
     double hsq = 0.0;
     for (int i = 0; i < k; ++i) { const double h = hw[i]; hsq += h * h; rec[i] = h; coef[i] = -h; }
     const double b2 = ww - hsq;
-    const bool ok = ww > 0.0 && b2 > 1e-8 * ww && b2 >= eta2 * ww;
+    const bool ok = ww > 0.0 && b2 > 1e-8 * ww;
     const double be = ok ? sqrt(b2) : 1.0;
     rec[kMaxBasis] = ok ? be : 0.0;
     rec[kMaxBasis + 1] = ok ? 0.0 : 1.0;
     coef[kMaxBasis] = 1.0 / be;
+    coef[kMaxBasis + 1] = (ok && b2 < eta2 * ww) ? 1.0 : 0.0;
+}
+
+// second ("twice is enough") pass: s = V'v_k, vv = v_k'v_k from hw; v_k <- (v_k - V s) / cn, h += beta s, beta *= cn with the
+// Pythagorean cn^2 = vv - |s|^2 (no cancellation after a first pass).  Runs only when the gate is set.
+__global__ void arnoldi_coef2_kernel(const double* __restrict__ hw, int k, double* __restrict__ rec, double* __restrict__ coef) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (coef[kMaxBasis + 1] == 0.0) return;
+    const double vv = hw[k], be = rec[kMaxBasis];
+    double ssq = 0.0;
+    for (int i = 0; i < k; ++i) { const double s_ = hw[i]; ssq += s_ * s_; coef[i] = -s_; rec[i] += be * s_; }
+    const double n2 = vv - ssq;
+    const bool ok = n2 > 1e-8 * vv;
+    const double cn = ok ? sqrt(n2) : 1.0;
+    coef[kMaxBasis] = 1.0 / cn;
+    rec[kMaxBasis] = ok ? be * cn : 0.0;
+    if (!ok) rec[kMaxBasis + 1] = 1.0;
 }
 
 // dst = scale * (src + sum_j c[j] V_j) with c and scale read from device memory (written by arnoldi_coef_kernel)
 template <int KB, int VEC>
 __global__ void __launch_bounds__(kThreads) multiaxpy_dev_kernel(size_t n, const double* __restrict__ V, size_t ldv, int k,
                                                                  const double* __restrict__ coef, const double* src,
-                                                                 double* dst) {
+                                                                 double* dst, int gated) {
+    if (gated && coef[kMaxBasis + 1] == 0.0) return;
     const size_t stride = (size_t)gridDim.x * kThreads;
     const double scale = coef[kMaxBasis];
     double c[KB];
@@ -673,29 +693,29 @@ int v_arnoldi_step_dev(bk_ctx* ctx, size_t n, double* V, size_t ldv, int k, cons
     if (ctx->comm == COMM_HOST && ctx->nranks > 1) return set_error(ctx, "v_arnoldi_step_dev: needs a device-side all-reduce");
     const bool vec = aligned16(V) && aligned16(w) && (ldv % 2 == 0);
     const int grid = grid_for(n, vec ? 2 : 1, kRedBlocks);
-    {
-        ProfScope ps(ctx, "multidot", 8.0 * n * (k + 1));
-        if (k <= 4) launch_multidot<4>(ctx, vec, grid, n, V, ldv, k, w);
-        else if (k <= 8) launch_multidot<8>(ctx, vec, grid, n, V, ldv, k, w);
-        else if (k <= 16) launch_multidot<16>(ctx, vec, grid, n, V, ldv, k, w);
-        else if (k <= 24) launch_multidot<24>(ctx, vec, grid, n, V, ldv, k, w);
-        else if (k <= 32) launch_multidot<32>(ctx, vec, grid, n, V, ldv, k, w);
-        else if (k <= 48) launch_multidot<48>(ctx, vec, grid, n, V, ldv, k, w);
-        else launch_multidot<64>(ctx, vec, grid, n, V, ldv, k, w);
-        hipLaunchKernelGGL(reduce_stage2_dev, dim3(k + 1), dim3(256), 0, ctx->stream, ctx->d_partials, grid, k + 1, ctx->d_red);
-        BK_HIP(ctx, hipGetLastError());
-    }
-    if (ctx->comm == COMM_RCCL && ctx->nranks > 1)
-        BK_NCCL(ctx, ncclAllReduce(ctx->d_red, ctx->d_red, k + 1, ncclDouble, ncclSum, ctx->nccl, ctx->stream));
-    hipLaunchKernelGGL(arnoldi_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_red, k, eta * eta, rec, coef);
-    {
-        ProfScope ps(ctx, "multiaxpy", 8.0 * n * (k + 2));
-        const int g2 = grid_for(n, vec ? 2 : 1, kRedBlocks);
-        double* dst = V + (size_t)k * ldv;
+    double* dst = V + (size_t)k * ldv;
+    const double* gate = coef + kMaxBasis + 1;
+    auto dots = [&](const double* x, const double* g) {
+#define BK_MD_DEV(KB)                                                                                                           \
+    do {                                                                                                                        \
+        if (vec) hipLaunchKernelGGL((multidot_kernel<KB, 2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, x, ctx->d_partials, g); \
+        else hipLaunchKernelGGL((multidot_kernel<KB, 1>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, x, ctx->d_partials, g);     \
+    } while (0)
+        if (k <= 4) BK_MD_DEV(4);
+        else if (k <= 8) BK_MD_DEV(8);
+        else if (k <= 16) BK_MD_DEV(16);
+        else if (k <= 24) BK_MD_DEV(24);
+        else if (k <= 32) BK_MD_DEV(32);
+        else if (k <= 48) BK_MD_DEV(48);
+        else BK_MD_DEV(64);
+#undef BK_MD_DEV
+        hipLaunchKernelGGL(reduce_stage2_dev, dim3(k + 1), dim3(256), 0, ctx->stream, ctx->d_partials, grid, k + 1, ctx->d_red, g);
+    };
+    auto axpys = [&](const double* src, int gated) {
 #define BK_MA_DEV(KB)                                                                                                         \
     do {                                                                                                                      \
-        if (vec) hipLaunchKernelGGL((multiaxpy_dev_kernel<KB, 2>), dim3(g2), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, coef, w, dst); \
-        else hipLaunchKernelGGL((multiaxpy_dev_kernel<KB, 1>), dim3(g2), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, coef, w, dst);     \
+        if (vec) hipLaunchKernelGGL((multiaxpy_dev_kernel<KB, 2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, coef, src, dst, gated); \
+        else hipLaunchKernelGGL((multiaxpy_dev_kernel<KB, 1>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, coef, src, dst, gated);     \
     } while (0)
         if (k <= 4) BK_MA_DEV(4);
         else if (k <= 8) BK_MA_DEV(8);
@@ -705,8 +725,27 @@ int v_arnoldi_step_dev(bk_ctx* ctx, size_t n, double* V, size_t ldv, int k, cons
         else if (k <= 48) BK_MA_DEV(48);
         else BK_MA_DEV(64);
 #undef BK_MA_DEV
+    };
+    const bool rccl = ctx->comm == COMM_RCCL && ctx->nranks > 1;
+    {
+        ProfScope ps(ctx, "multidot", 8.0 * n * (k + 1));
+        dots(w, nullptr);
         BK_HIP(ctx, hipGetLastError());
     }
+    if (rccl) BK_NCCL(ctx, ncclAllReduce(ctx->d_red, ctx->d_red, k + 1, ncclDouble, ncclSum, ctx->nccl, ctx->stream));
+    hipLaunchKernelGGL(arnoldi_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_red, k, eta * eta, rec, coef);
+    {
+        ProfScope ps(ctx, "multiaxpy", 8.0 * n * (k + 2));
+        axpys(w, 0);
+        BK_HIP(ctx, hipGetLastError());
+    }
+    // DGKS second pass, gated on the device (kernels return at once when the first pass kept >= eta of ||w||).  With RCCL
+    // ranks the small all-reduce runs unconditionally (every rank takes the same decision from the same reduced numbers).
+    dots(dst, gate);
+    if (rccl) BK_NCCL(ctx, ncclAllReduce(ctx->d_red, ctx->d_red, k + 1, ncclDouble, ncclSum, ctx->nccl, ctx->stream));
+    hipLaunchKernelGGL(arnoldi_coef2_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_red, k, rec, coef);
+    axpys(dst, 1);
+    BK_HIP(ctx, hipGetLastError());
     return 0;
 }
 

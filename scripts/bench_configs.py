@@ -16,6 +16,8 @@ import torch  # noqa: E402
 from bk_amd import hip  # noqa: E402
 
 ctx = hip.Context(0)
+if os.environ.get("BK_GMRES_CHUNK"):
+    ctx.set_option("gmres_chunk", float(os.environ["BK_GMRES_CHUNK"]))      # 1: host-driven Arnoldi steps; >= 2: device-resident chunks
 
 
 def timeit(fn, reps=5, warm=1):

@@ -343,6 +343,36 @@ def test_gmres_unpreconditioned_shift_and_restart(ctx):
     assert abs(it - iti) <= 2, (it, iti)
 
 
+@pytest.mark.parametrize("flavor", ["krylovkit", "iterativesolvers"])
+def test_device_resident_arnoldi_chunks_match_host_driven_steps(ctx, flavor):
+    """gmres_chunk >= 2 (the default for cache-resident vectors): several Arnoldi steps are enqueued without a host round
+    trip (coefficients, DGKS decision and the second Gram-Schmidt pass stay on the device) and the host replays its Givens /
+    stopping logic on the collected Hessenberg columns.  Same solution, same counters as the host-driven path (chunk = 1),
+    with and without restarts, including a right-hand side that converges in the middle of a chunk."""
+    hip = _hip()
+    sh, prob, rng, u = _sh_setup(ctx, (20, 18, 16), (np.pi, 3.0, 2.5))
+    J = prob.jacobian(prob.vec(u), 0.1)
+    P = hip.DCTPreconditioner(prob, 1.0)
+    for seed, dim in ((1, 30), (2, 7), (3, 12)):
+        rhs = prob.vec(np.random.default_rng(seed).standard_normal(sh.N))
+        ls = (hip.GMRESKrylovKit(dim=dim, rtol=1e-10, atol=1e-13, maxiter=200, Pl=P) if flavor == "krylovkit"
+              else hip.GMRESIterativeSolvers(reltol=1e-10, restart=dim, maxiter=400, Pl=P))
+        out = {}
+        for chunk in (1, 2, 4, 8):
+            ctx.set_option("gmres_chunk", chunk)
+            try:
+                x, ok, it = ls(J, rhs, 0.2, 0.9)
+            finally:
+                ctx.set_option("gmres_chunk", 4)
+            out[chunk] = (x.numpy(), ok, it)
+        x1, ok1, it1 = out[1]
+        assert ok1
+        for chunk in (2, 4, 8):
+            xc, okc, itc = out[chunk]
+            assert okc and abs(itc - it1) <= 1, (flavor, dim, chunk, itc, it1)
+            assert np.abs(xc - x1).max() <= 1e-9 * np.abs(x1).max()
+
+
 def test_gmres_nonconvergence_is_a_flag_not_an_error(ctx):
     hip = _hip()
     sh, prob, rng, u = _sh_setup(ctx, (12, 12, 12), (np.pi,) * 3)
