@@ -455,18 +455,21 @@ class GMRESIterativeSolvers(_GMRES):
 @dataclass
 class KrylovLS(_GMRES):
     """KrylovLS / KrylovLSInplace with KrylovAlg = :gmres (src/LinearSolver.jl:316-414): Krylov.jl's stopping rule
-    ||r|| <= atol + rtol ||r0||, `memory` Krylov vectors (used as the restart length), `itmax` iterations,
-    left preconditioner M = Pl applied to the shifted operator."""
+    ||r|| <= atol + rtol ||r0||, `itmax` iterations, left preconditioner M = Pl applied to the shifted operator.  Krylov.jl
+    restarts every `memory` steps only with ``restart = true``; by default the basis keeps growing past `memory` -- here it
+    grows up to the library's 63 vectors (then restarts), which is the package's behaviour for every solve of <= 63
+    iterations."""
     atol: float = 1.4901161193847656e-08
     rtol: float = 1.4901161193847656e-08
     memory: int = 20
     itmax: int = 2000
+    restart: bool = False
     Pl: DCTPreconditioner | None = None
     flavor = L.BK_GMRES_KRYLOVJL
 
     @property
     def dim(self):
-        return self.memory
+        return self.memory if self.restart else 63
 
     @property
     def maxiter(self):

@@ -233,7 +233,7 @@ end
 # (ls)(J, rhs1, rhs2) keeps the default of src/LinearSolver.jl:15-19 (two calls of the method above).
 
 """
-    HipKrylovLS(KrylovAlg = :gmres | :minres | :cg; atol, rtol, memory, itmax, Pl)
+    HipKrylovLS(KrylovAlg = :gmres | :minres | :cg; atol, rtol, memory, itmax, restart, Pl)
 
 `KrylovLS` (src/LinearSolver.jl:316-345): Krylov.jl semantics; `:minres` / `:cg` are the symmetric solvers with the
 centered preconditioner `M = Pl` (8 / 4 work vectors instead of a Krylov basis).
@@ -244,11 +244,12 @@ Base.@kwdef mutable struct HipKrylovLS{Tl} <: AbstractIterativeLinearSolver
     rtol::Float64 = sqrt(eps())
     memory::Int = 20
     itmax::Int = 0
+    restart::Bool = false      # Krylov.jl: restart every `memory` steps only when true; else the basis grows (here: up to 63)
     Pl::Tl = nothing
 end
 _flavor(l::HipKrylovLS) = l.KrylovAlg == :gmres ? Cint(2) : l.KrylovAlg == :minres ? Cint(3) : l.KrylovAlg == :cg ? Cint(4) :
                           error("HipKrylovLS: KrylovAlg must be :gmres, :minres or :cg")
-_opts(l::HipKrylovLS) = GmresOpts(_flavor(l), l.memory, l.KrylovAlg == :gmres && l.itmax == 0 ? 2000 : l.itmax, l.atol, l.rtol)
+_opts(l::HipKrylovLS) = GmresOpts(_flavor(l), l.restart ? l.memory : 63, l.KrylovAlg == :gmres && l.itmax == 0 ? 2000 : l.itmax, l.atol, l.rtol)
 function (l::HipKrylovLS)(J::HipJacobian, rhs::HipVec; a₀ = 0.0, a₁ = 1.0, kwargs...)
     ctx = rhs.ctx
     x = similar(rhs)

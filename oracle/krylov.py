@@ -312,6 +312,66 @@ def gmres_iterativesolvers(A, b, a0=0.0, a1=1.0, *, restart=200, maxiter=100, re
     return x, beta <= tol, iters
 
 
+def gmres_krylovjl(A, b, a0=0.0, a1=1.0, *, memory=20, restart=False, itmax=0, atol=np.sqrt(np.finfo(float).eps),
+                   rtol=np.sqrt(np.finfo(float).eps), M=None):
+    """Krylov.jl `gmres` as BifurcationKit's KrylovLS calls it (src/LinearSolver.jl:336-345: `krylov_solve(Val(:gmres), Jmap,
+    rhs; kwargs..., M = Pl, N = Pr)`) on v -> a0 v + a1 A v, x0 = 0: left preconditioner M, modified Gram-Schmidt, Givens QR
+    of the Hessenberg matrix, stop on ||M r|| <= atol + rtol ||M r0||.  `memory` is the initial basis size; with
+    `restart = false` (the package default) the basis simply keeps growing, with `restart = true` the method restarts
+    every `memory` steps.  Package knowledge, not verifiable here.  Returns (x, solved, niter)."""
+    b = np.asarray(b, dtype=float)
+    n = b.shape[0]
+    op = lambda v: axpy_op(A, v, a0, a1)
+    prec = (lambda v: v) if M is None else M
+    itmax = itmax if itmax > 0 else 2 * n
+    x = np.zeros(n)
+    r = prec(b.copy())
+    beta = np.linalg.norm(r)
+    tol = atol + rtol * beta
+    it = 0
+    if beta <= tol:
+        return x, True, 0
+    cap = memory if restart else itmax
+    while it < itmax:
+        V = [r / beta]
+        Hc, cs, sn, g = [], [], [], [beta]
+        k = 0
+        while k < cap and it < itmax:
+            w = prec(op(V[k]))
+            h = np.zeros(k + 2)
+            for i in range(k + 1):
+                h[i] = V[i] @ w
+                w = w - h[i] * V[i]
+            h[k + 1] = np.linalg.norm(w)
+            if h[k + 1] != 0.0:
+                V.append(w / h[k + 1])
+            for i in range(k):
+                t = cs[i] * h[i] + sn[i] * h[i + 1]
+                h[i + 1] = -sn[i] * h[i] + cs[i] * h[i + 1]
+                h[i] = t
+            c_, s_, rr = _givens(h[k], h[k + 1])
+            cs.append(c_); sn.append(s_)
+            h[k], h[k + 1] = rr, 0.0
+            Hc.append(h[:k + 1].copy())
+            g.append(-s_ * g[k])
+            g[k] = c_ * g[k]
+            k += 1
+            it += 1
+            beta = abs(g[k])
+            if beta <= tol or len(V) <= k:
+                break
+        R = np.zeros((k, k))
+        for j, col in enumerate(Hc):
+            R[:j + 1, j] = col
+        yk = sla.solve_triangular(R, np.asarray(g[:k]))
+        x = x + np.asarray(V[:k]).T @ yk
+        if beta <= tol:
+            return x, True, it
+        r = prec(b - op(x))
+        beta = np.linalg.norm(r)
+    return x, beta <= tol, it
+
+
 def _which_key(which):
     if which == "LM":
         return lambda lam: -np.abs(lam)

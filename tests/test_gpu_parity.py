@@ -330,7 +330,7 @@ def test_gmres_unpreconditioned_shift_and_restart(ctx):
     a0 = 2.0 * abs(Jm).sum(axis=1).max()                              # diagonally dominant shifted system
     for ls in (hip.GMRESKrylovKit(dim=10, rtol=1e-11, atol=0.0, maxiter=100),
                hip.GMRESIterativeSolvers(reltol=1e-11, restart=10, maxiter=500),
-               hip.KrylovLS(atol=0.0, rtol=1e-11, memory=10, itmax=500)):
+               hip.KrylovLS(atol=0.0, rtol=1e-11, memory=10, itmax=500, restart=True)):
         x, ok, it = ls(J, prob.vec(rhs), a0, 1.0)
         ref = spla.spsolve((a0 * sp.identity(sh.N) + Jm).tocsc(), rhs)
         assert ok and it > 10                                         # restarted at least once
@@ -341,6 +341,19 @@ def test_gmres_unpreconditioned_shift_and_restart(ctx):
     xi, oki, iti = krylov.gmres_iterativesolvers(Jm, rhs, a0, 1.0, restart=10, reltol=1e-11, maxiter=500)
     x, ok, it = hip.GMRESIterativeSolvers(reltol=1e-11, restart=10, maxiter=500)(J, prob.vec(rhs), a0, 1.0)
     assert abs(it - iti) <= 2, (it, iti)
+    # KrylovLS(:gmres) against the restatement of Krylov.jl's gmres: restarted every `memory` steps (restart = true) and the
+    # package default (restart = false: the basis grows past `memory`), with the left preconditioner M = Pl
+    for kw in (dict(memory=10, restart=True), dict(memory=10, restart=False)):
+        xj, okj, itj = krylov.gmres_krylovjl(Jm, rhs, a0, 1.0, atol=0.0, rtol=1e-11, itmax=500, **kw)
+        x, ok, it = hip.KrylovLS(atol=0.0, rtol=1e-11, itmax=500, **kw)(J, prob.vec(rhs), a0, 1.0)
+        assert ok and okj and abs(it - itj) <= 2, (kw, it, itj)
+        assert np.abs(x.numpy() - xj).max() <= 1e-8 * np.abs(xj).max()
+    P = hip.DCTPreconditioner(prob, 1.0)
+    Po = operators.dct_preconditioner((10, 9, 8), (1.0, 1.0, 1.0), 1.0)
+    xj, okj, itj = krylov.gmres_krylovjl(Jm, rhs, 0.0, 1.0, atol=1e-13, rtol=1e-10, itmax=500, M=Po)
+    x, ok, it = hip.KrylovLS(atol=1e-13, rtol=1e-10, itmax=500, Pl=P)(J, prob.vec(rhs))
+    assert ok and okj and abs(it - itj) <= 2, (it, itj)
+    assert np.abs(x.numpy() - xj).max() <= 1e-7 * np.abs(xj).max()
 
 
 @pytest.mark.parametrize("flavor", ["krylovkit", "iterativesolvers"])
