@@ -159,8 +159,8 @@ int v_multidot(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const 
 int v_multiaxpy(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const double* c,
                 const double* src, double scale, double* dst, double* nrm2sq);
 // device-resident orthogonalisation step (vecops.hip): rec / coef are device buffers of kMaxBasis + 2 doubles
-int v_arnoldi_step_dev(bk_ctx* ctx, size_t n, double* V, size_t ldv, int k, const double* w, double eta, double* rec,
-                       double* coef);
+int v_arnoldi_step_dev(bk_ctx* ctx, size_t n, double* V, size_t ldv, int k, const double* w, double eta, double orth_tol,
+                       double* rec, double* coef);
 // dst_j = sum_{i<m} Q(i,j) V_i for j < kout (Q host, column-major m x kout); dst may alias V
 int v_basis_combine(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int m, const double* Qhost, int kout,
                     double* dst, size_t lddst);

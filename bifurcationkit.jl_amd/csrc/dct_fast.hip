@@ -491,10 +491,18 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
     if (P.trace) { __builtin_amdgcn_s_waitcnt(0); stamp(6); }
 }
 
-inline int choose_lt(int N, int axis, int n0, size_t rows) {
+inline int choose_lt(int N, int axis, int n0, size_t rows, bool wide = false) {
     // 16 lines per tile (axis >= 1: one 128-B segment per line element), fewer only if the tile would not fit a
-    // 76 KiB LDS budget (two workgroups per CU): LT/2 pairs * (N+1) complex + N/2 twiddles, 16 B each
+    // 76 KiB LDS budget (two workgroups per CU): LT/2 pairs * (N+1) complex + N/2 twiddles, 16 B each.
+    // wide (fused kernel, axis >= 1, short transforms -- the z pass of a multi-GPU slab, 256^3 grids): keep the tile at
+    // 16 * 512 points, i.e. LT = 16 * 512 / N lines, so that every lane has work in the outer radix-8 stages and a line
+    // element is a 256-B ... 1-KiB segment
     int lt = 16;
+    if (wide && axis != 0 && N < 512) {
+        lt = 16 * (512 / N);
+        if (lt > 128) lt = 128;
+        while (lt > 16 && (n0 % lt != 0 || ((size_t)(lt / 2) * (N + 1) + (size_t)(N + 4)) * 16 > 76 * 1024)) lt /= 2;
+    }
     while (lt > 2 && ((size_t)(lt / 2) * (N + 1) + (size_t)(N / 2)) * 16 > 76 * 1024) lt -= 2;
     if (axis == 0) {
         if ((size_t)lt > rows) lt = (int)((rows + 1) & ~(size_t)1);
@@ -520,8 +528,8 @@ bool dct_axis_fused_ok(bk_ctx* ctx, int n0, int n1, int n2, int axis, const doub
     if ((size_t)n0 * n1 * n2 * sizeof(double) >= ((size_t)1 << 32)) return false;
     if (n0 % 2 != 0 || (((uintptr_t)in | (uintptr_t)out) & 15) != 0) return false;
     const size_t rows = (size_t)n1 * n2;
-    const int LT = choose_lt(N, axis, n0, rows);
-    if (LT != 16) return false;
+    const int LT = choose_lt(N, axis, n0, rows, ctx->opt("dct_lt_wide", 1.0) != 0.0);
+    if (LT != 16 && !(axis != 0 && (LT == 32 || LT == 64 || LT == 128))) return false;
     if (axis == 0) return fuse_scale != 2 && rows % LT == 0 && ctx->opt("dct_fused_ax0", 1.0) != 0.0;
     return n0 % LT == 0;
 }
@@ -546,13 +554,14 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
     P.fuse_scale = fuse_scale == 1 ? 1 : 0;
     P.roundtrip = fuse_scale == 2 ? 1 : 0;
     const size_t rows = (size_t)n1 * n2;
-    P.LT = choose_lt(P.N, axis, n0, rows);
+    const bool fused_ok = dct_axis_fused_ok(ctx, n0, n1, n2, axis, in, out, fuse_scale);
+    P.LT = choose_lt(P.N, axis, n0, rows, fused_ok && ctx->opt("dct_lt_wide", 1.0) != 0.0);
     {
         const int lt_opt = (int)ctx->opt("dct_lt", 0.0);      // experiment knob: lines per tile of the axis >= 1 passes
         if (lt_opt >= 2 && axis != 0 && lt_opt <= P.LT) P.LT = lt_opt & ~1;
     }
     P.ltbits = -1;
-    for (int b = 1; b <= 6; ++b) if ((1 << b) == P.LT) P.ltbits = b;
+    for (int b = 1; b <= 7; ++b) if ((1 << b) == P.LT) P.ltbits = b;
     unsigned grid;
     if (axis == 0) {
         P.tiles_x = 0;
@@ -595,7 +604,7 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
                             (axis == 0 ? (nt % P.N == 0) : (nt % npairs == 0 && P.pairvec));
         P.fast = (ctx->opt("dct_fastio", 1.0) != 0.0 && full_tiles && shapes) ? 1 : 0;
     }
-    if (dct_axis_fused_ok(ctx, n0, n1, n2, axis, in, out, fuse_scale) && P.LT == 16) {
+    if (fused_ok && (P.LT == 16 || (axis != 0 && (P.LT == 32 || P.LT == 64 || P.LT == 128)))) {
         const size_t ldsf = lds + ((size_t)(P.N / 2 + 2) + (P.roundtrip ? P.N / 2 : 0)) * sizeof(c2);
         const bool trace = ctx->opt("dct_trace", 0.0) != 0.0;
         P.trace = nullptr;

@@ -387,7 +387,9 @@ __global__ void __launch_bounds__(256) reduce_stage2_dev(const double* __restric
 // coef[0..k) = -h, coef[kMaxBasis] = 1 / beta feed the multiaxpy that follows in the stream.
 // (0: trustworthy; 1: severe cancellation or breakdown -- the host repeats that step on its own path).
 // coef[kMaxBasis + 1] is the gate of the DGKS second pass: 1 when the remainder kept less than eta of ||w||.
-__global__ void arnoldi_coef_kernel(const double* __restrict__ hw, int k, double eta2, double* __restrict__ rec,
+// coef[kMaxBasis + 2] carries the running defect estimate of the cycle (solver.hip: arnoldi_step; zeroed by the host at the
+// start of a cycle).
+__global__ void arnoldi_coef_kernel(const double* __restrict__ hw, int k, double eta2, double orth_tol, double* __restrict__ rec,
                                     double* __restrict__ coef) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const double ww = hw[k];
@@ -399,7 +401,14 @@ __global__ void arnoldi_coef_kernel(const double* __restrict__ hw, int k, double
     rec[kMaxBasis] = ok ? be : 0.0;
     rec[kMaxBasis + 1] = ok ? 0.0 : 1.0;
     coef[kMaxBasis] = 1.0 / be;
-    coef[kMaxBasis + 1] = (ok && b2 < eta2 * ww) ? 1.0 : 0.0;
+    double gate = 0.0;
+    if (ok) {
+        const double dlt = coef[kMaxBasis + 2];
+        const double grown = (dlt + 4.440892098500626e-16) * sqrt(ww / b2);
+        if (b2 < eta2 * ww || grown > orth_tol) gate = 1.0;
+        else if (grown > dlt) coef[kMaxBasis + 2] = grown;
+    }
+    coef[kMaxBasis + 1] = gate;
 }
 
 // second ("twice is enough") pass: s = V'v_k, vv = v_k'v_k from hw; v_k <- (v_k - V s) / cn, h += beta s, beta *= cn with the
@@ -687,8 +696,8 @@ int v_multiaxpy(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const
 // One speculative Arnoldi orthogonalisation step entirely in the stream: hw = [V'w ; w'w] (all-reduced over RCCL ranks),
 // coefficients, V_k = (w - V h) / beta.  Nothing is copied to the host; `rec` (kRecLen doubles, device) receives h, beta and
 // the trust flag for the host to pick up after a later synchronisation.
-int v_arnoldi_step_dev(bk_ctx* ctx, size_t n, double* V, size_t ldv, int k, const double* w, double eta, double* rec,
-                       double* coef) {
+int v_arnoldi_step_dev(bk_ctx* ctx, size_t n, double* V, size_t ldv, int k, const double* w, double eta, double orth_tol,
+                       double* rec, double* coef) {
     if (k < 1 || k > kMaxBasis - 1) return set_error(ctx, "v_arnoldi_step_dev: k=%d out of range", k);
     if (ctx->comm == COMM_HOST && ctx->nranks > 1) return set_error(ctx, "v_arnoldi_step_dev: needs a device-side all-reduce");
     const bool vec = aligned16(V) && aligned16(w) && (ldv % 2 == 0);
@@ -733,7 +742,7 @@ int v_arnoldi_step_dev(bk_ctx* ctx, size_t n, double* V, size_t ldv, int k, cons
         BK_HIP(ctx, hipGetLastError());
     }
     if (rccl) BK_NCCL(ctx, ncclAllReduce(ctx->d_red, ctx->d_red, k + 1, ncclDouble, ncclSum, ctx->nccl, ctx->stream));
-    hipLaunchKernelGGL(arnoldi_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_red, k, eta * eta, rec, coef);
+    hipLaunchKernelGGL(arnoldi_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_red, k, eta * eta, orth_tol, rec, coef);
     {
         ProfScope ps(ctx, "multiaxpy", 8.0 * n * (k + 2));
         axpys(w, 0);
