@@ -39,6 +39,7 @@ enum CommKind { COMM_NONE = 0, COMM_RCCL = 1, COMM_HOST = 2 };
 
 struct bk_ctx {
     int device = 0;
+    int num_cu = 256;              // compute units of the device (persistent-kernel grids)
     hipStream_t stream = nullptr;
     bool own_stream = false;
     // communicator

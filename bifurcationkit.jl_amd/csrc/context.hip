@@ -242,6 +242,10 @@ static int ctx_init_common(bk_ctx* ctx, int device, void* stream) {
     // stream, Julia's AMDGPU default queue) is ordered with the library's kernels without explicit events.
     ctx->stream = (hipStream_t)stream;
     ctx->own_stream = false;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->num_cu = cus;
+    }
     BK_HIP(ctx, hipMalloc(&ctx->d_partials, sizeof(double) * kRedBlocks * (kMaxBasis + 2)));
     BK_HIP(ctx, hipMalloc(&ctx->d_red, sizeof(double) * kRedSlots));
     BK_HIP(ctx, hipHostMalloc(&ctx->h_red, sizeof(double) * kRedSlots, hipHostMallocMapped));

@@ -377,15 +377,16 @@ BK_HD void fused_last(const c2* zp, int N, int bits, int gp, Store&& st) {
 // Contiguous-axis variants (the transform runs along the fastest index): a lane reads the two adjacent samples (2j, 2j+1)
 // of each line with one 16-B access.  The even one lands in Makhoul slot j, the odd one in slot N-1-j, i.e. for
 // j = gp + r N/8 (r < 4) in first-stage group gp (position r) and in group N/8-1-gp (position 7-r): an item owns BOTH
-// groups gp and gp' = N/8-1-gp, gp in [0, N/16).   ld2(j, ea, oa, eb, ob): samples 2j, 2j+1 of line a and of line b.
+// groups gp and gp' = N/8-1-gp, gp in [0, N/16).   ld2(slot, j, ea, oa, eb, ob): samples 2j, 2j+1 of line a and of
+// line b; slot = 0..7 is the compile-time position of the call (registers prefetched in exactly this order).
 template <class Load2>
 BK_HD void fused_first2(c2* zp, int N, int bits, int gp, Load2&& ld2) {
     const int G = N >> 3, gq = G - 1 - gp;
     c2 A[8], B[8];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        ld2(gp + G * r, A[r].x, B[7 - r].x, A[r].y, B[7 - r].y);
-        ld2(gq + G * r, B[r].x, A[7 - r].x, B[r].y, A[7 - r].y);
+        ld2(2 * r, gp + G * r, A[r].x, B[7 - r].x, A[r].y, B[7 - r].y);
+        ld2(2 * r + 1, gq + G * r, B[r].x, A[7 - r].x, B[r].y, A[7 - r].y);
     }
     c2 v[8];
 #pragma unroll

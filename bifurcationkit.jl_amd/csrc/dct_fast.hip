@@ -50,6 +50,8 @@ struct FftK {
     int fast;                 // full tiles, power-of-two shapes, < 2^31 elements: incremental addressing (host-checked)
     int nr_steps;             // Newton steps after v_rcp_f64 in the fused symbol (option dct_rcp_steps, default 2)
     int nt_load, nt_store;    // fused kernel: non-temporal hint on the tile loads / stores (every element is touched once)
+    int ntiles;               // fused kernel: tiles of the pass (persistent workgroups loop over them)
+    int xmap;                 // fused kernel: XCD-contiguous slot -> tile map (ntiles % 8 == 0)
 };
 
 template <int NT>
@@ -321,9 +323,24 @@ __device__ __forceinline__ double rcp_nr(double d, int steps = 2) {
     return __builtin_fma(y, e, y);
 }
 
+// Workgroup barrier that orders LDS accesses only: __syncthreads() also drains every outstanding global load
+// (s_waitcnt vmcnt(0)), which would put the latency of the prefetched next tile back on the critical path.  Global
+// memory needs no ordering inside the fused kernel: a lane consumes its own loads before its LDS writes, and tiles are
+// owned by one workgroup.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // AX0: the transform runs along the contiguous index (a tile is LT consecutive rows); lanes then walk along the row
 // (dct_core.h: fused_first2 / fused_last2) instead of across the LT lines.
-template <int NT, int MODE, bool AX0>      // MODE 0: forward, 1: inverse, 2: forward - symbol - inverse (AX0: 0 / 1 only)
+// Persistent workgroups: the grid is two workgroups per CU, each walks over tiles blockIdx.x, blockIdx.x + gridDim.x, ...
+// (twiddle tables are staged once), and the samples of the NEXT tile's first radix-8 stage are requested into
+// registers while the current tile is still in its LDS / store phases (MODE 0: right after the first stage, MODE 2:
+// after the merged middle, where the register pressure has dropped), so that the HBM latency of the tile loads is not
+// on the per-tile critical path.  NTM: non-temporal tile loads / stores (every element is touched once).
+template <int NT, int MODE, bool AX0, bool NTM>   // MODE 0: forward, 1: inverse, 2: forward - symbol - inverse (AX0: 0 / 1 only)
 __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int N = P.N, bits = P.bits, G = N >> 3;
@@ -333,7 +350,7 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
     c2* tw = z + (size_t)npairs * pstride;                    // N/2 FFT twiddles
     c2* ew = tw + (N >> 1);                                   // N/2 + 1 post twiddles exp(-i pi k / 2N), k <= N/2
     double* lamk = reinterpret_cast<double*>(ew + (N >> 1) + 2);   // MODE 2: eigenvalues along the transform axis
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
     const int nfirst = AX0 ? npairs * (G >> 1) : npairs * G;  // work items of the outer stages ...
     const int nmid = npairs * (G >> 1);                       // ... and of the merged middle
     const int hbits = bits - 4;                               // log2(G / 2)
@@ -342,36 +359,38 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
     const unsigned estride = AX0 ? 1u : (P.axis == 1 ? (unsigned)P.n0 : (unsigned)P.n0 * (unsigned)P.n1);
     const unsigned lstride = AX0 ? (unsigned)P.n0 : 1u;       // line a -> line b of a pair
 
-    const int tx = AX0 ? 0 : blockIdx.x % P.tiles_x;
-    const int other = AX0 ? 0 : blockIdx.x / P.tiles_x;       // i2 (axis 1) or i1 (axis 2)
-    const int x0 = tx * P.LT;
-    const size_t base = AX0 ? (size_t)blockIdx.x * P.LT * P.n0
-                            : (P.axis == 1 ? x0 + (size_t)P.n0 * P.n1 * other : x0 + (size_t)P.n0 * other);
+    // tile -> (x0, other, element offsets of its input / output)
+    auto tile_x0 = [&](int tile) { return AX0 ? 0 : (tile % P.tiles_x) * P.LT; };
+    auto tile_other = [&](int tile) { return AX0 ? 0 : tile / P.tiles_x; };     // i2 (axis 1) or i1 (axis 2)
+    auto tile_base = [&](int tile) {
+        const size_t x0 = (size_t)tile_x0(tile), other = (size_t)tile_other(tile);
+        return AX0 ? (size_t)tile * P.LT * P.n0 : (P.axis == 1 ? x0 + (size_t)P.n0 * P.n1 * other : x0 + (size_t)P.n0 * other);
+    };
     // distributed plan: one side of the y pass lives in the all-to-all block layout (dct.hip, dct_apply_dist)
-    const size_t sbase = (size_t)x0 + (size_t)other * P.split_plane;
-    const double* gin = P.in + (!AX0 && P.split == 2 ? sbase : base);
-    double* gout = P.out + (!AX0 && P.split == 1 ? sbase : base);
+    auto tile_sbase = [&](int tile) { return (size_t)tile_x0(tile) + (size_t)tile_other(tile) * P.split_plane; };
+    auto tile_in = [&](int tile) { return P.in + (!AX0 && P.split == 2 ? tile_sbase(tile) : tile_base(tile)); };
+    auto tile_out = [&](int tile) { return P.out + (!AX0 && P.split == 1 ? tile_sbase(tile) : tile_base(tile)); };
+    const double* gin = nullptr;
+    double* gout = nullptr;
     typedef double nt_d2 __attribute__((ext_vector_type(2)));
     auto ld16 = [&](const double* p) {
         c2 r;
-        if (P.nt_load) { const nt_d2 t = __builtin_nontemporal_load(reinterpret_cast<const nt_d2*>(p)); r.x = t.x; r.y = t.y; }
+        if (NTM) { const nt_d2 t = __builtin_nontemporal_load(reinterpret_cast<const nt_d2*>(p)); r.x = t.x; r.y = t.y; }
         else { const double2 t = *reinterpret_cast<const double2*>(p); r.x = t.x; r.y = t.y; }
         return r;
     };
     auto st16 = [&](double* p, double a, double b) {
-        if (P.nt_store) { nt_d2 t; t.x = a; t.y = b; __builtin_nontemporal_store(t, reinterpret_cast<nt_d2*>(p)); }
+        if (NTM) { nt_d2 t; t.x = a; t.y = b; __builtin_nontemporal_store(t, reinterpret_cast<nt_d2*>(p)); }
         else *reinterpret_cast<double2*>(p) = make_double2(a, b);
     };
-    auto ldg = [&](unsigned el) {
-        return ld16(reinterpret_cast<const double*>(reinterpret_cast<const char*>(gin) + (size_t)(el * 8u)));
+    auto ldfrom = [&](const double* g, unsigned el) {
+        return ld16(reinterpret_cast<const double*>(reinterpret_cast<const char*>(g) + (size_t)(el * 8u)));
     };
+    auto ldg = [&](unsigned el) { return ldfrom(gin, el); };
     auto stg = [&](unsigned el, c2 v) {
         st16(reinterpret_cast<double*>(reinterpret_cast<char*>(gout) + (size_t)(el * 8u)), v.x, v.y);
     };
     // AX0 accessors: one double of line a / b (merged middle), or the adjacent samples (2j, 2j+1) of both lines
-    auto ld1 = [&](unsigned el) {
-        c2 r; r.x = gin[el]; r.y = gin[el + lstride]; return r;
-    };
     auto st1 = [&](unsigned el, c2 v) { gout[el] = v.x; gout[el + lstride] = v.y; };
     auto stamp = [&](int i) {
         if (P.trace && tid == 0) P.trace[(size_t)blockIdx.x * 8 + i] = (long long)wall_clock64();
@@ -380,7 +399,6 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
     for (int q = tid; q < N + 1; q += NT) tw[q] = reinterpret_cast<const c2*>(P.twid)[q];
     if (MODE == 2)
         for (int q = tid; q < N; q += NT) lamk[q] = (P.axis == 1 ? P.lam1 : P.lam2)[q];
-    stamp(0);
 
     const double s0 = sqrt(1.0 / N), s2 = sqrt(2.0 / N);
     auto middle = [&](int lh, int R, bool inv) {
@@ -399,94 +417,165 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
                 else dctc::dif_group_inv<1>(zp, bits, lh, g, tw);
             }
         }
-        __syncthreads();
+        lds_barrier();
     };
     auto nold = [](int, int) { c2 r; r.x = 0.0; r.y = 0.0; return r; };
     auto nosym = [](int) { c2 r; r.x = 0.0; r.y = 0.0; return r; };
     auto nost = [](int, c2) {};
 
-    if (MODE != 1) {
+    // first-stage samples held in registers: (AX0) the 8 + 8 sample pairs of this lane's item, line a in pfa / line b in
+    // pfb; (axis >= 1) the 8 samples of item tid in pfa and of item tid + NT in pfb
+    c2 pfa[8], pfb[8];
+    // (the host launches this kernel only when nfirst <= NT (AX0) / 2 NT, so the two register sets cover the tile)
+    const bool act0 = tid < nfirst, act1 = !AX0 && tid + NT < nfirst;
+    auto issue = [&](int tile, bool real) {
+        // every lane requests unconditionally (idle lanes, and all lanes after the last tile (!real), re-read element 0 of
+        // the tile): a guarded request would carry the previous tile's registers through the merged middle as the "not
+        // taken" value and the kernel would spill
+        const double* g = tile_in(tile);
+        if (MODE == 1) {                                      // the 8 + 8 spectral pairs of this lane's merged-middle item
+            const bool act = real && tid < nmid;
+            const int pr = AX0 ? tid >> hbits : tid & (npairs - 1), t = AX0 ? tid & ((1 << hbits) - 1) : tid >> pbits;
+            const unsigned o = AX0 ? (unsigned)(2 * pr) * lstride : 2u * pr;
+            const int ga = t, gb = t == 0 ? (G >> 1) : G - t;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int ka = ga + q * G, kb = gb + q * G;
+                if (AX0) {
+                    const unsigned ea = act ? o + (unsigned)ka : 0u, eb = act ? o + (unsigned)kb : 0u;
+                    pfa[q].x = g[ea]; pfa[q].y = g[ea + lstride];
+                    pfb[q].x = g[eb]; pfb[q].y = g[eb + lstride];
+                } else if (P.split == 2) {
+                    pfa[q] = ldfrom(g, act ? o + P.kmap[ka] : 0u);
+                    pfb[q] = ldfrom(g, act ? o + P.kmap[kb] : 0u);
+                } else {
+                    pfa[q] = ldfrom(g, act ? o + (unsigned)ka * estride : 0u);
+                    pfb[q] = ldfrom(g, act ? o + (unsigned)kb * estride : 0u);
+                }
+            }
+            return;
+        }
+        const bool act0 = real && tid < nfirst, act1 = real && !AX0 && tid + NT < nfirst;
+        if (AX0) {
+            const int gp = tid & ((1 << hbits) - 1), gq = (G - 1) - gp;
+            const double* row = g + (act0 ? (size_t)(2 * (tid >> hbits)) * lstride : (size_t)0);
+            const int m = act0 ? 2 : 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pfa[2 * r] = ld16(row + m * (gp + G * r));
+                pfb[2 * r] = ld16(row + lstride + m * (gp + G * r));
+                pfa[2 * r + 1] = ld16(row + m * (gq + G * r));
+                pfb[2 * r + 1] = ld16(row + lstride + m * (gq + G * r));
+            }
+        } else {
+            const unsigned o = 2u * (tid & (npairs - 1));
+            const int g0 = tid >> pbits, g1 = (tid + NT) >> pbits;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                pfa[r] = ldfrom(g, act0 ? o + (unsigned)dctc::first_sample(g0, r, N) * estride : 0u);
+                pfb[r] = ldfrom(g, act1 ? o + (unsigned)dctc::first_sample(g1, r, N) * estride : 0u);
+            }
+        }
+    };
+    const int ntiles = P.ntiles;
+    // workgroup slot -> tile.  xmap: the workgroups of one XCD (slot % 8: consecutive workgroups go round-robin over the
+    // 8 XCDs) take a contiguous range of tiles, i.e. every XCD's L2 / TLB works on its own eighth of the array -- 10 % on
+    // the x / y access pattern (profiles/r2_seg_copy_512_xmap.json), nothing for z (every tile touches every plane)
+    auto slot_tile = [&](int slot) { return P.xmap ? (slot & 7) * (ntiles >> 3) + (slot >> 3) : slot; };
+    issue(slot_tile(blockIdx.x), true);                       // grid <= ntiles
+    lds_barrier();                                          // twiddle tables
+
+    for (int slot = blockIdx.x; slot < ntiles; slot += gridDim.x) {
+        const int tile = slot_tile(slot);
+        // the lane index is made opaque per tile: otherwise every tile-invariant LDS / global offset of every stage is
+        // hoisted out of the persistent loop and the kernel spills
+        asm volatile("" : "+v"(tid));
+        const bool more = slot + (int)gridDim.x < ntiles;
+        const int nxt = more ? slot_tile(slot + gridDim.x) : tile;
+        const int x0 = tile_x0(tile), other = tile_other(tile);
+        gin = tile_in(tile);
+        gout = tile_out(tile);
+        stamp(0);
+        if (MODE != 1) {
+            if (AX0) {
+                if (act0)
+                    dctc::fused_first2(z + (size_t)(tid >> hbits) * pstride, N, bits, tid & ((1 << hbits) - 1),
+                                       [&](int s, int, double& ea, double& oa, double& eb, double& ob) {
+                                           ea = pfa[s].x; oa = pfa[s].y; eb = pfb[s].x; ob = pfb[s].y;
+                                       });
+            } else {
+                c2* zp = z + (size_t)(tid & (npairs - 1)) * pstride;
+                if (act0) dctc::fused_first(zp, N, bits, tid >> pbits, [&](int r, int) { return pfa[r]; });
+                if (act1) dctc::fused_first(zp, N, bits, (tid + NT) >> pbits, [&](int r, int) { return pfb[r]; });
+            }
+            lds_barrier();
+            if (MODE == 0 && more) issue(nxt, true);
+            stamp(1);
+            for (int lh = 3; lh < bits - 3;) {
+                const int R = bits - 3 - lh >= 3 ? 3 : bits - 3 - lh;
+                middle(lh, R, false);
+                lh += R;
+            }
+            stamp(2);
+        }
+        if (MODE == 1) {
+            if (tid < nmid) {
+                const int pr = AX0 ? tid >> hbits : tid & (npairs - 1), t = AX0 ? tid & ((1 << hbits) - 1) : tid >> pbits;
+                dctc::fused_mid<1>(z + (size_t)pr * pstride, N, t, tw, ew, s0, s2,
+                                   [&](int slot, int) { return slot < 8 ? pfa[slot & 7] : pfb[slot & 7]; }, nost, nosym);
+            }
+        } else
+        for (int w = tid; w < nmid; w += NT) {
+            const int pr = AX0 ? w >> hbits : w & (npairs - 1), t = AX0 ? w & ((1 << hbits) - 1) : w >> pbits;
+            const unsigned o = AX0 ? (unsigned)(2 * pr) * lstride : 2u * pr;
+            c2* zp = z + (size_t)pr * pstride;
+            if (MODE == 2) {
+                const int i0 = x0 + 2 * pr;
+                const double la = P.lam0[i0], lb = P.lam0[i0 + 1];
+                const double lo_ = P.axis == 1 ? (P.lam2 ? P.lam2[other] : 0.0) : P.lam1[other];
+                // same association as the generic kernel: ((1 + lam0) + lam1) + lam2
+                auto sym = [&](int k) {
+                    const double lk = lamk[k];
+                    double sa, sb;
+                    if (P.axis == 1) { sa = 1.0 + la + lk + lo_; sb = 1.0 + lb + lk + lo_; }
+                    else { sa = 1.0 + la + lo_ + lk; sb = 1.0 + lb + lo_ + lk; }
+                    c2 r; r.x = rcp_nr(sa * sa + P.shift, P.nr_steps); r.y = rcp_nr(sb * sb + P.shift, P.nr_steps); return r;
+                };
+                dctc::fused_mid<2>(zp, N, t, tw, ew, s0, s2, nold, nost, sym);
+            } else if (MODE == 0) {
+                if (AX0) dctc::fused_mid<0>(zp, N, t, tw, ew, s0, s2, nold, [&](int k, c2 v) { st1(o + (unsigned)k, v); }, nosym);
+                else if (P.split == 1) dctc::fused_mid<0>(zp, N, t, tw, ew, s0, s2, nold, [&](int k, c2 v) { stg(o + P.kmap[k], v); }, nosym);
+                else dctc::fused_mid<0>(zp, N, t, tw, ew, s0, s2, nold, [&](int k, c2 v) { stg(o + (unsigned)k * estride, v); }, nosym);
+            }
+        }
+        stamp(3);
+        lds_barrier();
+        if (MODE == 0) continue;                              // (the barrier: the next tile's first stage overwrites z)
+        if (MODE == 2) issue(nxt, more);
+        else if (more) issue(nxt, true);
+        stamp(4);
+        for (int top = bits - 3; top > 3;) {
+            const int R = top - 3 >= 3 ? 3 : top - 3;
+            middle(top - R, R, true);
+            top -= R;
+        }
+        stamp(5);
         for (int w = tid; w < nfirst; w += NT) {
             if (AX0) {
                 const int pr = w >> hbits;
-                const double* row = gin + (size_t)(2 * pr) * lstride;
-                dctc::fused_first2(z + (size_t)pr * pstride, N, bits, w & ((1 << hbits) - 1),
-                                   [&](int j, double& ea, double& oa, double& eb, double& ob) {
-                                       const c2 ta = ld16(row + 2 * j);
-                                       const c2 tb = ld16(row + lstride + 2 * j);
-                                       ea = ta.x; oa = ta.y; eb = tb.x; ob = tb.y;
-                                   });
+                double* row = gout + (size_t)(2 * pr) * lstride;
+                dctc::fused_last2(z + (size_t)pr * pstride, N, bits, w & ((1 << hbits) - 1),
+                                  [&](int j, double ea, double oa, double eb, double ob) {
+                                      st16(row + 2 * j, ea, oa);
+                                      st16(row + lstride + 2 * j, eb, ob);
+                                  });
             } else {
                 const unsigned o = 2u * (w & (npairs - 1));
-                dctc::fused_first(z + (size_t)(w & (npairs - 1)) * pstride, N, bits, w >> pbits,
-                                  [&](int, int n) { return ldg(o + (unsigned)n * estride); });
+                dctc::fused_last(z + (size_t)(w & (npairs - 1)) * pstride, N, bits, w >> pbits,
+                                 [&](int n, c2 v) { stg(o + (unsigned)n * estride, v); });
             }
         }
-        __syncthreads();                                      // also covers the twiddle copy
-        stamp(1);
-        for (int lh = 3; lh < bits - 3;) {
-            const int R = bits - 3 - lh >= 3 ? 3 : bits - 3 - lh;
-            middle(lh, R, false);
-            lh += R;
-        }
-        stamp(2);
-    } else {
-        __syncthreads();                                      // twiddles
-    }
-    for (int w = tid; w < nmid; w += NT) {
-        const int pr = AX0 ? w >> hbits : w & (npairs - 1), t = AX0 ? w & ((1 << hbits) - 1) : w >> pbits;
-        const unsigned o = AX0 ? (unsigned)(2 * pr) * lstride : 2u * pr;
-        c2* zp = z + (size_t)pr * pstride;
-        if (MODE == 2) {
-            const int i0 = x0 + 2 * pr;
-            const double la = P.lam0[i0], lb = P.lam0[i0 + 1];
-            const double lo_ = P.axis == 1 ? (P.lam2 ? P.lam2[other] : 0.0) : P.lam1[other];
-            // same association as the generic kernel: ((1 + lam0) + lam1) + lam2
-            auto sym = [&](int k) {
-                const double lk = lamk[k];
-                double sa, sb;
-                if (P.axis == 1) { sa = 1.0 + la + lk + lo_; sb = 1.0 + lb + lk + lo_; }
-                else { sa = 1.0 + la + lo_ + lk; sb = 1.0 + lb + lo_ + lk; }
-                c2 r; r.x = rcp_nr(sa * sa + P.shift, P.nr_steps); r.y = rcp_nr(sb * sb + P.shift, P.nr_steps); return r;
-            };
-            dctc::fused_mid<2>(zp, N, t, tw, ew, s0, s2, nold, nost, sym);
-        } else if (MODE == 0) {
-            if (AX0) dctc::fused_mid<0>(zp, N, t, tw, ew, s0, s2, nold, [&](int k, c2 v) { st1(o + (unsigned)k, v); }, nosym);
-            else if (P.split == 1) dctc::fused_mid<0>(zp, N, t, tw, ew, s0, s2, nold, [&](int k, c2 v) { stg(o + P.kmap[k], v); }, nosym);
-            else dctc::fused_mid<0>(zp, N, t, tw, ew, s0, s2, nold, [&](int k, c2 v) { stg(o + (unsigned)k * estride, v); }, nosym);
-        } else {
-            if (AX0) dctc::fused_mid<1>(zp, N, t, tw, ew, s0, s2, [&](int, int k) { return ld1(o + (unsigned)k); }, nost, nosym);
-            else if (P.split == 2) dctc::fused_mid<1>(zp, N, t, tw, ew, s0, s2, [&](int, int k) { return ldg(o + P.kmap[k]); }, nost, nosym);
-            else dctc::fused_mid<1>(zp, N, t, tw, ew, s0, s2, [&](int, int k) { return ldg(o + (unsigned)k * estride); }, nost, nosym);
-        }
-    }
-    stamp(3);
-    if (MODE == 0) {
-        if (P.trace) { __builtin_amdgcn_s_waitcnt(0); stamp(6); }
-        return;
-    }
-    __syncthreads();
-    stamp(4);
-    for (int top = bits - 3; top > 3;) {
-        const int R = top - 3 >= 3 ? 3 : top - 3;
-        middle(top - R, R, true);
-        top -= R;
-    }
-    stamp(5);
-    for (int w = tid; w < nfirst; w += NT) {
-        if (AX0) {
-            const int pr = w >> hbits;
-            double* row = gout + (size_t)(2 * pr) * lstride;
-            dctc::fused_last2(z + (size_t)pr * pstride, N, bits, w & ((1 << hbits) - 1),
-                              [&](int j, double ea, double oa, double eb, double ob) {
-                                  st16(row + 2 * j, ea, oa);
-                                  st16(row + lstride + 2 * j, eb, ob);
-                              });
-        } else {
-            const unsigned o = 2u * (w & (npairs - 1));
-            dctc::fused_last(z + (size_t)(w & (npairs - 1)) * pstride, N, bits, w >> pbits,
-                             [&](int n, c2 v) { stg(o + (unsigned)n * estride, v); });
-        }
+        lds_barrier();                                      // the next tile overwrites z
     }
     if (P.trace) { __builtin_amdgcn_s_waitcnt(0); stamp(6); }
 }
@@ -530,6 +619,8 @@ bool dct_axis_fused_ok(bk_ctx* ctx, int n0, int n1, int n2, int axis, const doub
     const size_t rows = (size_t)n1 * n2;
     const int LT = choose_lt(N, axis, n0, rows, ctx->opt("dct_lt_wide", 1.0) != 0.0);
     if (LT != 16 && !(axis != 0 && (LT == 32 || LT == 64 || LT == 128))) return false;
+    // first-stage work items: one (axis 0) / two (axis >= 1) per lane of the 256-lane workgroup (prefetch registers)
+    if ((size_t)(LT / 2) * (N / 8) > (axis == 0 ? (size_t)512 : (size_t)512)) return false;
     if (axis == 0) return fuse_scale != 2 && rows % LT == 0 && ctx->opt("dct_fused_ax0", 1.0) != 0.0;
     return n0 % LT == 0;
 }
@@ -586,11 +677,16 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         BK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dct_fft_kernel<512>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        const void* fused[] = {reinterpret_cast<const void*>(dct_fused_kernel<256, 0, false>),
-                               reinterpret_cast<const void*>(dct_fused_kernel<256, 1, false>),
-                               reinterpret_cast<const void*>(dct_fused_kernel<256, 2, false>),
-                               reinterpret_cast<const void*>(dct_fused_kernel<256, 0, true>),
-                               reinterpret_cast<const void*>(dct_fused_kernel<256, 1, true>)};
+        const void* fused[] = {reinterpret_cast<const void*>(dct_fused_kernel<256, 0, false, false>),
+                               reinterpret_cast<const void*>(dct_fused_kernel<256, 1, false, false>),
+                               reinterpret_cast<const void*>(dct_fused_kernel<256, 2, false, false>),
+                               reinterpret_cast<const void*>(dct_fused_kernel<256, 0, true, false>),
+                               reinterpret_cast<const void*>(dct_fused_kernel<256, 1, true, false>),
+                               reinterpret_cast<const void*>(dct_fused_kernel<256, 0, false, true>),
+                               reinterpret_cast<const void*>(dct_fused_kernel<256, 1, false, true>),
+                               reinterpret_cast<const void*>(dct_fused_kernel<256, 2, false, true>),
+                               reinterpret_cast<const void*>(dct_fused_kernel<256, 0, true, true>),
+                               reinterpret_cast<const void*>(dct_fused_kernel<256, 1, true, true>)};
         for (const void* f : fused) BK_HIP(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;
     }
@@ -612,12 +708,26 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
             BK_HIP(ctx, hipMalloc(&P.trace, (size_t)grid * 8 * sizeof(long long)));
             BK_HIP(ctx, hipMemsetAsync(P.trace, 0, (size_t)grid * 8 * sizeof(long long), ctx->stream));
         }
+        // persistent workgroups: two per CU (the LDS budget), each walks over tiles b, b + grid, ...
+        P.ntiles = (int)grid;
+        P.xmap = (grid % 8 == 0 && ((int)ctx->opt("dct_xcd_map", 3.0) >> axis & 1)) ? 1 : 0;   // bit per axis; default x, y
+        const bool ntm = P.nt_load && P.nt_store;
+        const int mode = P.roundtrip ? 2 : (P.inverse ? 1 : 0);
+        {
+            // option dct_persist: bit mask of the passes that run persistent (1: x forward, 2: y/z forward, 4: round trip,
+            // 8: y/z inverse, 16: x inverse)
+            const int kind = mode == 2 ? 4 : (mode == 0 ? (axis == 0 ? 1 : 2) : (axis == 0 ? 16 : 8));
+            const unsigned pgrid = (unsigned)ctx->opt("dct_grid", 2.0 * ctx->num_cu);
+            if (((int)ctx->opt("dct_persist", 0.0) & kind) && pgrid >= 1 && pgrid < grid) grid = pgrid;
+        }
+#define BK_DCT_LAUNCH(M, A, T) hipLaunchKernelGGL((dct_fused_kernel<256, M, A, T>), dim3(grid), dim3(256), ldsf, ctx->stream, P)
         if (axis == 0) {
-            if (P.inverse) hipLaunchKernelGGL((dct_fused_kernel<256, 1, true>), dim3(grid), dim3(256), ldsf, ctx->stream, P);
-            else hipLaunchKernelGGL((dct_fused_kernel<256, 0, true>), dim3(grid), dim3(256), ldsf, ctx->stream, P);
-        } else if (P.roundtrip) hipLaunchKernelGGL((dct_fused_kernel<256, 2, false>), dim3(grid), dim3(256), ldsf, ctx->stream, P);
-        else if (P.inverse) hipLaunchKernelGGL((dct_fused_kernel<256, 1, false>), dim3(grid), dim3(256), ldsf, ctx->stream, P);
-        else hipLaunchKernelGGL((dct_fused_kernel<256, 0, false>), dim3(grid), dim3(256), ldsf, ctx->stream, P);
+            if (mode == 1) { if (ntm) BK_DCT_LAUNCH(1, true, true); else BK_DCT_LAUNCH(1, true, false); }
+            else { if (ntm) BK_DCT_LAUNCH(0, true, true); else BK_DCT_LAUNCH(0, true, false); }
+        } else if (mode == 2) { if (ntm) BK_DCT_LAUNCH(2, false, true); else BK_DCT_LAUNCH(2, false, false); }
+        else if (mode == 1) { if (ntm) BK_DCT_LAUNCH(1, false, true); else BK_DCT_LAUNCH(1, false, false); }
+        else { if (ntm) BK_DCT_LAUNCH(0, false, true); else BK_DCT_LAUNCH(0, false, false); }
+#undef BK_DCT_LAUNCH
         BK_HIP(ctx, hipGetLastError());
         if (trace) {
             // phase durations (wall_clock64 ticks of 10 ns) averaged over the tiles: stamps 0 start, 1 first stage done,

@@ -22,9 +22,36 @@ inline int grid_for(size_t n, int per_thread, int max_blocks) {
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// Index range of a streaming kernel's workgroup over n2 16-byte items.  xcd != 0: consecutive workgroups are dispatched
+// round-robin over the 8 XCDs, so workgroup b sits on XCD b % 8; each XCD then streams through its own contiguous eighth
+// of the vector (its 4 MiB L2 and its TLB see one region instead of 4-KiB pieces of the whole array) -- the grid is a
+// multiple of 8 and the eighths are multiples of kThreads items (4 KiB).  Otherwise: the plain grid-stride walk.
+struct StreamRange { size_t lo, hi, step; };
+__device__ __forceinline__ StreamRange stream_range(size_t n2, unsigned xcd) {
+    StreamRange r;
+    if (xcd) {
+        const size_t x = blockIdx.x & 7u, lb = blockIdx.x >> 3, nb = gridDim.x >> 3;
+        const size_t per = ((n2 + 7) / 8 + kThreads - 1) / kThreads * kThreads;
+        const size_t b0 = x * per < n2 ? x * per : n2, b1 = (x + 1) * per < n2 ? (x + 1) * per : n2;
+        r.lo = b0 + lb * kThreads + threadIdx.x; r.hi = b1; r.step = nb * kThreads;
+    } else {
+        r.lo = (size_t)blockIdx.x * kThreads + threadIdx.x; r.hi = n2; r.step = (size_t)gridDim.x * kThreads;
+    }
+    return r;
+}
+
 // non-temporal hint only for vectors that cannot live in the caches anyway (>= 32 MiB): the cache-resident 2-D configs keep
 // their operands in L2 / Infinity Cache between kernels
 inline bool nt_hint(bk_ctx* ctx, size_t n) { return n >= ((size_t)1 << 22) && ctx->opt("nt_hint", 1.0) != 0.0; }
+
+// XCD-blocked streaming (stream_range) for the same big vectors.  Measured at 512^3 (profiles/r2_xcd_streaming_512.jsonl):
+// multiaxpy gains 3-4 % from k = 12 streams on and loses 6 % at k = 8, multidot loses 10 % at every k >= 8 -- so the default
+// (option vec_xcd_map = 1) blocks only the multiaxpy with k >= 12; 2 = every launch, 0 = never.
+inline unsigned xcd_map(bk_ctx* ctx, size_t n, int grid, bool axpy, int k) {
+    const int mode = (int)ctx->opt("vec_xcd_map", 1.0);
+    if (!(nt_hint(ctx, n) && grid >= 8 && grid % 8 == 0) || mode == 0) return 0u;
+    return (mode >= 2 || (axpy && k >= 12)) ? 1u : 0u;
+}
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -234,7 +261,8 @@ __global__ void __launch_bounds__(kThreads) absmax_kernel(size_t n, const double
 template <int KB, int VEC, bool LDNT = false>
 __global__ void __launch_bounds__(kThreads) multidot_kernel(size_t n, const double* __restrict__ V, size_t ldv, int k,
                                                             const double* __restrict__ w,
-                                                            double* __restrict__ partials, const double* gate = nullptr) {
+                                                            double* __restrict__ partials, const double* gate = nullptr,
+                                                            unsigned xcd = 0) {
     if (gate && gate[0] == 0.0) return;        // device-resident Arnoldi: the DGKS second pass is not needed
     double acc[KB];
 #pragma unroll
@@ -242,8 +270,8 @@ __global__ void __launch_bounds__(kThreads) multidot_kernel(size_t n, const doub
     double ww = 0.0;
     const size_t stride = (size_t)gridDim.x * kThreads;
     if (VEC == 2) {
-        const size_t n2 = n >> 1;
-        for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += stride) {
+        const StreamRange rg = stream_range(n >> 1, xcd);
+        for (size_t i = rg.lo; i < rg.hi; i += rg.step) {
             const double2 wv = ld2<LDNT>(w, i);
             ww = fma(wv.x, wv.x, ww); ww = fma(wv.y, wv.y, ww);
 #pragma unroll
@@ -294,12 +322,12 @@ __global__ void __launch_bounds__(kThreads) multidot_kernel(size_t n, const doub
 template <int KB, int VEC, bool NT = false, bool LDNT = false, int U = 1>
 __global__ void __launch_bounds__(kThreads) multiaxpy_kernel(size_t n, const double* __restrict__ V, size_t ldv, int k,
                                                              Coefs cf, const double* src, double scale, double* dst,
-                                                             int want_norm, double* __restrict__ partials) {
-    const size_t stride = (size_t)gridDim.x * kThreads;
+                                                             int want_norm, double* __restrict__ partials, unsigned xcd = 0) {
     double nn = 0.0;
     if (VEC == 2) {
-        const size_t n2 = n >> 1;
-        for (size_t i0 = (size_t)blockIdx.x * kThreads + threadIdx.x; i0 < n2; i0 += stride * U) {
+        const StreamRange rg = stream_range(n >> 1, xcd);
+        const size_t n2 = rg.hi, stride = rg.step;
+        for (size_t i0 = rg.lo; i0 < n2; i0 += stride * U) {
             double2 r[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -344,6 +372,7 @@ __global__ void __launch_bounds__(kThreads) multiaxpy_kernel(size_t n, const dou
             nn = fma(r, r, nn);
         }
     } else {
+        const size_t stride = (size_t)gridDim.x * kThreads;
         for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
             double r = src ? src[i] : 0.0;
 #pragma unroll
@@ -624,7 +653,8 @@ int v_nrminf(bk_ctx* ctx, size_t n, const double* x, double* out) {
 
 template <int KB>
 static void launch_multidot(bk_ctx* ctx, bool vec, int grid, size_t n, const double* V, size_t ldv, int k, const double* w) {
-    if (vec && nt_hint(ctx, n) && ctx->opt("dot_variant", 1.0) == 1.0) hipLaunchKernelGGL((multidot_kernel<KB, 2, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, w, ctx->d_partials);
+    const unsigned xcd = xcd_map(ctx, n, grid, false, k);
+    if (vec && nt_hint(ctx, n) && ctx->opt("dot_variant", 1.0) == 1.0) hipLaunchKernelGGL((multidot_kernel<KB, 2, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, w, ctx->d_partials, (const double*)nullptr, xcd);
     else if (vec) hipLaunchKernelGGL((multidot_kernel<KB, 2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, w, ctx->d_partials);
     else hipLaunchKernelGGL((multidot_kernel<KB, 1>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, w, ctx->d_partials);
 }
@@ -654,9 +684,10 @@ static void launch_multiaxpy(bk_ctx* ctx, bool vec, int grid, size_t n, const do
                              const double* src, double scale, double* dst, int want_norm) {
     const bool nt = ctx->opt("axpy_nt", 1.0) != 0.0;       // non-temporal store of the one output stream: +1.5 % at 512^3
     const int variant = nt_hint(ctx, n) ? (int)ctx->opt("axpy_variant", 3.0) : 0; // 0 plain loads, 1 non-temporal loads of the basis, 2 two elements per lane, 3 both (default)
-    if (vec && variant == 1) hipLaunchKernelGGL((multiaxpy_kernel<KB, 2, true, true, 1>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials);
-    else if (vec && variant == 2) hipLaunchKernelGGL((multiaxpy_kernel<KB, 2, true, false, 2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials);
-    else if (vec && variant == 3) hipLaunchKernelGGL((multiaxpy_kernel<KB, 2, true, true, 2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials);
+    const unsigned xcd = xcd_map(ctx, n, grid, true, k);
+    if (vec && variant == 1) hipLaunchKernelGGL((multiaxpy_kernel<KB, 2, true, true, 1>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials, xcd);
+    else if (vec && variant == 2) hipLaunchKernelGGL((multiaxpy_kernel<KB, 2, true, false, 2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials, xcd);
+    else if (vec && variant == 3) hipLaunchKernelGGL((multiaxpy_kernel<KB, 2, true, true, 2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials, xcd);
     else if (vec && nt) hipLaunchKernelGGL((multiaxpy_kernel<KB, 2, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials);
     else if (vec) hipLaunchKernelGGL((multiaxpy_kernel<KB, 2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials);
     else hipLaunchKernelGGL((multiaxpy_kernel<KB, 1>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials);

@@ -169,6 +169,24 @@ if "variants" in what:
             report("dct_precond", t, 80.0 * N, rcp_steps=steps, rel_diff_vs_2steps=err, rep=rep)
     ctx.set_option("dct_rcp_steps", 2)
 
+if "xcd" in what:
+    # XCD-blocked streaming (vec_xcd_map) A/B, interleaved repetitions
+    ld = (N + 31) // 32 * 32
+    V = torch.rand(ld * 16, dtype=torch.float64, device="cuda", generator=g)
+    hbuf = (C.c_double * 65)()
+    for k in (4, 8, 12, 16):
+        cc = (C.c_double * k)(*([0.01] * k))
+        fa = lambda: ctx.check(ctx.lib.bk_krylov_multiaxpy(ctx.h, N, C.c_void_p(V.data_ptr()), ld, k, cc, C.c_void_p(v.t.data_ptr()),
+                                                           1.0, C.c_void_p(out.t.data_ptr()), None))
+        fd = lambda: ctx.check(ctx.lib.bk_krylov_multidot(ctx.h, N, C.c_void_p(V.data_ptr()), ld, k, C.c_void_p(v.t.data_ptr()), hbuf))
+        for rep in range(2):
+            for m in (0, 2):
+                ctx.set_option("vec_xcd_map", m)
+                report("multiaxpy", timeit(fa, reps=5, warm=1), 8.0 * N * (k + 2), k=k, xcd_map=m, rep=rep)
+                report("multidot", timeit(fd, reps=5, warm=1), 8.0 * N * (k + 1), k=k, xcd_map=m, rep=rep)
+    ctx.set_option("vec_xcd_map", 1)
+    del V
+
 if "jvp2" in what:
     J = prob.jacobian(u, 0.1)
     lib = ctx.lib

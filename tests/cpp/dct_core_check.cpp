@@ -54,7 +54,7 @@ int main() {
         if (fused != 2) {                                  // forward or roundtrip: first stage from the samples
             if (contiguous)
                 for (int gp = 0; gp < N / 16; ++gp)
-                    fused_first2(z.data(), N, bits, gp, [&](int j, double& ea, double& oa, double& eb, double& ob) {
+                    fused_first2(z.data(), N, bits, gp, [&](int, int j, double& ea, double& oa, double& eb, double& ob) {
                         ea = a[2 * j]; oa = a[2 * j + 1]; eb = b[2 * j]; ob = b[2 * j + 1];
                     });
             else
