@@ -435,13 +435,19 @@ BK_HD void mid_pair(c2& x, c2& y, int k, int N, const c2* ew, double hs2, double
     if (UPPER) { en = t; e.x = -t.y; e.y = -t.x; }
     else { e = t; en.x = -t.y; en.y = -t.x; }
     c2 X = x, Y = y;
-    if (MODE != 1) { X = post_one(x, y, e, hs2); Y = post_one(y, x, en, hs2); }
     if (MODE == 2) {
+        // round trip: the forward scale hs2 and the inverse scale f2 are folded into the symbol (8 multiplications per
+        // pair instead of 16); post_one / pre_one run unscaled
+        const double c = hs2 * f2;
+        X = post_one(x, y, e, 1.0); Y = post_one(y, x, en, 1.0);
         c2 f = sym(k);
-        X.x *= f.x; X.y *= f.y;
+        X.x *= f.x * c; X.y *= f.y * c;
         f = sym(N - k);
-        Y.x *= f.x; Y.y *= f.y;
+        Y.x *= f.x * c; Y.y *= f.y * c;
+        x = pre_one(X, Y, e, 1.0, 1.0); y = pre_one(Y, X, en, 1.0, 1.0);
+        return;
     }
+    if (MODE != 1) { X = post_one(x, y, e, hs2); Y = post_one(y, x, en, hs2); }
     if (MODE != 0) { x = pre_one(X, Y, e, f2, f2); y = pre_one(Y, X, en, f2, f2); }
     else { x = X; y = Y; }
 }

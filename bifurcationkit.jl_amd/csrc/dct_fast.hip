@@ -48,7 +48,6 @@ struct FftK {
     int split;
     long long* trace;         // debug (option dct_trace): per-tile phase timestamps, 8 per workgroup, or NULL
     int fast;                 // full tiles, power-of-two shapes, < 2^31 elements: incremental addressing (host-checked)
-    int nr_steps;             // Newton steps after v_rcp_f64 in the fused symbol (option dct_rcp_steps, default 2)
     int nt_load, nt_store;    // fused kernel: non-temporal hint on the tile loads / stores (every element is touched once)
     int ntiles;               // fused kernel: tiles of the pass (persistent workgroups loop over them)
     int xmap;                 // fused kernel: XCD-contiguous slot -> tile map (ntiles % 8 == 0)
@@ -496,6 +495,18 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
         gin = tile_in(tile);
         gout = tile_out(tile);
         stamp(0);
+        // MODE 2: per-line constants of the inverse symbol, requested here so that the loads are long back when the merged
+        // middle needs them.  Same association as the generic kernel, ((1 + lam0) + lam1) + lam2, in one form for both
+        // axes: the per-line constant first, the last-axis eigenvalue per k, then lam2 (y pass of a 3-D array) or an exact
+        // + 0.0.  (One merged-middle item per lane: nmid <= NT, host-checked.)
+        double ca = 0.0, cb = 0.0, lo2 = 0.0;
+        if (MODE == 2) {
+            const int i0 = x0 + 2 * (tid & (npairs - 1));
+            const double l1 = P.axis == 1 ? 0.0 : P.lam1[other];
+            lo2 = P.axis == 1 ? (P.lam2 ? P.lam2[other] : 0.0) : 0.0;
+            ca = 1.0 + P.lam0[i0] + l1;
+            cb = 1.0 + P.lam0[i0 + 1] + l1;
+        }
         if (MODE != 1) {
             if (AX0) {
                 if (act0)
@@ -530,16 +541,10 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
             const unsigned o = AX0 ? (unsigned)(2 * pr) * lstride : 2u * pr;
             c2* zp = z + (size_t)pr * pstride;
             if (MODE == 2) {
-                const int i0 = x0 + 2 * pr;
-                const double la = P.lam0[i0], lb = P.lam0[i0 + 1];
-                const double lo_ = P.axis == 1 ? (P.lam2 ? P.lam2[other] : 0.0) : P.lam1[other];
-                // same association as the generic kernel: ((1 + lam0) + lam1) + lam2
                 auto sym = [&](int k) {
                     const double lk = lamk[k];
-                    double sa, sb;
-                    if (P.axis == 1) { sa = 1.0 + la + lk + lo_; sb = 1.0 + lb + lk + lo_; }
-                    else { sa = 1.0 + la + lo_ + lk; sb = 1.0 + lb + lo_ + lk; }
-                    c2 r; r.x = rcp_nr(sa * sa + P.shift, P.nr_steps); r.y = rcp_nr(sb * sb + P.shift, P.nr_steps); return r;
+                    const double sa = ca + lk + lo2, sb = cb + lk + lo2;
+                    c2 r; r.x = rcp_nr(sa * sa + P.shift, 2); r.y = rcp_nr(sb * sb + P.shift, 2); return r;
                 };
                 dctc::fused_mid<2>(zp, N, t, tw, ew, s0, s2, nold, nost, sym);
             } else if (MODE == 0) {
@@ -663,7 +668,6 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
     }
     P.pairvec = (axis != 0 && (n0 % 2 == 0) && (((uintptr_t)in | (uintptr_t)out) & 15) == 0) ? 1 : 0;
     P.fast = 0;            // decided after the thread count is known
-    P.nr_steps = (int)ctx->opt("dct_rcp_steps", 2.0);
     {
         const bool big = (size_t)n0 * n1 * n2 >= ((size_t)1 << 22);
         P.nt_load = big && ctx->opt("dct_nt_load", 1.0) != 0.0;
