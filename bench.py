@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--no-steady", action="store_true", help="skip the steady-state record (corrector of a running branch)")
     ap.add_argument("--nev", type=int, default=15)
     ap.add_argument("--eig-tol", type=float, default=1e-8)
+    ap.add_argument("--eig-sigma", type=float, default=0.1, help="branch workload: shift of the shift-invert eigensolver (SH3d.jl: 0.1)")
     ap.add_argument("--eig-dim", type=int, default=0, help="Krylov dimension of the eigensolver (0: max(30, nev + 30), examples/SH3d.jl:109)")
     ap.add_argument("--eig-inner-rtol", type=float, default=1e-9, help="branch workload: rtol of the eigensolver's inner solves (SH3d.jl:115: 1e-9)")
     ap.add_argument("--eig-thick", type=int, default=1, help="branch workload: eigensolve starts from the previous step's Ritz vectors")
@@ -496,7 +497,7 @@ def run_branch_workload(args, ctx, hip, Cn, prob, P, ls, u0, branch_setup, barri
     import torch
     els = (hip.KrylovLSSymmetric("minres", rtol=args.eig_inner_rtol, atol=1e-12, itmax=4000, Pl=P) if args.eig_inner == "minres"
            else hip.GMRESKrylovKit(dim=30, rtol=args.eig_inner_rtol, atol=1e-12, maxiter=150, Pl=P))
-    eig = hip.ShiftInvert(0.1, els, tol=args.eig_tol, maxiter=20, hermitian=True, save_vectors=False,
+    eig = hip.ShiftInvert(args.eig_sigma, els, tol=args.eig_tol, maxiter=20, hermitian=True, save_vectors=False,
                           krylovdim=args.eig_dim if args.eig_dim > 0 else None)
     cp, alg = branch_setup(eig)
     cp.max_steps = args.steps
@@ -536,7 +537,7 @@ def run_branch_workload(args, ctx, hip, Cn, prob, P, ls, u0, branch_setup, barri
             "steps": nst, "warmup": 0, "ms_per_step": t_steps / max(nst, 1) * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"SH3d {n}^3 PALC branch (BASELINE config 5): corrector + {args.nev} eigenvalues "
-                                   f"(ShiftInvert sigma 0.1, Krylov-Schur dim {args.eig_dim if args.eig_dim > 0 else max(30, args.nev + 30)}, tol {args.eig_tol:g}, inner "
+                                   f"(ShiftInvert sigma {args.eig_sigma:g}, Krylov-Schur dim {args.eig_dim if args.eig_dim > 0 else max(30, args.nev + 30)}, tol {args.eig_tol:g}, inner "
                                    f"{args.eig_inner} rtol {args.eig_inner_rtol:g}, thick start {args.eig_thick}) + Bordered tangent + "
                                    f"predictor per step",
                        "grid": [n, n, n], "tiles": list(tiles), "parallelism": f"z-slabs x{world}",
