@@ -216,6 +216,11 @@ int bk_bls_bordering(bk_ctx* ctx, bk_op* J, const double* dR, const double* dzu,
                      double shift, double dotscale, const bk_bordering_opts* bopts,
                      const bk_gmres_opts* lsopts, bk_precond* pl, double* dX, double* dl,
                      int* converged, int itlinear[2]);                   /* BorderingBLS :88-166 */
+/* Iteration accounting with check_precision (k refinement passes, :111-121): the reference's BEC solves
+ * (shift I + J) x = dR again on every pass (:134) and returns the counts of the LAST pass.  dR does not change between
+ * the passes, so this implementation solves it once and reports that solve's count and flag for every pass -- the same
+ * numbers the repeated (deterministic) solve would return, at one solve less per pass; itlinear[0] is the last pass's
+ * solve with the refreshed right-hand side, as in the reference.                                                      */
 int bk_bls_matrixfree(bk_ctx* ctx, bk_op* J, const double* dR, const double* dzu, double dzp,
                       const double* R, double n, double xiu, double xip, int has_shift,
                       double shift, double dotscale, const bk_gmres_opts* lsopts, double* dX,
