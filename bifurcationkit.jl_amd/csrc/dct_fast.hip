@@ -49,7 +49,7 @@ struct FftK {
     long long* trace;         // debug (option dct_trace): per-tile phase timestamps, 8 per workgroup, or NULL
     int fast;                 // full tiles, power-of-two shapes, < 2^31 elements: incremental addressing (host-checked)
     int nt_load, nt_store;    // fused kernel: non-temporal hint on the tile loads / stores (every element is touched once)
-    int ntiles;               // fused kernel: tiles of the pass (persistent workgroups loop over them)
+    int ntiles;               // fused kernel: tiles of the pass (= workgroups)
     int xmap;                 // fused kernel: XCD-contiguous slot -> tile map (ntiles % 8 == 0)
 };
 
@@ -334,11 +334,11 @@ __device__ __forceinline__ void lds_barrier() {
 
 // AX0: the transform runs along the contiguous index (a tile is LT consecutive rows); lanes then walk along the row
 // (dct_core.h: fused_first2 / fused_last2) instead of across the LT lines.
-// Persistent workgroups: the grid is two workgroups per CU, each walks over tiles blockIdx.x, blockIdx.x + gridDim.x, ...
-// (twiddle tables are staged once), and the samples of the NEXT tile's first radix-8 stage are requested into
-// registers while the current tile is still in its LDS / store phases (MODE 0: right after the first stage, MODE 2:
-// after the merged middle, where the register pressure has dropped), so that the HBM latency of the tile loads is not
-// on the per-tile critical path.  NTM: non-temporal tile loads / stores (every element is touched once).
+// One tile per workgroup.  The tile's global loads (first-stage samples; MODE 1: the spectral pairs of the merged
+// middle) are requested into registers before the twiddle tables are staged, so that the two latencies overlap.
+// (A persistent variant -- two workgroups per CU walking over the tiles with the next tile's samples prefetched across
+// the LDS phases -- was measured 5-12 % slower in every pass, also with only 2 tiles per workgroup: DESIGN.md section 4;
+// it lived in this file up to commit 96342eb.)  NTM: non-temporal tile loads / stores (every element is touched once).
 template <int NT, int MODE, bool AX0, bool NTM>   // MODE 0: forward, 1: inverse, 2: forward - symbol - inverse (AX0: 0 / 1 only)
 __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
     c2* tw = z + (size_t)npairs * pstride;                    // N/2 FFT twiddles
     c2* ew = tw + (N >> 1);                                   // N/2 + 1 post twiddles exp(-i pi k / 2N), k <= N/2
     double* lamk = reinterpret_cast<double*>(ew + (N >> 1) + 2);   // MODE 2: eigenvalues along the transform axis
-    int tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int nfirst = AX0 ? npairs * (G >> 1) : npairs * G;  // work items of the outer stages ...
     const int nmid = npairs * (G >> 1);                       // ... and of the merged middle
     const int hbits = bits - 4;                               // log2(G / 2)
@@ -369,7 +369,6 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
     auto tile_sbase = [&](int tile) { return (size_t)tile_x0(tile) + (size_t)tile_other(tile) * P.split_plane; };
     auto tile_in = [&](int tile) { return P.in + (!AX0 && P.split == 2 ? tile_sbase(tile) : tile_base(tile)); };
     auto tile_out = [&](int tile) { return P.out + (!AX0 && P.split == 1 ? tile_sbase(tile) : tile_base(tile)); };
-    const double* gin = nullptr;
     double* gout = nullptr;
     typedef double nt_d2 __attribute__((ext_vector_type(2)));
     auto ld16 = [&](const double* p) {
@@ -385,7 +384,6 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
     auto ldfrom = [&](const double* g, unsigned el) {
         return ld16(reinterpret_cast<const double*>(reinterpret_cast<const char*>(g) + (size_t)(el * 8u)));
     };
-    auto ldg = [&](unsigned el) { return ldfrom(gin, el); };
     auto stg = [&](unsigned el, c2 v) {
         st16(reinterpret_cast<double*>(reinterpret_cast<char*>(gout) + (size_t)(el * 8u)), v.x, v.y);
     };
@@ -395,9 +393,6 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
         if (P.trace && tid == 0) P.trace[(size_t)blockIdx.x * 8 + i] = (long long)wall_clock64();
     };
 
-    for (int q = tid; q < N + 1; q += NT) tw[q] = reinterpret_cast<const c2*>(P.twid)[q];
-    if (MODE == 2)
-        for (int q = tid; q < N; q += NT) lamk[q] = (P.axis == 1 ? P.lam1 : P.lam2)[q];
 
     const double s0 = sqrt(1.0 / N), s2 = sqrt(2.0 / N);
     auto middle = [&](int lh, int R, bool inv) {
@@ -427,13 +422,11 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
     c2 pfa[8], pfb[8];
     // (the host launches this kernel only when nfirst <= NT (AX0) / 2 NT, so the two register sets cover the tile)
     const bool act0 = tid < nfirst, act1 = !AX0 && tid + NT < nfirst;
-    auto issue = [&](int tile, bool real) {
-        // every lane requests unconditionally (idle lanes, and all lanes after the last tile (!real), re-read element 0 of
-        // the tile): a guarded request would carry the previous tile's registers through the merged middle as the "not
-        // taken" value and the kernel would spill
+    auto issue = [&](int tile) {
+        // every lane requests unconditionally (idle lanes re-read element 0 of the tile)
         const double* g = tile_in(tile);
         if (MODE == 1) {                                      // the 8 + 8 spectral pairs of this lane's merged-middle item
-            const bool act = real && tid < nmid;
+            const bool act = tid < nmid;
             const int pr = AX0 ? tid >> hbits : tid & (npairs - 1), t = AX0 ? tid & ((1 << hbits) - 1) : tid >> pbits;
             const unsigned o = AX0 ? (unsigned)(2 * pr) * lstride : 2u * pr;
             const int ga = t, gb = t == 0 ? (G >> 1) : G - t;
@@ -454,7 +447,6 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
             }
             return;
         }
-        const bool act0 = real && tid < nfirst, act1 = real && !AX0 && tid + NT < nfirst;
         if (AX0) {
             const int gp = tid & ((1 << hbits) - 1), gq = (G - 1) - gp;
             const double* row = g + (act0 ? (size_t)(2 * (tid >> hbits)) * lstride : (size_t)0);
@@ -481,18 +473,18 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
     // 8 XCDs) take a contiguous range of tiles, i.e. every XCD's L2 / TLB works on its own eighth of the array -- 10 % on
     // the x / y access pattern (profiles/r2_seg_copy_512_xmap.json), nothing for z (every tile touches every plane)
     auto slot_tile = [&](int slot) { return P.xmap ? (slot & 7) * (ntiles >> 3) + (slot >> 3) : slot; };
-    issue(slot_tile(blockIdx.x), true);                       // grid <= ntiles
-    lds_barrier();                                          // twiddle tables
-
-    for (int slot = blockIdx.x; slot < ntiles; slot += gridDim.x) {
-        const int tile = slot_tile(slot);
-        // the lane index is made opaque per tile: otherwise every tile-invariant LDS / global offset of every stage is
-        // hoisted out of the persistent loop and the kernel spills
-        asm volatile("" : "+v"(tid));
-        const bool more = slot + (int)gridDim.x < ntiles;
-        const int nxt = more ? slot_tile(slot + gridDim.x) : tile;
+    {
+        const int tile = slot_tile(blockIdx.x);
+        // Order of the loads: the twiddle tables (L2 hits) are staged first, then the tile's samples are requested and every
+        // wave consumes its own samples as they arrive.  Requesting the tile first and the tables behind it -- in either
+        // form, tables stored before or after the first stage -- costs 20-30 % in every pass (measured): the in-order return
+        // puts the short table loads behind 16 HBM loads per lane.
+        for (int q = tid; q < N + 1; q += NT) tw[q] = reinterpret_cast<const c2*>(P.twid)[q];
+        if (MODE == 2)
+            for (int q = tid; q < N; q += NT) lamk[q] = (P.axis == 1 ? P.lam1 : P.lam2)[q];
+        issue(tile);
+        lds_barrier();
         const int x0 = tile_x0(tile), other = tile_other(tile);
-        gin = tile_in(tile);
         gout = tile_out(tile);
         stamp(0);
         // MODE 2: per-line constants of the inverse symbol, requested here so that the loads are long back when the merged
@@ -520,7 +512,6 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
                 if (act1) dctc::fused_first(zp, N, bits, (tid + NT) >> pbits, [&](int r, int) { return pfb[r]; });
             }
             lds_barrier();
-            if (MODE == 0 && more) issue(nxt, true);
             stamp(1);
             for (int lh = 3; lh < bits - 3;) {
                 const int R = bits - 3 - lh >= 3 ? 3 : bits - 3 - lh;
@@ -554,10 +545,11 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
             }
         }
         stamp(3);
+        if (MODE == 0) {
+            if (P.trace) { __builtin_amdgcn_s_waitcnt(0); stamp(6); }
+            return;
+        }
         lds_barrier();
-        if (MODE == 0) continue;                              // (the barrier: the next tile's first stage overwrites z)
-        if (MODE == 2) issue(nxt, more);
-        else if (more) issue(nxt, true);
         stamp(4);
         for (int top = bits - 3; top > 3;) {
             const int R = top - 3 >= 3 ? 3 : top - 3;
@@ -580,7 +572,6 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
                                  [&](int n, c2 v) { stg(o + (unsigned)n * estride, v); });
             }
         }
-        lds_barrier();                                      // the next tile overwrites z
     }
     if (P.trace) { __builtin_amdgcn_s_waitcnt(0); stamp(6); }
 }
@@ -712,18 +703,10 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
             BK_HIP(ctx, hipMalloc(&P.trace, (size_t)grid * 8 * sizeof(long long)));
             BK_HIP(ctx, hipMemsetAsync(P.trace, 0, (size_t)grid * 8 * sizeof(long long), ctx->stream));
         }
-        // persistent workgroups: two per CU (the LDS budget), each walks over tiles b, b + grid, ...
         P.ntiles = (int)grid;
         P.xmap = (grid % 8 == 0 && ((int)ctx->opt("dct_xcd_map", 3.0) >> axis & 1)) ? 1 : 0;   // bit per axis; default x, y
         const bool ntm = P.nt_load && P.nt_store;
         const int mode = P.roundtrip ? 2 : (P.inverse ? 1 : 0);
-        {
-            // option dct_persist: bit mask of the passes that run persistent (1: x forward, 2: y/z forward, 4: round trip,
-            // 8: y/z inverse, 16: x inverse)
-            const int kind = mode == 2 ? 4 : (mode == 0 ? (axis == 0 ? 1 : 2) : (axis == 0 ? 16 : 8));
-            const unsigned pgrid = (unsigned)ctx->opt("dct_grid", 2.0 * ctx->num_cu);
-            if (((int)ctx->opt("dct_persist", 0.0) & kind) && pgrid >= 1 && pgrid < grid) grid = pgrid;
-        }
 #define BK_DCT_LAUNCH(M, A, T) hipLaunchKernelGGL((dct_fused_kernel<256, M, A, T>), dim3(grid), dim3(256), ldsf, ctx->stream, P)
         if (axis == 0) {
             if (mode == 1) { if (ntm) BK_DCT_LAUNCH(1, true, true); else BK_DCT_LAUNCH(1, true, false); }
