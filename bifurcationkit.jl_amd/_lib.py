@@ -134,6 +134,7 @@ SIGNATURES = {
     "bk_op_apply": (I, [VP, VP, D, D, VP]),
     "bk_precond_sh_create": (I, [VP, D, C.POINTER(VP)]),
     "bk_precond_lap_create": (I, [VP, D, C.POINTER(VP)]),
+    "bk_precond_cgl_create": (I, [VP, D, D, C.POINTER(VP)]),
     "bk_precond_destroy": (I, [VP]),
     "bk_precond_apply": (I, [VP, VP, VP]),
     "bk_gmres_default_opts": (None, [C.POINTER(GmresOpts), I]),

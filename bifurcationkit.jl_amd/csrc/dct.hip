@@ -38,7 +38,9 @@ struct DctPlan {
     double* t1 = nullptr;
     double* t2 = nullptr;
     size_t total = 0;
-    int kind = 0;                             // 0: DCT-II / SH symbol 1/((1+sum lam)^2 + shift); 1: DST-I / 1/(sum lam - shift)
+    int kind = 0;                             // 0: DCT-II / SH symbol 1/((1+sum lam)^2 + shift); 1: DST-I / 1/(sum lam - shift);
+                                              // 2: DST-I, 2x2 block symbol of the two cGL fields (blk_a, blk_b)
+    double blk_a = 0.0, blk_b = 0.0;
     int batch = 1;                            // stacked fields sharing the transform (cGL: 2)
     // distributed (z-slab) variant: transposes to y-slabs for the z pass
     bool dist = false;
@@ -124,6 +126,23 @@ __global__ void __launch_bounds__(256) spectral_scale_lap_kernel(int n0, int n1,
     const int i0 = (int)(idx % n0);
     const int i1 = (int)((idx / n0) % n1);
     a[idx] = a[idx] / (lx[i0] + ly[i1] - c);
+}
+
+// cGL block symbol: per sine mode the two stacked fields are coupled by [[m, -b], [b, m]], m = lam_x + lam_y + a;
+// (x1, x2) <- [[m, b], [-b, m]] (x1, x2) / (m^2 + b^2).  b != 0 keeps the block invertible also where m = 0.
+__global__ void __launch_bounds__(256) spectral_block_cgl_kernel(int n0, int n1, const double* __restrict__ lx,
+                                                                 const double* __restrict__ ly, double a, double b,
+                                                                 double* __restrict__ t) {
+    const size_t n = (size_t)n0 * n1;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int i0 = (int)(idx % n0);
+    const int i1 = (int)(idx / n0);
+    const double m = lx[i0] + ly[i1] + a;
+    const double x1 = t[idx], x2 = t[idx + n];
+    const double d = 1.0 / (m * m + b * b);
+    t[idx] = (m * x1 + b * x2) * d;
+    t[idx + n] = (m * x2 - b * x1) * d;
 }
 
 }  // namespace
@@ -303,8 +322,14 @@ static int dst_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out) {
     };
     BK_TRY(pass(0, v, p->t1));
     BK_TRY(pass(1, p->t1, p->t2));
-    hipLaunchKernelGGL(spectral_scale_lap_kernel, dim3(grid), dim3(256), 0, ctx->stream, n0, n1, nb, p->lam[0], p->lam[1],
-                       p->shift, p->t2);
+    if (p->kind == 2) {
+        const unsigned g2 = (unsigned)(((size_t)n0 * n1 + 255) / 256);
+        hipLaunchKernelGGL(spectral_block_cgl_kernel, dim3(g2), dim3(256), 0, ctx->stream, n0, n1, p->lam[0], p->lam[1],
+                           p->blk_a, p->blk_b, p->t2);
+    } else {
+        hipLaunchKernelGGL(spectral_scale_lap_kernel, dim3(grid), dim3(256), 0, ctx->stream, n0, n1, nb, p->lam[0], p->lam[1],
+                           p->shift, p->t2);
+    }
     BK_HIP(ctx, hipGetLastError());
     BK_TRY(pass(1, p->t2, p->t1));
     BK_TRY(pass(0, p->t1, out));
@@ -612,7 +637,7 @@ struct ShDctPrecond : bk_precond {
     DctPlan* plan = nullptr;
     ~ShDctPrecond() override { dct_plan_destroy(plan); }
     int apply(const double* v, double* out) override {
-        if (plan->kind == 1) return dst_apply(ctx, plan, v, out);
+        if (plan->kind >= 1) return dst_apply(ctx, plan, v, out);
         return plan->dist ? dct_apply_dist(ctx, plan, v, out) : dct_apply(ctx, plan, v, out);
     }
 };
@@ -657,6 +682,24 @@ int bk_precond_lap_create(bk_problem* prob, double c, bk_precond** out) {
     P->n = prob->nloc;
     int s = dst_plan_create(ctx, prob->desc.n, prob->ainv, c, 2, &P->plan);
     if (s != 0) { delete P; return s; }
+    *out = P;
+    return 0;
+}
+
+int bk_precond_cgl_create(bk_problem* prob, double a, double b, bk_precond** out) {
+    if (!prob || !out) return -1;
+    bk_ctx* ctx = prob->ctx;
+    if (prob->desc.pde != BK_PDE_CGL2D) return set_error(ctx, "bk_precond_cgl_create: cGL2d problems only");
+    ShDctPrecond* P = new ShDctPrecond();
+    P->ctx = ctx;
+    P->n = prob->nloc;
+    int s = dst_plan_create(ctx, prob->desc.n, prob->ainv, 0.0, 2, &P->plan);
+    if (s != 0) { delete P; return s; }
+    // singular only if b = 0 and -a is an eigenvalue of the Laplacian: refuse the b = 0, a >= 0 corner outright
+    if (b == 0.0 && !(a < 0.0)) { delete P; return set_error(ctx, "bk_precond_cgl_create: b = 0 needs a < 0 (Lap + a I definite)"); }
+    P->plan->kind = 2;
+    P->plan->blk_a = a;
+    P->plan->blk_b = b;
     *out = P;
     return 0;
 }

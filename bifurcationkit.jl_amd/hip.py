@@ -364,6 +364,18 @@ class LaplacePreconditioner(DCTPreconditioner):
         self.h = h
 
 
+class CGLBlockPreconditioner(DCTPreconditioner):
+    """``Pl`` = (Lap (x) I_2 + [[a, -b], [b, a]])^-1 on the stacked cGL fields: with a = r, b = nu the exact inverse of the
+    Jacobian of the trivial state (Jcgl, examples/cGL2d.jl:57-79), with a = r - sigma that of the shift-inverted operator
+    of ``EigArpack(sigma, :LM)`` (cGL2d.jl:96) -- what the reference's sparse LU provides there."""
+
+    def __init__(self, prob: "CGL2d", a: float, b: float):
+        self.ctx, self.prob = prob.ctx, prob
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.bk_precond_cgl_create(prob.h, float(a), float(b), C.byref(h)), "bk_precond_cgl_create")
+        self.h = h
+
+
 # ------------------------------------------------------------------------------------------ linear solvers
 class _GMRES:
     flavor = L.BK_GMRES_KRYLOVKIT

@@ -160,6 +160,12 @@ int bk_precond_sh_create(bk_problem* prob, double shift, bk_precond** out);
  * cGL2d runs use sparse LU (DefaultLS, and `EigArpack(1.0, :LM)` factorises J - sigma I inside ARPACK,
  * examples/cGL2d.jl:96, src/EigSolver.jl:85); this is the matrix-free replacement that keeps GMRES mesh-independent. */
 int bk_precond_lap_create(bk_problem* prob, double c, bk_precond** out);
+/* Pl^-1 = (Lap (x) I_2 + [[a, -b], [b, a]])^-1 on the stacked fields (u1, u2) of a BK_PDE_CGL2D problem: the 2x2 block is
+ * inverted per sine mode.  With a = r, b = nu this IS the Jacobian of the trivial state u = 0 (Jcgl, examples/cGL2d.jl:57-79:
+ * f1u = r, f1v = -nu, f2u = nu, f2v = r), i.e. the exact solve the reference gets from its sparse LU there; a = r - sigma
+ * gives the shift-inverted operator of `EigArpack(sigma, :LM)` (cGL2d.jl:96).  b != 0 keeps every block invertible
+ * (also at a Hopf point, where Lap + r I is singular); b = 0 requires a < 0.                                          */
+int bk_precond_cgl_create(bk_problem* prob, double a, double b, bk_precond** out);
 int bk_precond_destroy(bk_precond* pc);
 int bk_precond_apply(bk_precond* pc, const double* v, double* out);   /* out = Pl \ v             */
 

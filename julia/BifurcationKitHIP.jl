@@ -201,8 +201,34 @@ function HipDCTPreconditioner(prob::HipProblem, shift::Real = 0.0)
     P = HipDCTPreconditioner(prob, r[])
     finalizer(x -> ccall((:bk_precond_destroy, libbkhip[]), Cint, (Ptr{Cvoid},), x.h), P)
 end
+"Pl = (Lap - c I)^-1 on both cGL fields (DST-I of the Dirichlet Laplacian, examples/cGL2d.jl:6-22)."
+mutable struct HipLaplacePreconditioner
+    prob::HipProblem
+    h::Ptr{Cvoid}
+end
+function HipLaplacePreconditioner(prob::HipProblem, c::Real = 1.0)
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    check(prob.ctx, ccall((:bk_precond_lap_create, libbkhip[]), Cint, (Ptr{Cvoid}, Cdouble, Ref{Ptr{Cvoid}}), prob.h, c, r), "bk_precond_lap_create")
+    P = HipLaplacePreconditioner(prob, r[])
+    finalizer(x -> ccall((:bk_precond_destroy, libbkhip[]), Cint, (Ptr{Cvoid},), x.h), P)
+end
+"""
+Pl = (Lap (x) I_2 + [[a, -b], [b, a]])^-1 on the stacked cGL fields: with `a = r, b = nu` the exact inverse of the Jacobian of
+the trivial state (Jcgl, examples/cGL2d.jl:57-79) -- what `DefaultLS` computes there by sparse LU --, with `a = r - sigma` that
+of the shift-inverted operator of `EigArpack(sigma, :LM)` (cGL2d.jl:96).
+"""
+mutable struct HipCGLBlockPreconditioner
+    prob::HipProblem
+    h::Ptr{Cvoid}
+end
+function HipCGLBlockPreconditioner(prob::HipProblem, a::Real, b::Real)
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    check(prob.ctx, ccall((:bk_precond_cgl_create, libbkhip[]), Cint, (Ptr{Cvoid}, Cdouble, Cdouble, Ref{Ptr{Cvoid}}), prob.h, a, b, r), "bk_precond_cgl_create")
+    P = HipCGLBlockPreconditioner(prob, r[])
+    finalizer(x -> ccall((:bk_precond_destroy, libbkhip[]), Cint, (Ptr{Cvoid},), x.h), P)
+end
 _plh(::Nothing) = C_NULL
-_plh(P::HipDCTPreconditioner) = P.h
+_plh(P::Union{HipDCTPreconditioner, HipLaplacePreconditioner, HipCGLBlockPreconditioner}) = P.h
 
 # ------------------------------------------------------------------------------------------------ linear solver
 """

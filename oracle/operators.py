@@ -193,3 +193,34 @@ def dct_preconditioner(dims, ls, shift=0.0, workers=1):
         return sfft.idctn(s, type=2, norm="ortho", workers=workers).reshape(-1)
 
     return apply
+
+
+def dst_block_preconditioner_cgl(dims, ls, a, b, workers=1):
+    """Exact ``(Lap (x) I_2 + [[a, -b], [b, a]])^-1`` on the stacked cGL fields through the orthonormal DST-I of the
+    Dirichlet Laplacian (cGL2d.jl:6-22: eigenvectors sin(pi (k+1)(j+1)/(N+1)), eigenvalues -(4/h^2) sin^2(pi (k+1)/2(N+1))).
+    With a = r, b = nu: the inverse of Jcgl at u = 0 (cGL2d.jl:57-79) -- the CPU stand-in for the sparse LU the reference
+    uses on this problem.  Returns a callable on flat [u1; u2] vectors."""
+    import scipy.fft as sfft
+    dims = tuple(int(d) for d in dims)
+    lam = []
+    for n, l in zip(dims, ls):
+        h = 2.0 * l / n
+        lam.append(-(4.0 / h**2) * np.sin(np.pi * (np.arange(n) + 1) / (2.0 * (n + 1))) ** 2)
+    shape = dims[::-1]
+    m = sum(np.meshgrid(*lam[::-1], indexing="ij")) + a
+    det = m * m + b * b
+    nn = int(np.prod(dims))
+
+    def apply(v):
+        v = np.asarray(v, dtype=float)
+        s1 = sfft.dstn(v[:nn].reshape(shape), type=1, norm="ortho", workers=workers)
+        s2 = sfft.dstn(v[nn:].reshape(shape), type=1, norm="ortho", workers=workers)
+        y1 = (m * s1 + b * s2) / det
+        y2 = (m * s2 - b * s1) / det
+        out = np.empty_like(v)
+        out[:nn] = sfft.idstn(y1, type=1, norm="ortho", workers=workers).reshape(-1)
+        out[nn:] = sfft.idstn(y2, type=1, norm="ortho", workers=workers).reshape(-1)
+        return out
+
+    return apply
+

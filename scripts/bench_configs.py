@@ -81,3 +81,15 @@ tb, rb = timeit(lambda: hip.BorderingBLS(ls3_, check_precision=False)(J3, dR, dz
                 reps=3, warm=1)
 print(json.dumps(dict(config="C3 cGL2d 1024x1024", jvp_us=tj3 * 1e6, jvp_gbs=24.0 * n2 / tj3 / 1e9, precond_ms=tp3 * 1e3,
                       bordered_solve_ms=tb * 1e3, bordered_itlinear=list(rb[3]), bordered_converged=bool(rb[2]))))
+# the workload SURVEY section 8(d) names for C3 is the TRIVIAL branch (u = 0, continuation in r from 0.5): there the 2x2-block
+# spectral preconditioner (bk_precond_cgl_create) is the exact inverse -- the role of the reference's sparse LU
+z3 = p3.vec(np.zeros(n2))
+J30 = p3.jacobian(z3, 0.5)
+for name, Pk in (("laplace", P3), ("block", hip.CGLBlockPreconditioner(p3, 0.5, 1.0))):
+    lsk = hip.GMRESIterativeSolvers(reltol=1e-10, restart=60, maxiter=900, Pl=Pk)
+    tk, rk = timeit(lambda: hip.BorderingBLS(lsk, check_precision=False)(J30, dR, dzu, 0.4, R, 0.3, 0.5, 0.5, dotscale=1.0 / n2),
+                    reps=3, warm=1)
+    tpk, _ = timeit(lambda: Pk.ldiv(v3), reps=20, warm=2)
+    print(json.dumps(dict(config="C3 cGL2d 1024x1024, trivial branch r = 0.5", precond=name, precond_ms=tpk * 1e3,
+                          bordered_solve_ms=tk * 1e3, bordered_itlinear=list(rk[3]), bordered_converged=bool(rk[2]))))
+

@@ -2,7 +2,9 @@
 trivial branch u = 0.  (i) ShiftInvert(sigma = 1, nev = 9) (EigArpack(1.0, :LM), cGL2d.jl:96,100) against the closed-form
 spectrum r + lam_Lap(i, j) +- i nu; (ii) native PALC continuation in r across the first Hopf point r* = -lam_Lap(1, 1) with
 detection and bisection (detect_bifurcation = 3).  Prints one JSON line per part.
-Usage: python scripts/c3_fullsize.py [n=1024] [part: eig,hopf]"""
+Preconditioner: "block" = the 2x2-block spectral preconditioner (bk_precond_cgl_create: exact on the trivial branch at the
+reference value of r, the role of the reference's sparse LU) or "laplace" = (Lap - I)^-1 per field (round 1).
+Usage: python scripts/c3_fullsize.py [n=1024] [part: eig,hopf] [precond: block|laplace]"""
 import json
 import os
 import sys
@@ -27,8 +29,18 @@ for n_, l_ in zip(dims, ls_):
     h = 2 * l_ / n_
     lam.append(-(4 / h ** 2) * np.sin(np.pi * np.arange(1, n_ + 1) / (2 * (n_ + 1))) ** 2)
 lap = np.sort((lam[0][:, None] + lam[1][None, :]).ravel())[::-1]              # Laplacian eigenvalues, descending
-P = hip.LaplacePreconditioner(prob, 1.0)
-ls = hip.GMRESIterativeSolvers(reltol=1e-10, restart=60, maxiter=600, Pl=P)
+kind = sys.argv[3] if len(sys.argv) > 3 else "block"
+NU, SIGMA = 1.0, 1.0
+
+
+def solvers(r0):
+    if kind == "laplace":
+        ls_ = hip.GMRESIterativeSolvers(reltol=1e-10, restart=60, maxiter=600, Pl=hip.LaplacePreconditioner(prob, 1.0))
+        return ls_, ls_
+    return (hip.GMRESIterativeSolvers(reltol=1e-10, restart=60, maxiter=600, Pl=hip.CGLBlockPreconditioner(prob, r0, NU)),
+            hip.GMRESIterativeSolvers(reltol=1e-10, restart=60, maxiter=600, Pl=hip.CGLBlockPreconditioner(prob, r0 - SIGMA, NU)))
+
+
 zero = prob.vec(np.zeros(n2))
 
 
@@ -43,14 +55,15 @@ def timed(fn):
 if "eig" in parts:
     r0 = 0.5
     J = prob.jacobian(zero, r0)
-    eig = hip.ShiftInvert(1.0, ls, tol=1e-8, maxiter=300, hermitian=False, save_vectors=False)
+    ls, lse = solvers(r0)
+    eig = hip.ShiftInvert(SIGMA, lse, tol=1e-8, maxiter=300, hermitian=False, save_vectors=False)
     dt, (vals, _, ok, nops) = timed(lambda: eig(J, 9))
     exact = np.array([complex(r0 + l, s) for l in lap[:5] for s in (1.0, -1.0)])
     good = vals[~np.isnan(vals.real)]
     err = max(np.abs(exact - v).min() for v in good) if len(good) else None
     # every returned value is an eigenvalue AND the returned set is the rightmost one (no pair skipped)
     miss = max(np.abs(good - e).min() for e in exact[:len(good) - len(good) % 2]) if len(good) else None
-    print(json.dumps(dict(part="C3 shift-invert eigensolve", n=n, seconds=dt, converged=bool(ok), inner_solves=nops,
+    print(json.dumps(dict(part="C3 shift-invert eigensolve", precond=kind, n=n, seconds=dt, converged=bool(ok), inner_solves=nops,
                           inner_iterations=int(ctx.get_option("eig_last_inner_ops")), nvals=len(vals), n_converged=len(good),
                           max_error_vs_closed_form=err, max_missing=miss,
                           vals=[[float(v.real), float(v.imag)] for v in vals], exact_real=[float(r0 + l) for l in lap[:5]])),
@@ -58,7 +71,8 @@ if "eig" in parts:
 
 if "hopf" in parts:
     rstar = -lap[:3]                                   # r* of the first Hopf points (lam + r = 0)
-    eig = hip.ShiftInvert(1.0, ls, tol=1e-8, maxiter=300, hermitian=False, save_vectors=False)
+    ls, lse = solvers(float(rstar[0]))
+    eig = hip.ShiftInvert(SIGMA, lse, tol=1e-8, maxiter=300, hermitian=False, save_vectors=False)
     nopt = Cn.NewtonPar(tol=1e-9, max_iterations=20, linsolver=ls, eigsolver=eig)
     width = float(rstar[1] - rstar[0])
     p_start = float(rstar[0] - 1.6 * width)
@@ -70,7 +84,7 @@ if "hopf" in parts:
     steps = []
     dt, br = timed(lambda: Cn.continuation_native(prob, zero, p_start, alg, cp, normC=Cn.norminf, bisection=True,
                                                   finalise_solution=lambda get, r: steps.append((r.p, r.n_unstable, r.eig_numops)) or True))
-    print(json.dumps(dict(part="C3 Hopf detection + bisection", n=n, seconds=dt, rstar=[float(x) for x in rstar], param=br.param,
+    print(json.dumps(dict(part="C3 Hopf detection + bisection", precond=kind, n=n, seconds=dt, rstar=[float(x) for x in rstar], param=br.param,
                           n_unstable=br.n_unstable, n_imag=br.n_imag, steps=steps,
                           specialpoint=[{k: (list(v) if isinstance(v, tuple) else v) for k, v in sp.items()} for sp in br.specialpoint])),
           flush=True)

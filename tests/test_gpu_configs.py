@@ -153,7 +153,20 @@ def _cgl_full():
     return dims, ls_, lap
 
 
-def test_c3_cgl_1024_shift_invert_eigenvalues_match_closed_form(ctx):
+def _cgl_solvers(hip, prob, kind, r0=0.5, sigma=1.0, nu=1.0):
+    """(linear solver, eigensolver) with the (Lap - I)^-1 preconditioner of round 1 ("laplace") or the 2x2-block spectral
+    preconditioner ("block": exact on the trivial branch at r0 -- the role of the reference's sparse LU)."""
+    if kind == "laplace":
+        P = hip.LaplacePreconditioner(prob, 1.0)
+        ls = hip.GMRESIterativeSolvers(reltol=1e-10, restart=60, maxiter=600, Pl=P)
+        return ls, hip.ShiftInvert(sigma, ls, tol=1e-8, maxiter=300, hermitian=False, save_vectors=False)
+    ls = hip.GMRESIterativeSolvers(reltol=1e-10, restart=60, maxiter=600, Pl=hip.CGLBlockPreconditioner(prob, r0, nu))
+    lse = hip.GMRESIterativeSolvers(reltol=1e-10, restart=60, maxiter=600, Pl=hip.CGLBlockPreconditioner(prob, r0 - sigma, nu))
+    return ls, hip.ShiftInvert(sigma, lse, tol=1e-8, maxiter=300, hermitian=False, save_vectors=False)
+
+
+@pytest.mark.parametrize("precond", ["laplace", "block"])
+def test_c3_cgl_1024_shift_invert_eigenvalues_match_closed_form(ctx, precond):
     """examples/cGL2d.jl:96,100 at full size: ShiftInvert(sigma = 1, nev = 9) (EigArpack(1.0, :LM)) on the trivial state at
     r = 0.5.  The Jacobian at u = 0 is Lap (+) Lap + [[r, -nu], [nu, r]], so its eigenvalues are r + lam_Lap(i, j) +- i nu in
     closed form; on this domain (25 x the example's) consecutive ones are 1e-3 apart, 1.118 away from the shift."""
@@ -161,10 +174,10 @@ def test_c3_cgl_1024_shift_invert_eigenvalues_match_closed_form(ctx):
     dims, ls_, lap = _cgl_full()
     prob = hip.CGL2d(ctx, dims, ls_, r=0.5)
     n2 = 2 * dims[0] * dims[1]
-    P = hip.LaplacePreconditioner(prob, 1.0)
-    ls = hip.GMRESIterativeSolvers(reltol=1e-10, restart=60, maxiter=600, Pl=P)
-    eig = hip.ShiftInvert(1.0, ls, tol=1e-8, maxiter=300, hermitian=False, save_vectors=False)
+    ls, eig = _cgl_solvers(hip, prob, precond)
     vals, _, ok, nops = eig(prob.jacobian(prob.vec(np.zeros(n2)), 0.5), 9)
+    if precond == "block":                      # Pl^-1 (J - sigma I) = I on the trivial state: one GMRES iteration per solve
+        assert int(ctx.get_option("eig_last_inner_ops")) <= 2 * nops
     assert ok and len(vals) == 10 and not np.isnan(vals.real).any()            # 9 -> 10: the cut never splits a conjugate pair
     exact = np.array([complex(0.5 + l, s) for l in lap[:5] for s in (1.0, -1.0)])
     # the returned set IS the rightmost five pairs (nothing skipped, nothing spurious), to 1e-8
@@ -173,7 +186,8 @@ def test_c3_cgl_1024_shift_invert_eigenvalues_match_closed_form(ctx):
     assert np.all(np.diff(vals.real) <= 1e-12)                                  # sorted by decreasing real part
 
 
-def test_c3_cgl_1024_first_hopf_point_is_detected_and_bracketed(ctx):
+@pytest.mark.parametrize("precond", ["laplace", "block"])
+def test_c3_cgl_1024_first_hopf_point_is_detected_and_bracketed(ctx, precond):
     """Native PALC continuation in r along the trivial branch at full size across the first Hopf point r* = -lam_Lap(1, 1)
     (closed form): n_unstable goes 0 -> 2 with a complex pair, the special point is classified `hopf`, and the bisection
     (locate_bifurcation!, src/Bifurcations.jl:159-349; a few steps only, each is a full eigensolve) brackets r*."""
@@ -182,10 +196,8 @@ def test_c3_cgl_1024_first_hopf_point_is_detected_and_bracketed(ctx):
     dims, ls_, lap = _cgl_full()
     prob = hip.CGL2d(ctx, dims, ls_, r=0.5)
     n2 = 2 * dims[0] * dims[1]
-    P = hip.LaplacePreconditioner(prob, 1.0)
-    ls = hip.GMRESIterativeSolvers(reltol=1e-10, restart=60, maxiter=600, Pl=P)
-    eig = hip.ShiftInvert(1.0, ls, tol=1e-8, maxiter=300, hermitian=False, save_vectors=False)
     rstar = -lap[:2]
+    ls, eig = _cgl_solvers(hip, prob, precond, r0=float(rstar[0]))
     width = float(rstar[1] - rstar[0])
     nopt = Cn.NewtonPar(tol=1e-9, max_iterations=20, linsolver=ls, eigsolver=eig)
     cp = Cn.ContinuationPar(ds=0.5 * width, dsmin=1e-3 * width, dsmax=0.6 * width, p_min=float(rstar[0] - 2 * width),

@@ -1092,6 +1092,55 @@ def test_cgl_laplace_preconditioner_and_bordered_solve(ctx):
     assert okb and np.abs(dX.numpy() - refb[:-1]).max() <= 1e-7 * np.abs(refb).max() and np.isclose(dl, refb[-1], rtol=1e-7)
 
 
+def test_cgl_block_preconditioner_is_exact_on_the_trivial_state(ctx):
+    """bk_precond_cgl_create: (Lap (x) I_2 + [[a, -b], [b, a]])^-1 through the DST-I with the 2x2 block inverted per mode.
+    With a = r, b = nu it is the inverse of Jcgl(u = 0) (examples/cGL2d.jl:57-79) -- the solve the reference's sparse LU
+    performs there: HIP == oracle restatement == sparse LU; GMRES on the trivial-state Jacobian then needs ONE iteration,
+    at a Hopf point (Lap + r I singular) too, and the shift-invert operator of EigArpack(sigma = 1) likewise; on a
+    non-trivial state it cuts the iteration count of the (Lap - I)^-1 preconditioner several times."""
+    hip = _hip()
+    dims, ls_ = (24, 13), (np.pi, np.pi / 2)
+    c = operators.CGL2d(dims, ls_)
+    prob = hip.CGL2d(ctx, dims, ls_)
+    rng = np.random.default_rng(5)
+    n2 = 2 * c.n
+    p = c.default_params()
+    J0m = c.J(np.zeros(n2), **p)
+    v = rng.standard_normal(n2)
+    P = hip.CGLBlockPreconditioner(prob, p["r"], p["nu"])
+    Po = operators.dst_block_preconditioner_cgl(dims, ls_, p["r"], p["nu"])
+    got, ref = P.ldiv(prob.vec(v)).numpy(), spla.spsolve(J0m.tocsc(), v)
+    assert np.abs(got - ref).max() <= 1e-11 * np.abs(ref).max() and np.abs(Po(v) - ref).max() <= 1e-11 * np.abs(ref).max()
+    J0 = prob.jacobian(prob.vec(np.zeros(n2)), p["r"])
+    ls = hip.GMRESIterativeSolvers(reltol=1e-12, restart=60, maxiter=600, Pl=P)
+    x, ok, it = ls(J0, prob.vec(v))
+    assert ok and it <= 2 and np.abs(x.numpy() - ref).max() <= 1e-10 * np.abs(ref).max()
+    # the first Hopf point r* = -lam_max(Lap): Lap + r* I is singular, the block is not (nu != 0)
+    lam = np.sort(np.linalg.eigvalsh(c.lap.toarray()))[::-1]
+    rs = -lam[0]
+    ph = dict(p, r=rs)
+    Jh = c.J(np.zeros(n2), **ph)
+    Ph = hip.CGLBlockPreconditioner(prob, rs, p["nu"])
+    xh, okh, ith = hip.GMRESIterativeSolvers(reltol=1e-12, restart=60, maxiter=600, Pl=Ph)(prob.jacobian(prob.vec(np.zeros(n2)), rs), prob.vec(v))
+    refh = spla.spsolve(Jh.tocsc(), v)
+    assert okh and ith <= 2 and np.abs(xh.numpy() - refh).max() <= 1e-9 * np.abs(refh).max()
+    # shift-invert operator (J - sigma I)^-1 of EigArpack(1.0, :LM): a = r - sigma
+    Ps = hip.CGLBlockPreconditioner(prob, p["r"] - 1.0, p["nu"])
+    xs, oks, its = hip.GMRESIterativeSolvers(reltol=1e-12, restart=60, maxiter=600, Pl=Ps)(J0, prob.vec(v), -1.0, 1.0)
+    refs = spla.spsolve((J0m - sp.identity(n2)).tocsc(), v)
+    assert oks and its <= 2 and np.abs(xs.numpy() - refs).max() <= 1e-10 * np.abs(refs).max()
+    # non-trivial state: still a preconditioner (the nonlinear terms are a bounded perturbation), and a much better one
+    u = 0.3 * rng.standard_normal(n2)
+    p2 = dict(p, r=1.2)
+    Jm = c.J(u, **p2)
+    J = prob.jacobian(prob.vec(u), 1.2)
+    xr = spla.spsolve(Jm.tocsc(), v)
+    xb, okb, itb = hip.GMRESIterativeSolvers(reltol=1e-12, restart=60, maxiter=600, Pl=hip.CGLBlockPreconditioner(prob, 1.2, p["nu"]))(J, prob.vec(v))
+    xl, okl, itl = hip.GMRESIterativeSolvers(reltol=1e-12, restart=60, maxiter=600, Pl=hip.LaplacePreconditioner(prob, 1.0))(J, prob.vec(v))
+    assert okb and okl and np.abs(xb.numpy() - xr).max() <= 1e-8 * np.abs(xr).max()
+    assert itb < itl, (itb, itl)
+
+
 def test_cgl_hopf_detection_along_trivial_branch(ctx):
     """examples/cGL2d.jl:96-100: continuation in r of the trivial state with shift-invert eigenvalues each step; the
     number of unstable eigenvalues (complex pairs crossing: Hopf points) must follow the dense spectrum."""

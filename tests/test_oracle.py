@@ -424,3 +424,26 @@ def test_slab_zsolve_woodbury_equals_the_global_dct_inverse(n, R):
         x, xe = Z.slab_zsolve(f, c, 1.0, R, a), Z.exact_zsolve(f, c, 1.0, a)
         worst = max(worst, np.abs(x - xe).max() / np.abs(xe).max())
     assert worst <= 1e-11, worst
+
+
+def test_cgl_block_preconditioner_inverts_the_trivial_state_jacobian():
+    """oracle.operators.dst_block_preconditioner_cgl (checker of bk_precond_cgl_create): with a = r, b = nu the exact inverse
+    of Jcgl(u = 0) (examples/cGL2d.jl:57-79) -- the reference solves this system with a sparse LU; also for the
+    shift-inverted operator J - sigma I of EigArpack(sigma, :LM) (cGL2d.jl:96) and at the first Hopf point."""
+    dims, ls_ = (16, 9), (np.pi * 16 / 41, np.pi / 2 * 9 / 21)
+    g = operators.CGL2d(dims, ls_)
+    p = g.default_params()
+    n2 = 2 * g.n
+    v = np.random.default_rng(0).standard_normal(n2)
+    J0 = g.J(np.zeros(n2), **p)
+    P = operators.dst_block_preconditioner_cgl(dims, ls_, p["r"], p["nu"])
+    assert np.abs(P(J0 @ v) - v).max() < 1e-13 and np.abs(J0 @ P(v) - v).max() < 1e-12
+    Ps = operators.dst_block_preconditioner_cgl(dims, ls_, p["r"] - 1.0, p["nu"])
+    assert np.abs(Ps((J0 - sp.identity(n2)) @ v) - v).max() < 1e-13
+    rs = -np.sort(np.linalg.eigvalsh(g.lap.toarray()))[-1]                 # Lap + rs I is singular
+    Jh = g.J(np.zeros(n2), **dict(p, r=rs))
+    Ph = operators.dst_block_preconditioner_cgl(dims, ls_, rs, p["nu"])
+    assert np.abs(Ph(Jh @ v) - v).max() < 1e-12
+    x, ok, it = krylov.gmres_iterativesolvers(lambda w: J0 @ w, v, reltol=1e-12, restart=30, maxiter=50, Pl=P)[:3]
+    assert ok and it <= 2 and np.abs(J0 @ x - v).max() < 1e-10
+
