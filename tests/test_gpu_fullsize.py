@@ -58,6 +58,38 @@ def test_fullsize_jacobian_symmetric_linear_deterministic(ctx, big):
     assert Jv0.add_(Jv, -1.0).norminf() <= 1e-11 * Jv.norminf()
 
 
+def test_fullsize_krylov_block_kernels_do_not_depend_on_the_xcd_blocking(ctx, big):
+    """multiaxpy / multidot at full size with the XCD-blocked index ranges (option vec_xcd_map; default: multiaxpy with
+    k >= 12 streams) against the plain grid-stride walk: the update is elementwise, hence bitwise equal; the dots differ
+    only by the summation order."""
+    import ctypes as C
+    import torch
+    n = big.nlocal
+    ld = (n + 31) // 32 * 32
+    k = 13
+    g = torch.Generator(device="cuda").manual_seed(7)
+    V = torch.rand(ld * k, dtype=torch.float64, device="cuda", generator=g) - 0.5
+    w = _rand(ctx, big, 8)
+    cc = (C.c_double * k)(*[0.1 * (j + 1) for j in range(k)])
+    outs, dots = [], []
+    try:
+        for mode in (0, 2, 1):
+            ctx.set_option("vec_xcd_map", mode)
+            o = w.similar()
+            ctx.check(ctx.lib.bk_krylov_multiaxpy(ctx.h, n, C.c_void_p(V.data_ptr()), ld, k, cc, C.c_void_p(w.t.data_ptr()), 0.5,
+                                                  C.c_void_p(o.t.data_ptr()), None))
+            h = (C.c_double * (k + 1))()
+            ctx.check(ctx.lib.bk_krylov_multidot(ctx.h, n, C.c_void_p(V.data_ptr()), ld, k, C.c_void_p(w.t.data_ptr()), h))
+            outs.append(o)
+            dots.append(np.array(h[:]))
+    finally:
+        ctx.set_option("vec_xcd_map", 1)
+    assert torch.equal(outs[0].t, outs[1].t) and torch.equal(outs[0].t, outs[2].t)
+    ref = (V.view(k, ld)[:, :n] @ w.t).cpu().numpy()
+    for d in dots:
+        assert np.abs(d[:k] - ref).max() <= 1e-12 * np.abs(ref).max() + 1e-9 and abs(d[k] - float(w.t @ w.t)) <= 1e-12 * d[k]
+
+
 def test_fullsize_preconditioner_roundtrip(ctx, big):
     from bk_amd import hip
     import torch
