@@ -81,6 +81,8 @@ class ContinuationPar:
     n_inversion: int = 2                     # src/ContParameters.jl:78-81
     max_bisection_steps: int = 25
     tol_bisection_eigenvalue: float = 1e-16
+    save_sol_every_step: int = 0             # src/ContParameters.jl:65 -- every how many steps br.sol keeps the solution
+    save_to_file: bool = False               # :64 -- checkpoint every accepted step (save_to_file, ext/JLD2Ext/save.jl:8-30)
     newton_options: NewtonPar = field(default_factory=NewtonPar)
 
 
@@ -265,11 +267,65 @@ class ContResult:
     sol: list = field(default_factory=list)
 
 
+def mod_counter(step, every):
+    """src/Utils.jl:183-188."""
+    if step == 0 or every == 0:
+        return False
+    return True if every == 1 else step % every == 0
+
+
+def _to_host(x):
+    """Download a state vector (HipVec -> NumPy; the checkpoint is the one place where the state leaves the device)."""
+    if hasattr(x, "numpy"):
+        return np.asarray(x.numpy())
+    return np.asarray(getattr(x, "a", x), dtype=float)
+
+
+def _rank_suffix(x):
+    ctx = getattr(x, "ctx", None)
+    nr = getattr(ctx, "nranks", 1) if ctx is not None else 1
+    return f"-rank{ctx.rank}of{nr}" if nr > 1 else ""
+
+
+def save_to_file(filename, ds, sol, p, i, br):
+    """save_to_file(iter, sol, p, i, br), ext/JLD2Ext/save.jl:8-30: the solution of step ``i`` goes to the group
+    ``sol-fw-i`` / ``sol-bw-i`` (forward / backward branch by the sign of ds) with its parameter, and the branch record is
+    rewritten next to it.  JLD2 groups become one ``.npz`` per step, ``<filename>-sol-<fw|bw>-<i>.npz`` (a rank suffix when
+    the state is a z-slab of a distributed run), the branch ``<filename>-branch.json``."""
+    import json
+    fd = "fw" if ds >= 0 else "bw"
+    np.savez(f"{filename}-sol-{fd}-{i}{_rank_suffix(sol)}.npz", sol=_to_host(sol), param=float(p), step=int(i))
+    rec = dict(param=[float(x) for x in br.param], itnewton=list(br.itnewton), itlinear=list(br.itlinear),
+               ds=[float(x) for x in br.ds], n_unstable=list(br.n_unstable), n_imag=list(br.n_imag),
+               eig=[None if v is None else [[float(z.real), float(z.imag)] for z in np.atleast_1d(v)] for v in br.eig],
+               specialpoint=[{k: (list(v) if isinstance(v, tuple) else v) for k, v in sp.items()} for sp in br.specialpoint])
+    with open(f"{filename}-branch.json", "w") as f:
+        json.dump({"branch" + fd: rec}, f)
+
+
+def load_solution(filename, i, fd="fw", rank_suffix=""):
+    """Read a checkpoint written by :func:`save_to_file`: (solution as a NumPy array, parameter)."""
+    with np.load(f"{filename}-sol-{fd}-{i}{rank_suffix}.npz") as z:
+        return np.array(z["sol"]), float(z["param"])
+
+
+def load_branch(filename):
+    import json
+    with open(f"{filename}-branch.json") as f:
+        d = json.load(f)
+    return next(iter(d.values()))
+
+
 def continuation(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm2, verbosity=0, save_sol=False,
-                 corrector=newton_palc, callback_newton=cb_default) -> ContResult:
+                 corrector=newton_palc, callback_newton=cb_default, filename=None) -> ContResult:
     """PALC branch.  Continuation.jl:349-456 (two Newton solves + secant tangent), :458-504 (one step:
-    corrector!, compute_eigenvalues!, step_size_control!, getpredictor!)."""
+    corrector!, compute_eigenvalues!, step_size_control!, getpredictor!).  ``br.sol`` keeps (x, p, step) every
+    ``cp.save_sol_every_step`` steps and at the last point (save!, :280-292); ``cp.save_to_file`` writes a checkpoint after
+    every accepted step (:579) under ``filename``."""
     alg = alg.update(cp)
+    if cp.save_to_file and filename is None:
+        import datetime
+        filename = "branch-" + datetime.datetime.now().isoformat()      # ContIterable default, Continuation.jl:46
     nopt = cp.newton_options
     eig = nopt.eigsolver if cp.detect_bifurcation > 0 else None
     sol0 = newton(prob, x0, p0, nopt, normC, callback_newton)
@@ -296,6 +352,10 @@ def continuation(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm2, verb
         br.residuals.append(list(sol.residuals)); br.eig.append(vals)
         if save_sol:
             br.sol.append(z.u.copy())
+        elif cp.save_sol_every_step > 0:
+            finished = not (step < cp.max_steps and (cp.p_min < z.p < cp.p_max or step == 0))
+            if mod_counter(step, cp.save_sol_every_step) or finished:
+                br.sol.append(dict(x=z.u.copy(), p=z.p, step=step))
 
     vals = None
     n_unst_prev = -1
@@ -306,8 +366,8 @@ def continuation(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm2, verb
     z = z0.copy()
     z_old = z0.copy()
     z_pred = z.copy().add_(tau, ds)                                     # addtangent!
-    record(z, sol0, ds, vals)
     step = 0
+    record(z, sol0, ds, vals)
     while step < cp.max_steps and (cp.p_min < z.p < cp.p_max or step == 0):        # done, Continuation.jl:254-257
         if z_pred.p <= cp.p_min or z_pred.p >= cp.p_max:
             # corrector!(::PALC) hands over to Natural at the clamped parameter (Palc.jl:157-160, Natural.jl:38-58)
@@ -333,6 +393,8 @@ def continuation(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm2, verb
                     br.specialpoint.append(dict(step=step + 1, param=z.p, n_unstable=(prev_unst, n_unst)))
             step += 1
             record(z, sol, ds, vals)
+            if cp.save_to_file:
+                save_to_file(filename, cp.ds, z.u, z.p, step, br)
         ds, stop = step_size_control(ds, conv, sol.itnewton, cp)
         if stop:
             break
@@ -346,7 +408,7 @@ def continuation(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm2, verb
 
 
 def continuation_native(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm2, verbosity=0, save_sol=False,
-                        bisection=False, finalise_solution=None, callback_newton=None, on_init=None) -> ContResult:
+                        bisection=False, finalise_solution=None, callback_newton=None, on_init=None, filename=None) -> ContResult:
     """The same branch with every step issued as ONE library call (``bk_cont_step``: corrector, eigenvalues, step-size
     control, tangent and predictor -- the body of ``iterate``, src/Continuation.jl:458-504) and the two initial Newton
     solves as ``bk_newton``.  Needs the native solver types (GMRES* + BorderingBLS + ShiftInvert); ``normC`` must be
@@ -354,7 +416,8 @@ def continuation_native(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm
     ``detect_bifurcation = 3``): every detected change of stability is located by ``bk_cont_locate_bifurcation``
     (locate_bifurcation!, src/Bifurcations.jl:159-349) and the special point carries its interval, status and type.
     ``finalise_solution(state, r) -> bool`` (the reference's hook of the same name, src/Continuation.jl:296-310) is called
-    after every accepted step with a ``get()`` accessor of the device state; returning False stops the run."""
+    after every accepted step with a ``get()`` accessor of the device state; returning False stops the run.
+    ``cp.save_sol_every_step`` / ``cp.save_to_file`` / ``filename`` as in :func:`continuation`."""
     import ctypes as C
 
     from . import _lib as L
@@ -398,6 +461,14 @@ def continuation_native(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm
         C.byref(eo) if eo is not None else None, C.byref(elo) if elo is not None else None, epl, C.byref(r),
         C.byref(h)), "bk_cont_create")
     br = ContResult()
+    if cp.save_to_file and filename is None:
+        import datetime
+        filename = "branch-" + datetime.datetime.now().isoformat()
+
+    def state_vec():
+        u = s0["u"].similar()
+        ctx.check(ctx.lib.bk_cont_get(h, hip._ptr(u.t), None, None, None, None), "bk_cont_get")
+        return u
 
     def vals_of(r):
         return np.array([complex(r.vals_re[i], r.vals_im[i]) for i in range(r.nvals)]) if eig is not None else None
@@ -407,15 +478,17 @@ def continuation_native(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm
         br.ds.append(r.ds_used); br.n_unstable.append(r.n_unstable); br.n_imag.append(r.n_imag)
         br.residuals.append(residuals); br.eig.append(vals_of(r))
         if save_sol:
-            u = s0["u"].similar()
-            ctx.check(ctx.lib.bk_cont_get(h, hip._ptr(u.t), None, None, None, None), "bk_cont_get")
-            br.sol.append(u)
+            br.sol.append(state_vec())
+        elif cp.save_sol_every_step > 0:
+            finished = not (step < cp.max_steps and (cp.p_min < r.p < cp.p_max or step == 0)) or bool(r.stop)
+            if mod_counter(step, cp.save_sol_every_step) or finished:
+                br.sol.append(dict(x=state_vec(), p=r.p, step=step))
 
+    step = 0
     try:
         record(r, s0["itnewton"], s0["itlineartot"], list(s0["residuals"]))
         if on_init is not None:
             on_init(r)
-        step = 0
         while step < cp.max_steps:
             prev_unst = r.n_unstable
             ctx.check(ctx.lib.bk_cont_step(h, C.byref(r)), "bk_cont_step")
@@ -449,6 +522,8 @@ def continuation_native(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm
                         br.specialpoint.append(sp)
                 step += 1
                 record(r, r.itnewton, r.itlinear, [r.residuals[i] for i in range(r.itnewton + 1)])
+                if cp.save_to_file:
+                    save_to_file(filename, cp.ds, state_vec(), r.p, step, br)
                 if finalise_solution is not None:
                     def get():
                         u, tu = s0["u"].similar(), s0["u"].similar()

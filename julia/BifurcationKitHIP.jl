@@ -83,6 +83,10 @@ function Base.Array(v::HipVec)
     check(v.ctx, ccall((:bk_download, libbkhip[]), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Csize_t), v.ctx.h, a, v.p, v.n), "bk_download")
     a
 end
+# Checkpoints (`save_to_file`, ext/JLD2Ext/save.jl:8-30; `save_solution` of the problem, src/Continuation.jl:289): the state
+# leaves the device as a plain Vector{Float64}.  With JLD2 loaded, `JLD2.writeas(::Type{HipVec}) = Vector{Float64}` together
+# with `Base.convert(::Type{Vector{Float64}}, v::HipVec) = Array(v)` makes the extension serialise branches unchanged.
+Base.convert(::Type{Vector{Float64}}, v::HipVec) = Array(v)
 Base.length(v::HipVec) = v.n
 Base.eltype(::HipVec) = Float64
 Base.similar(v::HipVec) = HipVec(v.ctx, v.n)

@@ -696,6 +696,35 @@ def test_native_continuation_step_matches_mirror(ctx, tangent):
         assert np.abs(sh.F(u_.numpy(), p_, 1.2)).max() < 1e-8
 
 
+def test_native_continuation_checkpoints_download_the_device_state(ctx, tmp_path):
+    """`save_to_file` (ext/JLD2Ext/save.jl:8-30, called at src/Continuation.jl:579) and the solution
+    sampling of save! (:280-292) on the native run: every accepted step downloads the device state into a checkpoint; the
+    checkpoints are the points of the branch, and a run restarted from one continues the same branch."""
+    hip = _hip()
+    from bk_amd import continuation as Cn
+    dims, ls_ = (12, 12, 12), (np.pi,) * 3
+    sh, prob, rng, u = _sh_setup(ctx, dims, ls_)
+    P = hip.DCTPreconditioner(prob, 0.0)
+    ls = hip.GMRESKrylovKit(dim=30, rtol=1e-9, atol=1e-12, maxiter=150, Pl=P)
+    nopt = Cn.NewtonPar(tol=1e-9, max_iterations=15, linsolver=ls)
+    cp = Cn.ContinuationPar(ds=-0.001, dsmin=1e-4, dsmax=0.005, p_min=-0.1, p_max=0.15, max_steps=4, detect_bifurcation=0,
+                            newton_options=nopt, save_sol_every_step=3, save_to_file=True)
+    alg = Cn.PALC(tangent="secant", theta=0.5, bls=hip.BorderingBLS(None, check_precision=False))
+    fn = str(tmp_path / "sh3d")
+    bn = Cn.continuation_native(prob, prob.vec(u), 0.1, alg, cp, normC=Cn.norminf, filename=fn)
+    assert len(bn.param) == 5 and [s_["step"] for s_ in bn.sol] == [3, 4]
+    for i in range(1, 5):
+        x, p = Cn.load_solution(fn, i, "bw")                                # ds < 0: the backward group
+        assert p == bn.param[i] and np.abs(sh.F(x, p, 1.2)).max() < 1e-8
+    x3, p3 = Cn.load_solution(fn, 3, "bw")
+    assert np.array_equal(x3, bn.sol[0]["x"].numpy())
+    assert np.allclose(Cn.load_branch(fn)["param"], bn.param)
+    cp2 = Cn.ContinuationPar(ds=bn.ds[4], dsmin=1e-4, dsmax=0.005, p_min=-0.1, p_max=0.15, max_steps=1, detect_bifurcation=0,
+                             newton_options=nopt)
+    b2 = Cn.continuation_native(prob, prob.vec(x3), p3, alg, cp2, normC=Cn.norminf)
+    assert b2.param[0] == p3 and b2.param[1] < p3 and b2.itnewton[0] <= 1   # the checkpoint is already converged
+
+
 def test_continuation_reaches_the_parameter_bound_with_the_natural_corrector(ctx):
     """Palc.jl:157-160 + Natural.jl:38-58: when the predictor leaves [p_min, p_max] its parameter is clamped and the step
     is corrected by a plain Newton at the boundary; that point is recorded and `done` (Continuation.jl:254-257) ends the

@@ -88,6 +88,43 @@ def test_continuation_driver_matches_oracle():
         assert np.allclose(a, b, rtol=1e-6, atol=1e-13)
 
 
+def test_solution_sampling_and_checkpoints(tmp_path):
+    """save! (src/Continuation.jl:280-292): br.sol keeps (x, p, step) every save_sol_every_step steps and at the last
+    point; save_to_file (ext/JLD2Ext/save.jl:8-30): one checkpoint per accepted step plus the branch record, and a run
+    restarted from a checkpoint continues on the same branch."""
+    sh = operators.SwiftHohenberg((9, 8), (3.0, 2.5))
+    prob = Prob(sh, 1.3)
+    oprob = palc.Problem(F=lambda x, p: sh.F(x, p, 1.3), J=lambda x, p: sh.J(x, p, 1.3))
+    s0 = palc.newton(oprob, 0.8 * sh.guess(), -0.1, bordered.default_ls, tol=1e-10, max_iterations=30, normN=palc.norminf)
+    eig_p = lambda J, nev: krylov.default_eig(J.M, nev)
+    nopt = C.NewtonPar(tol=1e-10, max_iterations=15, linsolver=direct_ls, eigsolver=eig_p)
+    cp = C.ContinuationPar(ds=0.002, dsmin=1e-4, dsmax=0.01, p_min=-0.3, p_max=0.3, max_steps=5, nev=4,
+                           newton_options=nopt, save_sol_every_step=2, save_to_file=True)
+    alg = C.PALC(tangent="secant", theta=0.5, bls=hip.BorderingBLS(None, check_precision=False))
+    fn = str(tmp_path / "branch")
+    br = C.continuation(prob, NumpyVec(s0["u"]), -0.1, alg, cp, normC=C.norminf, filename=fn)
+    assert [s["step"] for s in br.sol] == [2, 4, 5]                         # mod_counter(step, 2) or the last point
+    assert all(np.isclose(s["p"], br.param[s["step"]]) for s in br.sol)
+    assert C.mod_counter(0, 1) is False and C.mod_counter(3, 0) is False and C.mod_counter(3, 1) and not C.mod_counter(3, 2)
+    for i in range(1, 6):
+        x, p = C.load_solution(fn, i, "fw")
+        assert np.isclose(p, br.param[i])
+        assert np.abs(sh.F(x, p, 1.3)).max() < 1e-9                         # every checkpoint is a point of the branch
+    x4, p4 = C.load_solution(fn, 4)
+    assert np.array_equal(x4, br.sol[1]["x"].a)
+    rec = C.load_branch(fn)
+    assert np.allclose(rec["param"], br.param) and rec["n_unstable"] == br.n_unstable and len(rec["eig"]) == len(br.param)
+    # restart from the checkpoint of step 3: the first new point lies on the same solution curve, beyond the checkpoint
+    x3, p3 = C.load_solution(fn, 3)
+    cp2 = C.ContinuationPar(ds=0.002, dsmin=1e-4, dsmax=0.01, p_min=-0.3, p_max=0.3, max_steps=1, nev=4, newton_options=nopt)
+    br2 = C.continuation(prob, NumpyVec(x3), p3, alg, cp2, normC=C.norminf)
+    assert np.isclose(br2.param[0], p3) and br2.param[1] > p3
+    cpb = C.ContinuationPar(ds=-0.002, dsmin=1e-4, dsmax=0.01, p_min=-0.3, p_max=0.3, max_steps=1, nev=4, newton_options=nopt,
+                            save_to_file=True)
+    C.continuation(prob, NumpyVec(x3), p3, alg, cpb, normC=C.norminf, filename=fn)
+    assert C.load_solution(fn, 1, "bw")[1] < p3                             # backward branch: the `bw` group
+
+
 def test_step_size_control_and_stability():
     cp = C.ContinuationPar(dsmin=1e-3, dsmax=0.1, a=0.5, newton_options=C.NewtonPar(max_iterations=10))
     ds, stop = C.step_size_control(0.01, True, 2, cp)
