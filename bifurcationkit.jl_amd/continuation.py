@@ -77,6 +77,7 @@ class ContinuationPar:
     nev: int = 3
     tol_stability: float = 1e-10
     detect_bifurcation: int = 3
+    detect_fold: bool = True                 # src/ContParameters.jl:75 (acts only when detect_bifurcation < 2)
     dsmin_bisection: float = 1e-16           # bisection of detected bifurcations (detect_bifurcation = 3),
     n_inversion: int = 2                     # src/ContParameters.jl:78-81
     max_bisection_steps: int = 25
@@ -84,6 +85,23 @@ class ContinuationPar:
     save_sol_every_step: int = 0             # src/ContParameters.jl:65 -- every how many steps br.sol keeps the solution
     save_to_file: bool = False               # :64 -- checkpoint every accepted step (save_to_file, ext/JLD2Ext/save.jl:8-30)
     newton_options: NewtonPar = field(default_factory=NewtonPar)
+
+    def __post_init__(self):
+        """The consistency checks of the reference's constructor (src/ContParameters.jl:89-99)."""
+        if not self.tol_stability >= 0:
+            raise ValueError("You must provide a positive tolerance for tol_stability")
+        if not (self.dsmax >= abs(self.ds) >= self.dsmin >= 0):
+            raise ValueError(f"You must provide a valid interval (ordered) for ds. You passed {self.dsmax} >= {abs(self.ds)} >= {self.dsmin}")
+        if not (abs(self.ds) >= self.dsmin_bisection >= 0):
+            raise ValueError("You must provide a valid interval for `ds` and `dsmin_bisection`")
+        if not self.p_max >= self.p_min:
+            raise ValueError("You must provide a valid interval [p_min, p_max]")
+        if self.n_inversion % 2 != 0:
+            raise ValueError("The option `n_inversion` number must be even")
+        if not 0 <= self.detect_bifurcation <= 3:
+            raise ValueError("The option `detect_bifurcation` must belong to {0,1,2,3}")
+        if not self.tol_bisection_eigenvalue >= 0:
+            raise ValueError("The option `tol_bisection_eigenvalue` must be positive")
 
 
 @dataclass
@@ -267,6 +285,23 @@ class ContResult:
     sol: list = field(default_factory=list)
 
 
+def detect_fold(p1, p2, p3):
+    """src/Bifurcations.jl:32."""
+    return (p3 - p2) * (p2 - p1) < 0
+
+
+def locate_fold(br, cp):
+    """locate_fold!(contres, iter, state), src/Bifurcations.jl:35-69: a fold is flagged by the loss of monotony of the
+    parameter along the last three points of the branch; only when bifurcations are not detected through eigenvalues
+    (detect_bifurcation < 2, src/Continuation.jl:524, "to avoid duplicates")."""
+    n = len(br.param)
+    if cp.detect_fold and cp.detect_bifurcation < 2 and n > 2 and detect_fold(br.param[-3], br.param[-2], br.param[-1]):
+        br.specialpoint.append(dict(type="fold", step=n - 1, idx=n - 1, param=br.param[-1], status="guess",
+                                    interval=(br.param[-2], br.param[-2])))
+        return True
+    return False
+
+
 def mod_counter(step, every):
     """src/Utils.jl:183-188."""
     if step == 0 or every == 0:
@@ -389,10 +424,11 @@ def continuation(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm2, verb
             if eig is not None:
                 vals, n_unst, n_imag = eigen(z, n_unst_prev)
                 n_unst_prev = prev_unst
-                if prev_unst != -1 and n_unst != prev_unst:             # detect_bifurcation, Bifurcations.jl:22-28
+                if cp.detect_bifurcation > 1 and prev_unst != -1 and n_unst != prev_unst:   # Continuation.jl:530, Bifurcations.jl:22-28
                     br.specialpoint.append(dict(step=step + 1, param=z.p, n_unstable=(prev_unst, n_unst)))
             step += 1
             record(z, sol, ds, vals)
+            locate_fold(br, cp)
             if cp.save_to_file:
                 save_to_file(filename, cp.ds, z.u, z.p, step, br)
         ds, stop = step_size_control(ds, conv, sol.itnewton, cp)
@@ -498,11 +534,11 @@ def continuation_native(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm
                 print(f"step {step:3d} ds={r.ds_used:+.3e} -> p={r.p:+.6f} conv={bool(r.converged)} "
                       f"itnewton={r.itnewton} itlinear={r.itlinear}")
             if r.converged:
-                if r.bifurcation:
+                if r.bifurcation and cp.detect_bifurcation > 1:                # Continuation.jl:530
                     sp = dict(step=step + 1, param=r.p, n_unstable=(prev_unst, r.n_unstable))
                     on_boundary = r.p in (cp.p_min, cp.p_max)
                     keep = True
-                    if bisection and not on_boundary:                          # Continuation.jl:537-541
+                    if bisection and cp.detect_bifurcation > 2 and not on_boundary:   # Continuation.jl:537-541
                         bo = L.BisectionOpts(cp.dsmin_bisection, cp.n_inversion, cp.max_bisection_steps,
                                              cp.tol_bisection_eigenvalue, cp.max_steps)
                         res = L.BisectionResult()
@@ -522,6 +558,7 @@ def continuation_native(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm
                         br.specialpoint.append(sp)
                 step += 1
                 record(r, r.itnewton, r.itlinear, [r.residuals[i] for i in range(r.itnewton + 1)])
+                locate_fold(br, cp)
                 if cp.save_to_file:
                     save_to_file(filename, cp.ds, state_vec(), r.p, step, br)
                 if finalise_solution is not None:

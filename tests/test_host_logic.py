@@ -125,6 +125,51 @@ def test_solution_sampling_and_checkpoints(tmp_path):
     assert C.load_solution(fn, 1, "bw")[1] < p3                             # backward branch: the `bw` group
 
 
+class FoldProb:
+    """F(x, p) = p - x_i^2 + 0.1 (x_i - mean x): a turning point at p ~ 0 (the cubic-with-a-fold pattern of
+    test/newton/test_newton.jl:23-52 / test/continuation/simple_continuation.jl)."""
+    delta = palc.EPS_FD
+
+    def F(self, x, p):
+        return p - x**2 + 0.1 * (x - x.mean())
+
+    def Jm(self, x, p):
+        n = x.size
+        return np.diag(-2 * x + 0.1) - 0.1 / n * np.ones((n, n))
+
+    def residual(self, x, p): return NumpyVec(self.F(x.a, p))
+    def jacobian(self, x, p): return OpaqueJacobian(self.Jm(x.a, p))
+
+
+def test_fold_detection_by_parameter_monotony_and_parameter_checks():
+    """locate_fold! (src/Bifurcations.jl:32-69): with detect_bifurcation < 2 a fold is recorded where the parameter stops
+    being monotone along the branch, at the step and with the interval the reference stores; with eigenvalue-based
+    detection (>= 2) the fold test is off (Continuation.jl:524).  ContinuationPar refuses inconsistent settings
+    (src/ContParameters.jl:89-99)."""
+    prob = FoldProb()
+    nopt = C.NewtonPar(tol=1e-11, max_iterations=15, linsolver=direct_ls, eigsolver=lambda J, nev: krylov.default_eig(J.M, nev))
+    alg = C.PALC(tangent="secant", theta=0.5, bls=hip.BorderingBLS(None, check_precision=False))
+    x0 = NumpyVec(np.full(5, 0.5))
+    for level in (0, 1):
+        cp = C.ContinuationPar(ds=-0.02, dsmin=1e-4, dsmax=0.03, p_min=-1.0, p_max=1.0, max_steps=40, nev=3,
+                               detect_bifurcation=level, newton_options=nopt)
+        br = C.continuation(prob, x0, 0.25, alg, cp, normC=C.norminf)
+        folds = [sp for sp in br.specialpoint if sp.get("type") == "fold"]
+        assert len(folds) == 1, br.specialpoint
+        k = folds[0]["step"]
+        assert C.detect_fold(br.param[k - 2], br.param[k - 1], br.param[k]) and folds[0]["param"] == br.param[k]
+        assert folds[0]["interval"] == (br.param[k - 1], br.param[k - 1]) and abs(br.param[k - 1]) < 0.01
+        assert all(sp.get("type") == "fold" for sp in br.specialpoint)    # level 1 computes eigenvalues but flags nothing
+    cp2 = C.ContinuationPar(ds=-0.02, dsmin=1e-4, dsmax=0.03, p_min=-1.0, p_max=1.0, max_steps=40, nev=3,
+                            detect_bifurcation=2, newton_options=nopt)
+    br2 = C.continuation(prob, x0, 0.25, alg, cp2, normC=C.norminf)
+    assert not any(sp.get("type") == "fold" for sp in br2.specialpoint) and len(br2.specialpoint) >= 1
+    for bad in (dict(ds=0.2, dsmax=0.1), dict(ds=1e-5, dsmin=1e-4), dict(p_min=1.0, p_max=0.0), dict(n_inversion=3),
+                dict(detect_bifurcation=4), dict(tol_stability=-1.0)):
+        with pytest.raises(ValueError):
+            C.ContinuationPar(**bad)
+
+
 def test_step_size_control_and_stability():
     cp = C.ContinuationPar(dsmin=1e-3, dsmax=0.1, a=0.5, newton_options=C.NewtonPar(max_iterations=10))
     ds, stop = C.step_size_control(0.01, True, 2, cp)
