@@ -1,6 +1,6 @@
 #!/bin/bash
 # per-kernel durations of the DCT pass kernels (rocprofv3 kernel trace of a short bench) for a list of option settings:
-#   VARIANTS="dct_xcd_map=0 dct_xcd_map=3 dct_xcd_map=7" bash scripts/gpu_round2_o.sh
+#   VARIANTS="dct_xcd_map=0 dct_xcd_map=3 dct_xcd_map=7" bash scripts/gpu_dct_kernel_stats.sh
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out

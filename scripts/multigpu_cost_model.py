@@ -1,7 +1,7 @@
 """Cost model of the 512^3 corrector step on 2 / 4 / 8 MI355X from MEASURED 1-GPU kernel times (no multi-GPU node was
 available to this round; every RCCL number below is an assumption, stated).
 
-Inputs (written by scripts/gpu_round2_h.sh on the GPU box, copied to profiles/):
+Inputs (written by scripts/gpu_cost_model_inputs.sh on the GPU box, copied to profiles/):
   bench_slab{64,128,256}.json   bench.py --size 512 --size-z nz: the corrector step on the z-slab one of 8 / 4 / 2 ranks owns,
                                 i.e. every local kernel at its distributed size with the real iteration counts
   slabemu.jsonl                 one preconditioner application on that slab: transposed-DCT local part (5 passes) vs the slab
