@@ -42,6 +42,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# multi-process GPU work on this driver stack needs dmabuf IPC (RCCL / hipIpcGetMemHandle fail with the legacy mode); the
+# launcher normally exports it -- keep it for a bare `torchrun bench.py` as well (must be set before the HIP runtime loads)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 

@@ -14,6 +14,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for multi-process GPU work (before the HIP runtime loads)
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
