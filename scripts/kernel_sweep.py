@@ -169,6 +169,26 @@ if "variants" in what:
             report("dct_precond", t, 80.0 * N, rcp_steps=steps, rel_diff_vs_2steps=err, rep=rep)
     ctx.set_option("dct_rcp_steps", 2)
 
+if "pad" in what:
+    # stride of the Krylov basis: N doubles = 2^30 bytes at 512^3 puts element i of every basis vector on the same HBM
+    # channel / bank; pad the stride by a few KiB and compare (interleaved repetitions)
+    kmax = 13
+    pads = (0, 32, 512, 2048 + 32, 8192 + 32, 65536 + 512 + 32)
+    hbuf = (C.c_double * 65)()
+    V = torch.rand((N + max(pads)) * kmax, dtype=torch.float64, device="cuda", generator=g)
+    for k in (4, 8, 12):
+        cc = (C.c_double * k)(*([0.01] * k))
+        for rep in range(2):
+            for pad in pads:
+                ld = N + pad
+                dst = V[ld * k:].data_ptr()      # the next basis vector, as in the Arnoldi step
+                fa = lambda: ctx.check(ctx.lib.bk_krylov_multiaxpy(ctx.h, N, C.c_void_p(V.data_ptr()), ld, k, cc, C.c_void_p(v.t.data_ptr()),
+                                                                   1.0, C.c_void_p(dst), None))
+                fd = lambda: ctx.check(ctx.lib.bk_krylov_multidot(ctx.h, N, C.c_void_p(V.data_ptr()), ld, k, C.c_void_p(v.t.data_ptr()), hbuf))
+                report("multiaxpy", timeit(fa, reps=5, warm=1), 8.0 * N * (k + 2), k=k, pad=pad, rep=rep)
+                report("multidot", timeit(fd, reps=5, warm=1), 8.0 * N * (k + 1), k=k, pad=pad, rep=rep)
+    del V
+
 if "xcd" in what:
     # XCD-blocked streaming (vec_xcd_map) A/B, interleaved repetitions
     ld = (N + 31) // 32 * 32
