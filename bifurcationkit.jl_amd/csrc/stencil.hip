@@ -48,7 +48,7 @@ struct ShK {                // kernel-side copy of ShArgs (+ derived constants)
     const double* halo_lo;
     const double* halo_hi;
     int zchunk, ntx, nty, nzc, nblocks, grid8;
-    int zc0;                // first z-chunk of this launch (multi-GPU: interior and face chunks go in separate launches)
+    int zc0, zcstep;        // z-chunks zc0, zc0 + zcstep, ... of this launch (multi-GPU: interior and face chunks go in separate launches)
     int vec_ok;
     int vload;              // plane staging with 16-B loads (nx a multiple of the tile width, 16-B aligned planes)
     int nt;                 // non-temporal hint on the u loads and the output stores (touched once)
@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(256) sh_stream_kernel(ShK P) {
     if (L >= P.nblocks) return;
     const int tix = L % P.ntx;
     const int tiy = (L / P.ntx) % P.nty;
-    const int zc = P.zc0 + L / (P.ntx * P.nty);
+    const int zc = P.zc0 + (L / (P.ntx * P.nty)) * P.zcstep;
     const int x0 = tix * TX, y0 = tiy * TY;
     const int zs = zc * P.zchunk;
     const int ze = min(zs + P.zchunk, P.nz);
@@ -500,7 +500,7 @@ int sh_apply(bk_ctx* ctx, const ShArgs& a) {
     const size_t n = (size_t)a.nx * a.ny * a.nz;
     const bool dim3d = a.az != 0.0;
     const int variant = (int)ctx->opt("sh_kernel", 1.0);
-    P.zc0 = 0;
+    P.zc0 = 0; P.zcstep = 1;
     if (variant == 0) {
         if (a.part == 1) return 0;                            // the gather cross-check runs whole once the halos are in
         ProfScope ps(ctx, a.mode == 0 ? "jvp" : "residual", (a.mode == 0 ? 24.0 : 16.0) * n);
@@ -513,11 +513,26 @@ int sh_apply(bk_ctx* ctx, const ShArgs& a) {
         P.nty = (a.ny + TY - 1) / TY;
         if (!dim3d) zchunk = 1;
         if (zchunk <= 0) {
-            // aim at >= ~2048 blocks (8 per CU) without making chunks shorter than 16 planes
+            // The kernel keeps 3 workgroups per CU resident (162 VGPRs), i.e. R = 3 * CUs blocks run as one round, and a block
+            // walks zchunk + 4 planes (4 to prime its plane pipeline).  Pick the number of chunks that minimises
+            // rounds * planes per block: 3 chunks of 171 planes at 512^3 (256 tiles x 3 = 768 blocks = exactly one round,
+            // 2 % priming) run 6.8 % faster than the 8 x 64 of rounds 1-2 (2048 blocks = 2.67 rounds), the 64-plane slab of 8
+            // ranks 17 % (3 x 22 against 4 x 16: profiles/r2_jvp_zchunk_sweep_512.jsonl).  With the halo exchange overlapped
+            // the interior chunks and the two face chunks are separate launches, costed separately.
             const int tiles = P.ntx * P.nty;
-            int want = (2048 + tiles - 1) / tiles;
-            zchunk = (a.nz + want - 1) / want;
-            if (zchunk < 16) zchunk = 16;
+            const long R = 3L * (ctx->num_cu > 0 ? ctx->num_cu : 256);
+            const bool split = a.part != 0;
+            long best = -1;
+            for (int c = 1; c <= 64; ++c) {
+                const int zc = (a.nz + c - 1) / c;
+                if (zc < 8 && c > 1) break;
+                const int nzc = (a.nz + zc - 1) / zc;
+                const long per = zc + 4;
+                long cost;
+                if (split && nzc >= 3) cost = (((long)(nzc - 2) * tiles + R - 1) / R + (2L * tiles + R - 1) / R) * per;
+                else cost = (((long)nzc * tiles + R - 1) / R) * per;
+                if (best < 0 || cost < best) { best = cost; zchunk = zc; }
+            }
         }
         if (zchunk > a.nz) zchunk = a.nz;
         P.zchunk = zchunk;
@@ -530,9 +545,9 @@ int sh_apply(bk_ctx* ctx, const ShArgs& a) {
                   (!a.halo_hi || ((uintptr_t)a.halo_hi & 15) == 0);
         P.nt = n >= ((size_t)1 << 22) && ctx->opt("sh_nt", 1.0) != 0.0;
         // part 0: everything; part 1: the chunks that touch no halo plane (1 .. nzc-2); part 2: the two face chunks
-        auto launch = [&](int zc0, int count) {
+        auto launch = [&](int zc0, int count, int step = 1) {
             if (count <= 0) return;
-            P.zc0 = zc0;
+            P.zc0 = zc0; P.zcstep = step;
             P.nblocks = P.ntx * P.nty * count;
             P.grid8 = (P.nblocks + 7) / 8 * 8;
             ProfScope ps(ctx, a.mode == 0 ? "jvp" : "residual", (a.mode == 0 ? 24.0 : 16.0) * n * count / P.nzc);
@@ -549,6 +564,8 @@ int sh_apply(bk_ctx* ctx, const ShArgs& a) {
             if (a.part != 1) launch(0, P.nzc);                // nothing can be split off: everything waits for the halos
         } else if (a.part == 1) {
             launch(1, inner);
+        } else if (tail == 1) {
+            launch(0, 2, P.nzc - 1);                          // both face chunks (first and last) in one launch
         } else {
             launch(0, 1);
             launch(1 + inner, tail);
