@@ -252,6 +252,13 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if os.environ.get("BK_BENCH_HOSTCOMM") == "1":
         local = 0                                   # test mode: all ranks share GPU 0
+    if world > 1:
+        # a collective that never completes (a rank died, a link is down) must end the run with a traceback instead of
+        # hanging the node: every rank exits after BK_BENCH_WATCHDOG_S seconds (default 15 min; 0 disables)
+        import faulthandler
+        wd = int(os.environ.get("BK_BENCH_WATCHDOG_S", "900"))
+        if wd > 0:
+            faulthandler.dump_traceback_later(wd, exit=True)
     torch.cuda.set_device(local)
     from bk_amd import hip
 
