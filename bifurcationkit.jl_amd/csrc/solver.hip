@@ -187,18 +187,25 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     // discarded (they cost launch-bound microseconds at these sizes); a step whose classical Gram-Schmidt pass needs the
     // DGKS second pass (or broke down) is flagged by the device and repeated on the host path.  Counters (numops / iters)
     // count consumed steps only, so they equal the host-driven run.
-    int chunk = (int)ctx->opt("gmres_chunk", n <= ((size_t)1 << 22) ? 4.0 : 1.0);
+    // (default: vectors up to 8 MiB.  At 16 MiB -- cGL 1024^2 -- a chunk gains nothing even on a 192-iteration solve, and every
+    // step speculated past convergence costs a whole operator application there: 0.3 ms with the dense sine transforms)
+    int chunk = (int)ctx->opt("gmres_chunk", n <= ((size_t)1 << 20) ? 4.0 : 1.0);
     if (nt != 0 || (ctx->comm == COMM_HOST && ctx->nranks > 1) || chunk < 2 || !ctx->h_rec_dev) chunk = 1;
     if (chunk > kRecChunks) chunk = kRecChunks;
     double* d_coef = nullptr;
     const double* h_rec = ctx->h_rec;          // the records land in pinned, device-mapped host memory: no copy operation
     int q_first = 0, q_count = 0;              // columns q_first .. q_first + q_count - 1 of this cycle wait in h_rec
+    // Speculation ramp: a solve whose predecessor on this context needed <= 2 steps (an exact preconditioner: config 3 on the
+    // trivial branch converges in ONE) starts with a chunk of 1 and doubles from there, so that it does not pay for 3
+    // speculative operator applications per solve (cGL 1024^2 eigensolve: 1.38 -> 0.70 s); everything else starts with full chunks
+    int ramp = (ctx->gmres_last_steps <= 2) ? 1 : chunk;
     if (chunk > 1) BK_TRY(ws.get((size_t)kMaxBasis + 4, &d_coef));
     // next Hessenberg column (Arnoldi step from V[j]): from the queue of device-computed columns, else computed now
     auto next_column = [&](int j, double* hcol, double* hnext_out) -> int {
         if (chunk > 1) {
             if (!(q_count > 0 && j >= q_first && j < q_first + q_count)) {
-                const int steps = std::min(chunk, m - j);
+                const int steps = std::min(std::min(ramp, chunk), m - j);
+                ramp = std::min(chunk, 2 * ramp);
                 for (int s2 = 0; s2 < steps; ++s2) {
                     BK_TRY(A->apply(B.vec(j + s2), nullptr, op_a0, op_a1, w, nullptr));
                     BK_TRY(v_arnoldi_step_dev(ctx, n, B.V, B.ld, j + s2 + 1, w, eta, B.orth_tol,
@@ -346,6 +353,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     }
     res->niter = kk ? numops : iters;
     res->resnorm = beta;
+    ctx->gmres_last_steps = iters;
     if (xt) for (int q = 0; q < nt; ++q) xt[q] = xtail[q];
     return 0;
 }

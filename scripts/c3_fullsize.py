@@ -22,6 +22,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 parts = sys.argv[2].split(",") if len(sys.argv) > 2 else ["eig", "hopf"]
 dims, ls_ = (n, n), (np.pi * n / 41, (np.pi / 2) * n / 21)
 ctx = hip.Context(0)
+if os.environ.get("BK_GMRES_CHUNK"):
+    ctx.set_option("gmres_chunk", float(os.environ["BK_GMRES_CHUNK"]))      # 1: host-driven Arnoldi steps; >= 2: device-resident chunks
 prob = hip.CGL2d(ctx, dims, ls_, r=0.5)
 n2 = 2 * n * n
 lam = []
