@@ -5,7 +5,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 TAG=${1:-r2}
 mkdir -p gpurun_out
 export PYTHONPATH="$PWD"
-timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -30 | tee gpurun_out/pytest_gpu.log
+[ "${SKIP_TESTS:-0}" = 1 ] || timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -30 | tee gpurun_out/pytest_gpu.log
 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2 | tee gpurun_out/smoke.log
 timeout 900 python bench.py 2> gpurun_out/bench_${TAG}.err | tail -1 > gpurun_out/bench_${TAG}.log
 cd /tmp && export TMPDIR=/tmp
