@@ -24,6 +24,7 @@
 //                      (B + az Sz)^2 = B^2 + 2 az B Sz + az^2 Sz^2.  HBM traffic = read v + read u +
 //                      write out = 24 B/point (16 B/point for the residual) + halo re-reads that hit
 //                      L2 because the blockIdx -> tile map keeps neighbouring tiles on one XCD.
+#include "launch_plan.h"
 #include "ops.h"
 
 namespace bk {
@@ -512,28 +513,8 @@ int sh_apply(bk_ctx* ctx, const ShArgs& a) {
         P.ntx = (a.nx + TX - 1) / TX;
         P.nty = (a.ny + TY - 1) / TY;
         if (!dim3d) zchunk = 1;
-        if (zchunk <= 0) {
-            // The kernel keeps 3 workgroups per CU resident (162 VGPRs), i.e. R = 3 * CUs blocks run as one round, and a block
-            // walks zchunk + 4 planes (4 to prime its plane pipeline).  Pick the number of chunks that minimises
-            // rounds * planes per block: 3 chunks of 171 planes at 512^3 (256 tiles x 3 = 768 blocks = exactly one round,
-            // 2 % priming) run 6.8 % faster than the 8 x 64 of rounds 1-2 (2048 blocks = 2.67 rounds), the 64-plane slab of 8
-            // ranks 17 % (3 x 22 against 4 x 16: profiles/r2_jvp_zchunk_sweep_512.jsonl).  With the halo exchange overlapped
-            // the interior chunks and the two face chunks are separate launches, costed separately.
-            const int tiles = P.ntx * P.nty;
-            const long R = 3L * (ctx->num_cu > 0 ? ctx->num_cu : 256);
-            const bool split = a.part != 0;
-            long best = -1;
-            for (int c = 1; c <= 64; ++c) {
-                const int zc = (a.nz + c - 1) / c;
-                if (zc < 8 && c > 1) break;
-                const int nzc = (a.nz + zc - 1) / zc;
-                const long per = zc + 4;
-                long cost;
-                if (split && nzc >= 3) cost = (((long)(nzc - 2) * tiles + R - 1) / R + (2L * tiles + R - 1) / R) * per;
-                else cost = (((long)nzc * tiles + R - 1) / R) * per;
-                if (best < 0 || cost < best) { best = cost; zchunk = zc; }
-            }
-        }
+        if (zchunk <= 0)        // rounds x planes per workgroup (launch_plan.h); 3 workgroups per CU stay resident (162 VGPRs)
+            zchunk = sh_plan_zchunk(a.nz, P.ntx * P.nty, 3L * (ctx->num_cu > 0 ? ctx->num_cu : 256), a.part != 0);
         if (zchunk > a.nz) zchunk = a.nz;
         P.zchunk = zchunk;
         P.nzc = (a.nz + zchunk - 1) / zchunk;
