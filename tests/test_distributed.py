@@ -1,4 +1,4 @@
-"""Two-rank tests of the distributed path.  CPU (gloo): decomposition algorithm + communicator callbacks.
+"""Multi-rank tests of the distributed path.  CPU (gloo, 2 / 3 / 8 ranks): decomposition algorithm + communicator callbacks.
 GPU: both ranks on cuda:0 through the host-staged test communicator vs the 1-rank HIP result."""
 import os
 import socket
@@ -40,8 +40,9 @@ def _run(mode, world=2, timeout=600):
         assert "checks OK" in o, o[-2000:]
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_decomposition_gloo_cpu(world):
+    """2 and 3 ranks (ragged split), and the 8 ranks of the node the scaling runs use (slabs of 3-4 planes)."""
     _run("cpu", world)
 
 
