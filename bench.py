@@ -1,7 +1,13 @@
 #!/usr/bin/env python
 """bench.py -- Newton-Krylov PALC corrector steps/s on the 3-D Swift-Hohenberg grid (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU.  Either the caller launches the ranks (`python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment) or -- when WORLD_SIZE is not
+set -- bench.py re-executes itself through torch.distributed.run on 127.0.0.1 with a free port, so the bare
+`python bench.py --gpus 8` works as well.  Rank 0 prints the ONE JSON line either way.  `--dry-launch` only proves the
+launch path (every rank joins a gloo group, rank 0 prints a JSON record; no GPU needed).
 
 Workload (BASELINE.json configs[4]/[3]): SH3d on an n^3 grid (default 512^3, fp64, 1 GiB per
 vector), l = 0.1, nu = 1.2 (examples/SH3d.jl:86), GMRES(30) rtol 1e-9 (SH3d.jl:93) with the exact spectral
@@ -74,6 +80,8 @@ def parse():
     ap.add_argument("--eig-inner-rtol", type=float, default=1e-9, help="branch workload: rtol of the eigensolver's inner solves (SH3d.jl:115: 1e-9)")
     ap.add_argument("--eig-thick", type=int, default=1, help="branch workload: eigensolve starts from the previous step's Ritz vectors")
     ap.add_argument("--eig-inner", default="minres", choices=["gmres", "minres"], help="branch workload: inner solver of the shift-invert eigensolver")
+    ap.add_argument("--dry-launch", action="store_true", help="launch-path check only: every rank joins a gloo group and reports "
+                                                              "in, rank 0 prints a JSON record (no GPU work)")
     ap.add_argument("--linsolver", default="gmres", choices=["gmres", "minres"],
                     help="gmres: GMRESKrylovKit(30), the reference example's solver (the headline workload); minres: "
                          "KrylovLS(KrylovAlg = :minres), valid because the SH Jacobian is symmetric (experiment)")
@@ -239,17 +247,59 @@ def thread_counts():
     return cand
 
 
-def main():
-    args = parse()
+def self_launch(args):
+    """`python bench.py --gpus N` from a bare shell (no WORLD_SIZE in the environment): start the N ranks through
+    torch.distributed.run on the loopback address with a free port and hand their output through.  Returns the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, available_cpus() // max(args.gpus, 1))))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_launch(args, rank, world):
+    """Launch-path check: all ranks meet in a gloo group; rank 0 prints what it saw."""
     import torch
     import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t)
+        seen = int(round(float(t.item())))
+        dist.destroy_process_group()
+    else:
+        seen = 1
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": args.gpus, "world_size": world,
+                          "rank_sum": seen, "ranks_reported": seen == world * (world + 1) // 2,
+                          "launcher": "external" if os.environ.get("BK_BENCH_SELF_LAUNCHED") != "1" else "self"}))
 
+
+def main():
+    args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        os.environ["BK_BENCH_SELF_LAUNCHED"] = "1"
+        raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE = {world}: launch one rank per GPU "
+                         f"(torch.distributed.run --nproc-per-node {args.gpus}), or unset WORLD_SIZE to let bench.py start them")
+    if args.dry_launch:
+        dry_launch(args, rank, world)
+        return
+    import torch
+    import torch.distributed as dist
+
+    if world > 1 and os.environ.get("BK_BENCH_HOSTCOMM") != "1" and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} needs {world} visible GPUs, found {torch.cuda.device_count()} "
+                         f"(BK_BENCH_HOSTCOMM=1 shares GPU 0 between the ranks over a host-staged test communicator)")
     if os.environ.get("BK_BENCH_HOSTCOMM") == "1":
         local = 0                                   # test mode: all ranks share GPU 0
     if world > 1:
@@ -412,6 +462,23 @@ def main():
         inner = dict(alg_gb=gb, kernel_ms=ms, gbs=gb / max(ms, 1e-9) * 1e3, frac_of_peak=gb / max(ms, 1e-9) * 1e3 / HBM_PEAK_GBS,
                      kernel_time_share_of_wall=ms / max(dt * 1e3, 1e-9))
     dom = max(compute, key=lambda k: compute[k]["ms_total"]) if compute else None
+    # what a reader of a multi-GPU number needs to believe it: the ranks the communicator itself reports (ncclCommCount), the
+    # measured cost of the two collectives of the hot path on THIS node, and their share of the timed region
+    comm_rec = None
+    if world > 1:
+        kind, crank, cranks = ctx.comm_info()
+        ar_us = ctx.comm_probe("allreduce", 32, 50)                 # the projections of one Arnoldi step
+        halo_cnt = 2 * n * n                                        # 2 planes per side
+        halo_us = ctx.comm_probe("halo", halo_cnt, 20)
+        nb = 2 if 0 < rank < world - 1 else 1
+        wall_ms = dt * 1e3
+        comm_rec = {"backend": kind, "ranks_in_communicator": cranks, "allreduce_32_doubles_us": ar_us,
+                    "halo_exchange_us": halo_us, "halo_bytes_per_neighbour": 8 * halo_cnt,
+                    "halo_gbs_per_direction": 8.0 * halo_cnt / max(halo_us, 1e-9) / 1e3, "halo_neighbours_rank0": nb,
+                    "share_of_wall": {k_: kernels[k_]["ms_total"] / max(wall_ms, 1e-9) for k_ in ("halo", "alltoall", "transpose")
+                                      if k_ in kernels},
+                    "note": "halo / alltoall shares are event-timed spans on rank 0's streams (the halo exchange runs on its own "
+                            "stream under the interior z-chunks of the JVP)"}
     roofline = None
     if dom:
         k = kernels[dom]
@@ -474,7 +541,7 @@ def main():
                                           "p": cfull["u"].p},
                        "setup_seconds": t_setup, "sh_kernel": args.sh_kernel, "linsolver": args.linsolver,
                        "preconditioner": "none" if P is None else "dct"},
-            "roofline": roofline, "inner_loop": inner, "steady_state": steady, "kernels": kernels,
+            "roofline": roofline, "inner_loop": inner, "steady_state": steady, "kernels": kernels, "comm": comm_rec,
         }
         cb = None
         if world == 1 and args.cpu_sample > 0:

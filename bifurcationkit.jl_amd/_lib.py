@@ -101,6 +101,8 @@ SIGNATURES = {
     "bk_comm_unique_id": (I, [VP]),
     "bk_ctx_create_dist": (I, [C.POINTER(VP), I, VP, I, I, VP]),
     "bk_ctx_create_hostcomm": (I, [C.POINTER(VP), I, VP, I, I, ALLREDUCE_FN, SENDRECV_FN, VP]),
+    "bk_comm_info": (I, [VP, c_int_p, c_int_p, c_int_p]),
+    "bk_comm_probe": (I, [VP, I, SZ, I, c_double_p]),
     "bk_ctx_destroy": (I, [VP]),
     "bk_last_error": (C.c_char_p, [VP]),
     "bk_ctx_sync": (I, [VP]),

@@ -1,4 +1,6 @@
 // Context, workspace pool, profiling scopes, deterministic reduction finish, communicator glue.
+#include <chrono>
+
 #include "common.h"
 #include "ops.h"
 
@@ -333,6 +335,58 @@ int bk_ctx_create_hostcomm(bk_ctx** out, int device, void* stream, int rank, int
     ctx->h_sendrecv = sendrecv;
     ctx->h_user = user;
     *out = ctx;
+    return 0;
+}
+
+int bk_comm_info(bk_ctx* ctx, int* kind, int* rank, int* nranks) {
+    if (!ctx) return -1;
+    int r = ctx->rank, n = ctx->nranks;
+    if (ctx->comm == COMM_RCCL && ctx->nccl) {
+        BK_NCCL(ctx, ncclCommUserRank(ctx->nccl, &r));
+        BK_NCCL(ctx, ncclCommCount(ctx->nccl, &n));
+    }
+    if (kind) *kind = (int)ctx->comm;
+    if (rank) *rank = r;
+    if (nranks) *nranks = n;
+    return 0;
+}
+
+int bk_comm_probe(bk_ctx* ctx, int what, size_t count, int reps, double* us_per_call) {
+    if (!ctx || !us_per_call || reps < 1 || count < 1) return -1;
+    *us_per_call = 0.0;
+    if (ctx->comm == COMM_NONE || ctx->nranks == 1) return 0;
+    WsGuard ws(ctx);
+    double *v = nullptr, *lo = nullptr, *hi = nullptr;
+    if (what == 0) {
+        if (count > (size_t)kRedSlots) return set_error(ctx, "bk_comm_probe: at most %d doubles per all-reduce", kRedSlots);
+        BK_HIP(ctx, hipMemsetAsync(ctx->d_red, 0, count * sizeof(double), ctx->stream));
+    } else if (what == 1) {
+        BK_TRY(ws.get(2 * count, &v));
+        BK_TRY(ws.get(count, &lo));
+        BK_TRY(ws.get(count, &hi));
+        BK_HIP(ctx, hipMemsetAsync(v, 0, 2 * count * sizeof(double), ctx->stream));
+    } else {
+        return set_error(ctx, "bk_comm_probe: unknown probe %d", what);
+    }
+    std::vector<double> hbuf(what == 0 ? count : 0, 0.0);
+    for (int pass = 0; pass < 2; ++pass) {           // pass 0 = warm-up (connection set-up of the first call)
+        const int n = pass == 0 ? 2 : reps;
+        BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < n; ++i) {
+            if (what == 0) {
+                if (ctx->comm == COMM_RCCL)
+                    BK_NCCL(ctx, ncclAllReduce(ctx->d_red, ctx->d_red, count, ncclDouble, ncclSum, ctx->nccl, ctx->stream));
+                else
+                    BK_TRY(comm_allreduce_host(ctx, hbuf.data(), (int)count, 0));
+            } else {
+                BK_TRY(halo_exchange(ctx, ctx->stream, v, count, 2, 1, lo, hi));
+            }
+        }
+        BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (pass == 1)
+            *us_per_call = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+    }
     return 0;
 }
 

@@ -189,9 +189,22 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     // count consumed steps only, so they equal the host-driven run.
     // (default: vectors up to 8 MiB.  At 16 MiB -- cGL 1024^2 -- a chunk gains nothing even on a 192-iteration solve, and every
     // step speculated past convergence costs a whole operator application there: 0.3 ms with the dense sine transforms)
-    int chunk = (int)ctx->opt("gmres_chunk", n <= ((size_t)1 << 20) ? 4.0 : 1.0);
+    // The decision must be the same on every rank (a rank on the device path issues in-stream all-reduces its peer on the
+    // host path never joins): with RCCL ranks it does not look at the rank-local length at all -- ragged z-slabs may
+    // straddle any size threshold -- and defaults to chunks of "gmres_chunk_dist" (4) steps, whose speculation is capped by
+    // the convergence prediction below; a single rank keeps the size rule.
+    const bool rccl_ranks = ctx->comm == COMM_RCCL && ctx->nranks > 1;
+    int chunk = (int)ctx->opt("gmres_chunk", rccl_ranks ? ctx->opt("gmres_chunk_dist", 4.0) : (n <= ((size_t)1 << 20) ? 4.0 : 1.0));
     if (nt != 0 || (ctx->comm == COMM_HOST && ctx->nranks > 1) || chunk < 2 || !ctx->h_rec_dev) chunk = 1;
     if (chunk > kRecChunks) chunk = kRecChunks;
+    // Speculation cap from the residual history (all quantities are all-reduced, i.e. identical on every rank): with the
+    // last reduction factor rho = beta_k / beta_{k-1} the estimate reaches the tolerance after `need` further steps; never
+    // enqueue more than that.  GMRES converges at least that fast from there on (superlinearly, usually), so a speculated
+    // step is rarely wasted, and when the prediction was too optimistic the next chunk simply follows.  For vectors that
+    // stream from HBM a wasted step is a whole operator application; the cache-resident sizes keep the plain ramp
+    // (option gmres_predict: 1 = always, 0 = never, default: HBM-sized vectors and RCCL ranks).
+    const bool predict = ctx->opt("gmres_predict", (rccl_ranks || n > ((size_t)1 << 20)) ? 1.0 : 0.0) != 0.0;
+    double beta_prev = 0.0, beta_now = 0.0, tol_now = 0.0;
     double* d_coef = nullptr;
     const double* h_rec = ctx->h_rec;          // the records land in pinned, device-mapped host memory: no copy operation
     int q_first = 0, q_count = 0;              // columns q_first .. q_first + q_count - 1 of this cycle wait in h_rec
@@ -204,7 +217,13 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     auto next_column = [&](int j, double* hcol, double* hnext_out) -> int {
         if (chunk > 1) {
             if (!(q_count > 0 && j >= q_first && j < q_first + q_count)) {
-                const int steps = std::min(std::min(ramp, chunk), m - j);
+                int steps = std::min(std::min(ramp, chunk), m - j);
+                if (predict && steps > 1 && beta_now > 0.0) {
+                    const double rho = (beta_prev > 0.0 && beta_now < beta_prev) ? beta_now / beta_prev : 1.0;
+                    int need = 1;
+                    for (double b_ = beta_now * rho; b_ > 2.0 * tol_now && need < steps; b_ *= rho) ++need;
+                    steps = need;
+                }
                 ramp = std::min(chunk, 2 * ramp);
                 for (int s2 = 0; s2 < steps; ++s2) {
                     BK_TRY(A->apply(B.vec(j + s2), nullptr, op_a0, op_a1, w, nullptr));
@@ -221,7 +240,12 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
                 return 0;
             }
             q_count = j - q_first;             // flagged: this and the later speculative steps are void; redo on the host path
-            B.dlt = B.orth_tol;                // (the device kept the defect estimate: stay on the safe side on the host)
+            B.dlt = B.orth_tol;                // (the device kept the defect estimate: stay on the safe side on the host ...
+            {                                  //  ... and on the device, whose later chunks would otherwise trust a stale estimate)
+                const double ot = B.orth_tol;
+                BK_HIP(ctx, hipMemcpyAsync(d_coef + kMaxBasis + 2, &ot, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+                BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            }
         }
         return arnoldi_step(ctx, A, B, j, w, hcol, hnext_out, op_a0, op_a1, eta);
     };
@@ -262,6 +286,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
         B.dlt = 0.0;                           // a single vector is orthonormal
         if (chunk > 1) BK_HIP(ctx, hipMemsetAsync(d_coef + kMaxBasis + 2, 0, sizeof(double), ctx->stream));
         q_count = 0;                           // a new cycle: nothing speculative carries over
+        beta_prev = 0.0; beta_now = beta; tol_now = tol;
         BK_TRY(next_column(0, h.data(), &hnext));
         numops += 1;
         return 0;
@@ -292,7 +317,9 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
             for (int i = 0; i < k; ++i) Rat(i, k - 1) = col[i];
             y[k] = -sn[k - 1] * y[k - 1];
             y[k - 1] = cs[k - 1] * y[k - 1];
+            beta_prev = beta;
             beta = std::fabs(y[k]);
+            beta_now = beta;
             if (trace) ctx->hist.push_back(beta);
             const bool conv = kk ? !(beta > tol) : (beta <= tol);
             if (conv || k >= m || hnext == 0.0) break;

@@ -319,10 +319,19 @@ __global__ void __launch_bounds__(kThreads) multidot_kernel(size_t n, const doub
 
 // ------------------------------------------------------------------ fused multi-axpy (+scale, +norm)
 // dst = scale * (src + sum_{j<k} c[j] V_j);  partials[block] = sum_chunk dst^2 (if want_norm).
-template <int KB, int VEC, bool NT = false, bool LDNT = false, int U = 1>
+// DEV: coefficients, scale and the gate of the DGKS second pass come from device memory (dcoef: arnoldi_coef_kernel's
+// layout) instead of the by-value argument -- the device-resident Arnoldi step; same body, same access pattern.
+template <int KB, int VEC, bool NT = false, bool LDNT = false, int U = 1, bool DEV = false>
 __global__ void __launch_bounds__(kThreads) multiaxpy_kernel(size_t n, const double* __restrict__ V, size_t ldv, int k,
                                                              Coefs cf, const double* src, double scale, double* dst,
-                                                             int want_norm, double* __restrict__ partials, unsigned xcd = 0) {
+                                                             int want_norm, double* __restrict__ partials, unsigned xcd = 0,
+                                                             const double* __restrict__ dcoef = nullptr, int gated = 0) {
+    if (DEV) {
+        if (gated && dcoef[kMaxBasis + 1] == 0.0) return;
+        scale = dcoef[kMaxBasis];
+#pragma unroll
+        for (int j = 0; j < KB; ++j) cf.c[j] = j < k ? dcoef[j] : 0.0;
+    }
     double nn = 0.0;
     if (VEC == 2) {
         const StreamRange rg = stream_range(n >> 1, xcd);
@@ -454,51 +463,6 @@ __global__ void arnoldi_coef2_kernel(const double* __restrict__ hw, int k, doubl
     coef[kMaxBasis] = 1.0 / cn;
     rec[kMaxBasis] = ok ? be * cn : 0.0;
     if (!ok) rec[kMaxBasis + 1] = 1.0;
-}
-
-// dst = scale * (src + sum_j c[j] V_j) with c and scale read from device memory (written by arnoldi_coef_kernel)
-template <int KB, int VEC>
-__global__ void __launch_bounds__(kThreads) multiaxpy_dev_kernel(size_t n, const double* __restrict__ V, size_t ldv, int k,
-                                                                 const double* __restrict__ coef, const double* src,
-                                                                 double* dst, int gated) {
-    if (gated && coef[kMaxBasis + 1] == 0.0) return;
-    const size_t stride = (size_t)gridDim.x * kThreads;
-    const double scale = coef[kMaxBasis];
-    double c[KB];
-#pragma unroll
-    for (int j = 0; j < KB; ++j) c[j] = j < k ? coef[j] : 0.0;
-    if (VEC == 2) {
-        const size_t n2 = n >> 1;
-        for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += stride) {
-            double2 r = reinterpret_cast<const double2*>(src)[i];
-#pragma unroll
-            for (int j = 0; j < KB; ++j) {
-                if (j < k) {
-                    const double2 vv = reinterpret_cast<const double2*>(V + (size_t)j * ldv)[i];
-                    r.x = fma(c[j], vv.x, r.x);
-                    r.y = fma(c[j], vv.y, r.y);
-                }
-            }
-            r.x *= scale; r.y *= scale;
-            reinterpret_cast<double2*>(dst)[i] = r;
-        }
-        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-            const size_t i = n - 1;
-            double r = src[i];
-#pragma unroll
-            for (int j = 0; j < KB; ++j)
-                if (j < k) r = fma(c[j], V[(size_t)j * ldv + i], r);
-            dst[i] = r * scale;
-        }
-    } else {
-        for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
-            double r = src[i];
-#pragma unroll
-            for (int j = 0; j < KB; ++j)
-                if (j < k) r = fma(c[j], V[(size_t)j * ldv + i], r);
-            dst[i] = r * scale;
-        }
-    }
 }
 
 // ------------------------------------------------------------------ basis rotation  dst_j = sum_i Q(i,j) V_i
@@ -735,10 +699,15 @@ int v_arnoldi_step_dev(bk_ctx* ctx, size_t n, double* V, size_t ldv, int k, cons
     const int grid = grid_for(n, vec ? 2 : 1, kRedBlocks);
     double* dst = V + (size_t)k * ldv;
     const double* gate = coef + kMaxBasis + 1;
+    // the same tuned instantiations as the host-driven step (non-temporal loads, two elements per lane) for vectors that
+    // stream from HBM; plain accesses for the cache-resident sizes
+    const bool big = vec && nt_hint(ctx, n);
+    const Coefs cf0{};
     auto dots = [&](const double* x, const double* g) {
 #define BK_MD_DEV(KB)                                                                                                           \
     do {                                                                                                                        \
-        if (vec) hipLaunchKernelGGL((multidot_kernel<KB, 2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, x, ctx->d_partials, g); \
+        if (big) hipLaunchKernelGGL((multidot_kernel<KB, 2, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, x, ctx->d_partials, g, 0u); \
+        else if (vec) hipLaunchKernelGGL((multidot_kernel<KB, 2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, x, ctx->d_partials, g); \
         else hipLaunchKernelGGL((multidot_kernel<KB, 1>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, x, ctx->d_partials, g);     \
     } while (0)
         if (k <= 4) BK_MD_DEV(4);
@@ -752,10 +721,12 @@ int v_arnoldi_step_dev(bk_ctx* ctx, size_t n, double* V, size_t ldv, int k, cons
         hipLaunchKernelGGL(reduce_stage2_dev, dim3(k + 1), dim3(256), 0, ctx->stream, ctx->d_partials, grid, k + 1, ctx->d_red, g);
     };
     auto axpys = [&](const double* src, int gated) {
+        const unsigned xcd = xcd_map(ctx, n, grid, true, k);
 #define BK_MA_DEV(KB)                                                                                                         \
     do {                                                                                                                      \
-        if (vec) hipLaunchKernelGGL((multiaxpy_dev_kernel<KB, 2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, coef, src, dst, gated); \
-        else hipLaunchKernelGGL((multiaxpy_dev_kernel<KB, 1>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, coef, src, dst, gated);     \
+        if (big) hipLaunchKernelGGL((multiaxpy_kernel<KB, 2, true, true, 2, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf0, src, 1.0, dst, 0, ctx->d_partials, xcd, coef, gated); \
+        else if (vec) hipLaunchKernelGGL((multiaxpy_kernel<KB, 2, false, false, 1, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf0, src, 1.0, dst, 0, ctx->d_partials, 0u, coef, gated); \
+        else hipLaunchKernelGGL((multiaxpy_kernel<KB, 1, false, false, 1, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf0, src, 1.0, dst, 0, ctx->d_partials, 0u, coef, gated);     \
     } while (0)
         if (k <= 4) BK_MA_DEV(4);
         else if (k <= 8) BK_MA_DEV(8);

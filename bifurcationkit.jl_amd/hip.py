@@ -90,6 +90,20 @@ class Context:
     def sync(self):
         self.check(self.lib.bk_ctx_sync(self.h), "bk_ctx_sync")
 
+    def comm_info(self):
+        """(kind, rank, nranks) as the communicator itself reports them (RCCL: ncclCommUserRank / ncclCommCount)."""
+        k, r, n = C.c_int(), C.c_int(), C.c_int()
+        self.check(self.lib.bk_comm_info(self.h, C.byref(k), C.byref(r), C.byref(n)), "bk_comm_info")
+        return {0: "none", 1: "rccl", 2: "host"}[k.value], r.value, n.value
+
+    def comm_probe(self, what: str, count: int, reps: int = 20) -> float:
+        """Microseconds per call of the hot path's collectives on this communicator (collective: all ranks call it):
+        what = "allreduce" (count doubles, in-stream) | "halo" (count doubles to / from each z-neighbour)."""
+        us = C.c_double()
+        self.check(self.lib.bk_comm_probe(self.h, {"allreduce": 0, "halo": 1}[what], int(count), int(reps), C.byref(us)),
+                   "bk_comm_probe")
+        return us.value
+
     def prof_enable(self, on=True):
         self.check(self.lib.bk_prof_enable(self.h, 1 if on else 0))
 

@@ -57,6 +57,15 @@ typedef int (*bk_sendrecv_fn)(void* user, const double* sendbuf, size_t nsend, i
                               double* recvbuf, size_t nrecv, int src);
 int bk_ctx_create_hostcomm(bk_ctx** ctx, int device, void* stream, int rank, int nranks,
                            bk_allreduce_fn allreduce, bk_sendrecv_fn sendrecv, void* user);
+/* What the communicator of this context is: *kind 0 = none, 1 = RCCL, 2 = host-staged test communicator; *rank /
+ * *nranks as the communicator itself reports them (RCCL: ncclCommUserRank / ncclCommCount -- the number of ranks RCCL
+ * actually connected, bench.py prints it next to a multi-GPU number).  No reference counterpart.                    */
+int bk_comm_info(bk_ctx* ctx, int* kind, int* rank, int* nranks);
+/* Time the two collectives of the hot path on this context's communicator (collective call: every rank must make it):
+ * what 0 = in-stream all-reduce (sum) of `count` doubles (count <= 256: the projections of one Arnoldi step),
+ * what 1 = halo exchange of `count` doubles with each z-neighbour (ncclSend/ncclRecv group).  `reps` back-to-back calls
+ * between two stream synchronisations; *us_per_call = host wall time / reps.  No reference counterpart.               */
+int bk_comm_probe(bk_ctx* ctx, int what, size_t count, int reps, double* us_per_call);
 int bk_ctx_destroy(bk_ctx* ctx);
 const char* bk_last_error(bk_ctx* ctx);
 int bk_ctx_sync(bk_ctx* ctx);

@@ -66,3 +66,41 @@ def test_real_rccl_ranks_when_two_gpus_are_visible():
     if torch.cuda.device_count() < 2:
         pytest.skip("needs >= 2 visible GPUs")
     _run("rccl", 2)
+
+
+def _bench(args, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PYTHONPATH=ROOT, OMP_NUM_THREADS="2", **(env_extra or {}))
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                          timeout=timeout, cwd="/tmp")
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_self_launches_its_ranks_from_a_bare_shell(world):
+    """`python bench.py --gpus N` without WORLD_SIZE in the environment (the form the driver uses) must start the N ranks
+    itself; --dry-launch stops after every rank has reported in (no GPU here).  Exactly one JSON line on stdout."""
+    import json
+    r = _bench(["--gpus", str(world), "--dry-launch"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["dry_launch"] and rec["world_size"] == world and rec["ranks_reported"] and rec["launcher"] == "self"
+
+
+def test_bench_under_an_external_launcher_does_not_relaunch():
+    import json
+    port = _free_port()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(PYTHONPATH=ROOT, OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["launcher"] == "external"
+
+
+def test_bench_rejects_a_world_size_that_contradicts_gpus():
+    r = _bench(["--gpus", "2", "--dry-launch"], env_extra={"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
