@@ -290,13 +290,17 @@ def detect_fold(p1, p2, p3):
     return (p3 - p2) * (p2 - p1) < 0
 
 
-def locate_fold(br, cp):
+def locate_fold(br, cp, p_state):
     """locate_fold!(contres, iter, state), src/Bifurcations.jl:35-69: a fold is flagged by the loss of monotony of the
-    parameter along the last three points of the branch; only when bifurcations are not detected through eigenvalues
-    (detect_bifurcation < 2, src/Continuation.jl:524, "to avoid duplicates")."""
+    parameter along the last three points ALREADY in the branch record -- the reference calls it before save!
+    (src/Continuation.jl:524 vs :579), so the point just computed is not among them and only supplies ``param =
+    getp(state)``; only when bifurcations are not detected through eigenvalues (detect_bifurcation < 2, "to avoid
+    duplicates").  Call it before the new point is recorded."""
     n = len(br.param)
     if cp.detect_fold and cp.detect_bifurcation < 2 and n > 2 and detect_fold(br.param[-3], br.param[-2], br.param[-1]):
-        br.specialpoint.append(dict(type="fold", step=n - 1, idx=n - 1, param=br.param[-1], status="guess",
+        # Julia's 1-based branch[n_br - 1] is the MIDDLE point of the three: 0-based index n - 2; `step` = n_br - 1 is the
+        # (0-based) step number of the last recorded point
+        br.specialpoint.append(dict(type="fold", step=n - 1, idx=n - 2, param=float(p_state), status="guess",
                                     interval=(br.param[-2], br.param[-2])))
         return True
     return False
@@ -334,8 +338,26 @@ def save_to_file(filename, ds, sol, p, i, br):
                ds=[float(x) for x in br.ds], n_unstable=list(br.n_unstable), n_imag=list(br.n_imag),
                eig=[None if v is None else [[float(z.real), float(z.imag)] for z in np.atleast_1d(v)] for v in br.eig],
                specialpoint=[{k: (list(v) if isinstance(v, tuple) else v) for k, v in sp.items()} for sp in br.specialpoint])
-    with open(f"{filename}-branch.json", "w") as f:
-        json.dump({"branch" + fd: rec}, f)
+    # the branch record is identical on every rank of a distributed run: rank 0 writes it.  The reference opens the file
+    # with "a+" and keeps the other direction's branch (ext/JLD2Ext/save.jl:22-28): merge with what is there, and replace
+    # the file atomically so that a reader (or a crash) never sees a truncated record
+    ctx = getattr(sol, "ctx", None)
+    if ctx is not None and getattr(ctx, "nranks", 1) > 1 and ctx.rank != 0:
+        return
+    import os
+    path = f"{filename}-branch.json"
+    doc = {}
+    if os.path.exists(path):
+        try:
+            with open(path) as f:
+                doc = json.load(f)
+        except (OSError, ValueError):
+            doc = {}
+    doc["branch" + fd] = rec
+    tmp = f"{path}.tmp{os.getpid()}"
+    with open(tmp, "w") as f:
+        json.dump(doc, f)
+    os.replace(tmp, path)
 
 
 def load_solution(filename, i, fd="fw", rank_suffix=""):
@@ -344,11 +366,12 @@ def load_solution(filename, i, fd="fw", rank_suffix=""):
         return np.array(z["sol"]), float(z["param"])
 
 
-def load_branch(filename):
+def load_branch(filename, fd=None):
+    """The branch record written by :func:`save_to_file`; ``fd`` = "fw" / "bw" picks a direction (default: the only / first one)."""
     import json
     with open(f"{filename}-branch.json") as f:
         d = json.load(f)
-    return next(iter(d.values()))
+    return d["branch" + fd] if fd else next(iter(d.values()))
 
 
 def continuation(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm2, verbosity=0, save_sol=False,
@@ -427,8 +450,8 @@ def continuation(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm2, verb
                 if cp.detect_bifurcation > 1 and prev_unst != -1 and n_unst != prev_unst:   # Continuation.jl:530, Bifurcations.jl:22-28
                     br.specialpoint.append(dict(step=step + 1, param=z.p, n_unstable=(prev_unst, n_unst)))
             step += 1
+            locate_fold(br, cp, z.p)
             record(z, sol, ds, vals)
-            locate_fold(br, cp)
             if cp.save_to_file:
                 save_to_file(filename, cp.ds, z.u, z.p, step, br)
         ds, stop = step_size_control(ds, conv, sol.itnewton, cp)
@@ -557,8 +580,8 @@ def continuation_native(prob, x0, p0, alg: PALC, cp: ContinuationPar, normC=norm
                     if keep:
                         br.specialpoint.append(sp)
                 step += 1
+                locate_fold(br, cp, r.p)
                 record(r, r.itnewton, r.itlinear, [r.residuals[i] for i in range(r.itnewton + 1)])
-                locate_fold(br, cp)
                 if cp.save_to_file:
                     save_to_file(filename, cp.ds, state_vec(), r.p, step, br)
                 if finalise_solution is not None:

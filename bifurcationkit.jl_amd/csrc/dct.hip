@@ -472,7 +472,7 @@ int dct_plan_create_dist(bk_ctx* ctx, const int n[3], const double ainv[3], doub
         (void)hipMemcpy(p->kmap, km.data(), sizeof(unsigned) * km.size(), hipMemcpyHostToDevice);
     }
     // slab z-solve: equal power-of-two slabs, lines divisible among the ranks, a positive shift (B_r SPD, well conditioned)
-    BK_TRY(slab_tables_create(ctx, p, n[2] / R, n[2] % R == 0, ainv[2]));
+    if (slab_tables_create(ctx, p, n[2] / R, n[2] % R == 0, ainv[2]) != 0) { dct_plan_destroy(p); return -1; }
     *out = p;
     return 0;
 }
@@ -503,7 +503,7 @@ static int slab_tables_create(bk_ctx* ctx, DctPlan* p, int nl, bool even, double
                 hipMalloc(&p->phi_loc, sizeof(double) * 2 * nl) != hipSuccess ||
                 hipMalloc(&p->fsend, sizeof(double) * fb) != hipSuccess ||
                 hipMalloc(&p->frecv, sizeof(double) * fb) != hipSuccess) {
-                dct_plan_destroy(p);
+                // the plan stays with its owner (dct_plan_create_dist / the preconditioner object), which destroys it once
                 return set_error(ctx, "distributed DCT: slab tables allocation failed");
             }
             (void)hipMemcpy(p->twid_loc, tw.data(), sizeof(double) * tw.size(), hipMemcpyHostToDevice);

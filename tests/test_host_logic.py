@@ -157,8 +157,12 @@ def test_fold_detection_by_parameter_monotony_and_parameter_checks():
         folds = [sp for sp in br.specialpoint if sp.get("type") == "fold"]
         assert len(folds) == 1, br.specialpoint
         k = folds[0]["step"]
-        assert C.detect_fold(br.param[k - 2], br.param[k - 1], br.param[k]) and folds[0]["param"] == br.param[k]
-        assert folds[0]["interval"] == (br.param[k - 1], br.param[k - 1]) and abs(br.param[k - 1]) < 0.01
+        # the reference runs locate_fold! BEFORE save! (Continuation.jl:524 vs :579): the three points are the last three
+        # already recorded (steps k-2, k-1, k), `param` is the state computed after them, idx / interval the middle point
+        assert C.detect_fold(br.param[k - 2], br.param[k - 1], br.param[k]) and folds[0]["param"] == br.param[k + 1]
+        assert not C.detect_fold(br.param[k - 3], br.param[k - 2], br.param[k - 1])       # not flagged one step early
+        assert folds[0]["idx"] == k - 1 and folds[0]["interval"] == (br.param[k - 1], br.param[k - 1])
+        assert abs(br.param[k - 1]) < 0.01
         assert all(sp.get("type") == "fold" for sp in br.specialpoint)    # level 1 computes eigenvalues but flags nothing
     cp2 = C.ContinuationPar(ds=-0.02, dsmin=1e-4, dsmax=0.03, p_min=-1.0, p_max=1.0, max_steps=40, nev=3,
                             detect_bifurcation=2, newton_options=nopt)
