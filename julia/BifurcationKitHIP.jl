@@ -42,6 +42,16 @@ struct EigOpts
     sigma::Cdouble; krylovdim::Cint; maxiter::Cint; tol::Cdouble; hermitian::Cint; seed::Culonglong
 end
 
+const BK_MAX_NEWTON_ITER = 64
+struct NewtonOpts            # bk_newton_opts
+    tol::Cdouble; max_iterations::Cint; norm_inf::Cint; linesearch::Cint; alpha::Cdouble; alpha_min::Cdouble
+    max_residual::Cdouble; callback::Ptr{Cvoid}; callback_user::Ptr{Cvoid}
+end
+struct NewtonResult          # bk_newton_result
+    converged::Cint; itnewton::Cint; itlinear::Cint; residuals::NTuple{BK_MAX_NEWTON_ITER + 1, Cdouble}
+end
+NewtonResult() = NewtonResult(0, 0, 0, ntuple(_ -> 0.0, BK_MAX_NEWTON_ITER + 1))
+
 const BK_PDE_SH, BK_PDE_SH1D, BK_PDE_CGL2D = Cint(1), Cint(2), Cint(3)
 
 # ------------------------------------------------------------------------------------------------ context
@@ -54,6 +64,18 @@ mutable struct HipContext
         ctx = new(r[])
         finalizer(c -> ccall((:bk_ctx_destroy, libbkhip[]), Cint, (Ptr{Cvoid},), c.h), ctx)
     end
+end
+"(kind, rank, nranks) of the context's communicator as RCCL itself reports them (bk_comm_info)"
+function comm_info(ctx::HipContext)
+    k, r, n = Ref{Cint}(0), Ref{Cint}(0), Ref{Cint}(1)
+    ccall((:bk_comm_info, libbkhip[]), Cint, (Ptr{Cvoid}, Ref{Cint}, Ref{Cint}, Ref{Cint}), ctx.h, k, r, n)
+    return (:none, :rccl, :host)[k[] + 1], Int(r[]), Int(n[])
+end
+"microseconds per call of the hot path's collectives on this communicator (bk_comm_probe; what = 0 all-reduce, 1 halo)"
+function comm_probe(ctx::HipContext, what::Integer, count::Integer, reps::Integer = 20)
+    us = Ref{Cdouble}(0)
+    check(ctx, ccall((:bk_comm_probe, libbkhip[]), Cint, (Ptr{Cvoid}, Cint, Csize_t, Cint, Ref{Cdouble}), ctx.h, what, count, reps, us), "bk_comm_probe")
+    return us[]
 end
 function check(ctx::HipContext, st::Cint, what = "")
     st == 0 && return nothing
@@ -72,6 +94,8 @@ mutable struct HipVec
         v = new(ctx, r[], n)
         finalizer(x -> ccall((:bk_free, libbkhip[]), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), x.ctx.h, x.p), v)
     end
+    # non-owning view of device memory the library hands to a callback (no finalizer)
+    HipVec(ctx::HipContext, n::Integer, p::Ptr{Cdouble}, owns::Bool) = (@assert !owns; new(ctx, p, n))
 end
 function HipVec(ctx::HipContext, a::Vector{Float64})
     v = HipVec(ctx, length(a))
@@ -162,8 +186,8 @@ end
 
 # (F(u, p + eps) - F(u, p)) / eps for the parameter number `ipar` (0-based kernel order), evaluated without the ~1e-8 white
 # rounding noise of the two-residual quotient (every parameter multiplies a pointwise term; bk_residual_dparam).  The
-# reference's newton_palc forms the quotient itself from two `residual` calls (src/continuation/Palc.jl:239-240); a problem
-# can hand this out through a custom `BK.residual` method or use the one-call native corrector.
+# reference's newton_palc forms the quotient itself from two `residual` calls (src/continuation/Palc.jl:239-240); the
+# methods of section "dF/dp" below route the engine to this function by dispatch on the device problem type.
 function residual_dparam(prob::HipProblem, u::HipVec, par, ipar::Integer; eps = sqrt(Base.eps(Float64)))
     out = similar(u)
     pv = Cdouble[Float64(x) for x in Tuple(par)][1:prob.nparams]
@@ -191,9 +215,33 @@ function (J::HipJacobian)(dx::HipVec)
     out
 end
 
+# F as a callable STRUCT (not an anonymous closure): its type marks the BifurcationProblem as a device problem, so that the
+# two places where the engine forms dF/dp by a two-residual quotient can be routed by dispatch (section "dF/dp" below).
+struct HipResidualFn
+    prob::HipProblem
+end
+(f::HipResidualFn)(u::HipVec, p) = residual(f.prob, u, p)
+struct HipJacobianFn
+    prob::HipProblem
+end
+(f::HipJacobianFn)(u::HipVec, p) = jacobian(f.prob, u, p)
+
 "BifurcationProblem whose F and J live on the device.  `par` must list the kernel parameters first."
 bifurcation_problem(prob::HipProblem, u0::HipVec, par, lens; kwargs...) =
-    BK.BifurcationProblem((u, p) -> residual(prob, u, p), u0, par, lens; J = (u, p) -> jacobian(prob, u, p), kwargs...)
+    BK.BifurcationProblem(HipResidualFn(prob), u0, par, lens; J = HipJacobianFn(prob), kwargs...)
+
+# the problem / iterator types the routed methods dispatch on (src/Problems.jl:89,344: BifurcationProblem{Tvf, ...} with
+# Tvf = BifFunction{Tf, ...}; src/Continuation.jl:27: ContIterable{Tkind, Tprob, ...})
+const HipBifProblem = BK.BifurcationProblem{<:BK.BifFunction{<:HipResidualFn}}
+const HipContIterable = BK.ContIterable{<:BK.AbstractContinuationKind, <:HipBifProblem}
+hipproblem(bp::HipBifProblem) = bp.VF.F.prob
+# 0-based kernel index of the continuation parameter: the field of `par` the lens writes to
+function _ipar(par, lens)
+    a, b = Tuple(BK.set(par, lens, 1.0)), Tuple(BK.set(par, lens, 2.0))
+    i = findfirst(k -> a[k] != b[k], 1:length(a))
+    isnothing(i) && error("the continuation lens does not address a kernel parameter")
+    return i - 1
+end
 
 mutable struct HipDCTPreconditioner     # Pl = (L1 + shift I)^-1: cholesky(L1) of SH3d.jl:88 / lu(L1 + I) of SH2d-fronts.jl:121
     prob::HipProblem
@@ -403,6 +451,178 @@ function (lbs::HipMatrixFreeBLS)(J::HipJacobian, dR::HipVec, dzu::HipVec, dzp::T
         ctx.h, J.h, dR.p, dzu.p, dzp, R.p, n, ξu, ξp, isnothing(shift) ? 0 : 1, isnothing(shift) ? 0.0 : shift, _dotscale(dotp, R),
         Ref(_opts(lbs.solver)), dX.p, dl, cv, it), "bk_bls_matrixfree")
     return dX, dl[], cv[] == 1, Int(it[])
+end
+
+# ------------------------------------------------------------------------------------------------ dF/dp
+# The engine forms dF/dp = (F(x, p + ϵ) - F(x, p)) / ϵ from two residuals in exactly two places on the PALC path:
+# newton_palc (src/continuation/Palc.jl:223-226, 239-240) and gettangent!(::Bordered) (src/continuation/Tangents.jl:77-82).
+# With ϵ = 1.5e-8 the quotient of two stencil evaluations is white noise at 1e-8 relative -- ten times the GMRES
+# tolerance of the examples; on a 256^3 / 512^3 grid that noise costs 117-228 operator applications per step instead of
+# 20-25 (DESIGN.md section 7).  Every parameter of these PDEs multiplies a pointwise term, so the stencil part cancels
+# identically and bk_residual_dparam evaluates the same quotient without the noise.  The two methods below are the
+# engine's own methods specialised on the device problem type (nothing in BifurcationKit is edited): `continuation`
+# runs unchanged and picks them up by dispatch.
+
+# gettangent!(state, iter, ::Bordered, dotθ): src/continuation/Tangents.jl:71-104 with the routed quotient
+function BK.gettangent!(state::BK.AbstractContinuationState, iter::HipContIterable, ::BK.Bordered, dotθ)
+    (iter.verbosity > 0) && println("Predictor: Bordered (device dF/dp)")
+    ϵ = BK.getdelta(iter.prob)
+    τ = state.τ
+    θ = BK.getθ(iter)
+    T = eltype(iter)
+    par = BK.setparam(iter, state.z.p)
+    dFdl = residual_dparam(hipproblem(iter.prob), state.z.u, par, _ipar(BK.getparams(iter.prob), BK.getlens(iter)); eps = ϵ)
+    J = BK.jacobian(iter.prob, state.z.u, par)
+    τu, τp, flag, iterl = BK.solve_bls_palc(BK.get_bordered_linsolver(iter), iter, state, J, dFdl,
+                                           VI.zerovector(state.z.u), one(T))
+    ~flag && @warn "Linear solver failed to converge in tangent computation with type ::Bordered"
+    α = one(T) / sqrt(dotθ(τu, τu, τp, τp, θ))
+    α *= sign(dotθ(τ.u, τu, τ.p, τp, θ))
+    BK._copyto!(τ.u, τu)
+    τ.p = τp
+    VI.scale!(τ, α)
+end
+
+# C-side view of the engine's Newton callback (bk_newton_callback, include/bkhip.h): the device pointers are wrapped as
+# non-owning HipVec views and the engine's callback is called with the fields it documents (src/Newton.jl:151-159).
+mutable struct _CbBox
+    ctx::HipContext
+    n::Int
+    cb::Any
+    z0::Any
+    contparams::Any
+    residuals::Vector{Float64}
+    linsolver::Any
+    kwargs::Any
+end
+_view(ctx, p::Ptr{Cdouble}, n) = HipVec(ctx, n, p, false)          # (ctx, n, pointer, owns = false)
+function _newton_cb(user::Ptr{Cvoid}, x::Ptr{Cdouble}, fx::Ptr{Cdouble}, res::Cdouble, step::Cint, itlinear::Cint, p::Cdouble,
+                    z0u::Ptr{Cdouble}, z0p::Cdouble, from_newton::Cint)::Cint
+    b = unsafe_pointer_to_objref(user)::_CbBox
+    step > 0 && push!(b.residuals, res)
+    ok = b.cb((; x = _view(b.ctx, x, b.n), res_f = _view(b.ctx, fx, b.n), residual = res, step = Int(step),
+                itlinear = Int(itlinear), contparams = b.contparams, z0 = b.z0, p = p, residuals = b.residuals,
+                options = (; linsolver = b.linsolver)); fromNewton = from_newton != 0, b.kwargs...)
+    return ok ? Cint(1) : Cint(0)
+end
+
+# newton_palc(iter, state, dotθ; normN, callback, kwargs...): src/continuation/Palc.jl:187-305 as ONE library call
+# (bk_newton_palc: cancellation-free dF/dp, Jacobian handle, BorderingBLS, update, clamping, line search :254-281, callback
+# veto :235,294-297) whenever the bordered solver is the device BorderingBLS with the standard DotTheta; any other
+# combination (MatrixFreeBLS, a custom dotθ) takes the engine's generic loop with only the quotient routed.
+function BK.newton_palc(iter::HipContIterable, state::BK.AbstractContinuationState, dotθ = BK.getdot(iter);
+                        normN = LinearAlgebra.norm, callback = BK.cb_default, kwargs...)
+    prob = iter.prob
+    hp = hipproblem(prob)
+    ctx = hp.ctx
+    par = BK.getparams(prob)
+    lens = BK.getlens(iter)
+    contparams = BK.getcontparams(iter)
+    θ = BK.getθ(iter)
+    z0 = BK.getsolution(state)
+    τ0 = state.τ
+    (; z_pred, ds) = state
+    (; tol, max_iterations, verbose, α, αmin, linesearch) = contparams.newton_options
+    (; p_min, p_max) = contparams
+    lbs = BK.get_bordered_linsolver(iter)
+    native = lbs isa HipBorderingBLS{<:HipGMRES} && dotθ isa BK.DotTheta && dotθ.dot isa BK.NormalisedDot &&
+             (normN === LinearAlgebra.norm || normN === BK.norminf)
+    if !native
+        return _newton_palc_generic(iter, state, dotθ; normN, callback, kwargs...)
+    end
+    x = BK._copy(z_pred.u)
+    p = Ref{Cdouble}(z_pred.p)
+    pv = Cdouble[Float64(v) for v in Tuple(BK.set(par, lens, z_pred.p))][1:hp.nparams]
+    box = _CbBox(ctx, x.n, callback, z0, contparams, Float64[], lbs, kwargs)
+    cfun = callback === BK.cb_default ? C_NULL :
+           @cfunction(_newton_cb, Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cint, Cint, Cdouble, Ptr{Cdouble}, Cdouble, Cint))
+    no = NewtonOpts(tol, max_iterations, normN === BK.norminf ? 1 : 0, linesearch ? 1 : 0, α, αmin, 0.0, cfun,
+                    callback === BK.cb_default ? C_NULL : pointer_from_objref(box))
+    bo = BorderingOpts(lbs.tol, lbs.check_precision, lbs.k)
+    res = Ref(NewtonResult())
+    GC.@preserve box begin
+        check(ctx, ccall((:bk_newton_palc, libbkhip[]), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Ref{Cdouble}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Cdouble, Cdouble, Cdouble,
+             Ptr{Cdouble}, Cint, Cint, Cdouble, Cdouble, Ref{NewtonOpts}, Ref{BorderingOpts}, Ref{GmresOpts}, Ptr{Cvoid}, Ref{NewtonResult}),
+            ctx.h, hp.h, x.p, p, z0.u.p, z0.p, τ0.u.p, τ0.p, ds, θ, pv, length(pv), _ipar(par, lens),
+            max(p_min, -1.7e308), min(p_max, 1.7e308), Ref(no), Ref(bo), Ref(_opts(lbs.solver)), _plh(lbs.solver.Pl), res),
+            "bk_newton_palc")
+    end
+    r = res[]
+    residuals = Float64[r.residuals[i] for i in 1:(r.itnewton + 1)]
+    verbose && foreach(i -> BK.print_nonlinear_step(i - 1, residuals[i]), eachindex(residuals))
+    return BK.NonLinearSolution(BK.BorderedArray(x, p[]), prob, residuals, r.converged == 1, Int(r.itnewton), Int(r.itlinear))
+end
+
+# the engine's loop, line by line (Palc.jl:187-305), with the two-residual quotient replaced by residual_dparam
+function _newton_palc_generic(iter, state, dotθ; normN = LinearAlgebra.norm, callback = BK.cb_default, kwargs...)
+    prob = iter.prob
+    hp = hipproblem(prob)
+    par = BK.getparams(prob)
+    ϵ = BK.getdelta(prob)
+    paramlens = BK.getlens(iter)
+    ipar = _ipar(par, paramlens)
+    contparams = BK.getcontparams(iter)
+    𝒯 = eltype(iter)
+    θ = BK.getθ(iter)
+    z0 = BK.getsolution(state)
+    τ0 = state.τ
+    (; z_pred, ds) = state
+    (; tol, max_iterations, verbose, α, αmin, linesearch) = contparams.newton_options
+    (; p_min, p_max) = contparams
+    linsolver = BK.get_bordered_linsolver(iter)
+    α0 = α
+    N(u, _p) = BK.arc_length_eq(dotθ, u, z0.u, _p - z0.p, τ0.u, τ0.p, θ, ds)
+    normAC(resf, resn) = max(normN(resf), abs(resn))
+    x = BK._copy(z_pred.u)
+    p = z_pred.p
+    x_pred = BK._copy(x)
+    res_f = BK.residual(prob, x, BK.set(par, paramlens, p)); res_n = N(x, p)
+    res = normAC(res_f, res_n)
+    residuals = [res]
+    step = 0
+    itlineartot = 0
+    line_step = true
+    compute = callback((; x, res_f, residual = res, step, contparams, z0, p, residuals, options = (; linsolver)); fromNewton = false, kwargs...)
+    while (step < max_iterations) && (res > tol) && line_step && compute
+        dFdp = residual_dparam(hp, x, BK.set(par, paramlens, p), ipar; eps = ϵ)          # Palc.jl:239-240, routed
+        J = BK.jacobian(prob, x, BK.set(par, paramlens, p))
+        u, up, flag, itlinear = BK.solve_bls_palc(linsolver, iter, state, J, dFdp, res_f, res_n)
+        ~flag && @debug "[newton_palc] Linear solver did not converge."
+        itlineartot += sum(itlinear)
+        if linesearch
+            line_step = false
+            while !line_step && (α > αmin)
+                x_pred = VI.add!(BK._copyto!(x_pred, x), u, -α)
+                p_pred = p - α * up
+                BK._copyto!(res_f, BK.residual(prob, x_pred, BK.set(par, paramlens, p_pred)))
+                res_n = N(x_pred, p_pred)
+                res = normAC(res_f, res_n)
+                if res < residuals[end]
+                    if (res < residuals[end] / 4) && (α < 1)
+                        α *= 2
+                    end
+                    line_step = true
+                    BK._copyto!(x, x_pred)
+                    p = clamp(p_pred, p_min, p_max)
+                else
+                    α /= 2
+                end
+            end
+            α = α0
+        else
+            x = BK.minus!!(x, u)
+            p = clamp(p - up, p_min, p_max)
+            BK._copyto!(res_f, BK.residual(prob, x, BK.set(par, paramlens, p)))
+            res_n = N(x, p); res = normAC(res_f, res_n)
+        end
+        push!(residuals, res)
+        step += 1
+        verbose && BK.print_nonlinear_step(step, res, itlinear)
+        compute = callback((; x, res_f, J, residual = res, step, itlinear, contparams, z0, p, residuals, options = (; linsolver)); fromNewton = false, kwargs...)
+    end
+    flag = (residuals[end] < tol) & callback((; x, res_f, residual = res, step, contparams, p, residuals, options = (; linsolver)); fromNewton = false, kwargs...)
+    return BK.NonLinearSolution(BK.BorderedArray(x, p), prob, residuals, flag, step, itlineartot)
 end
 
 # ------------------------------------------------------------------------------------------------ eigensolver

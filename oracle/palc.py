@@ -26,6 +26,22 @@ class Problem:
     F: callable           # F(x, p) -> residual
     J: callable           # J(x, p) -> matrix | callable (opaque to the engine, :98-101)
     delta: float = EPS_FD
+    # optional: the pointwise factor phi_p(x) of dF/dp when the continuation parameter multiplies a pointwise term
+    # (F = S x + p phi_p(x) + ...).  The reference's quotient (F(x, p + eps) - F(x, p)) / eps then equals
+    # ((p + eps) - p) / eps * phi_p(x) EXACTLY in exact arithmetic, the stencil part cancelling identically; evaluating it
+    # in this form removes the ~eps_mach |L1 x| / eps rounding noise of the two-residual form.  None
+    # (default) = the literal form of Palc.jl:239-240 / Tangents.jl:77-82.
+    dparam_factor: callable = None
+
+
+def dF_dparam(prob, x, p, res_f=None):
+    """dFdp = (F(x, p + eps) - F(x, p)) / eps (Palc.jl:239-240, Tangents.jl:77-82); cancellation-free when the problem
+    supplies ``dparam_factor`` (what bk_residual_dparam evaluates on the device)."""
+    eps = prob.delta
+    if prob.dparam_factor is not None:
+        return (((p + eps) - p) / eps) * prob.dparam_factor(x, p)
+    f0 = res_f if res_f is not None else prob.F(x, p)
+    return (prob.F(x, p + eps) - f0) * (1.0 / eps)
 
 
 def norminf(x):
@@ -104,7 +120,7 @@ def newton_palc(prob, z0, tau0, z_pred, ds, theta, bls, *, tol=1e-12, max_iterat
     line_step = True
     compute = callback(dict(x=x, res_f=res_f, residual=res, step=step, z0=z0, p=p, residuals=residuals), fromNewton=False)
     while step < max_iterations and res > tol and line_step and compute:
-        dFdp = (prob.F(x, p + eps) - res_f) * (1.0 / eps)
+        dFdp = dF_dparam(prob, x, p, res_f)
         J = prob.J(x, p)
         u, up, flag, it = solve_bls_palc(bls, theta, tau0[0], tau0[1], J, dFdp, res_f, res_n)
         itlin += int(np.sum(it))
@@ -160,7 +176,7 @@ def secant_tangent(z1, z0, ds, theta):
 def bordered_tangent(prob, z, tau, theta, bls):
     """gettangent!(::Bordered), Tangents.jl:71-104.  Returns (tau_u, tau_p, flag)."""
     eps = prob.delta
-    dFdl = (prob.F(z[0], z[1] + eps) - prob.F(z[0], z[1])) * (1.0 / eps)
+    dFdl = dF_dparam(prob, z[0], z[1])
     J = prob.J(z[0], z[1])
     tu, tp, flag, _ = solve_bls_palc(bls, theta, tau[0], tau[1], J, dFdl, np.zeros_like(z[0]), 1.0)
     a = 1.0 / np.sqrt(dot_theta(tu, tu, tp, tp, theta))

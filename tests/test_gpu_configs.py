@@ -78,7 +78,13 @@ def test_c2_sh2d_512_residual_jvp_gmres_corrector_match_oracle(ctx):
     z0, z1 = (u, -0.1), (u1, -0.1 + ds / 150.0)
     tau = palc.secant_tangent(z1, z0, ds, theta)
     zp = palc.add_tangent(z0, tau, ds)
-    oprob = palc.Problem(lambda x_, p: sh.F(x_, p, 1.3), lambda x_, p: (lambda dx: sh.dF(x_, p, 1.3, dx)))
+    # dF/dp on both sides in the cancellation-free form ((p + eps) - p) / eps * u (dF/dl = u; bk_residual_dparam on the
+    # device, Problem.dparam_factor in the oracle): both sides then solve THE SAME right-hand sides and the operator-
+    # application counts can be compared two-sidedly.  (The literal two-residual quotient of Palc.jl:239-240 puts 4e-5
+    # relative white noise -- eps_mach |L1 u| / eps -- on dF/dp, far above rtol = 1e-9: oracle 44 + 13 applications with a
+    # restart, another noise realisation on the device; that comparison was one-sided in round 2.)
+    oprob = palc.Problem(lambda x_, p: sh.F(x_, p, 1.3), lambda x_, p: (lambda dx: sh.dF(x_, p, 1.3, dx)),
+                         dparam_factor=lambda x_, p: x_)
     obls = lambda *a, **k: bordered.bordering_bls(ols, *a, check_precision=False, **k)
     so = palc.newton_palc(oprob, z0, tau, zp, ds, theta, obls, tol=5e-9, max_iterations=15, normN=palc.norminf)
     B = hip.BorderedArray
@@ -88,14 +94,20 @@ def test_c2_sh2d_512_residual_jvp_gmres_corrector_match_oracle(ctx):
     assert so["converged"] and sg["converged"] and sg["itnewton"] == so["itnewton"] >= 1
     r0 = so["residuals"][0]
     # same predictor => same residual up to the rounding of one stencil evaluation, eps * |L1| * |u| ~ 4e-10 at h_y = 0.057
-    # (the 1e-10-relative figure of the 3-D configs, h = 0.196, is below that floor here)
-    assert abs(sg["residuals"][0] - r0) <= scale * np.abs(u).max(), (sg["residuals"], so["residuals"])
+    # (the 1e-10-relative figure of the 3-D configs, h = 0.196, is below that floor here); the later entries of the
+    # history additionally carry the linear-solve error rtol * |rhs| of either side
+    floor = scale * np.abs(u).max()
+    assert abs(sg["residuals"][0] - r0) <= floor, (sg["residuals"], so["residuals"])
+    for rg, ro in zip(sg["residuals"][1:], so["residuals"][1:]):
+        assert abs(rg - ro) <= 2 * floor + 1e-7 * r0, (sg["residuals"], so["residuals"])
     assert abs(sg["u"].p - so["p"]) <= 1e-9 and np.abs(sg["u"].u.numpy() - so["u"]).max() <= 1e-6
-    # the right-hand sides carry that rounding noise at 4e-5 relative, far above rtol = 1e-9: the solves chase different
-    # noise on the two sides, so the operator-application counts agree only roughly
-    # (measured: oracle 44 + 13 -- the R solve needs a restart --, HIP 32 with its own noise realisation); what is asserted is
-    # that the HIP side never needs substantially MORE applications than the reference algorithm
-    assert sg["itlineartot"] <= so["itlineartot"] + max(4, so["itlineartot"] // 3), (sg["itlineartot"], so["itlineartot"])
+    # two-sided: the same right-hand sides, the same algorithm => the same operator-application counts (+-1 per solve where
+    # the estimate crosses the tolerance within rounding)
+    assert abs(sg["itlineartot"] - so["itlineartot"]) <= 2 * sg["itnewton"], (sg["itlineartot"], so["itlineartot"])
+    # and the literal quotient still reproduces the round-2 pathology on the oracle side (the reference's own formula)
+    oprob_lit = palc.Problem(lambda x_, p: sh.F(x_, p, 1.3), lambda x_, p: (lambda dx: sh.dF(x_, p, 1.3, dx)))
+    sl = palc.newton_palc(oprob_lit, z0, tau, zp, ds, theta, obls, tol=5e-9, max_iterations=15, normN=palc.norminf)
+    assert sl["converged"] and sl["itlineartot"] > so["itlineartot"], (sl["itlineartot"], so["itlineartot"])
 
 
 def test_c3_cgl2d_1024_jvp_preconditioner_bordered_solve(ctx):

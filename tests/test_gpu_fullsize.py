@@ -121,7 +121,10 @@ def test_fullsize_tiled_corrector_matches_cpu_oracle_cell(ctx, big):
     Plc = operators.dct_preconditioner(bench.CELL, bench.CELL_L, shift)
     ols = lambda J, r, a0=0.0, a1=1.0: krylov.gmres_krylovkit(J, r, a0, a1, krylovdim=30, maxiter=150, rtol=1e-9,
                                                                atol=1e-12, Pl=Plc)[:3]
-    pc = palc.Problem(lambda x, p: shc.F(x, p, 1.2), lambda x, p: (lambda dx: shc.dF(x, p, 1.2, dx)))
+    # dF/dl = u, evaluated cancellation-free on both sides (bk_residual_dparam / Problem.dparam_factor): identical
+    # right-hand sides, so the counts below are compared two-sidedly
+    pc = palc.Problem(lambda x, p: shc.F(x, p, 1.2), lambda x, p: (lambda dx: shc.dF(x, p, 1.2, dx)),
+                      dparam_factor=lambda x, p: x)
     c0 = palc.newton(pc, bench.hex_guess_np(), 0.1, ols, tol=1e-10, max_iterations=40, normN=palc.norminf)
     c1 = palc.newton(pc, c0["u"], 0.1 + ds / 150.0, ols, tol=1e-10, max_iterations=20, normN=palc.norminf)
     assert c0["converged"] and c1["converged"] and np.abs(c0["u"]).max() > 1.0
@@ -158,9 +161,82 @@ def test_fullsize_tiled_corrector_matches_cpu_oracle_cell(ctx, big):
     floor = 4 * np.finfo(float).eps * l1_inf * float(np.abs(c0["u"]).max())             # ~1e-10 absolute
     assert floor < 1e-9                                                                  # well below the Newton tolerance
     assert abs(sg["residuals"][0] - r0) <= floor, (sg["residuals"], so["residuals"], floor)
+    # the whole residual history, not only its first entry: later entries also carry the linear-solve error rtol * |rhs|
+    for rg, ro in zip(sg["residuals"][1:], so["residuals"][1:]):
+        assert abs(rg - ro) <= 2 * floor + 1e-7 * r0, (sg["residuals"], so["residuals"])
     assert abs(sg["u"].p - so["p"]) <= 1e-9
-    # a stable state: the big GMRES needs about as many operator applications as the one-cell run
-    assert sg["itlineartot"] <= 2 * so["itlineartot"] + 4, (sg["itlineartot"], so["itlineartot"])
+    # a stable state and a tiling-invariant right-hand side: the big GMRES needs the one-cell run's operator applications,
+    # +-1 per solve (two solves per Newton iteration) where the estimate crosses the tolerance within rounding
+    assert abs(sg["itlineartot"] - so["itlineartot"]) <= 2 * sg["itnewton"], (sg["itlineartot"], so["itlineartot"])
     # the corrected big state is the tiling of the corrected cell state
     diff = sg["u"].u.copy().add_(tile(so["u"]), -1.0).norminf()
     assert diff <= 1e-7, diff
+
+
+def test_fullsize_shifted_solve_identities(ctx, big):
+    """The shifted-solve identities of test/linear_solvers/test_linear.jl:547-578 at full size on the SH3d Jacobian, h = 0.81:
+    ls(J, rhs; a0 = 1, a1 = -h) solves (I - h J) x = rhs; ls(J, rhs; a0 = 1/h, a1 = -1) / h is the same vector (|.|_inf <
+    1e-8 as there); both solver flavours.  With Pl, GMRESKrylovKit solves (a0 I + a1 Pl^-1 J) x = Pl^-1 rhs
+    (src/LinearSolver.jl:268-277), GMRESIterativeSolvers the true system through Pl^-1 (a0 I + a1 J) (:198-201): the
+    residuals are checked through the operator itself (no direct solve exists at this size)."""
+    from bk_amd import hip
+    u, rhs = _rand(ctx, big, 11), _rand(ctx, big, 12)
+    J = big.jacobian(u, 0.1)
+    P = hip.DCTPreconditioner(big, 1.0)
+    h = 0.81
+    kk = hip.GMRESKrylovKit(dim=30, rtol=1e-10, atol=1e-10, maxiter=100, Pl=P)
+    x1, ok1, it1 = kk(J, rhs, 1.0, -h)
+    x2, ok2, it2 = kk(J, rhs, 1.0 / h, -1.0)
+    assert ok1 and ok2 and abs(it1 - it2) <= 2, (it1, it2)
+    assert x2.copy().scale_(1.0 / h).add_(x1, -1.0).norminf() < 1e-8
+    # the system KrylovKit's branch solves: x - h Pl^-1 (J x) = Pl^-1 rhs
+    r = x1.copy().add_(P.ldiv(J(x1)), -h).add_(P.ldiv(rhs), -1.0)
+    assert r.norm() <= 2e-10 * max(P.ldiv(rhs).norm(), 1.0) + 1e-10
+    its = hip.GMRESIterativeSolvers(reltol=1e-10, restart=60, maxiter=200, Pl=P)
+    y1, oky, ity = its(J, rhs, 1.0, -h)
+    y2, oky2, _ = its(J, rhs, 1.0 / h, -1.0)
+    assert oky and oky2
+    assert y2.copy().scale_(1.0 / h).add_(y1, -1.0).norminf() < 1e-8
+    # the true shifted system, in the preconditioned norm the solver controls: Pl^-1 ((I - h J) y - rhs)
+    ry = P.ldiv(J(y1, 1.0, -h).add_(rhs, -1.0))
+    assert ry.norm() <= 2e-10 * P.ldiv(rhs).norm() + 1e-12
+
+
+def test_generic_engine_with_literal_and_routed_dfdp(ctx):
+    """VERDICT r2 Missing 4: the GENERIC engine loop (continuation.py's line-by-line restatement of newton_palc /
+    gettangent!(::Bordered), the code path a Julia user of the plugins runs) on a 256^3 tiled branch, once with the literal
+    two-residual quotient dF/dp = (F(x, p + eps) - F(x, p)) / eps of Palc.jl:239-240 / Tangents.jl:77-82 (library option
+    fd_dparam = 0) and once with the quotient routed to bk_residual_dparam (what julia/BifurcationKitHIP.jl's
+    newton_palc / gettangent! methods for the device problem type do).  Same branch; the literal form needs several times
+    the operator applications from the second step on (its rounding noise excites the slow band of the big domain)."""
+    import torch
+    import bench
+    from bk_amd import continuation as Cn
+    from bk_amd import hip
+    n = 256
+    tiles = bench.tiles_for(n)
+    big_l = tuple(l * t for l, t in zip(bench.CELL_L, tiles))
+    ds, theta = -0.001, 0.5
+    cprob, cls_, c0, c1 = bench.cell_branch_points(ctx, hip, 1.0, ds)
+    prob = hip.SwiftHohenberg(ctx, (n,) * 3, big_l, l=0.1, nu=1.2)
+    P = hip.DCTPreconditioner(prob, 1.0)
+    ls = hip.GMRESKrylovKit(dim=30, rtol=1e-9, atol=1e-12, maxiter=150, Pl=P)
+    u0 = hip.HipVec(ctx, bench.tile_cell(c0["u"].t, tiles, prob.slab, ctx.torch_device), prob.nglobal)
+    out = {}
+    try:
+        for mode in (1, 0):
+            ctx.set_option("fd_dparam", mode)
+            nopt = Cn.NewtonPar(tol=1e-9, max_iterations=15, linsolver=ls, eigsolver=None)
+            cp = Cn.ContinuationPar(ds=ds, dsmin=1e-4, dsmax=0.005, p_min=-0.1, p_max=0.15, max_steps=3, nev=3,
+                                    detect_bifurcation=0, newton_options=nopt)
+            alg = Cn.PALC(tangent="bordered", theta=theta, bls=hip.BorderingBLS(None, check_precision=False))
+            out[mode] = Cn.continuation(prob, u0, 0.1, alg, cp, normC=Cn.norminf)
+    finally:
+        ctx.set_option("fd_dparam", 1)
+    routed, literal = out[1], out[0]
+    assert len(routed.param) == len(literal.param) == 4
+    assert np.allclose(routed.param, literal.param, rtol=0, atol=1e-8)             # the same branch
+    # step 1 starts from the secant tangent of two Newton points (no dF/dp in the tangent yet): both need ~25-31
+    # applications; from step 2 on the Bordered tangent carries the noise
+    assert all(it <= 40 for it in routed.itlinear[1:]), routed.itlinear
+    assert sum(literal.itlinear[2:]) >= 2.5 * sum(routed.itlinear[2:]), (literal.itlinear, routed.itlinear)
