@@ -327,6 +327,24 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
             BK_TRY(next_column(k, h.data(), &hnext));
             numops += 1;
         }
+        if (ctx->opt("orth_probe", 0.0) != 0.0 && nt == 0) {
+            // diagnostics (tests): the MEASURED orthogonality defect max |V'V - I| of this cycle's basis V[0..k] next to the
+            // running estimate the single-pass policy steers by -- options gmres_last_orth_defect / gmres_last_orth_estimate
+            double worst = 0.0, row[kMaxBasis + 1];
+            const int nb = hnext != 0.0 ? k + 1 : k;
+            for (int i = 0; i < nb; ++i) {
+                BK_TRY(v_multidot(ctx, n, B.V, B.ld, nb, B.vec(i), row));
+                for (int j = 0; j < nb; ++j) worst = std::max(worst, std::fabs(row[j] - (i == j ? 1.0 : 0.0)));
+            }
+            double est = B.dlt;
+            if (chunk > 1) {
+                BK_HIP(ctx, hipMemcpyAsync(&est, d_coef + kMaxBasis + 2, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                est = std::max(est, B.dlt);
+            }
+            ctx->opts["gmres_last_orth_defect"] = std::max(worst, numiter > 1 ? ctx->opt("gmres_last_orth_defect", 0.0) : 0.0);
+            ctx->opts["gmres_last_orth_estimate"] = est;
+        }
         // solve R yk = y[0..k) and update x += V[0..k) yk
         std::vector<double> yk(k);
         for (int i = k - 1; i >= 0; --i) {

