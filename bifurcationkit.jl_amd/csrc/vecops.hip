@@ -5,6 +5,8 @@
 //
 // They replace the VectorInterface calls of the reference's Krylov loops (src/BorderedArrays.jl:86-217
 // and the orthogonalisation inside KrylovKit / IterativeSolvers).
+#include <type_traits>
+
 #include "common.h"
 
 namespace bk {
@@ -401,6 +403,134 @@ __global__ void __launch_bounds__(kThreads) multiaxpy_kernel(size_t n, const dou
     }
 }
 
+// ------------------------------------------------------------------ exact-K, branch-free variants of the two fused passes
+// The bucketed kernels above skip absent vectors with a wave-uniform `if (j < k)`.  The compiler turns every such guard into
+// a branch and -- because it cannot hoist a load across one -- emits  load V_j ; s_waitcnt vmcnt(0) ; fma  per vector: ONE
+// 16-byte load in flight per lane and k + 1 exposed memory latencies per loop iteration (ISA of round 2's kernels: 25 VGPRs
+// for KB = 8).  With the number of vectors a template constant there is no guard: all (K + 1) * U loads of an iteration
+// are issued back to back, then consumed.  Bytes in flight per wave: (K + 1) * U KiB instead of 1-2 KiB.
+// Full iterations carry no guard at all; the ragged end of the range is walked one item at a time.
+template <int K, int U, bool LDNT>
+__global__ void __launch_bounds__(kThreads) multidot_x_kernel(size_t n, const double* __restrict__ V, size_t ldv,
+                                                              const double* __restrict__ w, double* __restrict__ partials,
+                                                              const double* gate, unsigned xcd) {
+    if (gate && gate[0] == 0.0) return;
+    double acc[K + 1];
+#pragma unroll
+    for (int j = 0; j <= K; ++j) acc[j] = 0.0;
+    const StreamRange rg = stream_range(n >> 1, xcd);
+    // full iterations (all U items in range: no guards anywhere, (K + 1) * U loads back to back), then the tail one by one
+    auto body = [&](auto uc, size_t i0) {
+        constexpr int UU = decltype(uc)::value;
+        double2 wv[UU], vv[K][UU];
+#pragma unroll
+        for (int u = 0; u < UU; ++u) wv[u] = ld2<LDNT>(w, i0 + u * rg.step);
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+#pragma unroll
+            for (int u = 0; u < UU; ++u) vv[j][u] = ld2<LDNT>(V + (size_t)j * ldv, i0 + u * rg.step);
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+            acc[K] = fma(wv[u].x, wv[u].x, acc[K]); acc[K] = fma(wv[u].y, wv[u].y, acc[K]);
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                acc[j] = fma(vv[j][u].x, wv[u].x, acc[j]);
+                acc[j] = fma(vv[j][u].y, wv[u].y, acc[j]);
+            }
+        }
+    };
+    size_t i0 = rg.lo;
+    for (; i0 + (U - 1) * rg.step < rg.hi; i0 += rg.step * U) body(std::integral_constant<int, U>{}, i0);
+    for (; i0 < rg.hi; i0 += rg.step) body(std::integral_constant<int, 1>{}, i0);
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const double wv = w[n - 1];
+        acc[K] = fma(wv, wv, acc[K]);
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc[j] = fma(V[(size_t)j * ldv + n - 1], wv, acc[j]);
+    }
+    __shared__ double sm[4][K + 1];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j <= K; ++j) {
+        const double s_ = wave_sum(acc[j]);
+        if (lane == 0) sm[wid][j] = s_;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j <= K; j += kThreads)
+        partials[(size_t)blockIdx.x * (K + 1) + j] = (sm[0][j] + sm[1][j]) + (sm[2][j] + sm[3][j]);
+}
+
+template <int K, int U, bool NT, bool LDNT, bool DEV>
+__global__ void __launch_bounds__(kThreads) multiaxpy_x_kernel(size_t n, const double* __restrict__ V, size_t ldv, Coefs cf,
+                                                               const double* src, double scale, double* dst, int want_norm,
+                                                               double* __restrict__ partials, unsigned xcd,
+                                                               const double* __restrict__ dcoef, int gated) {
+    double c[K > 0 ? K : 1];
+    if (DEV) {
+        if (gated && dcoef[kMaxBasis + 1] == 0.0) return;
+        scale = dcoef[kMaxBasis];
+#pragma unroll
+        for (int j = 0; j < K; ++j) c[j] = dcoef[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < K; ++j) c[j] = cf.c[j];
+    }
+    double nn = 0.0;
+    const StreamRange rg = stream_range(n >> 1, xcd);
+    auto body = [&](auto uc, size_t i0) {
+        constexpr int UU = decltype(uc)::value;
+        double2 r[UU], vv[K > 0 ? K : 1][UU];
+#pragma unroll
+        for (int u = 0; u < UU; ++u) r[u] = src ? ld2<LDNT>(src, i0 + u * rg.step) : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+#pragma unroll
+            for (int u = 0; u < UU; ++u) vv[j][u] = ld2<LDNT>(V + (size_t)j * ldv, i0 + u * rg.step);
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                r[u].x = fma(c[j], vv[j][u].x, r[u].x);
+                r[u].y = fma(c[j], vv[j][u].y, r[u].y);
+            }
+            r[u].x *= scale; r[u].y *= scale;
+            if (NT) st2nt(dst, i0 + u * rg.step, r[u]);
+            else reinterpret_cast<double2*>(dst)[i0 + u * rg.step] = r[u];
+            nn = fma(r[u].x, r[u].x, nn); nn = fma(r[u].y, r[u].y, nn);
+        }
+    };
+    size_t i0 = rg.lo;
+    for (; i0 + (U - 1) * rg.step < rg.hi; i0 += rg.step * U) body(std::integral_constant<int, U>{}, i0);
+    for (; i0 < rg.hi; i0 += rg.step) body(std::integral_constant<int, 1>{}, i0);
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const size_t i = n - 1;
+        double r = src ? src[i] : 0.0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) r = fma(c[j], V[(size_t)j * ldv + i], r);
+        r *= scale;
+        dst[i] = r;
+        nn = fma(r, r, nn);
+    }
+    if (want_norm) {
+        __shared__ double sm[4];
+        nn = wave_sum(nn);
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = nn;
+        __syncthreads();
+        if (threadIdx.x == 0) partials[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    }
+}
+
+constexpr int kExactMax = 32;          // exact-K instantiations for 1 <= k <= 32 (GMRES(30) cycles); above: the bucketed kernels
+// elements in flight per lane: enough bytes per wave for small K, bounded registers for large K
+#define BK_EXACT_U(K) ((K) <= 2 ? 4 : ((K) <= 12 ? 2 : 1))
+#define BK_EXACT_SWITCH(k, CASE)                                                                                         \
+    switch (k) {                                                                                                         \
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13)      \
+        CASE(14) CASE(15) CASE(16) CASE(17) CASE(18) CASE(19) CASE(20) CASE(21) CASE(22) CASE(23) CASE(24) CASE(25)     \
+        CASE(26) CASE(27) CASE(28) CASE(29) CASE(30) CASE(31) CASE(32)                                                   \
+        default: break;                                                                                                  \
+    }
+
 // second reduction stage into a DEVICE buffer: the same fixed summation order as reduce_stage2_kernel (context.hip), so the
 // device-resident and the host-driven Arnoldi steps produce bitwise identical projections
 __global__ void __launch_bounds__(256) reduce_stage2_dev(const double* __restrict__ partials, int nblocks, int nvals,
@@ -615,6 +745,39 @@ int v_nrminf(bk_ctx* ctx, size_t n, const double* x, double* out) {
     return 0;
 }
 
+// exact-K kernels: 16-byte aligned operands, at least one full sweep of items (the tail clamps to the last item)
+static bool exact_ok(bk_ctx* ctx, bool vec, size_t n, int k) {
+    return vec && k >= 1 && k <= kExactMax && n >= 2 && ctx->opt("krylov_exact", 1.0) != 0.0;
+}
+static void launch_multidot_exact(bk_ctx* ctx, int grid, size_t n, const double* V, size_t ldv, int k, const double* w, const double* gate) {
+    const unsigned xcd = xcd_map(ctx, n, grid, false, k);
+    const bool nt = nt_hint(ctx, n);
+#define BK_CASE(K)                                                                                                                  \
+    case K:                                                                                                                          \
+        if (nt) hipLaunchKernelGGL((multidot_x_kernel<K, BK_EXACT_U(K), true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, w, ctx->d_partials, gate, xcd); \
+        else hipLaunchKernelGGL((multidot_x_kernel<K, BK_EXACT_U(K), false>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, w, ctx->d_partials, gate, xcd);   \
+        break;
+    BK_EXACT_SWITCH(k, BK_CASE)
+#undef BK_CASE
+}
+static void launch_multiaxpy_exact(bk_ctx* ctx, int grid, size_t n, const double* V, size_t ldv, int k, const Coefs& cf, const double* src,
+                                   double scale, double* dst, int want_norm, const double* dcoef, int gated) {
+    const unsigned xcd = xcd_map(ctx, n, grid, true, k);
+    const bool nt = nt_hint(ctx, n);
+#define BK_CASE(K)                                                                                                                  \
+    case K:                                                                                                                          \
+        if (dcoef) {                                                                                                                 \
+            if (nt) hipLaunchKernelGGL((multiaxpy_x_kernel<K, BK_EXACT_U(K), true, true, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, cf, src, scale, dst, want_norm, ctx->d_partials, xcd, dcoef, gated); \
+            else hipLaunchKernelGGL((multiaxpy_x_kernel<K, BK_EXACT_U(K), false, false, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, cf, src, scale, dst, want_norm, ctx->d_partials, xcd, dcoef, gated); \
+        } else {                                                                                                                     \
+            if (nt) hipLaunchKernelGGL((multiaxpy_x_kernel<K, BK_EXACT_U(K), true, true, false>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, cf, src, scale, dst, want_norm, ctx->d_partials, xcd, dcoef, gated); \
+            else hipLaunchKernelGGL((multiaxpy_x_kernel<K, BK_EXACT_U(K), false, false, false>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, cf, src, scale, dst, want_norm, ctx->d_partials, xcd, dcoef, gated); \
+        }                                                                                                                            \
+        break;
+    BK_EXACT_SWITCH(k, BK_CASE)
+#undef BK_CASE
+}
+
 template <int KB>
 static void launch_multidot(bk_ctx* ctx, bool vec, int grid, size_t n, const double* V, size_t ldv, int k, const double* w) {
     const unsigned xcd = xcd_map(ctx, n, grid, false, k);
@@ -629,7 +792,8 @@ int v_multidot(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const 
     const int grid = grid_for(n, vec ? 2 : 1, kRedBlocks);
     {
         ProfScope ps(ctx, "multidot", 8.0 * n * (k + 1));
-        if (k <= 4) launch_multidot<4>(ctx, vec, grid, n, V, ldv, k, w);
+        if (exact_ok(ctx, vec, n, k)) launch_multidot_exact(ctx, grid, n, V, ldv, k, w, nullptr);
+        else if (k <= 4) launch_multidot<4>(ctx, vec, grid, n, V, ldv, k, w);
         else if (k <= 8) launch_multidot<8>(ctx, vec, grid, n, V, ldv, k, w);
         else if (k <= 16) launch_multidot<16>(ctx, vec, grid, n, V, ldv, k, w);
         else if (k <= 24) launch_multidot<24>(ctx, vec, grid, n, V, ldv, k, w);
@@ -671,7 +835,8 @@ int v_multiaxpy(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const
     const int grid = grid_for(n, vec ? 2 : 1, cap);
     {
         ProfScope ps(ctx, "multiaxpy", 8.0 * n * (k + 1 + (src ? 1 : 0)));
-        if (k <= 4) launch_multiaxpy<4>(ctx, vec, grid, n, V, ldv, k, cf, src, scale, dst, want);
+        if (exact_ok(ctx, vec, n, k)) launch_multiaxpy_exact(ctx, grid, n, V, ldv, k, cf, src, scale, dst, want, nullptr, 0);
+        else if (k <= 4) launch_multiaxpy<4>(ctx, vec, grid, n, V, ldv, k, cf, src, scale, dst, want);
         else if (k <= 8) launch_multiaxpy<8>(ctx, vec, grid, n, V, ldv, k, cf, src, scale, dst, want);
         else if (k <= 16) launch_multiaxpy<16>(ctx, vec, grid, n, V, ldv, k, cf, src, scale, dst, want);
         else if (k <= 24) launch_multiaxpy<24>(ctx, vec, grid, n, V, ldv, k, cf, src, scale, dst, want);
@@ -703,7 +868,13 @@ int v_arnoldi_step_dev(bk_ctx* ctx, size_t n, double* V, size_t ldv, int k, cons
     // stream from HBM; plain accesses for the cache-resident sizes
     const bool big = vec && nt_hint(ctx, n);
     const Coefs cf0{};
+    const bool exact = exact_ok(ctx, vec, n, k);
     auto dots = [&](const double* x, const double* g) {
+        if (exact) {
+            launch_multidot_exact(ctx, grid, n, V, ldv, k, x, g);
+            hipLaunchKernelGGL(reduce_stage2_dev, dim3(k + 1), dim3(256), 0, ctx->stream, ctx->d_partials, grid, k + 1, ctx->d_red, g);
+            return;
+        }
 #define BK_MD_DEV(KB)                                                                                                           \
     do {                                                                                                                        \
         if (big) hipLaunchKernelGGL((multidot_kernel<KB, 2, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, x, ctx->d_partials, g, 0u); \
@@ -721,6 +892,7 @@ int v_arnoldi_step_dev(bk_ctx* ctx, size_t n, double* V, size_t ldv, int k, cons
         hipLaunchKernelGGL(reduce_stage2_dev, dim3(k + 1), dim3(256), 0, ctx->stream, ctx->d_partials, grid, k + 1, ctx->d_red, g);
     };
     auto axpys = [&](const double* src, int gated) {
+        if (exact) { launch_multiaxpy_exact(ctx, grid, n, V, ldv, k, cf0, src, 1.0, dst, 0, coef, gated); return; }
         const unsigned xcd = xcd_map(ctx, n, grid, true, k);
 #define BK_MA_DEV(KB)                                                                                                         \
     do {                                                                                                                      \

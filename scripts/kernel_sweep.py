@@ -112,6 +112,27 @@ if "krylov" in what:
         report("multiaxpy", timeit(f, reps=3, warm=1), 8.0 * N * (k + 2), k=k)
     del V
 
+if "exact" in what:
+    # round 3: exact-K branch-free kernels (krylov_exact = 1) against the bucketed `if (j < k)` kernels (0), interleaved
+    ld = (N + 31) // 32 * 32
+    kmax = 30 if n >= 512 else 32
+    V = torch.rand(ld * kmax, dtype=torch.float64, device="cuda", generator=g)
+    hbuf = (C.c_double * 65)()
+    for k in (1, 2, 3, 4, 6, 8, 10, 12, 13, 16, 20, 24, 30):
+        if k > kmax:
+            continue
+        cc = (C.c_double * k)(*([0.01] * k))
+        fa = lambda: ctx.check(ctx.lib.bk_krylov_multiaxpy(ctx.h, N, C.c_void_p(V.data_ptr()), ld, k, cc, C.c_void_p(v.t.data_ptr()),
+                                                           1.0, C.c_void_p(out.t.data_ptr()), None))
+        fd = lambda: ctx.check(ctx.lib.bk_krylov_multidot(ctx.h, N, C.c_void_p(V.data_ptr()), ld, k, C.c_void_p(v.t.data_ptr()), hbuf))
+        for rep in range(2):
+            for ex in (0, 1):
+                ctx.set_option("krylov_exact", ex)
+                report("multiaxpy", timeit(fa, reps=5, warm=1), 8.0 * N * (k + 2), k=k, exact=ex, rep=rep)
+                report("multidot", timeit(fd, reps=5, warm=1), 8.0 * N * (k + 1), k=k, exact=ex, rep=rep)
+    ctx.set_option("krylov_exact", 1)
+    del V
+
 if "axpy" in what:
     ld = (N + 31) // 32 * 32
     V = torch.rand(ld * 16, dtype=torch.float64, device="cuda", generator=g)
