@@ -5,6 +5,7 @@
 //
 // They replace the VectorInterface calls of the reference's Krylov loops (src/BorderedArrays.jl:86-217
 // and the orthogonalisation inside KrylovKit / IterativeSolvers).
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
@@ -83,6 +84,23 @@ __device__ __forceinline__ void st2nt(double* p, size_t i, double2 v) {
     __builtin_nontemporal_store(r, reinterpret_cast<nt_d2*>(p) + i);
 }
 
+// Grid-stride walk over n2 16-byte items with U items per lane in flight: full iterations carry no bounds guard (the
+// body sees a compile-time item count, so all its loads are issued back to back -- a runtime guard per operand or per item
+// makes the compiler emit load / s_waitcnt vmcnt(0) pairs, i.e. one exposed memory latency per operand), the ragged end
+// runs item by item.  body(integral_constant<int, UU>, first_item, step).
+template <int U, class Body>
+__device__ __forceinline__ void stream_loop(size_t n2, Body&& body) {
+    // a workgroup owns U ADJACENT 4-KiB chunks per iteration (one 16-KiB contiguous burst per stream), not U chunks a whole
+    // grid stride apart: measured at 512^3, the strided form costs 25 % (axpby 0.55 vs 0.73 of peak) -- it multiplies the
+    // number of DRAM pages the chip has open per stream
+    const size_t chunk = (size_t)kThreads * U;
+    const size_t gstep = (size_t)gridDim.x * chunk;
+    size_t base = (size_t)blockIdx.x * chunk;
+    for (; base + chunk <= n2; base += gstep) body(std::integral_constant<int, U>{}, base + threadIdx.x, (size_t)kThreads);
+    if (base < n2)
+        for (size_t i = base + threadIdx.x; i < n2 && i < base + chunk; i += kThreads) body(std::integral_constant<int, 1>{}, i, (size_t)kThreads);
+}
+
 // ------------------------------------------------------------------ elementwise
 template <int VEC, bool NTH = false>
 __global__ void __launch_bounds__(kThreads) axpbyz_kernel(size_t n, double a, const double* __restrict__ x, double b,
@@ -90,13 +108,31 @@ __global__ void __launch_bounds__(kThreads) axpbyz_kernel(size_t n, double a, co
     const size_t stride = (size_t)gridDim.x * kThreads;
     if (VEC == 2) {
         const size_t n2 = n >> 1;
-        for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += stride) {
-            double2 r = make_double2(0.0, 0.0);
-            if (has_x) { const double2 xv = ld2<NTH>(x, i); r.x = a * xv.x; r.y = a * xv.y; }
-            if (has_y) { const double2 yv = ld2<NTH>(y, i); r.x += b * yv.x; r.y += b * yv.y; }
-            if (NTH) st2nt(z, i, r);
-            else reinterpret_cast<double2*>(z)[i] = r;
-        }
+        // operand presence is wave-uniform: hoist it out of the loop so that each variant's loads issue back to back
+        auto run = [&](auto hx, auto hy) {
+            constexpr bool HX = decltype(hx)::value, HY = decltype(hy)::value;
+            stream_loop<4>(n2, [&](auto uc, size_t i0, size_t st) {
+                constexpr int UU = decltype(uc)::value;
+                double2 xv[UU], yv[UU];
+#pragma unroll
+                for (int u = 0; u < UU; ++u) {
+                    if (HX) xv[u] = ld2<NTH>(x, i0 + u * st);
+                    if (HY) yv[u] = ld2<NTH>(y, i0 + u * st);
+                }
+#pragma unroll
+                for (int u = 0; u < UU; ++u) {
+                    double2 r = make_double2(0.0, 0.0);
+                    if (HX) { r.x = a * xv[u].x; r.y = a * xv[u].y; }
+                    if (HY) { r.x += b * yv[u].x; r.y += b * yv[u].y; }
+                    if (NTH) st2nt(z, i0 + u * st, r);
+                    else reinterpret_cast<double2*>(z)[i0 + u * st] = r;
+                }
+            });
+        };
+        if (has_x && has_y) run(std::true_type{}, std::true_type{});
+        else if (has_x) run(std::true_type{}, std::false_type{});
+        else if (has_y) run(std::false_type{}, std::true_type{});
+        else run(std::false_type{}, std::false_type{});
         if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
             const size_t i = n - 1;
             double r = 0.0;
@@ -137,15 +173,27 @@ __global__ void __launch_bounds__(kThreads) dot_kernel(size_t n, const double* _
     double s0 = 0.0, s1 = 0.0;
     if (VEC == 2) {
         const size_t n2 = n >> 1;
-        for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += stride) {
-            const double2 xv = ld2<NTH>(x, i);
-            const double2 a = ld2<NTH>(y0, i);
-            s0 = fma(xv.x, a.x, s0); s0 = fma(xv.y, a.y, s0);
-            if (NY == 2) {
-                const double2 b = ld2<NTH>(y1, i);
-                s1 = fma(xv.x, b.x, s1); s1 = fma(xv.y, b.y, s1);
-            }
-        }
+        const bool same = (x == y0);                      // squared norm: one stream
+        auto run = [&](auto sm_) {
+            constexpr bool SAME = decltype(sm_)::value;
+            stream_loop<4>(n2, [&](auto uc, size_t i0, size_t st) {
+                constexpr int UU = decltype(uc)::value;
+                double2 xv[UU], av[UU], bv[UU];
+#pragma unroll
+                for (int u = 0; u < UU; ++u) {
+                    xv[u] = ld2<NTH>(x, i0 + u * st);
+                    if (!SAME) av[u] = ld2<NTH>(y0, i0 + u * st);
+                    if (NY == 2) bv[u] = ld2<NTH>(y1, i0 + u * st);
+                }
+#pragma unroll
+                for (int u = 0; u < UU; ++u) {
+                    const double2 a = SAME ? xv[u] : av[u];
+                    s0 = fma(xv[u].x, a.x, s0); s0 = fma(xv[u].y, a.y, s0);
+                    if (NY == 2) { s1 = fma(xv[u].x, bv[u].x, s1); s1 = fma(xv[u].y, bv[u].y, s1); }
+                }
+            });
+        };
+        if (same) run(std::true_type{}); else run(std::false_type{});
         if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
             s0 = fma(x[n - 1], y0[n - 1], s0);
             if (NY == 2) s1 = fma(x[n - 1], y1[n - 1], s1);
@@ -178,17 +226,29 @@ __global__ void __launch_bounds__(kThreads) axpy_dot_kernel(size_t n, double c, 
     double s = 0.0;
     if (VEC == 2) {
         const size_t n2 = n >> 1;
-        for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += stride) {
-            double2 yv = ld2<NTH>(y, i);
-            if (has_r) {
-                const double2 rv = ld2<NTH>(r, i);
-                yv.x = fma(c, rv.x, yv.x); yv.y = fma(c, rv.y, yv.y);
-                if (NTH) st2nt(y, i, yv);
-                else reinterpret_cast<double2*>(y)[i] = yv;
-            }
-            const double2 zv = ld2<NTH>(z, i);
-            s = fma(zv.x, yv.x, s); s = fma(zv.y, yv.y, s);
-        }
+        auto run = [&](auto hr) {
+            constexpr bool HR = decltype(hr)::value;
+            stream_loop<2>(n2, [&](auto uc, size_t i0, size_t st) {
+                constexpr int UU = decltype(uc)::value;
+                double2 yv[UU], rv[UU], zv[UU];
+#pragma unroll
+                for (int u = 0; u < UU; ++u) {
+                    yv[u] = ld2<NTH>(y, i0 + u * st);
+                    if (HR) rv[u] = ld2<NTH>(r, i0 + u * st);
+                    zv[u] = ld2<NTH>(z, i0 + u * st);
+                }
+#pragma unroll
+                for (int u = 0; u < UU; ++u) {
+                    if (HR) {
+                        yv[u].x = fma(c, rv[u].x, yv[u].x); yv[u].y = fma(c, rv[u].y, yv[u].y);
+                        if (NTH) st2nt(y, i0 + u * st, yv[u]);
+                        else reinterpret_cast<double2*>(y)[i0 + u * st] = yv[u];
+                    }
+                    s = fma(zv[u].x, yv[u].x, s); s = fma(zv[u].y, yv[u].y, s);
+                }
+            });
+        };
+        if (has_r) run(std::true_type{}); else run(std::false_type{});
         if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
             double yv = y[n - 1];
             if (has_r) { yv = fma(c, r[n - 1], yv); y[n - 1] = yv; }
@@ -217,18 +277,26 @@ __global__ void __launch_bounds__(kThreads) minres_update_kernel(size_t n, doubl
     const size_t stride = (size_t)gridDim.x * kThreads;
     if (VEC == 2) {
         const size_t n2 = n >> 1;
-        for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += stride) {
-            const double2 zv = ld2<NTH>(z, i);
-            const double2 a = ld2<NTH>(w1, i);
-            const double2 b = ld2<NTH>(w2, i);
-            double2 xv = ld2<NTH>(x, i);
-            double2 wv;
-            wv.x = fma(c2, b.x, fma(c1, a.x, cz * zv.x));
-            wv.y = fma(c2, b.y, fma(c1, a.y, cz * zv.y));
-            xv.x = fma(phi, wv.x, xv.x); xv.y = fma(phi, wv.y, xv.y);
-            if (NTH) { st2nt(w, i, wv); st2nt(x, i, xv); }
-            else { reinterpret_cast<double2*>(w)[i] = wv; reinterpret_cast<double2*>(x)[i] = xv; }
-        }
+        stream_loop<2>(n2, [&](auto uc, size_t i0, size_t st) {
+            constexpr int UU = decltype(uc)::value;
+            double2 zv[UU], a[UU], b[UU], xv[UU];
+#pragma unroll
+            for (int u = 0; u < UU; ++u) {
+                zv[u] = ld2<NTH>(z, i0 + u * st);
+                a[u] = ld2<NTH>(w1, i0 + u * st);
+                b[u] = ld2<NTH>(w2, i0 + u * st);
+                xv[u] = ld2<NTH>(x, i0 + u * st);
+            }
+#pragma unroll
+            for (int u = 0; u < UU; ++u) {
+                double2 wv;
+                wv.x = fma(c2, b[u].x, fma(c1, a[u].x, cz * zv[u].x));
+                wv.y = fma(c2, b[u].y, fma(c1, a[u].y, cz * zv[u].y));
+                xv[u].x = fma(phi, wv.x, xv[u].x); xv[u].y = fma(phi, wv.y, xv[u].y);
+                if (NTH) { st2nt(w, i0 + u * st, wv); st2nt(x, i0 + u * st, xv[u]); }
+                else { reinterpret_cast<double2*>(w)[i0 + u * st] = wv; reinterpret_cast<double2*>(x)[i0 + u * st] = xv[u]; }
+            }
+        });
         if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
             const size_t i = n - 1;
             const double wv = fma(c2, w2[i], fma(c1, w1[i], cz * z[i]));
@@ -403,110 +471,103 @@ __global__ void __launch_bounds__(kThreads) multiaxpy_kernel(size_t n, const dou
     }
 }
 
-// ------------------------------------------------------------------ exact-K, branch-free variants of the two fused passes
-// The bucketed kernels above skip absent vectors with a wave-uniform `if (j < k)`.  The compiler turns every such guard into
-// a branch and -- because it cannot hoist a load across one -- emits  load V_j ; s_waitcnt vmcnt(0) ; fma  per vector: ONE
-// 16-byte load in flight per lane and k + 1 exposed memory latencies per loop iteration (ISA of round 2's kernels: 25 VGPRs
-// for KB = 8).  With the number of vectors a template constant there is no guard: all (K + 1) * U loads of an iteration
-// are issued back to back, then consumed.  Bytes in flight per wave: (K + 1) * U KiB instead of 1-2 KiB.
-// Full iterations carry no guard at all; the ragged end of the range is walked one item at a time.
-template <int K, int U, bool LDNT>
-__global__ void __launch_bounds__(kThreads) multidot_x_kernel(size_t n, const double* __restrict__ V, size_t ldv,
+// ------------------------------------------------------------------ bucketed kernels, contiguous bursts per stream
+// Same one-stream-at-a-time structure as the bucketed kernels above (the guard per vector keeps the streams apart in time,
+// which is what the DRAM likes: measured), but a workgroup takes U ADJACENT 4-KiB chunks of the stream per visit instead of
+// one (multidot) or two a whole grid stride apart (multiaxpy): U x 4 KiB contiguous per stream and workgroup.
+template <int KB, int U, bool LDNT>
+__global__ void __launch_bounds__(kThreads) multidot_c_kernel(size_t n, const double* __restrict__ V, size_t ldv, int k,
                                                               const double* __restrict__ w, double* __restrict__ partials,
-                                                              const double* gate, unsigned xcd) {
+                                                              const double* gate) {
     if (gate && gate[0] == 0.0) return;
-    double acc[K + 1];
+    double acc[KB];
 #pragma unroll
-    for (int j = 0; j <= K; ++j) acc[j] = 0.0;
-    const StreamRange rg = stream_range(n >> 1, xcd);
-    // full iterations (all U items in range: no guards anywhere, (K + 1) * U loads back to back), then the tail one by one
-    auto body = [&](auto uc, size_t i0) {
+    for (int j = 0; j < KB; ++j) acc[j] = 0.0;
+    double ww = 0.0;
+    stream_loop<U>(n >> 1, [&](auto uc, size_t i0, size_t st) {
         constexpr int UU = decltype(uc)::value;
-        double2 wv[UU], vv[K][UU];
+        double2 wv[UU];
 #pragma unroll
-        for (int u = 0; u < UU; ++u) wv[u] = ld2<LDNT>(w, i0 + u * rg.step);
+        for (int u = 0; u < UU; ++u) wv[u] = ld2<LDNT>(w, i0 + u * st);
 #pragma unroll
-        for (int j = 0; j < K; ++j)
+        for (int u = 0; u < UU; ++u) { ww = fma(wv[u].x, wv[u].x, ww); ww = fma(wv[u].y, wv[u].y, ww); }
 #pragma unroll
-            for (int u = 0; u < UU; ++u) vv[j][u] = ld2<LDNT>(V + (size_t)j * ldv, i0 + u * rg.step);
+        for (int j = 0; j < KB; ++j) {
+            if (j < k) {
+                double2 vv[UU];
 #pragma unroll
-        for (int u = 0; u < UU; ++u) {
-            acc[K] = fma(wv[u].x, wv[u].x, acc[K]); acc[K] = fma(wv[u].y, wv[u].y, acc[K]);
+                for (int u = 0; u < UU; ++u) vv[u] = ld2<LDNT>(V + (size_t)j * ldv, i0 + u * st);
 #pragma unroll
-            for (int j = 0; j < K; ++j) {
-                acc[j] = fma(vv[j][u].x, wv[u].x, acc[j]);
-                acc[j] = fma(vv[j][u].y, wv[u].y, acc[j]);
+                for (int u = 0; u < UU; ++u) { acc[j] = fma(vv[u].x, wv[u].x, acc[j]); acc[j] = fma(vv[u].y, wv[u].y, acc[j]); }
             }
         }
-    };
-    size_t i0 = rg.lo;
-    for (; i0 + (U - 1) * rg.step < rg.hi; i0 += rg.step * U) body(std::integral_constant<int, U>{}, i0);
-    for (; i0 < rg.hi; i0 += rg.step) body(std::integral_constant<int, 1>{}, i0);
+    });
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const double wv = w[n - 1];
-        acc[K] = fma(wv, wv, acc[K]);
+        ww = fma(wv, wv, ww);
 #pragma unroll
-        for (int j = 0; j < K; ++j) acc[j] = fma(V[(size_t)j * ldv + n - 1], wv, acc[j]);
+        for (int j = 0; j < KB; ++j)
+            if (j < k) acc[j] = fma(V[(size_t)j * ldv + n - 1], wv, acc[j]);
     }
-    __shared__ double sm[4][K + 1];
+    __shared__ double sm[4][KB + 1];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
-    for (int j = 0; j <= K; ++j) {
+    for (int j = 0; j < KB; ++j) {
         const double s_ = wave_sum(acc[j]);
         if (lane == 0) sm[wid][j] = s_;
     }
+    {
+        const double s_ = wave_sum(ww);
+        if (lane == 0) sm[wid][KB] = s_;
+    }
     __syncthreads();
-    for (int j = threadIdx.x; j <= K; j += kThreads)
-        partials[(size_t)blockIdx.x * (K + 1) + j] = (sm[0][j] + sm[1][j]) + (sm[2][j] + sm[3][j]);
+    for (int j = threadIdx.x; j <= k; j += kThreads) {
+        const int src = (j == k) ? KB : j;
+        partials[(size_t)blockIdx.x * (k + 1) + j] = (sm[0][src] + sm[1][src]) + (sm[2][src] + sm[3][src]);
+    }
 }
 
-template <int K, int U, bool NT, bool LDNT, bool DEV>
-__global__ void __launch_bounds__(kThreads) multiaxpy_x_kernel(size_t n, const double* __restrict__ V, size_t ldv, Coefs cf,
+template <int KB, int U, bool NT, bool LDNT, bool DEV>
+__global__ void __launch_bounds__(kThreads) multiaxpy_c_kernel(size_t n, const double* __restrict__ V, size_t ldv, int k, Coefs cf,
                                                                const double* src, double scale, double* dst, int want_norm,
-                                                               double* __restrict__ partials, unsigned xcd,
+                                                               double* __restrict__ partials,
                                                                const double* __restrict__ dcoef, int gated) {
-    double c[K > 0 ? K : 1];
     if (DEV) {
         if (gated && dcoef[kMaxBasis + 1] == 0.0) return;
         scale = dcoef[kMaxBasis];
 #pragma unroll
-        for (int j = 0; j < K; ++j) c[j] = dcoef[j];
-    } else {
-#pragma unroll
-        for (int j = 0; j < K; ++j) c[j] = cf.c[j];
+        for (int j = 0; j < KB; ++j) cf.c[j] = j < k ? dcoef[j] : 0.0;
     }
     double nn = 0.0;
-    const StreamRange rg = stream_range(n >> 1, xcd);
-    auto body = [&](auto uc, size_t i0) {
+    stream_loop<U>(n >> 1, [&](auto uc, size_t i0, size_t st) {
         constexpr int UU = decltype(uc)::value;
-        double2 r[UU], vv[K > 0 ? K : 1][UU];
+        double2 r[UU];
 #pragma unroll
-        for (int u = 0; u < UU; ++u) r[u] = src ? ld2<LDNT>(src, i0 + u * rg.step) : make_double2(0.0, 0.0);
+        for (int u = 0; u < UU; ++u) r[u] = src ? ld2<LDNT>(src, i0 + u * st) : make_double2(0.0, 0.0);
 #pragma unroll
-        for (int j = 0; j < K; ++j)
+        for (int j = 0; j < KB; ++j) {
+            if (j < k) {
+                double2 vv[UU];
 #pragma unroll
-            for (int u = 0; u < UU; ++u) vv[j][u] = ld2<LDNT>(V + (size_t)j * ldv, i0 + u * rg.step);
+                for (int u = 0; u < UU; ++u) vv[u] = ld2<LDNT>(V + (size_t)j * ldv, i0 + u * st);
+#pragma unroll
+                for (int u = 0; u < UU; ++u) { r[u].x = fma(cf.c[j], vv[u].x, r[u].x); r[u].y = fma(cf.c[j], vv[u].y, r[u].y); }
+            }
+        }
 #pragma unroll
         for (int u = 0; u < UU; ++u) {
-#pragma unroll
-            for (int j = 0; j < K; ++j) {
-                r[u].x = fma(c[j], vv[j][u].x, r[u].x);
-                r[u].y = fma(c[j], vv[j][u].y, r[u].y);
-            }
             r[u].x *= scale; r[u].y *= scale;
-            if (NT) st2nt(dst, i0 + u * rg.step, r[u]);
-            else reinterpret_cast<double2*>(dst)[i0 + u * rg.step] = r[u];
+            if (NT) st2nt(dst, i0 + u * st, r[u]);
+            else reinterpret_cast<double2*>(dst)[i0 + u * st] = r[u];
             nn = fma(r[u].x, r[u].x, nn); nn = fma(r[u].y, r[u].y, nn);
         }
-    };
-    size_t i0 = rg.lo;
-    for (; i0 + (U - 1) * rg.step < rg.hi; i0 += rg.step * U) body(std::integral_constant<int, U>{}, i0);
-    for (; i0 < rg.hi; i0 += rg.step) body(std::integral_constant<int, 1>{}, i0);
+    });
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const size_t i = n - 1;
         double r = src ? src[i] : 0.0;
 #pragma unroll
-        for (int j = 0; j < K; ++j) r = fma(c[j], V[(size_t)j * ldv + i], r);
+        for (int j = 0; j < KB; ++j)
+            if (j < k) r = fma(cf.c[j], V[(size_t)j * ldv + i], r);
         r *= scale;
         dst[i] = r;
         nn = fma(r, r, nn);
@@ -519,17 +580,6 @@ __global__ void __launch_bounds__(kThreads) multiaxpy_x_kernel(size_t n, const d
         if (threadIdx.x == 0) partials[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
     }
 }
-
-constexpr int kExactMax = 32;          // exact-K instantiations for 1 <= k <= 32 (GMRES(30) cycles); above: the bucketed kernels
-// elements in flight per lane: enough bytes per wave for small K, bounded registers for large K
-#define BK_EXACT_U(K) ((K) <= 2 ? 4 : ((K) <= 12 ? 2 : 1))
-#define BK_EXACT_SWITCH(k, CASE)                                                                                         \
-    switch (k) {                                                                                                         \
-        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13)      \
-        CASE(14) CASE(15) CASE(16) CASE(17) CASE(18) CASE(19) CASE(20) CASE(21) CASE(22) CASE(23) CASE(24) CASE(25)     \
-        CASE(26) CASE(27) CASE(28) CASE(29) CASE(30) CASE(31) CASE(32)                                                   \
-        default: break;                                                                                                  \
-    }
 
 // second reduction stage into a DEVICE buffer: the same fixed summation order as reduce_stage2_kernel (context.hip), so the
 // device-resident and the host-driven Arnoldi steps produce bitwise identical projections
@@ -745,37 +795,43 @@ int v_nrminf(bk_ctx* ctx, size_t n, const double* x, double* out) {
     return 0;
 }
 
-// exact-K kernels: 16-byte aligned operands, at least one full sweep of items (the tail clamps to the last item)
-static bool exact_ok(bk_ctx* ctx, bool vec, size_t n, int k) {
-    return vec && k >= 1 && k <= kExactMax && n >= 2 && ctx->opt("krylov_exact", 1.0) != 0.0;
+// Big (HBM-streaming) vectors, k <= 32: the contiguous-burst kernels.  Measured at 512^3 with the GMRES layout (dst = V[k];
+// profiles/r3_krylov_burst_sweep.txt): multidot 0.82-0.85 -> 0.88-0.91 of peak with 8 adjacent chunks and 512 workgroups
+// (4 chunks below 6 vectors), multiaxpy 0.67-0.69 -> 0.71-0.75 with 4 chunks and 512 workgroups.
+constexpr int kBurstMax = 32;
+static bool burst_ok(bk_ctx* ctx, bool vec, size_t n, int k) {
+    return vec && k >= 1 && k <= kBurstMax && nt_hint(ctx, n) && ctx->opt("krylov_burst", 1.0) != 0.0;
 }
-static void launch_multidot_exact(bk_ctx* ctx, int grid, size_t n, const double* V, size_t ldv, int k, const double* w, const double* gate) {
-    const unsigned xcd = xcd_map(ctx, n, grid, false, k);
-    const bool nt = nt_hint(ctx, n);
-#define BK_CASE(K)                                                                                                                  \
-    case K:                                                                                                                          \
-        if (nt) hipLaunchKernelGGL((multidot_x_kernel<K, BK_EXACT_U(K), true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, w, ctx->d_partials, gate, xcd); \
-        else hipLaunchKernelGGL((multidot_x_kernel<K, BK_EXACT_U(K), false>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, w, ctx->d_partials, gate, xcd);   \
-        break;
-    BK_EXACT_SWITCH(k, BK_CASE)
-#undef BK_CASE
+static int burst_grid(bk_ctx* ctx, size_t n, const char* key) {
+    return grid_for(n, 2, std::min(kRedBlocks, std::max(8, (int)ctx->opt(key, 512.0))));
 }
-static void launch_multiaxpy_exact(bk_ctx* ctx, int grid, size_t n, const double* V, size_t ldv, int k, const Coefs& cf, const double* src,
+static void launch_multidot_burst(bk_ctx* ctx, int grid, size_t n, const double* V, size_t ldv, int k, const double* w, const double* gate) {
+    const bool u8 = k >= 6 && ctx->opt("dot_burst", 0.0) != 4.0;
+#define BK_MDC(KB)                                                                                                                                  \
+    do {                                                                                                                                           \
+        if (u8) hipLaunchKernelGGL((multidot_c_kernel<KB, 8, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, w, ctx->d_partials, gate); \
+        else hipLaunchKernelGGL((multidot_c_kernel<KB, 4, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, w, ctx->d_partials, gate);    \
+    } while (0)
+    if (k <= 4) BK_MDC(4);
+    else if (k <= 8) BK_MDC(8);
+    else if (k <= 16) BK_MDC(16);
+    else if (k <= 24) BK_MDC(24);
+    else BK_MDC(32);
+#undef BK_MDC
+}
+static void launch_multiaxpy_burst(bk_ctx* ctx, int grid, size_t n, const double* V, size_t ldv, int k, const Coefs& cf, const double* src,
                                    double scale, double* dst, int want_norm, const double* dcoef, int gated) {
-    const unsigned xcd = xcd_map(ctx, n, grid, true, k);
-    const bool nt = nt_hint(ctx, n);
-#define BK_CASE(K)                                                                                                                  \
-    case K:                                                                                                                          \
-        if (dcoef) {                                                                                                                 \
-            if (nt) hipLaunchKernelGGL((multiaxpy_x_kernel<K, BK_EXACT_U(K), true, true, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, cf, src, scale, dst, want_norm, ctx->d_partials, xcd, dcoef, gated); \
-            else hipLaunchKernelGGL((multiaxpy_x_kernel<K, BK_EXACT_U(K), false, false, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, cf, src, scale, dst, want_norm, ctx->d_partials, xcd, dcoef, gated); \
-        } else {                                                                                                                     \
-            if (nt) hipLaunchKernelGGL((multiaxpy_x_kernel<K, BK_EXACT_U(K), true, true, false>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, cf, src, scale, dst, want_norm, ctx->d_partials, xcd, dcoef, gated); \
-            else hipLaunchKernelGGL((multiaxpy_x_kernel<K, BK_EXACT_U(K), false, false, false>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, cf, src, scale, dst, want_norm, ctx->d_partials, xcd, dcoef, gated); \
-        }                                                                                                                            \
-        break;
-    BK_EXACT_SWITCH(k, BK_CASE)
-#undef BK_CASE
+#define BK_MAC(KB)                                                                                                                                  \
+    do {                                                                                                                                           \
+        if (dcoef) hipLaunchKernelGGL((multiaxpy_c_kernel<KB, 4, true, true, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials, dcoef, gated); \
+        else hipLaunchKernelGGL((multiaxpy_c_kernel<KB, 4, true, true, false>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials, dcoef, gated);     \
+    } while (0)
+    if (k <= 4) BK_MAC(4);
+    else if (k <= 8) BK_MAC(8);
+    else if (k <= 16) BK_MAC(16);
+    else if (k <= 24) BK_MAC(24);
+    else BK_MAC(32);
+#undef BK_MAC
 }
 
 template <int KB>
@@ -789,10 +845,11 @@ static void launch_multidot(bk_ctx* ctx, bool vec, int grid, size_t n, const dou
 int v_multidot(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const double* w, double* out) {
     if (k < 0 || k > kMaxBasis) return set_error(ctx, "v_multidot: k=%d out of range", k);
     const bool vec = aligned16(V) && aligned16(w) && (ldv % 2 == 0);
-    const int grid = grid_for(n, vec ? 2 : 1, kRedBlocks);
+    const bool burst = burst_ok(ctx, vec, n, k);
+    const int grid = burst ? burst_grid(ctx, n, "dot_blocks") : grid_for(n, vec ? 2 : 1, kRedBlocks);
     {
         ProfScope ps(ctx, "multidot", 8.0 * n * (k + 1));
-        if (exact_ok(ctx, vec, n, k)) launch_multidot_exact(ctx, grid, n, V, ldv, k, w, nullptr);
+        if (burst) launch_multidot_burst(ctx, grid, n, V, ldv, k, w, nullptr);
         else if (k <= 4) launch_multidot<4>(ctx, vec, grid, n, V, ldv, k, w);
         else if (k <= 8) launch_multidot<8>(ctx, vec, grid, n, V, ldv, k, w);
         else if (k <= 16) launch_multidot<16>(ctx, vec, grid, n, V, ldv, k, w);
@@ -832,10 +889,11 @@ int v_multiaxpy(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const
     // 4096 blocks at 512^3 (DRAM page locality)
     int cap = (int)ctx->opt("axpy_blocks", kRedBlocks);
     if (want && cap > kRedBlocks) cap = kRedBlocks;
-    const int grid = grid_for(n, vec ? 2 : 1, cap);
+    const bool burst = burst_ok(ctx, vec, n, k);
+    const int grid = burst ? burst_grid(ctx, n, "axpy_burst_blocks") : grid_for(n, vec ? 2 : 1, cap);
     {
         ProfScope ps(ctx, "multiaxpy", 8.0 * n * (k + 1 + (src ? 1 : 0)));
-        if (exact_ok(ctx, vec, n, k)) launch_multiaxpy_exact(ctx, grid, n, V, ldv, k, cf, src, scale, dst, want, nullptr, 0);
+        if (burst) launch_multiaxpy_burst(ctx, grid, n, V, ldv, k, cf, src, scale, dst, want, nullptr, 0);
         else if (k <= 4) launch_multiaxpy<4>(ctx, vec, grid, n, V, ldv, k, cf, src, scale, dst, want);
         else if (k <= 8) launch_multiaxpy<8>(ctx, vec, grid, n, V, ldv, k, cf, src, scale, dst, want);
         else if (k <= 16) launch_multiaxpy<16>(ctx, vec, grid, n, V, ldv, k, cf, src, scale, dst, want);
@@ -868,11 +926,12 @@ int v_arnoldi_step_dev(bk_ctx* ctx, size_t n, double* V, size_t ldv, int k, cons
     // stream from HBM; plain accesses for the cache-resident sizes
     const bool big = vec && nt_hint(ctx, n);
     const Coefs cf0{};
-    const bool exact = exact_ok(ctx, vec, n, k);
+    const bool burst = burst_ok(ctx, vec, n, k);
+    const int grid_d = burst ? burst_grid(ctx, n, "dot_blocks") : grid, grid_a = burst ? burst_grid(ctx, n, "axpy_burst_blocks") : grid;
     auto dots = [&](const double* x, const double* g) {
-        if (exact) {
-            launch_multidot_exact(ctx, grid, n, V, ldv, k, x, g);
-            hipLaunchKernelGGL(reduce_stage2_dev, dim3(k + 1), dim3(256), 0, ctx->stream, ctx->d_partials, grid, k + 1, ctx->d_red, g);
+        if (burst) {
+            launch_multidot_burst(ctx, grid_d, n, V, ldv, k, x, g);
+            hipLaunchKernelGGL(reduce_stage2_dev, dim3(k + 1), dim3(256), 0, ctx->stream, ctx->d_partials, grid_d, k + 1, ctx->d_red, g);
             return;
         }
 #define BK_MD_DEV(KB)                                                                                                           \
@@ -892,7 +951,7 @@ int v_arnoldi_step_dev(bk_ctx* ctx, size_t n, double* V, size_t ldv, int k, cons
         hipLaunchKernelGGL(reduce_stage2_dev, dim3(k + 1), dim3(256), 0, ctx->stream, ctx->d_partials, grid, k + 1, ctx->d_red, g);
     };
     auto axpys = [&](const double* src, int gated) {
-        if (exact) { launch_multiaxpy_exact(ctx, grid, n, V, ldv, k, cf0, src, 1.0, dst, 0, coef, gated); return; }
+        if (burst) { launch_multiaxpy_burst(ctx, grid_a, n, V, ldv, k, cf0, src, 1.0, dst, 0, coef, gated); return; }
         const unsigned xcd = xcd_map(ctx, n, grid, true, k);
 #define BK_MA_DEV(KB)                                                                                                         \
     do {                                                                                                                      \

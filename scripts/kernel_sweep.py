@@ -112,25 +112,46 @@ if "krylov" in what:
         report("multiaxpy", timeit(f, reps=3, warm=1), 8.0 * N * (k + 2), k=k)
     del V
 
-if "exact" in what:
-    # round 3: exact-K branch-free kernels (krylov_exact = 1) against the bucketed `if (j < k)` kernels (0), interleaved
-    ld = (N + 31) // 32 * 32
-    kmax = 30 if n >= 512 else 32
-    V = torch.rand(ld * kmax, dtype=torch.float64, device="cuda", generator=g)
+if "gmrespad" in what:
+    # the multiaxpy exactly as GMRES issues it: dst = V[k] (the next basis vector, k strides above V[0]), src = w from another
+    # allocation; basis stride = N + pad.  Which pads separate the write stream from the concurrent read streams?
+    kmax = 13
     hbuf = (C.c_double * 65)()
-    for k in (1, 2, 3, 4, 6, 8, 10, 12, 13, 16, 20, 24, 30):
+    for pad in (0, 32, 64, 128, 256, 512, 544, 1024, 2048, 2080, 4096, 8192, 8224, 32768, 66080, 131072, 262144):
+        ld = (N + 31) // 32 * 32 + pad
+        V = torch.rand(ld * (kmax + 1), dtype=torch.float64, device="cuda", generator=g)
+        for k in (2, 4, 8, 12):
+            cc = (C.c_double * k)(*([0.01] * k))
+            dstp = C.c_void_p(V.data_ptr() + 8 * ld * k)
+            fa = lambda: ctx.check(ctx.lib.bk_krylov_multiaxpy(ctx.h, N, C.c_void_p(V.data_ptr()), ld, k, cc, C.c_void_p(v.t.data_ptr()),
+                                                               1.0, dstp, None))
+            fd = lambda: ctx.check(ctx.lib.bk_krylov_multidot(ctx.h, N, C.c_void_p(V.data_ptr()), ld, k, C.c_void_p(v.t.data_ptr()), hbuf))
+            report("multiaxpy", timeit(fa, reps=6, warm=1), 8.0 * N * (k + 2), k=k, pad=pad)
+            report("multidot", timeit(fd, reps=6, warm=1), 8.0 * N * (k + 1), k=k, pad=pad)
+        del V
+    torch.cuda.empty_cache()
+
+if "burst" in what:
+    # GMRES layout (dst = V[k]): the contiguous-burst kernels (krylov_burst = 1, the default for HBM-sized vectors) against the
+    # round-2 grid-stride kernels (0), interleaved
+    kmax = 30 if n >= 512 else 32
+    hbuf = (C.c_double * 65)()
+    ld = (N + 31) // 32 * 32
+    V = torch.rand(ld * (kmax + 1), dtype=torch.float64, device="cuda", generator=g)
+    for k in (1, 2, 4, 6, 8, 10, 12, 16, 20, 24, 30):
         if k > kmax:
             continue
         cc = (C.c_double * k)(*([0.01] * k))
+        dstp = C.c_void_p(V.data_ptr() + 8 * ld * k)
         fa = lambda: ctx.check(ctx.lib.bk_krylov_multiaxpy(ctx.h, N, C.c_void_p(V.data_ptr()), ld, k, cc, C.c_void_p(v.t.data_ptr()),
-                                                           1.0, C.c_void_p(out.t.data_ptr()), None))
+                                                           1.0, dstp, None))
         fd = lambda: ctx.check(ctx.lib.bk_krylov_multidot(ctx.h, N, C.c_void_p(V.data_ptr()), ld, k, C.c_void_p(v.t.data_ptr()), hbuf))
         for rep in range(2):
-            for ex in (0, 1):
-                ctx.set_option("krylov_exact", ex)
-                report("multiaxpy", timeit(fa, reps=5, warm=1), 8.0 * N * (k + 2), k=k, exact=ex, rep=rep)
-                report("multidot", timeit(fd, reps=5, warm=1), 8.0 * N * (k + 1), k=k, exact=ex, rep=rep)
-    ctx.set_option("krylov_exact", 1)
+            for b in (0, 1):
+                ctx.set_option("krylov_burst", b)
+                report("multiaxpy", timeit(fa, reps=6, warm=1), 8.0 * N * (k + 2), k=k, burst=b, rep=rep)
+                report("multidot", timeit(fd, reps=6, warm=1), 8.0 * N * (k + 1), k=k, burst=b, rep=rep)
+    ctx.set_option("krylov_burst", 1)
     del V
 
 if "axpy" in what:
