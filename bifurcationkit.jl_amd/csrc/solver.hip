@@ -59,9 +59,15 @@ struct VecOps {
 // rho = ||w|| / beta at EVERY single-pass step, whatever the DGKS test says (measured on Pl^-1 J: x3 per step, 1e-9 after 11
 // steps, O(1) after 21 -- GMRES then stagnates; a0 I + J with a large a0: stagnation at 3e-9 after 10 steps).  So the step also
 // carries the running estimate dlt <- (dlt + 2 eps) rho (it tracks the measured defect within a factor of 2) and takes
-// the second pass whenever the estimate would exceed orth_tol (1e-8: the true residual is within (1 + k dlt) of the
-// Givens estimate; the budget orth_tol / eps = 2e7 allows ~15 single-pass steps at rho = 3 -- the bench's 13-step solves
-// keep their single passes, long cycles are protected).
+// the second pass whenever the estimate would exceed orth_tol (1e-8; the budget orth_tol / eps = 2e7 allows ~15 single-pass
+// steps at rho = 3).  Round 3 tried to buy back the second passes of the 512^3 corrector (14 % of its time: the late
+// steps of each solve, rho > 10) by relaxing either knob -- both measured, both rejected:
+//  * orth_tol 1e-6 ... 1e-4: fine on the well-conditioned Pl^-1 J (measured defect <= 8 orth_tol, same iteration counts:
+//    tests/test_gpu_parity.py::test_single_pass_gram_schmidt_policy_...), worth <= 2 % there, but the shifted operator
+//    a0 I + J with a large a0 (rho ~ 10 at EVERY step) then needs 67 iterations instead of the oracle's 14
+//    (test_gmres_unpreconditioned_shift_and_restart) -- a basis that is only 1e-6-orthogonal does delay GMRES there;
+//  * DGKS eta 0.01 / 0.001 (single passes up to rho = 100 / 1000): the 512^3 corrector goes from 26 to 57-59 operator
+//    applications (profiles/r3_gram_schmidt_policy_512.txt).
 int arnoldi_step(bk_ctx* ctx, bk_op* A, Basis& B, int j, double* w, double* h, double* beta, double op_a0,
                  double op_a1, double eta) {
     const size_t n = A->n;
@@ -187,14 +193,15 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     // discarded (they cost launch-bound microseconds at these sizes); a step whose classical Gram-Schmidt pass needs the
     // DGKS second pass (or broke down) is flagged by the device and repeated on the host path.  Counters (numops / iters)
     // count consumed steps only, so they equal the host-driven run.
-    // (default: vectors up to 8 MiB.  At 16 MiB -- cGL 1024^2 -- a chunk gains nothing even on a 192-iteration solve, and every
-    // step speculated past convergence costs a whole operator application there: 0.3 ms with the dense sine transforms)
+    // (round 2 switched the chunks off above 8 MiB: every step speculated past convergence costs a whole operator application
+    // there.  With the convergence-predicted cap below the speculation is almost never wasted, and at 512^3 the chunks are worth
+    // 2 % -- 6.33 -> 6.19 ms per operator application, profiles/r3_bench_512_variants.txt -- and 8 % on the 128-MiB z-slab of an
+    // 8-rank run, where the host round trip per Arnoldi step is a larger share.)
     // The decision must be the same on every rank (a rank on the device path issues in-stream all-reduces its peer on the
-    // host path never joins): with RCCL ranks it does not look at the rank-local length at all -- ragged z-slabs may
-    // straddle any size threshold -- and defaults to chunks of "gmres_chunk_dist" (4) steps, whose speculation is capped by
-    // the convergence prediction below; a single rank keeps the size rule.
+    // host path never joins): it does not look at the rank-local length at all -- ragged z-slabs may straddle any size
+    // threshold -- only at options and at the communicator kind.
     const bool rccl_ranks = ctx->comm == COMM_RCCL && ctx->nranks > 1;
-    int chunk = (int)ctx->opt("gmres_chunk", rccl_ranks ? ctx->opt("gmres_chunk_dist", 4.0) : (n <= ((size_t)1 << 20) ? 4.0 : 1.0));
+    int chunk = (int)ctx->opt("gmres_chunk", 4.0);
     if (nt != 0 || (ctx->comm == COMM_HOST && ctx->nranks > 1) || chunk < 2 || !ctx->h_rec_dev) chunk = 1;
     if (chunk > kRecChunks) chunk = kRecChunks;
     // Speculation cap from the residual history (all quantities are all-reduced, i.e. identical on every rank): with the

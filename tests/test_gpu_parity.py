@@ -391,10 +391,10 @@ def test_single_pass_gram_schmidt_policy_bounds_the_measured_orthogonality_defec
     """The Arnoldi step takes ONE classical Gram-Schmidt pass while its running estimate of the orthogonality defect
     ||I - V'V|| stays below `orth_tol` and a second pass otherwise (solver.hip: arnoldi_step; KrylovKit's own default is
     two passes).  With option orth_probe the solver MEASURES the defect of each cycle's basis: it must stay within a small
-    factor of orth_tol for every setting (host-driven and device-resident steps), the iteration counts must not depend on
-    the setting, and the true residual must equal the Givens estimate to that accuracy -- the Arnoldi relation
-    A V_k = V_k+1 H holds to rounding whatever the orthogonality, so r = V_k+1 (beta e1 - H y) and
-    | |r| - estimate | <= defect * estimate."""
+    factor of orth_tol for every setting (host-driven and device-resident steps); on this well-conditioned preconditioned
+    operator the iteration counts do not depend on the setting up to 1e-5 (they DO on a0 I + J with a large a0, which is why
+    the default stays 1e-8: test_gmres_unpreconditioned_shift_and_restart), and the explicitly checked final residual meets
+    the tolerance whatever the setting."""
     hip = _hip()
     sh, prob, rng, u = _sh_setup(ctx, (24, 20, 16), (np.pi, 3.0, 2.5))
     J = prob.jacobian(prob.vec(u), 0.1)
@@ -420,7 +420,7 @@ def test_single_pass_gram_schmidt_policy_bounds_the_measured_orthogonality_defec
             assert np.linalg.norm(r) <= 1.5e-11 * np.linalg.norm(Plo(rhs_np)) + 1e-14
     finally:
         ctx.set_option("orth_probe", 0)
-        ctx.set_option("orth_tol", 1e-5)
+        ctx.set_option("orth_tol", 1e-8)
         ctx.set_option("gmres_chunk", 4)
     # relaxing the tolerance up to 1e-5 does not cost iterations (numops of the 1e-12 run = always-two-passes reference)
     assert abs(its[1e-8] - its[1e-12]) <= 1 and abs(its[1e-5] - its[1e-12]) <= 1, its
