@@ -156,13 +156,17 @@ int v_minres_update(bk_ctx* ctx, size_t n, double cz, const double* z, double c1
 int v_nrminf(bk_ctx* ctx, size_t n, const double* x, double* out);
 // out[i] = <V_i, w> for i < k, out[k] = <w, w>;  V_i = V + i*ldv
 int v_multidot(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const double* w, double* out);
+// the same plus gram[0..k) = <V_i, V_{k-1}>: the Gram column of the newest basis vector, from the same pass
+bool v_multidot_gram_ok(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const double* w);
+int v_multidot_gram(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const double* w, double* out, double* gram);
 // dst = scale * (src + sum_i c[i] V_i); src may be NULL (treated as 0); if nrm2sq != NULL the
 // squared 2-norm of dst is returned (global).  dst may alias src.
 int v_multiaxpy(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const double* c,
                 const double* src, double scale, double* dst, double* nrm2sq);
 // device-resident orthogonalisation step (vecops.hip): rec / coef are device buffers of kMaxBasis + 2 doubles
+// gram != NULL: the Gram-corrected single-pass step (device Gram matrix, (kMaxBasis + 1)^2 doubles, owned by the caller)
 int v_arnoldi_step_dev(bk_ctx* ctx, size_t n, double* V, size_t ldv, int k, const double* w, double eta, double orth_tol,
-                       double* rec, double* coef);
+                       double* rec, double* coef, double* gram = nullptr);
 // dst_j = sum_{i<m} Q(i,j) V_i for j < kout (Q host, column-major m x kout); dst may alias V
 int v_basis_combine(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int m, const double* Qhost, int kout,
                     double* dst, size_t lddst);

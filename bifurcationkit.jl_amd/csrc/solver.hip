@@ -32,6 +32,12 @@ struct Basis {                 // (m+1) device vectors + host tails (nt scalars 
     double dlt = 0.0;          // running estimate of the orthogonality defect ||I - V'V|| of the current cycle (arnoldi_step)
     double orth_tol = 1e-8;    // ... which single Gram-Schmidt passes may not push beyond this
     std::vector<double> t;     // tails, t[i * nt + q]
+    // Gram-corrected single-pass step (arnoldi_step): G(i, j) = <v_i, v_j> as MEASURED, column by column, by the fused
+    // multidot pass of the step that follows the creation of v_j; gram_n = columns known so far (reset per cycle)
+    bool use_gram = false;
+    int gram_n = 0;
+    std::vector<double> G;     // (kMaxBasis + 1)^2, column-major
+    double& g(int i, int j) { return G[(size_t)i + (size_t)j * (kMaxBasis + 1)]; }
     double* vec(int i) { return V + (size_t)i * ld; }
     double* tail(int i) { return t.data() + (size_t)i * nt; }
     double tdot(int i, const double* y) { double s = 0.0; for (int q = 0; q < nt; ++q) s += t[(size_t)i * nt + q] * y[q]; return s; }
@@ -76,12 +82,63 @@ int arnoldi_step(bk_ctx* ctx, bk_op* A, Basis& B, int j, double* w, double* h, d
     BK_TRY(A->apply(B.vec(j), nt ? B.tail(j) : nullptr, op_a0, op_a1, w, wt));
     const int k = j + 1;
     double hh[kMaxBasis + 1], c[kMaxBasis];
-    BK_TRY(v_multidot(ctx, n, B.V, B.ld, k, w, hh));
-    double ww = hh[k];
-    if (nt) {
-        for (int i = 0; i < k; ++i) hh[i] += B.tdot(i, wt);
-        for (int q = 0; q < nt; ++q) ww += wt[q] * wt[q];
+    // ---- Gram-corrected single pass (option gmres_gram, default on; GMRES only -- the eigensolver keeps two passes).
+    // The multidot pass also measures g = V'v_j, the Gram column of the newest vector (no extra traffic: v_j is one of the
+    // streams).  With G known, the coefficients of the ORTHOGONAL projection of w onto span(V) are c = G^-1 (V'w) -- for the
+    // nearly orthonormal V at hand c = a - E a + E E a, E = G - I -- and w - V c is orthogonal to every v_i up to the
+    // rounding of this one pass (eps * rho), whatever defect the earlier vectors carry: nothing accumulates, so the second
+    // "twice is enough" pass (14 % of the 512^3 corrector in round 2, all of its late steps) is not needed.
+    // The Arnoldi relation A v_j = V c + beta v_{j+1} holds exactly as before (H column = c), beta^2 = w'w - c'a.
+    if (B.use_gram && B.gram_n == j && v_multidot_gram_ok(ctx, n, B.V, B.ld, k, w)) {
+        double gcol[kMaxBasis];
+        BK_TRY(v_multidot_gram(ctx, n, B.V, B.ld, k, w, hh, gcol));
+        double ww = hh[k];
+        if (nt) {
+            for (int i = 0; i < k; ++i) { hh[i] += B.tdot(i, wt); gcol[i] += B.tdot(i, B.tail(j)); }
+            for (int q = 0; q < nt; ++q) ww += wt[q] * wt[q];
+        }
+        for (int i = 0; i < k; ++i) { B.g(i, j) = gcol[i]; B.g(j, i) = gcol[i]; }
+        B.gram_n = k;
+        if (ww == 0.0) { *beta = 0.0; return 0; }
+        double e1[kMaxBasis], e2[kMaxBasis];
+        for (int i = 0; i < k; ++i) {
+            double s_ = 0.0;
+            for (int l = 0; l < k; ++l) s_ += (B.g(i, l) - (i == l ? 1.0 : 0.0)) * hh[l];
+            e1[i] = s_;
+        }
+        double proj = 0.0;
+        for (int i = 0; i < k; ++i) {
+            double s_ = 0.0;
+            for (int l = 0; l < k; ++l) s_ += (B.g(i, l) - (i == l ? 1.0 : 0.0)) * e1[l];
+            e2[i] = s_;
+            c[i] = hh[i] - e1[i] + e2[i];
+            proj += c[i] * hh[i];
+        }
+        const double b2 = ww - proj;
+        if (b2 > 1e-8 * ww) {
+            const double be = std::sqrt(b2);
+            double cm[kMaxBasis];
+            for (int i = 0; i < k; ++i) { h[i] = c[i]; cm[i] = -c[i]; }
+            BK_TRY(v_multiaxpy(ctx, n, B.V, B.ld, k, cm, w, 1.0 / be, B.vec(k), nullptr));
+            for (int q = 0; q < nt; ++q) {
+                double t = wt[q];
+                for (int i = 0; i < k; ++i) t -= c[i] * B.tail(i)[q];
+                B.tail(k)[q] = t / be;
+            }
+            *beta = be;
+            return 0;
+        }
+        // severe cancellation (w is in span(V) to 1e-4): the explicit path below, on the raw projections
+        B.dlt = B.orth_tol;
+    } else {
+        if (B.use_gram) B.dlt = B.orth_tol;        // beyond the tracked columns: the two-pass policy, on the safe side
+        BK_TRY(v_multidot(ctx, n, B.V, B.ld, k, w, hh));
+        if (nt)
+            for (int i = 0; i < k; ++i) hh[i] += B.tdot(i, wt);
     }
+    double ww = hh[k];
+    if (nt)
+        for (int q = 0; q < nt; ++q) ww += wt[q] * wt[q];
     if (ww == 0.0) { *beta = 0.0; return 0; }
     double hsq = 0.0;
     for (int i = 0; i < k; ++i) { h[i] = hh[i]; hsq += hh[i] * hh[i]; c[i] = -hh[i]; }
@@ -182,6 +239,8 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     B.nt = nt;
     B.orth_tol = ctx->opt("orth_tol", 1e-8);
     B.t.assign((size_t)(m + 1) * (nt > 0 ? nt : 1), 0.0);
+    B.use_gram = ctx->opt("gmres_gram", 1.0) != 0.0;
+    if (B.use_gram) B.G.assign((size_t)(kMaxBasis + 1) * (kMaxBasis + 1), 0.0);
     double *w = nullptr, *r = nullptr;
     BK_TRY(ws.get(B.ld, &w));
     BK_TRY(ws.get(B.ld, &r));
@@ -220,9 +279,13 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     // speculative operator applications per solve (cGL 1024^2 eigensolve: 1.38 -> 0.70 s); everything else starts with full chunks
     int ramp = (ctx->gmres_last_steps <= 2) ? 1 : chunk;
     if (chunk > 1) BK_TRY(ws.get((size_t)kMaxBasis + 4, &d_coef));
+    // device Gram matrix of the Gram-corrected step; dev_gram: every column of this cycle was measured on the device so far
+    double* d_gram = nullptr;
+    bool dev_gram = false, cycle_on_host = false;
+    if (chunk > 1 && B.use_gram) BK_TRY(ws.get((size_t)(kMaxBasis + 1) * (kMaxBasis + 1), &d_gram));
     // next Hessenberg column (Arnoldi step from V[j]): from the queue of device-computed columns, else computed now
     auto next_column = [&](int j, double* hcol, double* hnext_out) -> int {
-        if (chunk > 1) {
+        if (chunk > 1 && !cycle_on_host) {
             if (!(q_count > 0 && j >= q_first && j < q_first + q_count)) {
                 int steps = std::min(std::min(ramp, chunk), m - j);
                 if (predict && steps > 1 && beta_now > 0.0) {
@@ -234,8 +297,16 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
                 ramp = std::min(chunk, 2 * ramp);
                 for (int s2 = 0; s2 < steps; ++s2) {
                     BK_TRY(A->apply(B.vec(j + s2), nullptr, op_a0, op_a1, w, nullptr));
+                    // beyond the Gram kernels' range (32 vectors) the cycle continues with the two-pass device policy
+                    const bool gstep = dev_gram && j + s2 + 1 <= 32;
+                    if (dev_gram && !gstep) {
+                        dev_gram = false;
+                        const double ot = B.orth_tol;
+                        BK_HIP(ctx, hipMemcpyAsync(d_coef + kMaxBasis + 2, &ot, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+                        BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    }
                     BK_TRY(v_arnoldi_step_dev(ctx, n, B.V, B.ld, j + s2 + 1, w, eta, B.orth_tol,
-                                              ctx->h_rec_dev + (size_t)s2 * (kMaxBasis + 2), d_coef));
+                                              ctx->h_rec_dev + (size_t)s2 * (kMaxBasis + 2), d_coef, gstep ? d_gram : nullptr));
                 }
                 BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 q_first = j; q_count = steps;
@@ -246,6 +317,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
                 *hnext_out = rec[kMaxBasis];
                 return 0;
             }
+            if (dev_gram) cycle_on_host = true;   // (the device Gram matrix misses this step's column: the cycle stays on the host)
             q_count = j - q_first;             // flagged: this and the later speculative steps are void; redo on the host path
             B.dlt = B.orth_tol;                // (the device kept the defect estimate: stay on the safe side on the host ...
             {                                  //  ... and on the device, whose later chunks would otherwise trust a stale estimate)
@@ -291,6 +363,9 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
         rsrc = r;
         for (int q = 0; q < nt; ++q) B.tail(0)[q] = rt[q] / beta;
         B.dlt = 0.0;                           // a single vector is orthonormal
+        B.gram_n = 0;                          // ... and its Gram column is measured by the first step
+        dev_gram = d_gram != nullptr;
+        cycle_on_host = false;
         if (chunk > 1) BK_HIP(ctx, hipMemsetAsync(d_coef + kMaxBasis + 2, 0, sizeof(double), ctx->stream));
         q_count = 0;                           // a new cycle: nothing speculative carries over
         beta_prev = 0.0; beta_now = beta; tol_now = tol;

@@ -475,41 +475,65 @@ __global__ void __launch_bounds__(kThreads) multiaxpy_kernel(size_t n, const dou
 // Same one-stream-at-a-time structure as the bucketed kernels above (the guard per vector keeps the streams apart in time,
 // which is what the DRAM likes: measured), but a workgroup takes U ADJACENT 4-KiB chunks of the stream per visit instead of
 // one (multidot) or two a whole grid stride apart (multiaxpy): U x 4 KiB contiguous per stream and workgroup.
-template <int KB, int U, bool LDNT>
+// GRAM: the same pass also returns g = V' V_{k-1}, the Gram column of the NEWEST basis vector (V_{k-1} is one of the streams
+// anyway: it is loaded first and every other V_j is dotted with both w and it) -- what the Gram-corrected single-pass
+// Arnoldi step of solver.hip needs, at no extra memory traffic.  Per block: a_0..a_{k-1}, w'w, then g_0..g_{k-1}.
+template <int KB, int U, bool LDNT, bool GRAM = false>
 __global__ void __launch_bounds__(kThreads) multidot_c_kernel(size_t n, const double* __restrict__ V, size_t ldv, int k,
                                                               const double* __restrict__ w, double* __restrict__ partials,
                                                               const double* gate) {
     if (gate && gate[0] == 0.0) return;
-    double acc[KB];
+    double acc[KB], accg[GRAM ? KB : 1];
 #pragma unroll
     for (int j = 0; j < KB; ++j) acc[j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < (GRAM ? KB : 1); ++j) accg[j] = 0.0;
     double ww = 0.0;
+    const int kl = GRAM ? k - 1 : k;                 // vectors visited by the loop (GRAM: all but the newest)
+    const double* __restrict__ Vn = V + (size_t)(k - 1) * ldv;
     stream_loop<U>(n >> 1, [&](auto uc, size_t i0, size_t st) {
         constexpr int UU = decltype(uc)::value;
-        double2 wv[UU];
+        double2 wv[UU], gv[GRAM ? UU : 1];
 #pragma unroll
         for (int u = 0; u < UU; ++u) wv[u] = ld2<LDNT>(w, i0 + u * st);
+        if (GRAM) {
+#pragma unroll
+            for (int u = 0; u < UU; ++u) gv[u] = ld2<LDNT>(Vn, i0 + u * st);
+        }
 #pragma unroll
         for (int u = 0; u < UU; ++u) { ww = fma(wv[u].x, wv[u].x, ww); ww = fma(wv[u].y, wv[u].y, ww); }
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
-            if (j < k) {
+            if (j < kl) {
                 double2 vv[UU];
 #pragma unroll
                 for (int u = 0; u < UU; ++u) vv[u] = ld2<LDNT>(V + (size_t)j * ldv, i0 + u * st);
 #pragma unroll
-                for (int u = 0; u < UU; ++u) { acc[j] = fma(vv[u].x, wv[u].x, acc[j]); acc[j] = fma(vv[u].y, wv[u].y, acc[j]); }
+                for (int u = 0; u < UU; ++u) {
+                    acc[j] = fma(vv[u].x, wv[u].x, acc[j]); acc[j] = fma(vv[u].y, wv[u].y, acc[j]);
+                    if (GRAM) { accg[j] = fma(vv[u].x, gv[u].x, accg[j]); accg[j] = fma(vv[u].y, gv[u].y, accg[j]); }
+                }
+            } else if (GRAM && j == kl) {
+#pragma unroll
+                for (int u = 0; u < UU; ++u) {
+                    acc[j] = fma(gv[u].x, wv[u].x, acc[j]); acc[j] = fma(gv[u].y, wv[u].y, acc[j]);
+                    accg[j] = fma(gv[u].x, gv[u].x, accg[j]); accg[j] = fma(gv[u].y, gv[u].y, accg[j]);
+                }
             }
         }
     });
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-        const double wv = w[n - 1];
+        const double wv = w[n - 1], gv = GRAM ? Vn[n - 1] : 0.0;
         ww = fma(wv, wv, ww);
 #pragma unroll
         for (int j = 0; j < KB; ++j)
-            if (j < k) acc[j] = fma(V[(size_t)j * ldv + n - 1], wv, acc[j]);
+            if (j < k) {
+                const double vj = V[(size_t)j * ldv + n - 1];
+                acc[j] = fma(vj, wv, acc[j]);
+                if (GRAM) accg[j] = fma(vj, gv, accg[j]);
+            }
     }
-    __shared__ double sm[4][KB + 1];
+    __shared__ double sm[4][(GRAM ? 2 : 1) * KB + 1];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < KB; ++j) {
@@ -520,10 +544,18 @@ __global__ void __launch_bounds__(kThreads) multidot_c_kernel(size_t n, const do
         const double s_ = wave_sum(ww);
         if (lane == 0) sm[wid][KB] = s_;
     }
+    if (GRAM) {
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            const double s_ = wave_sum(accg[j]);
+            if (lane == 0) sm[wid][KB + 1 + j] = s_;
+        }
+    }
     __syncthreads();
-    for (int j = threadIdx.x; j <= k; j += kThreads) {
-        const int src = (j == k) ? KB : j;
-        partials[(size_t)blockIdx.x * (k + 1) + j] = (sm[0][src] + sm[1][src]) + (sm[2][src] + sm[3][src]);
+    const int nv = GRAM ? 2 * k + 1 : k + 1;
+    for (int j = threadIdx.x; j < nv; j += kThreads) {
+        const int src = j < k ? j : (j == k ? KB : KB + 1 + (j - k - 1));
+        partials[(size_t)blockIdx.x * nv + j] = (sm[0][src] + sm[1][src]) + (sm[2][src] + sm[3][src]);
     }
 }
 
@@ -643,6 +675,46 @@ __global__ void arnoldi_coef2_kernel(const double* __restrict__ hw, int k, doubl
     coef[kMaxBasis] = 1.0 / cn;
     rec[kMaxBasis] = ok ? be * cn : 0.0;
     if (!ok) rec[kMaxBasis + 1] = 1.0;
+}
+
+// Gram-corrected single pass on the device (solver.hip: arnoldi_step's gram branch, same arithmetic up to the order of the
+// k-term sums): hw = [a = V'w (k) ; w'w ; g = V'v_{k-1} (k)], G (ldg = kMaxBasis + 1, column-major, device) holds the
+// measured Gram matrix of the cycle.  One wavefront; lane i owns row i (k <= 32).
+__global__ void __launch_bounds__(64) arnoldi_gram_coef_kernel(const double* __restrict__ hw, int k, double* __restrict__ G,
+                                                               double* __restrict__ rec, double* __restrict__ coef) {
+    __shared__ double sa[64], se[64];
+    const int i = threadIdx.x, ldg = kMaxBasis + 1;
+    const bool on = i < k;
+    const double ai = on ? hw[i] : 0.0;
+    if (on) {
+        const double gi = hw[k + 1 + i];
+        G[(size_t)i + (size_t)(k - 1) * ldg] = gi;
+        G[(size_t)(k - 1) + (size_t)i * ldg] = gi;
+    }
+    sa[i] = ai;
+    __syncthreads();
+    double e1 = 0.0;
+    if (on)
+        for (int l = 0; l < k; ++l) e1 += (G[(size_t)i + (size_t)l * ldg] - (i == l ? 1.0 : 0.0)) * sa[l];
+    se[i] = e1;
+    __syncthreads();
+    double e2 = 0.0;
+    if (on)
+        for (int l = 0; l < k; ++l) e2 += (G[(size_t)i + (size_t)l * ldg] - (i == l ? 1.0 : 0.0)) * se[l];
+    const double ci = ai - e1 + e2;
+    const double proj = wave_sum(ci * ai);           // lanes >= k contribute 0
+    const double pr = __shfl(proj, 0, 64);
+    const double ww = hw[k];
+    const double b2 = ww - pr;
+    const bool ok = ww > 0.0 && b2 > 1e-8 * ww;
+    const double be = ok ? sqrt(b2) : 1.0;
+    if (on) { rec[i] = ci; coef[i] = -ci; }
+    if (i == 0) {
+        rec[kMaxBasis] = ok ? be : 0.0;
+        rec[kMaxBasis + 1] = ok ? 0.0 : 1.0;
+        coef[kMaxBasis] = 1.0 / be;
+        coef[kMaxBasis + 1] = 0.0;                   // no second pass
+    }
 }
 
 // ------------------------------------------------------------------ basis rotation  dst_j = sum_i Q(i,j) V_i
@@ -819,6 +891,21 @@ static void launch_multidot_burst(bk_ctx* ctx, int grid, size_t n, const double*
     else BK_MDC(32);
 #undef BK_MDC
 }
+// h = V'w, w'w and the Gram column g = V'V_{k-1} in one pass (any vector size; non-temporal loads for HBM-sized ones)
+static void launch_multidot_gram(bk_ctx* ctx, int grid, size_t n, const double* V, size_t ldv, int k, const double* w, const double* gate) {
+    const bool nt = nt_hint(ctx, n);
+#define BK_MDG(KB)                                                                                                                                  \
+    do {                                                                                                                                           \
+        if (nt) hipLaunchKernelGGL((multidot_c_kernel<KB, 4, true, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, w, ctx->d_partials, gate); \
+        else hipLaunchKernelGGL((multidot_c_kernel<KB, 4, false, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, w, ctx->d_partials, gate);   \
+    } while (0)
+    if (k <= 4) BK_MDG(4);
+    else if (k <= 8) BK_MDG(8);
+    else if (k <= 16) BK_MDG(16);
+    else if (k <= 24) BK_MDG(24);
+    else BK_MDG(32);
+#undef BK_MDG
+}
 static void launch_multiaxpy_burst(bk_ctx* ctx, int grid, size_t n, const double* V, size_t ldv, int k, const Coefs& cf, const double* src,
                                    double scale, double* dst, int want_norm, const double* dcoef, int gated) {
 #define BK_MAC(KB)                                                                                                                                  \
@@ -861,6 +948,23 @@ int v_multidot(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const 
     }
     BK_TRY(reduce_finish(ctx, grid, k + 1, 0));
     for (int j = 0; j <= k; ++j) out[j] = ctx->h_red[j];
+    return 0;
+}
+
+// out[0..k) = V'w, out[k] = w'w, gram[0..k) = V'V_{k-1} (1 <= k <= 32, 16-byte aligned operands, even ldv)
+bool v_multidot_gram_ok(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const double* w) {
+    return k >= 1 && k <= kBurstMax && n >= 2 && aligned16(V) && aligned16(w) && (ldv % 2 == 0) && ctx->opt("gmres_gram", 1.0) != 0.0;
+}
+int v_multidot_gram(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const double* w, double* out, double* gram) {
+    const int grid = nt_hint(ctx, n) ? burst_grid(ctx, n, "dot_blocks") : grid_for(n, 2 * 4, 512);
+    {
+        ProfScope ps(ctx, "multidot", 8.0 * n * (k + 1));
+        launch_multidot_gram(ctx, grid, n, V, ldv, k, w, nullptr);
+        BK_HIP(ctx, hipGetLastError());
+    }
+    BK_TRY(reduce_finish(ctx, grid, 2 * k + 1, 0));
+    for (int j = 0; j <= k; ++j) out[j] = ctx->h_red[j];
+    for (int j = 0; j < k; ++j) gram[j] = ctx->h_red[k + 1 + j];
     return 0;
 }
 
@@ -915,7 +1019,7 @@ int v_multiaxpy(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const
 // coefficients, V_k = (w - V h) / beta.  Nothing is copied to the host; `rec` (kRecLen doubles, device) receives h, beta and
 // the trust flag for the host to pick up after a later synchronisation.
 int v_arnoldi_step_dev(bk_ctx* ctx, size_t n, double* V, size_t ldv, int k, const double* w, double eta, double orth_tol,
-                       double* rec, double* coef) {
+                       double* rec, double* coef, double* gram) {
     if (k < 1 || k > kMaxBasis - 1) return set_error(ctx, "v_arnoldi_step_dev: k=%d out of range", k);
     if (ctx->comm == COMM_HOST && ctx->nranks > 1) return set_error(ctx, "v_arnoldi_step_dev: needs a device-side all-reduce");
     const bool vec = aligned16(V) && aligned16(w) && (ldv % 2 == 0);
@@ -969,6 +1073,26 @@ int v_arnoldi_step_dev(bk_ctx* ctx, size_t n, double* V, size_t ldv, int k, cons
 #undef BK_MA_DEV
     };
     const bool rccl = ctx->comm == COMM_RCCL && ctx->nranks > 1;
+    if (gram) {
+        // Gram-corrected single pass: multidot with the Gram column, coefficients, ONE multiaxpy -- no second pass
+        if (!v_multidot_gram_ok(ctx, n, V, ldv, k, w)) return set_error(ctx, "v_arnoldi_step_dev: gram step out of range");
+        const int gg = nt_hint(ctx, n) ? burst_grid(ctx, n, "dot_blocks") : grid_for(n, 2 * 4, 512);
+        {
+            ProfScope ps(ctx, "multidot", 8.0 * n * (k + 1));
+            launch_multidot_gram(ctx, gg, n, V, ldv, k, w, nullptr);
+            hipLaunchKernelGGL(reduce_stage2_dev, dim3(2 * k + 1), dim3(256), 0, ctx->stream, ctx->d_partials, gg, 2 * k + 1, ctx->d_red,
+                               (const double*)nullptr);
+            BK_HIP(ctx, hipGetLastError());
+        }
+        if (rccl) BK_NCCL(ctx, ncclAllReduce(ctx->d_red, ctx->d_red, 2 * k + 1, ncclDouble, ncclSum, ctx->nccl, ctx->stream));
+        hipLaunchKernelGGL(arnoldi_gram_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_red, k, gram, rec, coef);
+        {
+            ProfScope ps(ctx, "multiaxpy", 8.0 * n * (k + 2));
+            axpys(w, 0);
+            BK_HIP(ctx, hipGetLastError());
+        }
+        return 0;
+    }
     {
         ProfScope ps(ctx, "multidot", 8.0 * n * (k + 1));
         dots(w, nullptr);
