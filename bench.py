@@ -506,10 +506,10 @@ def main():
             elif dom in ("multiaxpy", "multidot"):
                 # a family of <KB> instantiations with k + 2 (k + 1) streams each: launch-weighted mean over the PMC pass's own
                 # launches (the same step, hence the same distribution of k as the timed steps)
-                fam = [v for k_, v in pmc.items() if k_.startswith(dom + "_kernel<") and v.get("n")]
+                fam = [v for k_, v in pmc.items() if k_.startswith((dom + "_kernel<", dom + "_c_kernel<")) and v.get("n")]
                 if fam:
                     traffic = sum(v["n"] * (v["read_bytes"] + v["write_bytes"]) for v in fam) / sum(v["n"] for v in fam)
-                    tsrc = (f"{rel} (launch-weighted mean over the {dom}_kernel<KB> instantiations; rocprofv3 --pmc FETCH_SIZE / "
+                    tsrc = (f"{rel} (launch-weighted mean over the {dom}[_c]_kernel<KB> instantiations; rocprofv3 --pmc FETCH_SIZE / "
                             f"WRITE_SIZE in separate passes, FETCH x2 on gfx950; same kernel sources)")
         roofline = dict(kernel=dom, bound="hbm", achieved=k["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=k["gbs"] / HBM_PEAK_GBS, traffic=traffic, traffic_source=tsrc, avg_ms=k["avg_ms"],

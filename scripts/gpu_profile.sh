@@ -2,7 +2,7 @@
 # Full evidence run: GPU tests, smoke, default bench line, rocprofv3 kernel stats and PMC (FETCH_SIZE / WRITE_SIZE) passes.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-TAG=${1:-r2}
+TAG=${1:-r3}
 mkdir -p gpurun_out
 export PYTHONPATH="$PWD"
 [ "${SKIP_TESTS:-0}" = 1 ] || timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -30 | tee gpurun_out/pytest_gpu.log

@@ -235,7 +235,9 @@ def slab_checks(ctx, hip, rank, world, tag):
     all-to-all block layout): JVP (all split-launch variants), preconditioner, GMRES, bordered solve."""
     cases = [((16, 12, 4 * world + 2 if world > 2 else 20), (2.0, 1.5, 2.5)),      # ragged: some ranks own one plane more
              ((8, 6, 2 * world + 1), (1.0, 1.5, 2.0)),                               # thin: 2 or 3 planes per rank
-             ((32, 64, 64), (2.0, 3.0, 2.5))]                                        # power of two: fused DCT passes
+             ((32, 64, 64), (2.0, 3.0, 2.5)),                                        # power of two: fused DCT passes
+             ((32, 32, 16 * world), (2.0, 2.0, 0.6 * world))]                        # equal 16-plane slabs: the slab z-solve
+                                                                                     # (power-of-two world sizes), else transposes
     for ci, (dims, ls) in enumerate(cases):
         N = int(np.prod(dims))
         rng = np.random.default_rng(10 + ci)
@@ -257,6 +259,19 @@ def slab_checks(ctx, hip, rank, world, tag):
         out["x"], out["ok"], out["it"] = gather_slabs(x.numpy(), rank, world), ok, it
         dX, dl, okb, itb = hip.BorderingBLS(lsol, check_precision=False)(J, V, U, 0.3, Rv, 0.7, 0.5, 0.5, dotscale=1.0 / N)
         out["dX"], out["dl"] = gather_slabs(dX.numpy(), rank, world), dl
+        # one PALC corrector iteration (newton_palc, Palc.jl:237-295) as ONE library call: the bench's step on slabs
+        B = hip.BorderedArray
+        tn = np.sqrt(np.dot(v, v) / N * 0.5 + 0.3 * 0.3 * 0.5)
+        Z0, T = B(U, 0.1), B(prob.vec(v / tn), 0.3 / tn)
+        ZP = Z0.copy().add_(T, -0.01)
+        sc = hip.newton_palc_native(prob, Z0, T, ZP, -0.01, 0.5, hip.BorderingBLS(lsol, check_precision=False), tol=0.0,
+                                    max_iterations=1, norm_inf=True)
+        out["cor_p"], out["cor_res"], out["cor_it"] = sc["u"].p, sc["residuals"], sc["itlineartot"]
+        out["cor_x"] = gather_slabs(sc["u"].u.numpy(), rank, world)
+        if ctx.nranks > 1:
+            kind, crank, cranks = ctx.comm_info()
+            assert crank == rank and cranks == world, (tag, kind, crank, cranks)
+            assert ctx.comm_probe("allreduce", 8, 3) >= 0.0 and ctx.comm_probe("halo", 64, 3) >= 0.0
         if rank == 0:
             c1 = hip.Context(0)
             p1 = hip.SwiftHohenberg(c1, dims, ls)
@@ -278,6 +293,15 @@ def slab_checks(ctx, hip, rank, world, tag):
             dX1, dl1, _, _ = hip.BorderingBLS(l1, check_precision=False)(J1, V1, U1, 0.3, R1, 0.7, 0.5, 0.5, dotscale=1.0 / N)
             assert np.isclose(out["dl"], dl1, rtol=1e-7)
             assert np.allclose(out["dX"], dX1.numpy(), rtol=1e-6, atol=1e-8 * np.abs(dX1.numpy()).max())
+            B1 = hip.BorderedArray
+            Z1, T1 = B1(U1, 0.1), B1(p1.vec(v / tn), 0.3 / tn)
+            s1 = hip.newton_palc_native(p1, Z1, T1, Z1.copy().add_(T1, -0.01), -0.01, 0.5,
+                                        hip.BorderingBLS(l1, check_precision=False), tol=0.0, max_iterations=1, norm_inf=True)
+            assert abs(out["cor_p"] - s1["u"].p) <= 1e-9 * max(1.0, abs(s1["u"].p)), (tag, dims, out["cor_p"], s1["u"].p)
+            assert abs(out["cor_res"][0] - s1["residuals"][0]) <= 1e-12 * max(1.0, s1["residuals"][0])
+            assert abs(out["cor_it"] - s1["itlineartot"]) <= 2, (tag, dims, out["cor_it"], s1["itlineartot"])
+            x1c = s1["u"].u.numpy()
+            assert np.abs(out["cor_x"] - x1c).max() <= 1e-7 * np.abs(x1c).max(), (tag, dims)
             c1.close()
 
 
@@ -298,7 +322,16 @@ def main_rccl(rank, world):
     idt = [hip.Context.unique_id() if rank == 0 else None]
     dist.broadcast_object_list(idt, src=0)
     ctx = hip.Context(rank, ("rccl", rank, world, idt[0]))
+    kind, crank, cranks = ctx.comm_info()
+    assert kind == "rccl" and crank == rank and cranks == world, (kind, crank, cranks)      # what ncclCommCount reports
+    # default options: device-resident Arnoldi chunks with the in-stream all-reduce of the 2k + 1 projections / Gram
+    # column, halo exchange on the second stream under the interior z-chunks, slab z-solve where the slabs allow it
     slab_checks(ctx, hip, rank, world, f"rccl x{world}")
+    # and the host-driven variants of the same paths (one all-reduce + host synchronisation per Arnoldi step, halo
+    # exchange in line, transposed preconditioner)
+    for key, val in (("gmres_chunk", 1), ("halo_overlap", 0), ("dct_dist_slab", 0), ("gmres_gram", 0)):
+        ctx.set_option(key, val)
+        slab_checks(ctx, hip, rank, world, f"rccl x{world} {key}={val}")
     ctx.close()
     print(f"rank {rank}: gpu distributed checks OK", flush=True)
 

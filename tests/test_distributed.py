@@ -68,6 +68,38 @@ def test_real_rccl_ranks_when_two_gpus_are_visible():
     _run("rccl", 2)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [4, 8])
+def test_real_rccl_ranks_on_a_full_node(world):
+    """The driver's scaling node: 4 and 8 RCCL ranks (one per GPU) -- ragged and thin slabs, the slab z-solve with 16-plane
+    slabs, device-resident Arnoldi chunks with in-stream all-reduces, halo overlap on the second stream, one PALC corrector
+    iteration, each against the 1-rank result; then the host-driven variants of the same paths.  Fires the moment
+    >= `world` GPUs are visible; skipped on the 1-GPU box (the same checks run there over the host-staged communicator)."""
+    import torch
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs >= {world} visible GPUs")
+    _run("rccl", world, timeout=1200)
+
+
+@pytest.mark.gpu
+def test_branch_workload_on_two_rccl_ranks_matches_one_rank():
+    """BASELINE config 5 in miniature over RCCL: `bench.py --workload branch` (corrector + eigensolve + Bordered tangent per
+    step, every step ONE bk_cont_step call per rank) on 64 x 64 x 64 with 2 ranks reproduces the 1-rank branch."""
+    import json
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 visible GPUs")
+    args = ["--workload", "branch", "--size", "64", "--steps", "3", "--nev", "4", "--eig-tol", "1e-7"]
+    one = _bench(["--gpus", "1"] + args, timeout=900)
+    two = _bench(["--gpus", "2"] + args, timeout=900)
+    assert one.returncode == 0 and two.returncode == 0, (one.stderr[-1500:], two.stderr[-1500:])
+    a = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    b = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert b["n_gpus"] == 2 and len(a["param"]) == len(b["param"])
+    assert all(abs(x - y) <= 1e-8 for x, y in zip(a["param"], b["param"])), (a["param"], b["param"])
+    assert a["n_unstable"] == b["n_unstable"]
+
+
 def _bench(args, env_extra=None, timeout=300):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(PYTHONPATH=ROOT, OMP_NUM_THREADS="2", **(env_extra or {}))
