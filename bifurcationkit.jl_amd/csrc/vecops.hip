@@ -894,16 +894,18 @@ static void launch_multidot_burst(bk_ctx* ctx, int grid, size_t n, const double*
 // h = V'w, w'w and the Gram column g = V'V_{k-1} in one pass (any vector size; non-temporal loads for HBM-sized ones)
 static void launch_multidot_gram(bk_ctx* ctx, int grid, size_t n, const double* V, size_t ldv, int k, const double* w, const double* gate) {
     const bool nt = nt_hint(ctx, n);
-#define BK_MDG(KB)                                                                                                                                  \
+    // bursts of 8 adjacent chunks from 6 vectors on, as the plain multidot (4 for the two largest buckets: registers)
+#define BK_MDG(KB, UU)                                                                                                                              \
     do {                                                                                                                                           \
-        if (nt) hipLaunchKernelGGL((multidot_c_kernel<KB, 4, true, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, w, ctx->d_partials, gate); \
-        else hipLaunchKernelGGL((multidot_c_kernel<KB, 4, false, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, w, ctx->d_partials, gate);   \
+        if (nt) hipLaunchKernelGGL((multidot_c_kernel<KB, UU, true, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, w, ctx->d_partials, gate); \
+        else hipLaunchKernelGGL((multidot_c_kernel<KB, 4, false, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, w, ctx->d_partials, gate);    \
     } while (0)
-    if (k <= 4) BK_MDG(4);
-    else if (k <= 8) BK_MDG(8);
-    else if (k <= 16) BK_MDG(16);
-    else if (k <= 24) BK_MDG(24);
-    else BK_MDG(32);
+    if (k <= 4) BK_MDG(4, 4);
+    else if (k < 6) BK_MDG(8, 4);
+    else if (k <= 8) BK_MDG(8, 8);
+    else if (k <= 16) BK_MDG(16, 8);
+    else if (k <= 24) BK_MDG(24, 4);
+    else BK_MDG(32, 4);
 #undef BK_MDG
 }
 static void launch_multiaxpy_burst(bk_ctx* ctx, int grid, size_t n, const double* V, size_t ldv, int k, const Coefs& cf, const double* src,

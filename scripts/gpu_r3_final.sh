@@ -1,0 +1,33 @@
+#!/bin/bash
+# round 3 evidence on the final sources: GPU suite, smoke, bench (default + driver arguments), rocprofv3 stats + PMC passes,
+# cost-model inputs, the driver's 8-rank geometry from a bare shell over the host-staged communicator, RCCL bootstrap with 1 rank
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+export PYTHONPATH="$PWD"
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -30 > gpurun_out/r3f_pytest.log
+tail -6 gpurun_out/r3f_pytest.log | cut -c1-300
+SKIP_TESTS=1 bash scripts/gpu_profile.sh r3 > gpurun_out/r3f_profile.out 2>&1
+tail -3 gpurun_out/smoke.log
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/r3f_bench_driver_args.json
+timeout 300 python bench.py --size 256 --steps 10 --warmup 3 2>/dev/null | tail -1 > gpurun_out/r3f_bench_256.json
+bash scripts/gpu_cost_model_inputs.sh > gpurun_out/r3f_cost_inputs.out 2>&1
+tail -10 gpurun_out/r3f_cost_inputs.out | cut -c1-250
+BK_FORCE_DIST=1 timeout 300 python bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-steady 2> gpurun_out/r3f_forcedist.err | tail -1 > gpurun_out/r3f_forcedist.json
+OUT=gpurun_out/r3f_hostcomm8.jsonl
+: > $OUT
+BK_BENCH_HOSTCOMM=1 timeout 600 python bench.py --gpus 8 --size 256 --steps 1 --warmup 1 --cpu-sample 0 --no-steady 2> gpurun_out/r3f_hostcomm8_256.err | tail -1 >> $OUT
+BK_BENCH_HOSTCOMM=1 timeout 900 python bench.py --gpus 8 --size 512 --steps 1 --warmup 1 --cpu-sample 0 --no-steady 2> gpurun_out/r3f_hostcomm8_512.err | tail -1 >> $OUT
+python - <<'PY'
+import json
+def show(path):
+    for l in open(path):
+        try:
+            d = json.loads(l); c = d['config']
+            print(path.split('/')[-1], c['grid'], 'ranks', d['n_gpus'], 'ms %.2f' % d['ms_per_step'], 'steps/s %.3f' % d['value'], 'itlin', c['itlinear_per_step'], 'p', c['full_corrector']['p'],
+                  'roof', d['roofline'] and (d['roofline']['kernel'], round(d['roofline']['frac'], 3), d['roofline']['traffic']), 'comm', (d.get('comm') or {}).get('backend'), (d.get('comm') or {}).get('ranks_in_communicator'))
+        except Exception as e:
+            print('unparsed', path, e, l[:200])
+for p in ('gpurun_out/bench_r3.log', 'gpurun_out/r3f_bench_driver_args.json', 'gpurun_out/r3f_bench_256.json', 'gpurun_out/r3f_forcedist.json', 'gpurun_out/r3f_hostcomm8.jsonl'):
+    show(p)
+PY
