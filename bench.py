@@ -321,6 +321,11 @@ def main():
         dist.init_process_group("gloo")
         comm = hostcomm.comm_tuple()
     elif world > 1 or os.environ.get("BK_FORCE_DIST") == "1":       # BK_FORCE_DIST: exercise the RCCL bootstrap with 1 rank
+        if world == 1 and "MASTER_ADDR" not in os.environ:           # ... also from a bare shell
+            import socket
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s_.getsockname()[1]))
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:

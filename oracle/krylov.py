@@ -51,6 +51,47 @@ def _mgs2(w, V, k):
     return w, h
 
 
+class GramCGS:
+    """The library's Arnoldi orthogonalisation since round 3, restated (csrc/solver.hip: arnoldi_step, gram branch;
+    csrc/vecops.hip: multidot_c_kernel<GRAM>): ONE classical Gram-Schmidt pass whose projection coefficients are corrected
+    with the MEASURED Gram matrix of the basis.  The pass that computes a = V'w also returns g = V'v_{k-1}, the Gram column
+    of the newest vector; with G known, c = G^-1 a (c = a - E a + E E a, E = G - I) are the coefficients of the orthogonal
+    projection of w onto span(V), so w - V c is orthogonal to every v_i up to the rounding of this one pass whatever defect
+    the earlier vectors carry, and beta^2 = w'w - c'a.  Not a reference algorithm (KrylovKit: ModifiedGramSchmidt2, _mgs2
+    above): the tests show that it reproduces MGS2's Hessenberg / residual history / iteration counts."""
+
+    def __init__(self, m):
+        self.G = np.zeros((m + 1, m + 1))
+        self.n = 0
+
+    def reset(self):
+        self.n = 0
+
+    def __call__(self, w, V, k):
+        assert self.n == k - 1, "one call per Arnoldi step, in order"
+        a = V[:k] @ w
+        g = V[:k] @ V[k - 1]
+        self.G[:k, k - 1] = g
+        self.G[k - 1, :k] = g
+        self.n = k
+        E = self.G[:k, :k] - np.eye(k)
+        e1 = E @ a
+        c = a - e1 + E @ e1
+        b2 = float(w @ w) - float(c @ a)
+        wn = w - V[:k].T @ c
+        # the library normalises with the Pythagorean beta; hand the remainder back scaled so that ||.|| == sqrt(b2)
+        nrm = np.linalg.norm(wn)
+        if b2 > 1e-8 * float(w @ w) and nrm > 0.0:
+            wn = wn * (np.sqrt(b2) / nrm)
+        return wn, c
+
+
+def _cgs1(w, V, k):
+    """ONE classical Gram-Schmidt pass without any correction (control experiment of the tests: loses orthogonality)."""
+    h = V[:k] @ w
+    return w - V[:k].T @ h, h
+
+
 def _givens(f, g):
     """Real Givens (c, s, r) with [c s; -s c] [f; g] = [r; 0]."""
     if g == 0.0:
@@ -62,7 +103,7 @@ def _givens(f, g):
 
 
 def gmres_krylovkit(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, rtol=1e-12,
-                    Pl=None, history=None):
+                    Pl=None, history=None, orth="mgs2", basis_out=None):
     """Solve (a0 + a1 A) x = b from x0 = 0.  Returns (x, converged, numops, normres).
 
     ``Pl`` (callable applying Pl^-1) selects the preconditioned branch of GMRESKrylovKit,
@@ -73,7 +114,7 @@ def gmres_krylovkit(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-
         A_, a0_, a1_ = A, a0, a1
         lin = lambda dx: a1_ * Pl(apply(A_, dx)) + a0_ * dx
         return gmres_krylovkit(lin, Pl(np.asarray(b, dtype=float)), 0.0, 1.0, krylovdim=krylovdim,
-                               maxiter=maxiter, atol=atol, rtol=rtol, history=history)
+                               maxiter=maxiter, atol=atol, rtol=rtol, history=history, orth=orth, basis_out=basis_out)
     b = np.asarray(b, dtype=float)
     n = b.shape[0]
     x = np.zeros(n)
@@ -90,12 +131,18 @@ def gmres_krylovkit(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-
     cs = np.zeros(m)
     sn = np.zeros(m)
     numiter = 0
+    # orth: "mgs2" = KrylovKit's ModifiedGramSchmidt2 (the reference); "cgs_gram" = the library's Gram-corrected single pass;
+    # "cgs1" = one uncorrected classical pass (control)
+    gram = GramCGS(m) if orth == "cgs_gram" else None
+    ortho = {"mgs2": _mgs2, "cgs1": _cgs1}.get(orth, gram)
 
     def start(r, beta):
         # ArnoldiIterator initialize: v1 = r/||r||, w = A v1, h11, residual
         V[0] = r / beta
+        if gram is not None:
+            gram.reset()
         w = apply(A, V[0])
-        w, h = _mgs2(w, V, 1)
+        w, h = ortho(w, V, 1)
         return w, h, np.linalg.norm(w)
 
     w, h, nrm = start(r, beta)
@@ -116,7 +163,7 @@ def gmres_krylovkit(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-
             V[k] = w / nrm
             w = apply(A, V[k])
             numops += 1
-            w, h = _mgs2(w, V, k + 1)
+            w, h = ortho(w, V, k + 1)
             nrm = np.linalg.norm(w)
             k += 1
             col = a1 * h
@@ -134,6 +181,8 @@ def gmres_krylovkit(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-
                 history.append(beta)
         yk = sla.solve_triangular(R[:k, :k], y[:k])
         x = x + V[:k].T @ yk
+        if basis_out is not None:
+            basis_out.append(V[:k].copy())
         if beta > tol:
             # residual from the Krylov data: r = y[k+1] * (V_{k+1} G_1' ... G_k') e_{k+1}
             V[k] = w / nrm

@@ -16,7 +16,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out")
-one = json.load(open(sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r2_bench_512_1gpu_b.json")))
+one = json.load(open(sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r3_bench_512_1gpu.json")))
 emu = [json.loads(l) for l in open(os.path.join(src, "slabemu.jsonl"))]
 LAT, LINK = 25e-6, 7 * 45e9
 rows = []
