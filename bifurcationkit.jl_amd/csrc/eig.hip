@@ -15,7 +15,7 @@ namespace bk {
 
 // exposed by solver.hip (same translation unit would be nicer; keep one definition)
 int arnoldi_step_public(bk_ctx* ctx, bk_op* A, double* V, size_t ld, std::vector<double>& tails, int j, double* w,
-                        double* h, double* beta);
+                        double* h, double* beta, std::vector<double>* G = nullptr, int* gram_n = nullptr);
 
 namespace {
 
@@ -96,6 +96,14 @@ static int eig_core(bk_ctx* ctx, bk_op* Aop, bool invert, int nev, const bk_eig_
     if (!(nrm > 0.0)) return set_error(ctx, "eigensolver: the start vector is zero");
     BK_TRY(v_scale(ctx, n, 1.0 / nrm, V));
 
+    // Outer orthogonalisation: the Gram-corrected single pass of the linear solvers (solver.hip: arnoldi_step; option eig_gram,
+    // default on) -- KrylovKit runs Lanczos / Arnoldi with a full re-orthogonalisation against the kept basis here
+    // (src/EigSolver.jl:157-160, `ishermitian` of examples/SH3d.jl:109); the measured Gram matrix G of the basis is rotated
+    // with it at every thick restart (G <- Q'GQ), the newest vector's column is measured by the step that follows.
+    const bool use_gram = ctx->opt("eig_gram", 1.0) != 0.0 && ctx->opt("gmres_gram", 1.0) != 0.0;
+    const int ldg = kMaxBasis + 1;
+    std::vector<double> G(use_gram ? (size_t)ldg * ldg : 0, 0.0);
+    int gram_n = 0;
     dense::Mat H(m + 1, m);
     int k = 0, numiter = 0, nconv = 0, applied = 0;
     std::vector<cplx> mu;
@@ -109,7 +117,7 @@ static int eig_core(bk_ctx* ctx, bk_op* Aop, bool invert, int nev, const bk_eig_
         numiter += 1;
         while (k < meff) {
             double beta = 0.0;
-            BK_TRY(arnoldi_step_public(ctx, &A, V, ld, tails, k, w, h.data(), &beta));
+            BK_TRY(arnoldi_step_public(ctx, &A, V, ld, tails, k, w, h.data(), &beta, use_gram ? &G : nullptr, use_gram ? &gram_n : nullptr));
             applied += 1;
             for (int i = 0; i <= k; ++i) H(i, k) = h[i];
             H(k + 1, k) = beta;
@@ -181,6 +189,28 @@ static int eig_core(bk_ctx* ctx, bk_op* Aop, bool invert, int nev, const bk_eig_
         // V[0..kq) <- V[0..meff) Q  (in place), V[kq] <- V[meff]
         BK_TRY(v_basis_combine(ctx, n, V, ld, meff, Q.a.data(), kq, V, ld));
         BK_TRY(v_copy(ctx, n, V + (size_t)meff * ld, V + (size_t)kq * ld));
+        if (use_gram) {
+            if (gram_n >= meff) {
+                // Gram matrix of the rotated vectors; column kq (the old V[meff]) is measured by the next step
+                std::vector<double> GQ((size_t)meff * kq, 0.0), Gn((size_t)ldg * ldg, 0.0);
+                for (int c = 0; c < kq; ++c)
+                    for (int i = 0; i < meff; ++i) {
+                        double s_ = 0.0;
+                        for (int l = 0; l < meff; ++l) s_ += G[(size_t)i + (size_t)l * ldg] * Q(l, c);
+                        GQ[(size_t)i + (size_t)c * meff] = s_;
+                    }
+                for (int c = 0; c < kq; ++c)
+                    for (int r = 0; r < kq; ++r) {
+                        double s_ = 0.0;
+                        for (int i = 0; i < meff; ++i) s_ += Q(i, r) * GQ[(size_t)i + (size_t)c * meff];
+                        Gn[(size_t)r + (size_t)c * ldg] = s_;
+                    }
+                G.swap(Gn);
+                gram_n = kq;
+            } else {
+                gram_n = -1;                  // a column is missing (a fallback step): two passes for the rest of this solve
+            }
+        }
         dense::Mat Hn(m + 1, m);
         for (int c = 0; c < kq; ++c) {
             for (int r = 0; r < kq; ++r) {

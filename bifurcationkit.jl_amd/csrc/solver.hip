@@ -203,14 +203,18 @@ int arnoldi_step(bk_ctx* ctx, bk_op* A, Basis& B, int j, double* w, double* h, d
 }  // namespace
 
 // Arnoldi step on a caller-owned basis (eig.hip)
+// G / gram_n != NULL: the Gram-corrected single-pass step on the caller's Gram matrix ((kMaxBasis + 1)^2, column-major; the
+// caller rotates it with the basis at a thick restart); a step that cannot take it falls back to the two passes.
 int arnoldi_step_public(bk_ctx* ctx, bk_op* A, double* V, size_t ld, std::vector<double>& tails, int j, double* w,
-                        double* h, double* beta) {
+                        double* h, double* beta, std::vector<double>* G, int* gram_n) {
     Basis B;
     B.V = V;
     B.ld = ld;
     B.nt = A->ntail;
     B.t.swap(tails);
-    const int s = arnoldi_step(ctx, A, B, j, w, h, beta, 0.0, 1.0, 2.0);      // eigensolver: always two passes
+    if (G && gram_n) { B.use_gram = true; B.G.swap(*G); B.gram_n = *gram_n; }
+    const int s = arnoldi_step(ctx, A, B, j, w, h, beta, 0.0, 1.0, 2.0);      // eigensolver fallback: always two passes
+    if (G && gram_n) { B.G.swap(*G); *gram_n = B.gram_n; }
     B.t.swap(tails);
     return s;
 }

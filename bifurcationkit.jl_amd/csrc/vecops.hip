@@ -478,10 +478,12 @@ __global__ void __launch_bounds__(kThreads) multiaxpy_kernel(size_t n, const dou
 // GRAM: the same pass also returns g = V' V_{k-1}, the Gram column of the NEWEST basis vector (V_{k-1} is one of the streams
 // anyway: it is loaded first and every other V_j is dotted with both w and it) -- what the Gram-corrected single-pass
 // Arnoldi step of solver.hip needs, at no extra memory traffic.  Per block: a_0..a_{k-1}, w'w, then g_0..g_{k-1}.
+// vn != NULL (GRAM only): the newest vector lives OUTSIDE the k vectors of this launch (a basis of more than 32 vectors is
+// visited in two launches); every V_j of the launch is then dotted with both w and it, and g has no diagonal entry.
 template <int KB, int U, bool LDNT, bool GRAM = false>
 __global__ void __launch_bounds__(kThreads) multidot_c_kernel(size_t n, const double* __restrict__ V, size_t ldv, int k,
                                                               const double* __restrict__ w, double* __restrict__ partials,
-                                                              const double* gate) {
+                                                              const double* gate, const double* __restrict__ vn = nullptr) {
     if (gate && gate[0] == 0.0) return;
     double acc[KB], accg[GRAM ? KB : 1];
 #pragma unroll
@@ -489,8 +491,9 @@ __global__ void __launch_bounds__(kThreads) multidot_c_kernel(size_t n, const do
 #pragma unroll
     for (int j = 0; j < (GRAM ? KB : 1); ++j) accg[j] = 0.0;
     double ww = 0.0;
-    const int kl = GRAM ? k - 1 : k;                 // vectors visited by the loop (GRAM: all but the newest)
-    const double* __restrict__ Vn = V + (size_t)(k - 1) * ldv;
+    const bool ext = GRAM && vn != nullptr;
+    const int kl = (GRAM && !ext) ? k - 1 : k;       // vectors visited by the loop (GRAM: all but the newest, if it is one of them)
+    const double* __restrict__ Vn = ext ? vn : V + (size_t)(k - 1) * ldv;
     stream_loop<U>(n >> 1, [&](auto uc, size_t i0, size_t st) {
         constexpr int UU = decltype(uc)::value;
         double2 wv[UU], gv[GRAM ? UU : 1];
@@ -513,7 +516,7 @@ __global__ void __launch_bounds__(kThreads) multidot_c_kernel(size_t n, const do
                     acc[j] = fma(vv[u].x, wv[u].x, acc[j]); acc[j] = fma(vv[u].y, wv[u].y, acc[j]);
                     if (GRAM) { accg[j] = fma(vv[u].x, gv[u].x, accg[j]); accg[j] = fma(vv[u].y, gv[u].y, accg[j]); }
                 }
-            } else if (GRAM && j == kl) {
+            } else if (GRAM && !ext && j == kl) {
 #pragma unroll
                 for (int u = 0; u < UU; ++u) {
                     acc[j] = fma(gv[u].x, wv[u].x, acc[j]); acc[j] = fma(gv[u].y, wv[u].y, acc[j]);
@@ -892,13 +895,14 @@ static void launch_multidot_burst(bk_ctx* ctx, int grid, size_t n, const double*
 #undef BK_MDC
 }
 // h = V'w, w'w and the Gram column g = V'V_{k-1} in one pass (any vector size; non-temporal loads for HBM-sized ones)
-static void launch_multidot_gram(bk_ctx* ctx, int grid, size_t n, const double* V, size_t ldv, int k, const double* w, const double* gate) {
+static void launch_multidot_gram(bk_ctx* ctx, int grid, size_t n, const double* V, size_t ldv, int k, const double* w, const double* gate,
+                                 const double* vn = nullptr) {
     const bool nt = nt_hint(ctx, n);
     // bursts of 8 adjacent chunks from 6 vectors on, as the plain multidot (4 for the two largest buckets: registers)
 #define BK_MDG(KB, UU)                                                                                                                              \
     do {                                                                                                                                           \
-        if (nt) hipLaunchKernelGGL((multidot_c_kernel<KB, UU, true, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, w, ctx->d_partials, gate); \
-        else hipLaunchKernelGGL((multidot_c_kernel<KB, 4, false, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, w, ctx->d_partials, gate);    \
+        if (nt) hipLaunchKernelGGL((multidot_c_kernel<KB, UU, true, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, w, ctx->d_partials, gate, vn); \
+        else hipLaunchKernelGGL((multidot_c_kernel<KB, 4, false, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, w, ctx->d_partials, gate, vn);    \
     } while (0)
     if (k <= 4) BK_MDG(4, 4);
     else if (k < 6) BK_MDG(8, 4);
@@ -955,18 +959,39 @@ int v_multidot(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const 
 
 // out[0..k) = V'w, out[k] = w'w, gram[0..k) = V'V_{k-1} (1 <= k <= 32, 16-byte aligned operands, even ldv)
 bool v_multidot_gram_ok(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const double* w) {
-    return k >= 1 && k <= kBurstMax && n >= 2 && aligned16(V) && aligned16(w) && (ldv % 2 == 0) && ctx->opt("gmres_gram", 1.0) != 0.0;
+    return k >= 1 && k <= 2 * kBurstMax && n >= 2 && aligned16(V) && aligned16(w) && (ldv % 2 == 0) && ctx->opt("gmres_gram", 1.0) != 0.0;
 }
 int v_multidot_gram(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const double* w, double* out, double* gram) {
     const int grid = nt_hint(ctx, n) ? burst_grid(ctx, n, "dot_blocks") : grid_for(n, 2 * 4, 512);
+    if (k <= kBurstMax) {
+        {
+            ProfScope ps(ctx, "multidot", 8.0 * n * (k + 1));
+            launch_multidot_gram(ctx, grid, n, V, ldv, k, w, nullptr);
+            BK_HIP(ctx, hipGetLastError());
+        }
+        BK_TRY(reduce_finish(ctx, grid, 2 * k + 1, 0));
+        for (int j = 0; j <= k; ++j) out[j] = ctx->h_red[j];
+        for (int j = 0; j < k; ++j) gram[j] = ctx->h_red[k + 1 + j];
+        return 0;
+    }
+    // more than 32 vectors (the eigensolver's basis): two launches -- V[0..32) against w and the newest vector V[k-1] from
+    // outside, then V[32..k) which contains it.  (w and V[k-1] are read twice: 2 of k + 3 streams.)
+    const int k0 = kBurstMax, k1 = k - kBurstMax;
     {
-        ProfScope ps(ctx, "multidot", 8.0 * n * (k + 1));
-        launch_multidot_gram(ctx, grid, n, V, ldv, k, w, nullptr);
+        ProfScope ps(ctx, "multidot", 8.0 * n * (k0 + 2));
+        launch_multidot_gram(ctx, grid, n, V, ldv, k0, w, nullptr, V + (size_t)(k - 1) * ldv);
         BK_HIP(ctx, hipGetLastError());
     }
-    BK_TRY(reduce_finish(ctx, grid, 2 * k + 1, 0));
-    for (int j = 0; j <= k; ++j) out[j] = ctx->h_red[j];
-    for (int j = 0; j < k; ++j) gram[j] = ctx->h_red[k + 1 + j];
+    BK_TRY(reduce_finish(ctx, grid, 2 * k0 + 1, 0));
+    for (int j = 0; j < k0; ++j) { out[j] = ctx->h_red[j]; gram[j] = ctx->h_red[k0 + 1 + j]; }
+    {
+        ProfScope ps(ctx, "multidot", 8.0 * n * (k1 + 1));
+        launch_multidot_gram(ctx, grid, n, V + (size_t)k0 * ldv, ldv, k1, w, nullptr);
+        BK_HIP(ctx, hipGetLastError());
+    }
+    BK_TRY(reduce_finish(ctx, grid, 2 * k1 + 1, 0));
+    for (int j = 0; j < k1; ++j) { out[k0 + j] = ctx->h_red[j]; gram[k0 + j] = ctx->h_red[k1 + 1 + j]; }
+    out[k] = ctx->h_red[k1];
     return 0;
 }
 
@@ -1077,7 +1102,7 @@ int v_arnoldi_step_dev(bk_ctx* ctx, size_t n, double* V, size_t ldv, int k, cons
     const bool rccl = ctx->comm == COMM_RCCL && ctx->nranks > 1;
     if (gram) {
         // Gram-corrected single pass: multidot with the Gram column, coefficients, ONE multiaxpy -- no second pass
-        if (!v_multidot_gram_ok(ctx, n, V, ldv, k, w)) return set_error(ctx, "v_arnoldi_step_dev: gram step out of range");
+        if (k > kBurstMax || !v_multidot_gram_ok(ctx, n, V, ldv, k, w)) return set_error(ctx, "v_arnoldi_step_dev: gram step out of range");
         const int gg = nt_hint(ctx, n) ? burst_grid(ctx, n, "dot_blocks") : grid_for(n, 2 * 4, 512);
         {
             ProfScope ps(ctx, "multidot", 8.0 * n * (k + 1));
