@@ -574,7 +574,7 @@ def main():
             except Exception as e:  # the baseline must not take the bench line down
                 cb = {"value": None, "unit": "steps/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
         out["cpu_baseline"] = cb
-        print(json.dumps(out))
+        FINAL_LINE.append(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()
     ctx.close()
@@ -622,7 +622,7 @@ def run_branch_workload(args, ctx, hip, Cn, prob, P, ls, u0, branch_setup, barri
     t_init = init.get("seconds", 0.0)                         # two Newton solves + the eigensolve at the first point
     t_steps = sum(p_["seconds"] for p_ in per)
     if rank == 0:
-        print(json.dumps({
+        FINAL_LINE.append(json.dumps({
             "metric": "palc_continuation_steps_per_s", "value": nst / max(t_steps, 1e-9), "unit": "steps/s", "n_gpus": world,
             "steps": nst, "warmup": 0, "ms_per_step": t_steps / max(nst, 1) * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -635,5 +635,18 @@ def run_branch_workload(args, ctx, hip, Cn, prob, P, ls, u0, branch_setup, barri
             "per_step": per, "param": br.param, "n_unstable": br.n_unstable}))
 
 
+# The ONE JSON line is the last thing this process writes: communicator / context teardown first (RCCL and the runtime
+# print to stdout on their way out -- "Librccl path : ..." came AFTER the line when it was printed before the teardown),
+# then the line, flushed; a rank that has nothing to print exits quietly.
+FINAL_LINE = []
+
 if __name__ == "__main__":
     main()
+    sys.stdout.flush()
+    try:                                       # RCCL's version banner sits in the C stdio buffer when stdout is a pipe or a file
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if FINAL_LINE:
+        print(FINAL_LINE[-1], flush=True)

@@ -31,3 +31,13 @@ def show(path):
 for p in ('gpurun_out/bench_r3.log', 'gpurun_out/r3f_bench_driver_args.json', 'gpurun_out/r3f_bench_256.json', 'gpurun_out/r3f_forcedist.json', 'gpurun_out/r3f_hostcomm8.jsonl'):
     show(p)
 PY
+# config 5 at full size on one GPU: two continuation steps (corrector + 15 eigenvalues + Bordered tangent per step)
+timeout 1500 python bench.py --workload branch --size 512 --steps 2 2> gpurun_out/r3f_branch512.err | tail -1 > gpurun_out/r3f_branch_512_2steps.json
+python - <<'PY'
+import json
+try:
+    d = json.load(open('gpurun_out/r3f_branch_512_2steps.json'))
+    print('branch 512: s/step %.1f' % (d['ms_per_step'] / 1e3), 'init', d['config']['initialisation'], [(p['seconds'], p['eig_solves'], p['eig_inner_iterations'], p['itlinear']) for p in d['per_step']])
+except Exception as e:
+    print('branch 512 failed', e)
+PY
