@@ -75,6 +75,10 @@ struct bk_ctx {
     int hist_solves = 0;
     int gmres_last_steps = 1 << 20;   // Arnoldi steps of the previous GMRES solve (speculation ramp of the device-resident chunks)
     const double* eig_x0 = nullptr;   // one-shot start vector of the next eigensolve (bk_eig_set_start_vector)
+    // second execution lane (context.hip: ctx_lane): an independent context on the same device -- own non-blocking stream,
+    // reduction buffers, workspace pool, profile -- on which the second of two independent linear solves runs concurrently
+    // with the first (solver.hip: linsolve2).  Created on first use, destroyed with the context.
+    bk_ctx* lane2 = nullptr;
 
     double opt(const char* key, double dflt) const {
         auto it = opts.find(key);
@@ -107,6 +111,10 @@ int set_error(bk_ctx* ctx, const char* fmt, ...);
         int s_ = (call);         \
         if (s_ != 0) return s_;  \
     } while (0)
+
+// ---- second lane (context.hip) --------------------------------------------------------------
+bk_ctx* ctx_lane(bk_ctx* ctx);                    // creates it on first use; NULL on failure (error on ctx)
+void ctx_lane_merge(bk_ctx* ctx, bk_ctx* lane);   // after a joint solve: profile entries and solver history into ctx
 
 // ---- workspace pool ---------------------------------------------------------------------
 int ws_get(bk_ctx* ctx, size_t n, double** out);

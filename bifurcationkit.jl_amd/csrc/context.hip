@@ -263,6 +263,51 @@ static int ctx_init_common(bk_ctx* ctx, int device, void* stream) {
     return 0;
 }
 
+bk_ctx* ctx_lane(bk_ctx* ctx) {
+    if (ctx->lane2) {
+        ctx->lane2->opts = ctx->opts;                 // the lane follows the context's options
+        ctx->lane2->prof = ctx->prof;
+        return ctx->lane2;
+    }
+    hipStream_t st = nullptr;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+        set_error(ctx, "second lane: stream creation failed");
+        return nullptr;
+    }
+    bk_ctx* l = new bk_ctx();
+    if (ctx_init_common(l, ctx->device, st) != 0) {
+        set_error(ctx, "second lane: %s", l->err.c_str());
+        (void)hipStreamDestroy(st);
+        delete l;
+        return nullptr;
+    }
+    l->own_stream = true;
+    l->num_cu = ctx->num_cu;
+    l->opts = ctx->opts;
+    l->prof = ctx->prof;
+    ctx->lane2 = l;
+    return l;
+}
+
+void ctx_lane_merge(bk_ctx* ctx, bk_ctx* lane) {
+    prof_resolve(lane);
+    if (ctx->prof)
+        for (auto& kv : lane->prof_entries) {
+            ProfEntry& e = ctx->prof_entries[kv.first];
+            e.ms += kv.second.ms; e.calls += kv.second.calls; e.bytes += kv.second.bytes;
+        }
+    lane->prof_entries.clear();
+    if (!lane->hist.empty()) {
+        // the lane numbered its solves from 1: renumber them behind the context's own
+        for (double v : lane->hist) {
+            if (v < 0.0) { ctx->hist_solves += 1; ctx->hist.push_back(-(double)ctx->hist_solves); }
+            else ctx->hist.push_back(v);
+        }
+        lane->hist.clear();
+        lane->hist_solves = 0;
+    }
+}
+
 }  // namespace bk
 
 using namespace bk;
@@ -392,6 +437,7 @@ int bk_comm_probe(bk_ctx* ctx, int what, size_t count, int reps, double* us_per_
 
 int bk_ctx_destroy(bk_ctx* ctx) {
     if (!ctx) return 0;
+    if (ctx->lane2) { bk_ctx* l = ctx->lane2; ctx->lane2 = nullptr; (void)bk_ctx_destroy(l); }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->pool_all) (void)hipFree(kv.first);

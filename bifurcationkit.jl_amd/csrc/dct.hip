@@ -635,13 +635,32 @@ int dct_slab_emulate_tables(bk_ctx* ctx, DctPlan* p, double az) { return slab_ta
 namespace {
 struct ShDctPrecond : bk_precond {
     DctPlan* plan = nullptr;
-    ~ShDctPrecond() override { dct_plan_destroy(plan); }
+    bool shadow = false;                      // second-lane view: the tables belong to the original, only t1 / t2 are its own
+    ~ShDctPrecond() override {
+        if (!shadow) { dct_plan_destroy(plan); return; }
+        if (plan) { ws_put(ctx, plan->t1); ws_put(ctx, plan->t2); delete plan; }
+    }
     int apply(const double* v, double* out) override {
         if (plan->kind >= 1) return dst_apply(ctx, plan, v, out);
         return plan->dist ? dct_apply_dist(ctx, plan, v, out) : dct_apply(ctx, plan, v, out);
     }
 };
 }  // namespace
+
+bk_precond* precond_lane_shadow(bk_precond* pl, bk_ctx* lane) {
+    ShDctPrecond* P = dynamic_cast<ShDctPrecond*>(pl);
+    if (!P || !P->plan || P->plan->dist || P->plan->slab_ok) return nullptr;
+    DctPlan* q = new DctPlan(*P->plan);        // shares every table pointer; never handed to dct_plan_destroy
+    q->t1 = q->t2 = nullptr;
+    if (ws_get(lane, q->total, &q->t1) != 0 || ws_get(lane, q->total, &q->t2) != 0) {
+        ws_put(lane, q->t1);
+        delete q;
+        return nullptr;
+    }
+    ShDctPrecond* S = new ShDctPrecond();
+    S->ctx = lane; S->n = P->n; S->plan = q; S->shadow = true;
+    return S;
+}
 
 }  // namespace bk
 

@@ -119,6 +119,10 @@ struct PdeJacobian : bk_op {          // J(u, params) of a bk_problem; reference
     int apply(const double* x, const double* xt, double a0, double a1, double* out, double* outt) override;
 };
 
+// A preconditioner object for the second lane that shares the tables of `pl` (read-only) but has its own scratch arrays
+// and runs on `lane`; NULL when `pl` is of a kind that cannot be shared (distributed plans).  Delete it after the solve.
+bk_precond* precond_lane_shadow(bk_precond* pl, bk_ctx* lane);
+
 // GMRES core on an operator (solver.hip)
 struct GmresResult {
     int converged = 0;
@@ -131,5 +135,8 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
 // The public linear solve with optional left preconditioner (reference branch semantics)
 int linsolve(bk_ctx* ctx, bk_op* J, const double* rhs, double* x, double a0, double a1, const bk_gmres_opts& o,
              bk_precond* pl, GmresResult* res);
+// two independent solves with the same operator, concurrently on two lanes where supported (solver.hip)
+int linsolve2(bk_ctx* ctx, bk_op* J, const double* rhs1, double* x1, const double* rhs2, double* x2, double a0, double a1,
+              const bk_gmres_opts& o, bk_precond* pl, GmresResult* r1, GmresResult* r2);
 
 }  // namespace bk

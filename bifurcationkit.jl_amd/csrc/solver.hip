@@ -14,6 +14,7 @@
 // (re-orthogonalise with a second A/B pair only when beta < eta ||w||).  The Hessenberg matrix, Givens
 // rotations, the (a0, a1) shift and the restart logic stay on the host, as in the packages.
 #include <cmath>
+#include <thread>
 #include <vector>
 
 #include "dense.h"
@@ -665,6 +666,59 @@ int linsolve(bk_ctx* ctx, bk_op* J, const double* rhs, double* x, double a0, dou
     return gmres_core(ctx, &W, b, nullptr, x, nullptr, 0.0, 1.0, o, res);
 }
 
+// Two independent solves with the same operator and preconditioner -- the R and dF/dp solves of BorderingBLS, ls(J, rhs1,
+// rhs2) (src/LinearSolver.jl:15-19) -- on TWO LANES: the second runs on the context's second lane (own stream, reduction
+// buffers, workspace, scratch of the preconditioner; a host thread drives it) while the first runs where it always did.
+// Each solve's arithmetic is untouched, so results and counters are bitwise those of the sequential calls; what changes is
+// that the device always has the other solve's kernels to run while one solve waits for its host (a synchronisation per
+// Arnoldi chunk), fills the tail of a short kernel, or -- later, with a second communicator -- sits in a collective.
+// Used for vectors that do not saturate HBM by themselves (option two_lanes; default: single rank, n <= 2^24): there a
+// launch-bound 2-D corrector nearly doubles its rate; at 512^3 both solves are bandwidth-bound and nothing would be gained.
+// Supported operators: the PDE Jacobian with no or a single-GPU spectral preconditioner; everything else runs sequentially.
+int linsolve2(bk_ctx* ctx, bk_op* J, const double* rhs1, double* x1, const double* rhs2, double* x2, double a0, double a1,
+              const bk_gmres_opts& o, bk_precond* pl, GmresResult* r1, GmresResult* r2) {
+    PdeJacobian* PJ = dynamic_cast<PdeJacobian*>(J);
+    const bool want = ctx->opt("two_lanes", (ctx->nranks == 1 && J->n <= ((size_t)1 << 24)) ? 1.0 : 0.0) != 0.0;
+    bk_ctx* lane = (want && PJ && ctx->nranks == 1 && J->ntail == 0) ? ctx_lane(ctx) : nullptr;
+    bk_precond* pl2 = nullptr;
+    if (lane && pl) {
+        pl2 = precond_lane_shadow(pl, lane);
+        if (!pl2) lane = nullptr;
+    }
+    if (!lane) {
+        BK_TRY(linsolve(ctx, J, rhs1, x1, a0, a1, o, pl, r1));
+        return linsolve(ctx, J, rhs2, x2, a0, a1, o, pl, r2);
+    }
+    bk_problem prob2 = *PJ->prob;              // the problem on the lane (single rank: no halo buffers to own)
+    prob2.ctx = lane;
+    PdeJacobian J2 = *PJ;
+    J2.ctx = lane;
+    J2.prob = &prob2;
+    // the lane's stream starts after everything already enqueued on the context's stream (its inputs), and the context's
+    // stream continues after the lane has finished (the thread synchronises the lane's stream before it returns)
+    hipEvent_t ev = nullptr;
+    int s2 = 0;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, ctx->stream) != hipSuccess ||
+        hipStreamWaitEvent(lane->stream, ev, 0) != hipSuccess) {
+        if (ev) (void)hipEventDestroy(ev);
+        delete pl2;
+        return set_error(ctx, "linsolve2: lane hand-over failed");
+    }
+    std::thread th([&]() {
+        (void)hipSetDevice(lane->device);
+        s2 = linsolve(lane, &J2, rhs2, x2, a0, a1, o, pl2, r2);
+        if (hipStreamSynchronize(lane->stream) != hipSuccess && s2 == 0) s2 = set_error(lane, "linsolve2: lane synchronisation failed");
+    });
+    const int s1 = linsolve(ctx, J, rhs1, x1, a0, a1, o, pl, r1);
+    th.join();
+    (void)hipEventDestroy(ev);
+    delete pl2;
+    ctx_lane_merge(ctx, lane);
+    if (s1 != 0) return s1;
+    if (s2 != 0) return set_error(ctx, "second lane: %s", lane->err.c_str());
+    return 0;
+}
+
 }  // namespace bk
 
 using namespace bk;
@@ -703,8 +757,7 @@ int bk_gmres2(bk_ctx* ctx, bk_op* J, const double* rhs1, const double* rhs2, dou
     if (!ctx || !J || !rhs1 || !rhs2 || !x1 || !x2 || !opts) return -1;
     if (x1 == x2) return set_error(ctx, "bk_gmres2: x1 and x2 must be distinct buffers");
     GmresResult r1, r2;
-    BK_TRY(linsolve(ctx, J, rhs1, x1, a0, a1, *opts, pl, &r1));
-    BK_TRY(linsolve(ctx, J, rhs2, x2, a0, a1, *opts, pl, &r2));
+    BK_TRY(linsolve2(ctx, J, rhs1, x1, rhs2, x2, a0, a1, *opts, pl, &r1, &r2));
     if (converged) *converged = r1.converged & r2.converged;
     if (niter) { niter[0] = r1.niter; niter[1] = r2.niter; }
     return 0;
@@ -729,11 +782,12 @@ static int bec(bk_ctx* ctx, bk_op* J, const double* dR, const double* dzu, doubl
     const size_t n = J->n;
     GmresResult r1;
     const double a0 = has_shift ? shift : 0.0;
-    BK_TRY(linsolve(ctx, J, R, x1, a0, 1.0, ls, pl, &r1));
     if (!st.have_dx) {
-        GmresResult r2;
-        BK_TRY(linsolve(ctx, J, dR, st.dx, a0, 1.0, ls, pl, &r2));
+        GmresResult r2;                        // the two solves of the first BEC pass are independent: two lanes
+        BK_TRY(linsolve2(ctx, J, R, x1, dR, st.dx, a0, 1.0, ls, pl, &r1, &r2));
         st.have_dx = true; st.it_dx = r2.niter; st.cv_dx = r2.converged;
+    } else {
+        BK_TRY(linsolve(ctx, J, R, x1, a0, 1.0, ls, pl, &r1));
     }
     double d[2];
     BK_TRY(v_dot2(ctx, n, dzu, x1, st.dx, d));
