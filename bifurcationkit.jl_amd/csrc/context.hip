@@ -285,6 +285,26 @@ bk_ctx* ctx_lane(bk_ctx* ctx) {
     l->num_cu = ctx->num_cu;
     l->opts = ctx->opts;
     l->prof = ctx->prof;
+    // ranks: the lane gets its OWN communicator -- its collectives are issued by another host thread and must not be
+    // matched against the context's.  RCCL: ncclCommSplit of the context's communicator (collective: every rank creates
+    // its lane at the same call); host-staged test communicator: the same callbacks with user = lane number, which selects
+    // the lane's gloo group on the Python side (hostcomm.py).
+    l->rank = ctx->rank;
+    l->nranks = ctx->nranks;
+    l->comm = ctx->comm;
+    if (ctx->comm == COMM_RCCL && ctx->nranks > 1) {
+        ncclResult_t r = ncclCommSplit(ctx->nccl, 0, ctx->rank, &l->nccl, nullptr);
+        if (r != ncclSuccess) {
+            set_error(ctx, "second lane: ncclCommSplit failed: %s", ncclGetErrorString(r));
+            l->nccl = nullptr;
+            (void)bk_ctx_destroy(l);
+            return nullptr;
+        }
+    } else if (ctx->comm == COMM_HOST) {
+        l->h_allreduce = ctx->h_allreduce;
+        l->h_sendrecv = ctx->h_sendrecv;
+        l->h_user = reinterpret_cast<void*>(static_cast<uintptr_t>(1));
+    }
     ctx->lane2 = l;
     return l;
 }

@@ -635,10 +635,11 @@ int dct_slab_emulate_tables(bk_ctx* ctx, DctPlan* p, double az) { return slab_ta
 namespace {
 struct ShDctPrecond : bk_precond {
     DctPlan* plan = nullptr;
-    bool shadow = false;                      // second-lane view: the tables belong to the original, only t1 / t2 are its own
+    bool shadow = false;                      // second-lane view: the tables belong to the original, only the scratch
+                                              // arrays (t1, t2; fsend, frecv of the slab z-solve) are its own
     ~ShDctPrecond() override {
         if (!shadow) { dct_plan_destroy(plan); return; }
-        if (plan) { ws_put(ctx, plan->t1); ws_put(ctx, plan->t2); delete plan; }
+        if (plan) { ws_put(ctx, plan->t1); ws_put(ctx, plan->t2); ws_put(ctx, plan->fsend); ws_put(ctx, plan->frecv); delete plan; }
     }
     int apply(const double* v, double* out) override {
         if (plan->kind >= 1) return dst_apply(ctx, plan, v, out);
@@ -649,11 +650,16 @@ struct ShDctPrecond : bk_precond {
 
 bk_precond* precond_lane_shadow(bk_precond* pl, bk_ctx* lane) {
     ShDctPrecond* P = dynamic_cast<ShDctPrecond*>(pl);
-    if (!P || !P->plan || P->plan->dist || P->plan->slab_ok) return nullptr;
+    if (!P || !P->plan) return nullptr;
     DctPlan* q = new DctPlan(*P->plan);        // shares every table pointer; never handed to dct_plan_destroy
-    q->t1 = q->t2 = nullptr;
-    if (ws_get(lane, q->total, &q->t1) != 0 || ws_get(lane, q->total, &q->t2) != 0) {
-        ws_put(lane, q->t1);
+    q->t1 = q->t2 = q->fsend = q->frecv = nullptr;
+    bool ok = ws_get(lane, q->total, &q->t1) == 0 && ws_get(lane, q->total, &q->t2) == 0;
+    if (ok && P->plan->fsend) {                // slab z-solve: the face buffers are scratch too (4 doubles per line each)
+        const size_t fb = 4 * (size_t)q->n[0] * (size_t)q->n[1];
+        ok = ws_get(lane, fb, &q->fsend) == 0 && ws_get(lane, fb, &q->frecv) == 0;
+    }
+    if (!ok) {
+        ws_put(lane, q->t1); ws_put(lane, q->t2); ws_put(lane, q->fsend); ws_put(lane, q->frecv);
         delete q;
         return nullptr;
     }

@@ -678,8 +678,10 @@ int linsolve(bk_ctx* ctx, bk_op* J, const double* rhs, double* x, double a0, dou
 int linsolve2(bk_ctx* ctx, bk_op* J, const double* rhs1, double* x1, const double* rhs2, double* x2, double a0, double a1,
               const bk_gmres_opts& o, bk_precond* pl, GmresResult* r1, GmresResult* r2) {
     PdeJacobian* PJ = dynamic_cast<PdeJacobian*>(J);
+    // ranks: opt-in (two_lanes = 1) -- the lane needs its own communicator, and on RCCL that path has not seen hardware yet;
+    // the decision only looks at options, the communicator and the GLOBAL problem, so every rank takes the same one
     const bool want = ctx->opt("two_lanes", (ctx->nranks == 1 && J->n <= ((size_t)1 << 24)) ? 1.0 : 0.0) != 0.0;
-    bk_ctx* lane = (want && PJ && ctx->nranks == 1 && J->ntail == 0) ? ctx_lane(ctx) : nullptr;
+    bk_ctx* lane = (want && PJ && J->ntail == 0) ? ctx_lane(ctx) : nullptr;
     bk_precond* pl2 = nullptr;
     if (lane && pl) {
         pl2 = precond_lane_shadow(pl, lane);
@@ -689,8 +691,16 @@ int linsolve2(bk_ctx* ctx, bk_op* J, const double* rhs1, double* x1, const doubl
         BK_TRY(linsolve(ctx, J, rhs1, x1, a0, a1, o, pl, r1));
         return linsolve(ctx, J, rhs2, x2, a0, a1, o, pl, r2);
     }
-    bk_problem prob2 = *PJ->prob;              // the problem on the lane (single rank: no halo buffers to own)
+    bk_problem prob2 = *PJ->prob;              // the problem on the lane, with its own halo planes on ranks
     prob2.ctx = lane;
+    prob2.halo_lo = prob2.halo_hi = nullptr;
+    WsGuard lws(lane);
+    if (PJ->prob->halo_lo) {
+        if (lws.get(2 * prob2.plane, &prob2.halo_lo) != 0 || lws.get(2 * prob2.plane, &prob2.halo_hi) != 0) {
+            delete pl2;
+            return set_error(ctx, "linsolve2: halo buffers of the second lane: %s", lane->err.c_str());
+        }
+    }
     PdeJacobian J2 = *PJ;
     J2.ctx = lane;
     J2.prob = &prob2;

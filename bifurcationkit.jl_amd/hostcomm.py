@@ -10,11 +10,21 @@ import torch
 import torch.distributed as dist
 
 
+# Lane of the calling context (bk_ctx::h_user: NULL for the context itself, 1 for its second lane, which a library thread
+# drives concurrently): each lane has its own gloo group, so that the two threads' collectives cannot be matched crosswise.
+_groups = {}
+
+
+def _group(user):
+    lane = int(user) if user else 0
+    return _groups.get(lane)                     # None = the default group
+
+
 def allreduce(user, buf, n, op):
     try:
         arr = np.ctypeslib.as_array(buf, shape=(n,))
         t = torch.from_numpy(arr.copy())
-        dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX, group=_group(user))
         arr[:] = t.numpy()
         return 0
     except Exception as e:  # pragma: no cover - surfaced as a library error
@@ -28,10 +38,10 @@ def sendrecv(user, sbuf, ns, dst, rbuf, nr, src):
         rt = None
         if ns and dst >= 0:
             st = torch.from_numpy(np.ctypeslib.as_array(sbuf, shape=(ns,)).copy())
-            reqs.append(dist.isend(st, dst))
+            reqs.append(dist.isend(st, dst, group=_group(user)))
         if nr and src >= 0:
             rt = torch.empty(nr, dtype=torch.float64)
-            reqs.append(dist.irecv(rt, src))
+            reqs.append(dist.irecv(rt, src, group=_group(user)))
         for r in reqs:
             r.wait()
         if rt is not None:
@@ -43,7 +53,10 @@ def sendrecv(user, sbuf, ns, dst, rbuf, nr, src):
 
 
 def comm_tuple():
-    """Argument for ``hip.Context(device, comm=...)`` once ``torch.distributed`` (gloo) is initialised."""
+    """Argument for ``hip.Context(device, comm=...)`` once ``torch.distributed`` (gloo) is initialised.  Collective: also
+    creates the gloo group of the second lane."""
+    if 1 not in _groups and dist.get_world_size() > 1:
+        _groups[1] = dist.new_group(backend="gloo")
     return ("host", dist.get_rank(), dist.get_world_size(), allreduce, sendrecv)
 
 

@@ -35,7 +35,18 @@ for R, nz in ((2, 256), (4, 128), (8, 64)):
     t_red = n_red * LAT
     t_T = t_local + t_a2a_T + t_red
     t_S = t_local + applies * (e1 - e0) + t_a2a_S + t_red
-    rows.append(dict(gpus=R, slab_planes=nz, local_ms=t_local * 1e3, precond_applies=applies,
+    # two lanes: the two right-hand sides of the bordered solve in flight at once, each lane with its own
+    # communicator -- measured local step with two lanes; ASSUMED: half of the collective time of one solve hides behind the
+    # other solve's kernels (the second z round trip is real work and stays)
+    two = None
+    f2 = os.path.join(src, f"bench_slab{nz}_two_lanes.json")
+    if os.path.exists(f2):
+        b2 = json.load(open(f2))
+        t_loc2 = b2["ms_per_step"] * 1e-3
+        t_2 = t_loc2 + applies * (e1 - e0) + 0.5 * (t_a2a_S + t_red)
+        two = dict(local_ms=t_loc2 * 1e3, hidden_fraction_of_collectives=0.5, step_ms=t_2 * 1e3,
+                   speedup=one["ms_per_step"] * 1e-3 / t_2)
+    rows.append(dict(gpus=R, slab_planes=nz, local_ms=t_local * 1e3, precond_applies=applies, two_lanes=two,
                      precond_local_ms=dict(transposed=e0 * 1e3, slab_zsolve=e1 * 1e3), allreduce_ms=t_red * 1e3,
                      transposed=dict(alltoall_ms=t_a2a_T * 1e3, step_ms=t_T * 1e3, speedup=one["ms_per_step"] * 1e-3 / t_T),
                      slab_zsolve=dict(alltoall_ms=t_a2a_S * 1e3, step_ms=t_S * 1e3, speedup=one["ms_per_step"] * 1e-3 / t_S),

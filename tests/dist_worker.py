@@ -310,6 +310,10 @@ def main_gpu_many(rank, world):
     from bk_amd import hip
     ctx = hip.Context(0, hostcomm.comm_tuple())
     slab_checks(ctx, hip, rank, world, f"hostcomm x{world}")
+    # the two right-hand sides of the bordered solve on two lanes: the second lane has its own communicator (here: its own
+    # gloo group, driven from the library's thread), halo planes and preconditioner scratch
+    ctx.set_option("two_lanes", 1)
+    slab_checks(ctx, hip, rank, world, f"hostcomm x{world} two lanes")
     ctx.close()
     print(f"rank {rank}: gpu distributed checks OK", flush=True)
 
@@ -329,7 +333,7 @@ def main_rccl(rank, world):
     slab_checks(ctx, hip, rank, world, f"rccl x{world}")
     # and the host-driven variants of the same paths (one all-reduce + host synchronisation per Arnoldi step, halo
     # exchange in line, transposed preconditioner)
-    for key, val in (("gmres_chunk", 1), ("halo_overlap", 0), ("dct_dist_slab", 0), ("gmres_gram", 0)):
+    for key, val in (("two_lanes", 1), ("gmres_chunk", 1), ("halo_overlap", 0), ("dct_dist_slab", 0), ("gmres_gram", 0)):
         ctx.set_option(key, val)
         slab_checks(ctx, hip, rank, world, f"rccl x{world} {key}={val}")
     ctx.close()
