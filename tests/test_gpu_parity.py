@@ -428,6 +428,41 @@ def test_single_pass_gram_schmidt_policy_bounds_the_measured_orthogonality_defec
     assert defects[1e-12] <= 1e-12
 
 
+def test_two_lanes_reproduce_the_sequential_bordered_solve_bitwise(ctx):
+    """linsolve2 (solver.hip): the R and dF/dp solves of BorderingBLS / ls(J, rhs1, rhs2) (src/LinearBorderSolver.jl:125-144,
+    src/LinearSolver.jl:15-19) on two execution lanes -- the second on its own stream, reduction buffers, workspace and
+    preconditioner scratch, driven by a library thread.  Neither solve's arithmetic changes, so the solutions, dl and the
+    counters are BITWISE those of the sequential calls; with and without preconditioner, 3-D and 2-D, and for the complex
+    Ginzburg-Landau problem (dense sine transforms through the lane's own BLAS handle)."""
+    hip = _hip()
+    cases = []
+    sh, prob, rng, u = _sh_setup(ctx, (24, 20, 16), (np.pi, 3.0, 2.5))
+    cases.append((prob, prob.vec(u), 0.1, hip.DCTPreconditioner(prob, 1.0)))
+    cases.append((prob, prob.vec(u), 0.1, None))
+    sh2, prob2, _, u2 = _sh_setup(ctx, (64, 64), (8.0, 6.0))
+    cases.append((prob2, prob2.vec(u2), 0.1, hip.DCTPreconditioner(prob2, 1.0)))
+    cg = hip.CGL2d(ctx, (24, 16), (3.0, 2.0), r=0.5)
+    ucg = cg.vec(0.3 * np.random.default_rng(4).standard_normal(cg.nglobal))
+    cases.append((cg, ucg, 0.5, hip.LaplacePreconditioner(cg, 1.0)))
+    for pr, U, p0, P in cases:
+        n = pr.nglobal
+        g = np.random.default_rng(n)
+        R, dR, dz = (pr.vec(g.standard_normal(n)) for _ in range(3))
+        J = pr.jacobian(U, p0)
+        ls = hip.GMRESKrylovKit(dim=30, rtol=1e-10, atol=1e-13, maxiter=60, Pl=P)
+        out = {}
+        try:
+            for tl in (0, 1):
+                ctx.set_option("two_lanes", tl)
+                dX, dl, ok, it = hip.BorderingBLS(ls, check_precision=False)(J, dR, dz, 0.3, R, 0.7, 0.5, 0.5, dotscale=1.0 / n)
+                out[tl] = (dX.numpy(), dl, ok, it)
+        finally:
+            ctx.set_option("two_lanes", 1)
+        a, b = out[0], out[1]
+        assert a[2] == b[2] and a[3] == b[3], (a[2], b[2], a[3], b[3])      # same flags, same counters (converged or not) ...
+        assert a[1] == b[1] and np.array_equal(a[0], b[0])                  # ... and the same bits
+
+
 def test_gmres_nonconvergence_is_a_flag_not_an_error(ctx):
     hip = _hip()
     sh, prob, rng, u = _sh_setup(ctx, (12, 12, 12), (np.pi,) * 3)
