@@ -42,6 +42,10 @@ struct DctPlan {
                                               // 2: DST-I, 2x2 block symbol of the two cGL fields (blk_a, blk_b)
     double blk_a = 0.0, blk_b = 0.0;
     int batch = 1;                            // stacked fields sharing the transform (cGL: 2)
+    // hand-written fp64-MFMA path of the sine transforms (dense_mfma.hip): per axis the half-size blocks Te, To, their
+    // transposes, and the eigenvalues in the permuted spectral order [even k | odd k]
+    double* mf[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+    double* lamp[2] = {nullptr, nullptr};
     // distributed (z-slab) variant: transposes to y-slabs for the z pass
     bool dist = false;
     int R = 1, rank = 0;
@@ -60,6 +64,12 @@ struct DctPlan {
     double* frecv = nullptr;
     std::vector<size_t> cnt_s, dsp_s;
 };
+
+bool dense_mfma_supported(int n0, int n1, int nb);
+void dense_mfma_tables(int N, const std::vector<double>& T, const std::vector<double>& lam, std::vector<double>& Te,
+                       std::vector<double>& To, std::vector<double>& TeT, std::vector<double>& ToT, std::vector<double>& lamp);
+int dense_mfma_pass(bk_ctx* ctx, int n0, int n1, int nb, int axis, int inverse, const double* const tab[4], const double* in,
+                    double* out, double* work);
 
 struct SlabK;
 int slab_faces_gather(bk_ctx* ctx, const SlabK& P, const double* y, double* sbuf);
@@ -303,6 +313,18 @@ int dst_plan_create(bk_ctx* ctx, const int n[2], const double ainv[2], double c,
         }
         (void)hipMemcpy(p->T[a], T.data(), sizeof(double) * N * N, hipMemcpyHostToDevice);
         (void)hipMemcpy(p->lam[a], lam.data(), sizeof(double) * N, hipMemcpyHostToDevice);
+        if (dense_mfma_supported(n[0], n[1], batch)) {
+            std::vector<double> tb[4], lp;
+            dense_mfma_tables(N, T, lam, tb[0], tb[1], tb[2], tb[3], lp);
+            bool ok = hipMalloc(&p->lamp[a], sizeof(double) * N) == hipSuccess;
+            for (int t = 0; t < 4 && ok; ++t) ok = hipMalloc(&p->mf[a][t], sizeof(double) * tb[t].size()) == hipSuccess;
+            if (!ok) {
+                dct_plan_destroy(p);
+                return set_error(ctx, "dst plan: allocation failed");
+            }
+            (void)hipMemcpy(p->lamp[a], lp.data(), sizeof(double) * N, hipMemcpyHostToDevice);
+            for (int t = 0; t < 4; ++t) (void)hipMemcpy(p->mf[a][t], tb[t].data(), sizeof(double) * tb[t].size(), hipMemcpyHostToDevice);
+        }
     }
     if (hipMalloc(&p->t1, sizeof(double) * p->total) != hipSuccess || hipMalloc(&p->t2, sizeof(double) * p->total) != hipSuccess) {
         dct_plan_destroy(p);
@@ -316,6 +338,29 @@ int dst_plan_create(bk_ctx* ctx, const int n[2], const double ainv[2], double c,
 static int dst_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out) {
     const int n0 = p->n[0], n1 = p->n[1], nb = p->batch;
     const unsigned grid = (unsigned)((p->total + 255) / 256);
+    if (p->mf[0][0] && p->mf[1][0] && ctx->opt("dst_mfma", 1.0) != 0.0) {
+        // the hand-written path (dense_mfma.hip): fold + half-size fp64-MFMA products; the spectrum lives in the permuted
+        // order [even k | odd k] along both axes between the forward and the inverse passes, the symbol kernels read the
+        // permuted eigenvalue tables.  `out` (which may alias v) is free as soon as the first pass has read v.
+        auto mpass = [&](int a, int inverse, const double* in, double* o) -> int {
+            ProfScope ps(ctx, "dct_pass", 16.0 * p->total);
+            const double* tab[4] = {p->mf[a][0], p->mf[a][1], p->mf[a][2], p->mf[a][3]};
+            return dense_mfma_pass(ctx, n0, n1, nb, a, inverse, tab, in, o, p->t1);
+        };
+        BK_TRY(mpass(0, 0, v, p->t2));
+        BK_TRY(mpass(1, 0, p->t2, out));
+        if (p->kind == 2) {
+            const unsigned g2 = (unsigned)(((size_t)n0 * n1 + 255) / 256);
+            hipLaunchKernelGGL(spectral_block_cgl_kernel, dim3(g2), dim3(256), 0, ctx->stream, n0, n1, p->lamp[0], p->lamp[1],
+                               p->blk_a, p->blk_b, out);
+        } else {
+            hipLaunchKernelGGL(spectral_scale_lap_kernel, dim3(grid), dim3(256), 0, ctx->stream, n0, n1, nb, p->lamp[0], p->lamp[1],
+                               p->shift, out);
+        }
+        BK_HIP(ctx, hipGetLastError());
+        BK_TRY(mpass(1, 1, out, p->t2));
+        return mpass(0, 1, p->t2, out);
+    }
     auto pass = [&](int a, const double* in, double* o) -> int {
         ProfScope ps(ctx, "dct_pass", 16.0 * p->total);
         return dense_axis_pass(ctx, n0, n1, nb, a, p->T[a], in, o);
@@ -347,6 +392,11 @@ void dct_plan_destroy(DctPlan* p) {
     }
     if (p->t1) (void)hipFree(p->t1);
     if (p->t2) (void)hipFree(p->t2);
+    for (int a = 0; a < 2; ++a) {
+        if (p->lamp[a]) (void)hipFree(p->lamp[a]);
+        for (int t = 0; t < 4; ++t)
+            if (p->mf[a][t]) (void)hipFree(p->mf[a][t]);
+    }
     double* extra[] = {p->twid_loc, p->lam_loc, p->phi_loc, p->fsend, p->frecv};
     for (double* e : extra)
         if (e) (void)hipFree(e);

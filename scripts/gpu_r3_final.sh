@@ -31,8 +31,12 @@ def show(path):
 for p in ('gpurun_out/bench_r3.log', 'gpurun_out/r3f_bench_driver_args.json', 'gpurun_out/r3f_bench_256.json', 'gpurun_out/r3f_forcedist.json', 'gpurun_out/r3f_hostcomm8.jsonl'):
     show(p)
 PY
+# config 3 eigensolve under rocprofv3: the kernel list must not contain a rocBLAS kernel any more
+(cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_c3" -- python "$OLDPWD/scripts/c3_fullsize.py" 1024 eig block > "$OLDPWD/gpurun_out/r3f_c3_prof.log" 2>&1)
+python scripts/prof_summary.py gpurun_out/prof_c3 5 2>/dev/null | head -14 | cut -c1-200 > gpurun_out/r3f_c3_eigensolve_kernel_stats.txt
+cat gpurun_out/r3f_c3_eigensolve_kernel_stats.txt | cut -c1-160
 # config 5 at full size on one GPU: two continuation steps (corrector + 15 eigenvalues + Bordered tangent per step)
-timeout 1500 python bench.py --workload branch --size 512 --steps 2 2> gpurun_out/r3f_branch512.err | tail -1 > gpurun_out/r3f_branch_512_2steps.json
+[ "${SKIP_BRANCH512:-0}" = 1 ] || timeout 1500 python bench.py --workload branch --size 512 --steps 2 2> gpurun_out/r3f_branch512.err | tail -1 > gpurun_out/r3f_branch_512_2steps.json
 python - <<'PY'
 import json
 try:
