@@ -405,7 +405,8 @@ void dct_plan_destroy(DctPlan* p) {
 
 static int dct_apply_slab(bk_ctx* ctx, DctPlan* p, const double* v, double* out);
 
-int dct_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out) {
+int dct_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out, int* dot_blocks) {
+    if (dot_blocks) *dot_blocks = 0;
     if (p->slab_ok) return dct_apply_slab(ctx, p, v, out);      // cost-model emulation (option dct_slab_emulate), timing only
     const int n0 = p->n[0], n1 = p->n[1], n2 = p->n[2];
     const unsigned grid = (unsigned)((p->total + 255) / 256);
@@ -418,7 +419,7 @@ int dct_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out) {
         ProfScope ps(ctx, "dct_pass", 16.0 * p->total);          // one read + one write of the array per axis pass
         if (use_fft && p->twid[a]) {
             return dct_axis_fft(ctx, n0, n1, n2, a, inverse, p->twid[a], in, o, p->lam[0], p->lam[1],
-                                p->ndim == 3 ? p->lam[2] : nullptr, p->shift, fuse);
+                                p->ndim == 3 ? p->lam[2] : nullptr, p->shift, fuse, nullptr, fuse == 2 ? dot_blocks : nullptr);
         }
         // forward: out[k] = sum_n T[k][n] in[n]  -> M[q=n][o=k] = TT ; inverse: out[n] = sum_k T[k][n] in[k] -> M = T
         return dense_axis_pass(ctx, n0, n1, n2, a, inverse ? p->T[a] : p->TT[a], in, o);
@@ -694,6 +695,15 @@ struct ShDctPrecond : bk_precond {
     int apply(const double* v, double* out) override {
         if (plan->kind >= 1) return dst_apply(ctx, plan, v, out);
         return plan->dist ? dct_apply_dist(ctx, plan, v, out) : dct_apply(ctx, plan, v, out);
+    }
+    int apply_dot(const double* v, double* out, double* dot) override {
+        if (plan->kind >= 1 || plan->dist || plan->ndim < 2 || ctx->nranks != 1) return bk_precond::apply_dot(v, out, dot);
+        int nb = 0;
+        BK_TRY(dct_apply(ctx, plan, v, out, &nb));
+        if (nb == 0) return v_dot(ctx, n, v, out, dot);       // the merged middle did not run as the fused kernel
+        BK_TRY(reduce_finish(ctx, nb, 1, 0));
+        *dot = ctx->h_red[0];
+        return 0;
     }
 };
 }  // namespace

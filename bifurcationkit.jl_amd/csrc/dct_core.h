@@ -428,8 +428,10 @@ BK_HD void fused_last2(const c2* zp, int N, int bits, int gp, Store2&& st2) {
 
 // One (k, N-k) pair of the merged middle, in place: x = element k, y = element N-k, 0 < k < N, k != N/2.
 // e_{N-k} = -i conj(e_k) = (-e_k.y, -e_k.x).
-template <int MODE, bool UPPER, class Sym>      // UPPER: k > N/2 -- the table holds k <= N/2 only
-BK_HD void mid_pair(c2& x, c2& y, int k, int N, const c2* ew, double hs2, double f2, Sym&& sym) {
+// DOT (MODE 2): the caller also wants sum_k sym(k) |X_k|^2 per line -- with orthonormal transforms that is x . (M^-1 x).
+// pacc collects the pairs UNSCALED (times hs2^2 at the end), sacc the two self-paired indices (already scaled).
+template <int MODE, bool UPPER, bool DOT, class Sym>      // UPPER: k > N/2 -- the table holds k <= N/2 only
+BK_HD void mid_pair(c2& x, c2& y, int k, int N, const c2* ew, double hs2, double f2, Sym&& sym, c2& pacc) {
     const c2 t = ew[UPPER ? N - k : k];
     c2 e, en;
     if (UPPER) { en = t; e.x = -t.y; e.y = -t.x; }
@@ -441,8 +443,10 @@ BK_HD void mid_pair(c2& x, c2& y, int k, int N, const c2* ew, double hs2, double
         const double c = hs2 * f2;
         X = post_one(x, y, e, 1.0); Y = post_one(y, x, en, 1.0);
         c2 f = sym(k);
+        if (DOT) { pacc.x = fma(X.x * X.x, f.x, pacc.x); pacc.y = fma(X.y * X.y, f.y, pacc.y); }
         X.x *= f.x * c; X.y *= f.y * c;
         f = sym(N - k);
+        if (DOT) { pacc.x = fma(Y.x * Y.x, f.x, pacc.x); pacc.y = fma(Y.y * Y.y, f.y, pacc.y); }
         Y.x *= f.x * c; Y.y *= f.y * c;
         x = pre_one(X, Y, e, 1.0, 1.0); y = pre_one(Y, X, en, 1.0, 1.0);
         return;
@@ -452,12 +456,16 @@ BK_HD void mid_pair(c2& x, c2& y, int k, int N, const c2* ew, double hs2, double
     else { x = X; y = Y; }
 }
 // k = 0 or k = N/2: the partner is the element itself (k = 0: fn = 0, scales s0).
-template <int MODE, class Sym>
-BK_HD void mid_single(c2& x, int k, const c2* ew, double hs, double fk, double fn, Sym&& sym) {
+template <int MODE, bool DOT, class Sym>
+BK_HD void mid_single(c2& x, int k, const c2* ew, double hs, double fk, double fn, Sym&& sym, c2& sacc) {
     const c2 e = ew[k];
     c2 X = x;
     if (MODE != 1) X = post_one(x, x, e, hs);
-    if (MODE == 2) { const c2 f = sym(k); X.x *= f.x; X.y *= f.y; }
+    if (MODE == 2) {
+        const c2 f = sym(k);
+        if (DOT) { sacc.x = fma(X.x * X.x, f.x, sacc.x); sacc.y = fma(X.y * X.y, f.y, sacc.y); }
+        X.x *= f.x; X.y *= f.y;
+    }
     if (MODE != 0) x = pre_one(X, X, e, fk, fn);
     else x = X;
 }
@@ -467,9 +475,10 @@ BK_HD void mid_single(c2& x, int k, const c2* ew, double hs, double fk, double f
 //   MODE 0: LDS -> top DIT stage -> post -> st(k, X_k)
 //   MODE 1: ld(slot, k) (slot 0..7: group a, 8..15: group b) -> pre -> top inverse DIF stage -> LDS
 //   MODE 2: LDS -> top DIT -> post -> X_k *= sym(k) (per line) -> pre -> top inverse DIF -> LDS
-template <int MODE, class Load, class Store, class Sym>
+//   DOT (MODE 2): dacc.x / dacc.y += this item's share of sum_k sym(k) |X_k|^2 of line a / line b
+template <int MODE, bool DOT, class Load, class Store, class Sym>
 BK_HD void fused_mid(c2* zp, int N, int t, const c2* tw, const c2* ew, double s0, double s2, Load&& ld, Store&& st,
-                     Sym&& sym) {
+                     Sym&& sym, c2& dacc) {
     const int G = N >> 3;
     const bool self = t == 0;
     const int ga = t, gb = self ? (G >> 1) : G - t;
@@ -486,18 +495,24 @@ BK_HD void fused_mid(c2* zp, int N, int t, const c2* tw, const c2* ew, double s0
         for (int q = 0; q < 8; ++q) { va[q] = ld(q, ga + q * G); vb[q] = ld(8 + q, gb + q * G); }
     }
     const double rN = 1.0 / N, f2 = rN / s2, f0 = rN / s0, hs2 = 0.5 * s2;
+    c2 pacc, sacc;
+    pacc.x = pacc.y = sacc.x = sacc.y = 0.0;
     if (self) {
-        mid_single<MODE>(va[0], 0, ew, 0.5 * s0, f0, 0.0, sym);
-        mid_single<MODE>(va[4], N >> 1, ew, hs2, f2, f2, sym);
+        mid_single<MODE, DOT>(va[0], 0, ew, 0.5 * s0, f0, 0.0, sym, sacc);
+        mid_single<MODE, DOT>(va[4], N >> 1, ew, hs2, f2, f2, sym, sacc);
 #pragma unroll
-        for (int q = 1; q < 4; ++q) mid_pair<MODE, false>(va[q], va[8 - q], q * G, N, ew, hs2, f2, sym);
+        for (int q = 1; q < 4; ++q) mid_pair<MODE, false, DOT>(va[q], va[8 - q], q * G, N, ew, hs2, f2, sym, pacc);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) mid_pair<MODE, false>(vb[q], vb[7 - q], gb + q * G, N, ew, hs2, f2, sym);
+        for (int q = 0; q < 4; ++q) mid_pair<MODE, false, DOT>(vb[q], vb[7 - q], gb + q * G, N, ew, hs2, f2, sym, pacc);
     } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) mid_pair<MODE, false>(va[q], vb[7 - q], ga + q * G, N, ew, hs2, f2, sym);
+        for (int q = 0; q < 4; ++q) mid_pair<MODE, false, DOT>(va[q], vb[7 - q], ga + q * G, N, ew, hs2, f2, sym, pacc);
 #pragma unroll
-        for (int q = 4; q < 8; ++q) mid_pair<MODE, true>(va[q], vb[7 - q], ga + q * G, N, ew, hs2, f2, sym);
+        for (int q = 4; q < 8; ++q) mid_pair<MODE, true, DOT>(va[q], vb[7 - q], ga + q * G, N, ew, hs2, f2, sym, pacc);
+    }
+    if (MODE == 2 && DOT) {
+        dacc.x += fma(hs2 * hs2, pacc.x, sacc.x);
+        dacc.y += fma(hs2 * hs2, pacc.y, sacc.y);
     }
     if (MODE == 0) {
 #pragma unroll

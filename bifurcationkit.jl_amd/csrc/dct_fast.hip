@@ -39,6 +39,7 @@ struct FftK {
     const double* lam1;
     const double* lam2;       // may be NULL (2-D)
     double shift;
+    double* dotp;             // DOT kernels: per-workgroup partial sums
     int fuse_scale;           // 1: multiply by the inverse symbol while storing the forward result
     int roundtrip;            // 1: forward, inverse symbol, inverse -- all in LDS, one read + one write of the array
     int tiles_x;              // axis >= 1: number of LT-wide tiles along x
@@ -339,8 +340,11 @@ __device__ __forceinline__ void lds_barrier() {
 // (A persistent variant -- two workgroups per CU walking over the tiles with the next tile's samples prefetched across
 // the LDS phases -- was measured 5-12 % slower in every pass, also with only 2 tiles per workgroup: DESIGN.md section 4;
 // it lived in this file up to commit 96342eb.)  NTM: non-temporal tile loads / stores (every element is touched once).
-template <int NT, int MODE, bool AX0, bool NTM>   // MODE 0: forward, 1: inverse, 2: forward - symbol - inverse (AX0: 0 / 1 only)
+// DOT (MODE 2): the per-tile partial sum of sum_k symbol(k) |v^_k|^2 -- by Parseval (orthonormal transforms on every axis)
+// the dot product v . (M^-1 v) of this tile's lines -- goes to P.dotp[workgroup]; costs no memory traffic.
+template <int NT, int MODE, bool AX0, bool NTM, bool DOT = false>   // MODE 0: forward, 1: inverse, 2: forward - symbol - inverse (AX0: 0 / 1 only)
 __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
+    __shared__ double dsum[NT / 64];
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int N = P.N, bits = P.bits, G = N >> 3;
     const int npairs = P.LT >> 1, pbits = P.ltbits - 1;
@@ -520,11 +524,13 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
             }
             stamp(2);
         }
+        c2 dtot;
+        dtot.x = dtot.y = 0.0;
         if (MODE == 1) {
             if (tid < nmid) {
                 const int pr = AX0 ? tid >> hbits : tid & (npairs - 1), t = AX0 ? tid & ((1 << hbits) - 1) : tid >> pbits;
-                dctc::fused_mid<1>(z + (size_t)pr * pstride, N, t, tw, ew, s0, s2,
-                                   [&](int slot, int) { return slot < 8 ? pfa[slot & 7] : pfb[slot & 7]; }, nost, nosym);
+                dctc::fused_mid<1, false>(z + (size_t)pr * pstride, N, t, tw, ew, s0, s2,
+                                          [&](int slot, int) { return slot < 8 ? pfa[slot & 7] : pfb[slot & 7]; }, nost, nosym, dtot);
             }
         } else
         for (int w = tid; w < nmid; w += NT) {
@@ -537,11 +543,11 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
                     const double sa = ca + lk + lo2, sb = cb + lk + lo2;
                     c2 r; r.x = rcp_nr(sa * sa + P.shift, 2); r.y = rcp_nr(sb * sb + P.shift, 2); return r;
                 };
-                dctc::fused_mid<2>(zp, N, t, tw, ew, s0, s2, nold, nost, sym);
+                dctc::fused_mid<2, DOT>(zp, N, t, tw, ew, s0, s2, nold, nost, sym, dtot);
             } else if (MODE == 0) {
-                if (AX0) dctc::fused_mid<0>(zp, N, t, tw, ew, s0, s2, nold, [&](int k, c2 v) { st1(o + (unsigned)k, v); }, nosym);
-                else if (P.split == 1) dctc::fused_mid<0>(zp, N, t, tw, ew, s0, s2, nold, [&](int k, c2 v) { stg(o + P.kmap[k], v); }, nosym);
-                else dctc::fused_mid<0>(zp, N, t, tw, ew, s0, s2, nold, [&](int k, c2 v) { stg(o + (unsigned)k * estride, v); }, nosym);
+                if (AX0) dctc::fused_mid<0, false>(zp, N, t, tw, ew, s0, s2, nold, [&](int k, c2 v) { st1(o + (unsigned)k, v); }, nosym, dtot);
+                else if (P.split == 1) dctc::fused_mid<0, false>(zp, N, t, tw, ew, s0, s2, nold, [&](int k, c2 v) { stg(o + P.kmap[k], v); }, nosym, dtot);
+                else dctc::fused_mid<0, false>(zp, N, t, tw, ew, s0, s2, nold, [&](int k, c2 v) { stg(o + (unsigned)k * estride, v); }, nosym, dtot);
             }
         }
         stamp(3);
@@ -549,7 +555,17 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
             if (P.trace) { __builtin_amdgcn_s_waitcnt(0); stamp(6); }
             return;
         }
+        if (MODE == 2 && DOT) {
+            double d = dtot.x + dtot.y;
+            for (int off = 32; off > 0; off >>= 1) d += __shfl_down(d, off, 64);
+            if ((tid & 63) == 0) dsum[tid >> 6] = d;
+        }
         lds_barrier();
+        if (MODE == 2 && DOT && tid == 0) {
+            double d = dsum[0];
+            for (int w = 1; w < NT / 64; ++w) d += dsum[w];
+            P.dotp[blockIdx.x] = d;
+        }
         stamp(4);
         for (int top = bits - 3; top > 3;) {
             const int R = top - 3 >= 3 ? 3 : top - 3;
@@ -623,8 +639,10 @@ bool dct_axis_fused_ok(bk_ctx* ctx, int n0, int n1, int n2, int axis, const doub
 
 int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, const double* twid, const double* in,
                  double* out, const double* lam0, const double* lam1, const double* lam2, double shift,
-                 int fuse_scale, const DctSplit* split) {
+                 int fuse_scale, const DctSplit* split, int* dot_blocks) {
     FftK P;
+    P.dotp = nullptr;
+    if (dot_blocks) *dot_blocks = 0;
     P.kmap = nullptr; P.split_plane = 0; P.split = 0;
     if (split) {
         if (axis != 1 || fuse_scale != 0 || !dct_axis_fused_ok(ctx, n0, n1, n2, axis, in, out, fuse_scale))
@@ -680,6 +698,8 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
                                reinterpret_cast<const void*>(dct_fused_kernel<256, 0, false, true>),
                                reinterpret_cast<const void*>(dct_fused_kernel<256, 1, false, true>),
                                reinterpret_cast<const void*>(dct_fused_kernel<256, 2, false, true>),
+                               reinterpret_cast<const void*>(dct_fused_kernel<256, 2, false, false, true>),
+                               reinterpret_cast<const void*>(dct_fused_kernel<256, 2, false, true, true>),
                                reinterpret_cast<const void*>(dct_fused_kernel<256, 0, true, true>),
                                reinterpret_cast<const void*>(dct_fused_kernel<256, 1, true, true>)};
         for (const void* f : fused) BK_HIP(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
@@ -711,6 +731,11 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
         if (axis == 0) {
             if (mode == 1) { if (ntm) BK_DCT_LAUNCH(1, true, true); else BK_DCT_LAUNCH(1, true, false); }
             else { if (ntm) BK_DCT_LAUNCH(0, true, true); else BK_DCT_LAUNCH(0, true, false); }
+        } else if (mode == 2 && dot_blocks && grid <= (unsigned)kRedBlocks * (kMaxBasis + 2) && ctx->opt("dct_fused_dot", 1.0) != 0.0) {
+            P.dotp = ctx->d_partials;
+            if (ntm) hipLaunchKernelGGL((dct_fused_kernel<256, 2, false, true, true>), dim3(grid), dim3(256), ldsf, ctx->stream, P);
+            else hipLaunchKernelGGL((dct_fused_kernel<256, 2, false, false, true>), dim3(grid), dim3(256), ldsf, ctx->stream, P);
+            *dot_blocks = (int)grid;
         } else if (mode == 2) { if (ntm) BK_DCT_LAUNCH(2, false, true); else BK_DCT_LAUNCH(2, false, false); }
         else if (mode == 1) { if (ntm) BK_DCT_LAUNCH(1, false, true); else BK_DCT_LAUNCH(1, false, false); }
         else { if (ntm) BK_DCT_LAUNCH(0, false, true); else BK_DCT_LAUNCH(0, false, false); }

@@ -26,8 +26,14 @@ struct ShArgs {             // Swift-Hohenberg 2-D/3-D, Neumann-ghost (mirror) b
     const double* halo_lo;  // 2 planes below local plane 0 (multi-GPU interior boundary) or NULL
     const double* halo_hi;  // 2 planes above local plane nz-1 or NULL
     int part = 0;           // 0: all z-chunks; 1: the chunks that read no halo plane; 2: the two face chunks (halo overlap)
+    // fused Lanczos step (3-D streaming kernel, part 0 only; sh_fused_dot_ok): out += addc * addv (addv may be NULL), and the
+    // per-tile partial sums of v . out go to ctx->d_partials -- *dot_blocks receives their count for reduce_finish
+    int* dot_blocks = nullptr;
+    const double* addv = nullptr;
+    double addc = 0.0;
 };
 int sh_apply(bk_ctx* ctx, const ShArgs& a);
+bool sh_fused_dot_ok(bk_ctx* ctx, const ShArgs& a);
 
 struct CglArgs {            // 2-D cubic-quintic complex Ginzburg-Landau, Dirichlet, SoA [u1; u2]
     int nx, ny;
@@ -61,7 +67,10 @@ int dct_plan_create(bk_ctx* ctx, int ndim, const int n[3], const double ainv[3],
 // distributed (z-slab) variant: n = GLOBAL extents; this rank owns planes [zlo, zhi)
 int dct_plan_create_dist(bk_ctx* ctx, const int n[3], const double ainv[3], double shift, int zlo, int zhi, DctPlan** out);
 void dct_plan_destroy(DctPlan* p);
-int dct_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out);
+// dot_blocks (optional): when the merged middle pass runs as the fused LDS kernel it also leaves the per-tile partial sums
+// of v . out (= sum over the spectrum of symbol * |v^|^2: the transforms are orthonormal) in ctx->d_partials and their count
+// in *dot_blocks; 0 = not available on this path
+int dct_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out, int* dot_blocks = nullptr);
 // axis pass of the LDS FFT kernels (dct_fast.hip).  fuse_scale 0: plain, 1: forward + inverse symbol, 2: forward,
 // symbol, inverse in one pass.  split (distributed plan, y passes only): the output (forward) / input (inverse) side
 // uses the all-to-all block layout: element (x, k, other) at kmap[k] + other * plane + x.
@@ -71,7 +80,7 @@ struct DctSplit {
 };
 int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, const double* twid, const double* in,
                  double* out, const double* symx, const double* symy, const double* symz, double shift, int fuse_scale,
-                 const DctSplit* split = nullptr);
+                 const DctSplit* split = nullptr, int* dot_blocks = nullptr);
 bool dct_axis_fft_supported(int n);
 bool dct_axis_fused_ok(bk_ctx* ctx, int n0, int n1, int n2, int axis, const double* in, const double* out, int fuse_scale);
 
@@ -88,6 +97,10 @@ struct bk_problem {
     double* halo_lo = nullptr;
     double* halo_hi = nullptr;
     int apply(int mode, const double* v, const double* u, const double* params, double a0, double a1, double* out);
+    // out = a0 v + a1 J(u) v + c r (r may be NULL), *dot = v . out, in ONE pass where the stencil kernel supports it
+    // (*fused = 1), else *fused = 0 and nothing was done
+    int jvp_axpy_dot(const double* v, const double* u, const double* params, double a0, double a1, double c, const double* r,
+                     double* out, double* dot, int* fused);
     // dFdp = (F(u, p + eps) - F(u, p)) / eps for the parameter `ipar`; `f0` = F(u, p) when the caller already has it
     // (only read by the literal two-residual form, option "fd_dparam" = 0), `out` must not alias u or f0
     int dparam(const double* u, const double* params, int nparams, int ipar, double eps, const double* f0, double* out);
@@ -100,6 +113,9 @@ struct bk_op {              // a linear operator on (device vector [+ one host t
     virtual ~bk_op() {}
     // out = a0*x + a1*A(x)
     virtual int apply(const double* x, const double* xt, double a0, double a1, double* out, double* outt) = 0;   // xt / outt: ntail host scalars (bordered operators), else NULL
+    // The Lanczos step of the symmetric solvers (unbordered operators): out = a0 x + a1 A x + c r (r may be NULL),
+    // *dot = x . out.  Default: apply, then one fused axpy + dot pass; operators with a fused kernel override it.
+    virtual int apply_axpy_dot(const double* x, double a0, double a1, double c, const double* r, double* out, double* dot);
 };
 
 struct bk_precond {
@@ -107,6 +123,9 @@ struct bk_precond {
     size_t n = 0;
     virtual ~bk_precond() {}
     virtual int apply(const double* v, double* out) = 0;     // out = Pl \ v ; out may alias v
+    // out = Pl \ v and *dot = v . out (out must not alias v).  Default: apply, then a dot pass; the spectral
+    // preconditioner takes the dot from the spectrum (Parseval) inside its merged middle pass.
+    virtual int apply_dot(const double* v, double* out, double* dot);
 };
 
 namespace bk {
@@ -117,6 +136,7 @@ struct PdeJacobian : bk_op {          // J(u, params) of a bk_problem; reference
     double params[BK_MAX_PARAMS];
     bool adjoint = false;             // J' (cGL only; the SH Jacobians are symmetric)
     int apply(const double* x, const double* xt, double a0, double a1, double* out, double* outt) override;
+    int apply_axpy_dot(const double* x, double a0, double a1, double c, const double* r, double* out, double* dot) override;
 };
 
 // A preconditioner object for the second lane that shares the tables of `pl` (read-only) but has its own scratch arrays

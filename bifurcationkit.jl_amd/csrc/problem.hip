@@ -72,6 +72,29 @@ int bk_problem::apply(int mode, const double* v, const double* u, const double* 
     return set_error(ctx, "unknown pde kind %d", d.pde);
 }
 
+int bk_problem::jvp_axpy_dot(const double* v, const double* u, const double* params, double a0, double a1, double c,
+                             const double* r, double* out, double* dot, int* fused) {
+    *fused = 0;
+    const bk_problem_desc& d = desc;
+    if (d.pde != BK_PDE_SH || d.ndim != 3 || ctx->nranks != 1) return 0;
+    ShArgs a;
+    a.nx = d.n[0]; a.ny = d.n[1]; a.nz = hi - lo; a.nzg = d.n[2]; a.zoff = lo;
+    a.ax = ainv[0]; a.ay = ainv[1]; a.az = ainv[2];
+    a.l = params[0]; a.nu = params[1];
+    a.a0 = a0; a.a1 = a1; a.mode = 0;
+    a.v = v; a.u = u; a.out = out;
+    a.halo_lo = nullptr; a.halo_hi = nullptr;
+    a.addv = r; a.addc = r ? c : 0.0;
+    if (!sh_fused_dot_ok(ctx, a)) return 0;
+    int nb = 0;
+    a.dot_blocks = &nb;
+    BK_TRY(sh_apply(ctx, a));
+    BK_TRY(reduce_finish(ctx, nb, 1, 0));
+    *dot = ctx->h_red[0];
+    *fused = 1;
+    return 0;
+}
+
 int bk_problem::dparam(const double* u, const double* params, int nparams, int ipar, double eps, const double* f0,
                        double* out) {
     if (ctx->opt("fd_dparam", 1.0) != 0.0) {
@@ -97,6 +120,24 @@ int bk_problem::dparam(const double* u, const double* params, int nparams, int i
 int PdeJacobian::apply(const double* x, const double*, double a0, double a1, double* out, double*) {
     // the SH Jacobians are symmetric (issymmetric = true, examples/SH3d.jl:123): only cGL has a distinct adjoint
     return prob->apply(adjoint && prob->desc.pde == BK_PDE_CGL2D ? 2 : 0, x, u, params, a0, a1, out);
+}
+
+int PdeJacobian::apply_axpy_dot(const double* x, double a0, double a1, double c, const double* r, double* out, double* dot) {
+    int fused = 0;
+    if (!(adjoint && prob->desc.pde == BK_PDE_CGL2D)) BK_TRY(prob->jvp_axpy_dot(x, u, params, a0, a1, c, r, out, dot, &fused));
+    return fused ? 0 : bk_op::apply_axpy_dot(x, a0, a1, c, r, out, dot);
+}
+
+// defaults of the fused interfaces: the separate passes
+int bk_op::apply_axpy_dot(const double* x, double a0, double a1, double c, const double* r, double* out, double* dot) {
+    if (ntail != 0) return set_error(ctx, "apply_axpy_dot: unbordered operators only");
+    BK_TRY(apply(x, nullptr, a0, a1, out, nullptr));
+    return v_axpy_dot(ctx, n, c, r, out, x, dot);
+}
+
+int bk_precond::apply_dot(const double* v, double* out, double* dot) {
+    BK_TRY(apply(v, out));
+    return v_dot(ctx, n, v, out, dot);
 }
 
 static int nparams_of(int pde) { return pde == BK_PDE_CGL2D ? 6 : 2; }

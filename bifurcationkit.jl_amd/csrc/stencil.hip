@@ -53,6 +53,9 @@ struct ShK {                // kernel-side copy of ShArgs (+ derived constants)
     int vec_ok;
     int vload;              // plane staging with 16-B loads (nx a multiple of the tile width, 16-B aligned planes)
     int nt;                 // non-temporal hint on the u loads and the output stores (touched once)
+    const double* addv;     // FD kernels: out += addc * addv, and the block's share of v . out goes to dotp[tile]
+    double addc;
+    double* dotp;
 };
 
 // pointer to local plane lp in [-2, nz+2): halo buffers hold the two planes beyond each interior slab face
@@ -120,9 +123,16 @@ typedef double sh_nt_d2 __attribute__((ext_vector_type(2)));
 
 // VL: plane staging with 16-byte loads (host-checked shapes), else 8-byte gathers.  162 VGPRs -> 3 waves / SIMD; capping the
 // registers for a 4th wave (__launch_bounds__(256, 4)) spills and halves the rate (measured)
-template <bool DIM3, bool VL>
-__global__ void __launch_bounds__(256) sh_stream_kernel(ShK P) {
-    __shared__ __attribute__((aligned(16))) double lds[2][LH * LWP];
+// FD (3-D only): the Lanczos step of MINRES / CG in the same pass -- out = a0 v + a1 J v + addc * addv and the dot product
+// v . out (per-tile partial sums, reduced by reduce_finish).  The output plane p-2 becomes final while plane p is being
+// processed: the FD kernels stage the planes in a ring of FOUR LDS buffers instead of two, so that the input's own points of
+// plane p-2 are still there while plane p+1 is being staged (a register delay line costs 24 VGPRs and with them the third
+// resident workgroup per CU; a ring of three would need one more barrier per plane).
+// WPE: waves per SIMD the register allocation aims at -- the FD kernel needs 174 VGPRs, 6 above the 3-wave limit.
+template <bool DIM3, bool VL, bool FD = false, int WPE = 1>
+__global__ void __launch_bounds__(256, WPE) sh_stream_kernel(ShK P) {
+    constexpr int NBUF = FD ? 4 : 2;
+    __shared__ __attribute__((aligned(16))) double lds[NBUF][LH * LWP];
 
     // XCD-aware block -> tile map: hardware places block b on XCD b % 8; give each XCD a contiguous range
     // of tiles so that neighbouring tiles (which share halo cells) hit the same L2.
@@ -253,7 +263,26 @@ __global__ void __launch_bounds__(256) sh_stream_kernel(ShK P) {
     double uc[2][2] = {{ru[0][0], ru[0][1]}, {ru[1][0], ru[1][1]}};
     __syncthreads();
 
+    // FD state: the addend of the plane being emitted, the dot accumulator
+    double ad[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    double dacc = 0.0;
+    auto load_addend = [&](int k) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const double* as = P.addv + (size_t)k * plane + (size_t)oy[r] * P.nx + ox;
+            if (oky[r] && okx1 && P.vec_ok) {
+                const sh_nt_d2 t = __builtin_nontemporal_load(reinterpret_cast<const sh_nt_d2*>(as));
+                ad[r][0] = t.x; ad[r][1] = t.y;
+            } else {
+                ad[r][0] = (oky[r] && okx0) ? as[0] : 0.0;
+                ad[r][1] = (oky[r] && okx1) ? as[1] : 0.0;
+            }
+        }
+    };
+
     for (int p = p_first; p <= p_last; ++p) {
+        // (requested before the next plane's loads: they return in order, and the addend is needed first)
+        if (FD && P.addv && p - 2 >= zs && p - 2 < ze) load_addend(p - 2);
         if (p < p_last) load_plane(p + 1);          // global loads for the next plane in flight during compute
         const double* Lp = lds[cur];
         const int gp = p + P.zoff;
@@ -306,7 +335,13 @@ __global__ void __launch_bounds__(256) sh_stream_kernel(ShK P) {
             for (int r = 0; r < 2; ++r) {
                 if (!oky[r]) continue;
                 double* dst = P.out + (size_t)k * plane + (size_t)oy[r] * P.nx + ox;
-                const double o0 = acc[r][0][DIM3 ? 0 : 2], o1 = acc[r][1][DIM3 ? 0 : 2];
+                double o0 = acc[r][0][DIM3 ? 0 : 2], o1 = acc[r][1][DIM3 ? 0 : 2];
+                if (FD) {
+                    if (P.addv) { o0 = fma(P.addc, ad[r][0], o0); o1 = fma(P.addc, ad[r][1], o1); }
+                    const double* vo = lds[(cur + 2) & (NBUF - 1)] + (ty + r * NTY + 2) * LWP + 2 * tx + 2;      // plane p-2
+                    if (okx0) dacc = fma(vo[0], o0, dacc);
+                    if (okx1) dacc = fma(vo[1], o1, dacc);
+                }
                 if (okx1 && P.vec_ok) {
                     if (P.nt) {
                         sh_nt_d2 t; t.x = o0; t.y = o1;
@@ -327,30 +362,47 @@ __global__ void __launch_bounds__(256) sh_stream_kernel(ShK P) {
                     A[0] = A[1]; A[1] = A[2]; A[2] = A[3]; A[3] = A[4]; A[4] = 0.0;
                 }
         }
+        const int nxt = (cur + 1) & (NBUF - 1);
         if (p < p_last) {
-            stage_plane(cur ^ 1);
+            stage_plane(nxt);
 #pragma unroll
             for (int r = 0; r < 2; ++r) { uc[r][0] = ru[r][0]; uc[r][1] = ru[r][1]; }
         }
         __syncthreads();
-        cur ^= 1;
+        cur = nxt;
     }
     if (DIM3) {
         // flush: outputs k = p_last-1, p_last (only reached when the block's range ends at the global top)
         for (int k = p_last - 1; k <= p_last; ++k) {
             if (k >= zs && k < ze) {
                 const int q = k - (p_last - 1);
+                if (FD && P.addv) load_addend(k);
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     if (!oky[r]) continue;
                     double* dst = P.out + (size_t)k * plane + (size_t)oy[r] * P.nx + ox;
-                    const double o0 = q == 0 ? acc[r][0][0] : acc[r][0][1];
-                    const double o1 = q == 0 ? acc[r][1][0] : acc[r][1][1];
+                    double o0 = q == 0 ? acc[r][0][0] : acc[r][0][1];
+                    double o1 = q == 0 ? acc[r][1][0] : acc[r][1][1];
+                    if (FD) {
+                        // `cur` has moved one past plane p_last: p_last-1 / p_last are two / three slots further on
+                        if (P.addv) { o0 = fma(P.addc, ad[r][0], o0); o1 = fma(P.addc, ad[r][1], o1); }
+                        const double* vo = lds[(cur + 2 + q) & (NBUF - 1)] + (ty + r * NTY + 2) * LWP + 2 * tx + 2;
+                        if (okx0) dacc = fma(vo[0], o0, dacc);
+                        if (okx1) dacc = fma(vo[1], o1, dacc);
+                    }
                     if (okx0) dst[0] = o0;
                     if (okx1) dst[1] = o1;
                 }
             }
         }
+    }
+    if (FD) {
+        // the tile's share of v . out
+        __syncthreads();                                      // the flush above may still be reading the staging planes
+        for (int off = 32; off > 0; off >>= 1) dacc += __shfl_down(dacc, off, 64);
+        if ((tid & 63) == 0) lds[0][tid >> 6] = dacc;
+        __syncthreads();
+        if (tid == 0) P.dotp[L] = (lds[0][0] + lds[0][1]) + (lds[0][2] + lds[0][3]);
     }
 }
 
@@ -488,6 +540,21 @@ int pde_dparam(bk_ctx* ctx, int pde, int ipar, size_t npts, double c, const doub
     return 0;
 }
 
+// the fused Lanczos step needs the 3-D streaming kernel over the whole (single-rank) array and one partial sum per tile
+static int sh_zchunk_of(bk_ctx* ctx, const ShArgs& a, int tiles) {
+    int zchunk = (int)ctx->opt("sh_zchunk", 0.0);
+    if (zchunk <= 0) zchunk = sh_plan_zchunk(a.nz, tiles, 3L * (ctx->num_cu > 0 ? ctx->num_cu : 256), a.part != 0);
+    return zchunk > a.nz ? a.nz : zchunk;
+}
+bool sh_fused_dot_ok(bk_ctx* ctx, const ShArgs& a) {
+    if (a.az == 0.0 || a.mode != 0 || a.part != 0 || ctx->nranks != 1 || a.halo_lo || a.halo_hi) return false;
+    if ((int)ctx->opt("sh_kernel", 1.0) == 0 || ctx->opt("jvp_fused_dot", 1.0) == 0.0) return false;
+    const int tiles = ((a.nx + TX - 1) / TX) * ((a.ny + TY - 1) / TY);
+    const int zchunk = sh_zchunk_of(ctx, a, tiles);
+    const long nblocks = (long)tiles * ((a.nz + zchunk - 1) / zchunk);
+    return nblocks <= (long)kRedBlocks * (kMaxBasis + 2) && (!a.addv || (((uintptr_t)a.addv & 15) == 0));
+}
+
 int sh_apply(bk_ctx* ctx, const ShArgs& a) {
     if (a.nx < 2 || a.ny < 2 || (a.az != 0.0 && a.nzg < 2))
         return set_error(ctx, "sh_apply: every grid extent must be >= 2");
@@ -498,6 +565,11 @@ int sh_apply(bk_ctx* ctx, const ShArgs& a) {
     P.c0 = 1.0 - 2.0 * (a.ax + a.ay + a.az);
     P.l = a.l; P.nu = a.nu; P.a0 = a.a0; P.a1 = a.a1; P.mode = a.mode;
     P.v = a.v; P.u = a.u; P.out = a.out; P.halo_lo = a.halo_lo; P.halo_hi = a.halo_hi;
+    P.addv = nullptr; P.addc = 0.0; P.dotp = nullptr;
+    if (a.dot_blocks) {
+        if (!sh_fused_dot_ok(ctx, a)) return set_error(ctx, "sh_apply: fused dot requested on an unsupported path");
+        P.addv = (a.addc != 0.0) ? a.addv : nullptr; P.addc = a.addc; P.dotp = ctx->d_partials;
+    }
     const size_t n = (size_t)a.nx * a.ny * a.nz;
     const bool dim3d = a.az != 0.0;
     const int variant = (int)ctx->opt("sh_kernel", 1.0);
@@ -509,13 +581,10 @@ int sh_apply(bk_ctx* ctx, const ShArgs& a) {
         const size_t grid = (n + 255) / 256;
         hipLaunchKernelGGL(sh_gather_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, P);
     } else {
-        int zchunk = (int)ctx->opt("sh_zchunk", 0.0);
         P.ntx = (a.nx + TX - 1) / TX;
         P.nty = (a.ny + TY - 1) / TY;
-        if (!dim3d) zchunk = 1;
-        if (zchunk <= 0)        // rounds x planes per workgroup (launch_plan.h); 3 workgroups per CU stay resident (162 VGPRs)
-            zchunk = sh_plan_zchunk(a.nz, P.ntx * P.nty, 3L * (ctx->num_cu > 0 ? ctx->num_cu : 256), a.part != 0);
-        if (zchunk > a.nz) zchunk = a.nz;
+        // rounds x planes per workgroup (launch_plan.h); 3 workgroups per CU stay resident (162 VGPRs)
+        const int zchunk = dim3d ? sh_zchunk_of(ctx, a, P.ntx * P.nty) : 1;
         P.zchunk = zchunk;
         P.nzc = (a.nz + zchunk - 1) / zchunk;
         P.vec_ok = ((a.nx & 1) == 0) && (((uintptr_t)a.out & 15) == 0) &&
@@ -531,8 +600,15 @@ int sh_apply(bk_ctx* ctx, const ShArgs& a) {
             P.zc0 = zc0; P.zcstep = step;
             P.nblocks = P.ntx * P.nty * count;
             P.grid8 = (P.nblocks + 7) / 8 * 8;
-            ProfScope ps(ctx, a.mode == 0 ? "jvp" : "residual", (a.mode == 0 ? 24.0 : 16.0) * n * count / P.nzc);
-            if (dim3d && P.vload) hipLaunchKernelGGL((sh_stream_kernel<true, true>), dim3(P.grid8), dim3(256), 0, ctx->stream, P);
+            ProfScope ps(ctx, a.mode == 0 ? "jvp" : "residual", ((a.mode == 0 ? 24.0 : 16.0) + (P.addv ? 8.0 : 0.0)) * n * count / P.nzc);
+            if (P.dotp) {
+                const bool w3 = ctx->opt("jvp_fd_waves", 3.0) == 3.0;
+                if (P.vload && w3) hipLaunchKernelGGL((sh_stream_kernel<true, true, true, 3>), dim3(P.grid8), dim3(256), 0, ctx->stream, P);
+                else if (P.vload) hipLaunchKernelGGL((sh_stream_kernel<true, true, true, 2>), dim3(P.grid8), dim3(256), 0, ctx->stream, P);
+                else if (w3) hipLaunchKernelGGL((sh_stream_kernel<true, false, true, 3>), dim3(P.grid8), dim3(256), 0, ctx->stream, P);
+                else hipLaunchKernelGGL((sh_stream_kernel<true, false, true, 2>), dim3(P.grid8), dim3(256), 0, ctx->stream, P);
+                *a.dot_blocks = P.nblocks;
+            } else if (dim3d && P.vload) hipLaunchKernelGGL((sh_stream_kernel<true, true>), dim3(P.grid8), dim3(256), 0, ctx->stream, P);
             else if (dim3d) hipLaunchKernelGGL((sh_stream_kernel<true, false>), dim3(P.grid8), dim3(256), 0, ctx->stream, P);
             else if (P.vload) hipLaunchKernelGGL((sh_stream_kernel<false, true>), dim3(P.grid8), dim3(256), 0, ctx->stream, P);
             else hipLaunchKernelGGL((sh_stream_kernel<false, false>), dim3(P.grid8), dim3(256), 0, ctx->stream, P);

@@ -1,5 +1,5 @@
 // Host replay of the fast-DCT phases of bifurcationkit.jl_amd/csrc/dct_core.h for ONE pair of lines.
-// stdin: "mode N" (mode 0/1 = forward/inverse radix-2, 2/3 = the same with grouped radix-8 stages, 4/5/6 = fused schedule forward / inverse / forward-symbol-inverse, 7/8/9 = the same with the contiguous-axis outer stages) then N values of line a, N values of line b.  stdout: the two transformed lines.
+// stdin: "mode N" (mode 0/1 = forward/inverse radix-2, 2/3 = the same with grouped radix-8 stages, 4/5/6 = fused schedule forward / inverse / forward-symbol-inverse, 7/8/9 = the same with the contiguous-axis outer stages, 10 = 6 plus the spectral dot products, printed as one more line) then N values of line a, N values of line b.  stdout: the two transformed lines.
 #include <cmath>
 #include <cstdio>
 #include <vector>
@@ -8,7 +8,8 @@ using namespace bk::dctc;
 int main() {
     int inverse, N, grouped = 0, fused = 0;
     if (scanf("%d %d", &inverse, &N) != 2) return 2;
-    int contiguous = 0;
+    int contiguous = 0, want_dot = 0;
+    if (inverse == 10) { want_dot = 1; inverse = 6; }          // 10: fused roundtrip that also returns sum_k sym(k) X_k^2 per line
     if (inverse >= 7) { contiguous = 1; inverse -= 3; }        // 7/8/9: the same with the contiguous-axis first / last stage
     if (inverse >= 4) { fused = inverse - 3; inverse = 0; }   // 4: fused forward, 5: fused inverse, 6: fused roundtrip
     if (inverse >= 2) { grouped = 1; inverse -= 2; }     // modes 2/3: radix-8 grouped stages
@@ -61,10 +62,13 @@ int main() {
             for (int gp = 0; gp < N / 8; ++gp) fused_first(z.data(), N, bits, gp, ldin);
             middle_fwd();
         }
+        c2 dacc;
+        dacc.x = dacc.y = 0.0;
         for (int t = 0; t < N / 16; ++t) {
-            if (fused == 1) fused_mid<0>(z.data(), N, t, tw.data(), ewf.data(), s0, s2, ldin, stout, sym);
-            else if (fused == 2) fused_mid<1>(z.data(), N, t, tw.data(), ewf.data(), s0, s2, ldin, stout, sym);
-            else fused_mid<2>(z.data(), N, t, tw.data(), ewf.data(), s0, s2, ldin, stout, sym);
+            if (fused == 1) fused_mid<0, false>(z.data(), N, t, tw.data(), ewf.data(), s0, s2, ldin, stout, sym, dacc);
+            else if (fused == 2) fused_mid<1, false>(z.data(), N, t, tw.data(), ewf.data(), s0, s2, ldin, stout, sym, dacc);
+            else if (want_dot) fused_mid<2, true>(z.data(), N, t, tw.data(), ewf.data(), s0, s2, ldin, stout, sym, dacc);
+            else fused_mid<2, false>(z.data(), N, t, tw.data(), ewf.data(), s0, s2, ldin, stout, sym, dacc);
         }
         if (fused != 1) {
             middle_inv();
@@ -77,6 +81,7 @@ int main() {
             for (int gp = 0; gp < N / 8; ++gp) fused_last(z.data(), N, bits, gp, stout);
         }
         for (int k = 0; k < N; ++k) printf("%.17g %.17g\n", out[k].x, out[k].y);
+        if (want_dot) printf("%.17g %.17g\n", dacc.x, dacc.y);
         return 0;
     }
     if (!inverse) {

@@ -50,3 +50,21 @@ def test_dct_fused_schedule_matches_scipy(exe, N, mode):
     else:
         ra, rb = idct(sa * dct(a)), idct(sb * dct(b))
     assert np.abs(o[:, 0] - ra).max() < 1e-13 and np.abs(o[:, 1] - rb).max() < 1e-13
+
+
+@pytest.mark.parametrize("N", [64, 128, 256, 512])
+def test_fused_roundtrip_spectral_dot_is_the_physical_dot(exe, N):
+    """The merged middle pass can return sum_k sym(k) X_k^2 per line; the transforms are orthonormal, so that is
+    x . idct(sym * dct(x)) -- the r . M^-1 r that MINRES / CG need after every preconditioner application."""
+    rng = np.random.default_rng(N)
+    a, b = rng.standard_normal(N), rng.standard_normal(N)
+    inp = f"10 {N}\n" + " ".join(map(repr, a.tolist())) + "\n" + " ".join(map(repr, b.tolist()))
+    out = subprocess.run([exe], input=inp, capture_output=True, text=True, check=True).stdout.split()
+    o = np.array(list(map(float, out))).reshape(N + 1, 2)
+    k = np.arange(N)
+    sa, sb = 1.0 / (1.0 + 0.01 * k), 1.0 / (2.0 + 0.02 * k * k)
+    dct = lambda x: sfft.dct(x, type=2, norm="ortho")
+    idct = lambda x: sfft.idct(x, type=2, norm="ortho")
+    za, zb = idct(sa * dct(a)), idct(sb * dct(b))
+    assert np.abs(o[:N, 0] - za).max() < 1e-13 and np.abs(o[:N, 1] - zb).max() < 1e-13
+    assert abs(o[N, 0] - a @ za) < 1e-13 * abs(a @ za) * N and abs(o[N, 1] - b @ zb) < 1e-13 * abs(b @ zb) * N

@@ -518,6 +518,52 @@ def test_symmetric_krylov_solvers_match_oracle(ctx):
         hip.MatrixFreeBLS(mn)(J, prob.vec(dR), prob.vec(dzu), 0.4, prob.vec(R), 0.3, dotscale=1.0 / n)
 
 
+@pytest.mark.parametrize("dims", [(64, 64, 64), (70, 34, 20), (128, 64, 32)])
+def test_fused_minres_passes_reproduce_the_separate_ones(ctx, dims):
+    """Option minres_fused (default on): the Lanczos step's axpy + dot ride in the stencil kernel's store stage and
+    r . M^-1 r comes out of the preconditioner's spectrum (Parseval) -- same iterates as with the separate passes (counts,
+    solution to rounding), on grids where both, one or none of the two fused kernels apply (power-of-two extents take the
+    LDS transform kernels, the others the dense fallback; 70 x 34 x 20 has tile overhang and no 16-byte staging), and the
+    same iterates as the oracle's Krylov.jl restatement."""
+    hip = _hip()
+    ls3 = (np.pi, 2.5, 2.0)
+    sh, prob, rng, u = _sh_setup(ctx, dims, ls3, seed=sum(dims))
+    u = u + 0.1 * rng.standard_normal(sh.N)
+    J = prob.jacobian(prob.vec(u), 0.1)
+    rhs = rng.standard_normal(sh.N)
+    P = hip.DCTPreconditioner(prob, 1.0)
+    out = {}
+    try:
+        for alg, (a0, a1) in (("minres", (-0.1, 1.0)), ("cg", (2.0, -1.0))):
+            for fused in (0, 1):
+                ctx.set_option("minres_fused", fused)
+                ctx.set_option("solver_trace", 1)
+                ctx.solver_history(reset=True)
+                x, ok, it = hip.KrylovLSSymmetric(alg, atol=1e-13, rtol=1e-10, Pl=P)(J, prob.vec(rhs), a0, a1)
+                h = ctx.solver_history(reset=True)
+                r = prob.vec(rhs).numpy() - (a0 * x.numpy() + a1 * J(x).numpy())
+                out[alg, fused] = (x.numpy(), ok, it, np.linalg.norm(r) / np.linalg.norm(rhs), np.array(h[0]) if h else np.zeros(0))
+    finally:
+        ctx.set_option("minres_fused", 1)
+        ctx.set_option("solver_trace", 0)
+    # same iterates up to the rounding of the two dot products; that difference grows along the Lanczos recurrence (measured:
+    # 1e-12 relative in the residual estimate after 10 iterations, 1e-6 after 22), so near the stopping threshold the two
+    # runs may leave the final plateau a few iterations apart
+    for alg in ("minres", "cg"):
+        (x0, ok0, it0, r0, h0), (x1, ok1, it1, r1, h1) = out[alg, 0], out[alg, 1]
+        assert ok0 and ok1 and abs(it0 - it1) <= max(2, it0 // 4), (alg, it0, it1)
+        assert np.abs(x0 - x1).max() <= 1e-6 * np.abs(x0).max(), alg
+        assert r1 <= 1e-6 and r1 <= 10 * r0 + 1e-12, (alg, r0, r1)
+        if alg == "minres":
+            m = min(len(h0), len(h1)) // 2
+            assert m >= 5 and np.allclose(h1[:m], h0[:m], rtol=1e-7, atol=0), (h0[:m], h1[:m])
+    if dims == (64, 64, 64):
+        Plo = operators.dct_preconditioner(dims, ls3, 1.0)
+        xo, oko, ito = krylov.minres_krylovjl(sh.J(u, 0.1, 1.2), rhs, -0.1, 1.0, atol=1e-13, rtol=1e-10, M=Plo)
+        x1, _, it1, _, _ = out["minres", 1]
+        assert oko and abs(it1 - ito) <= max(2, ito // 4) and np.abs(x1 - xo).max() <= 1e-6 * np.abs(xo).max()
+
+
 # --------------------------------------------------------------------------------------------- bordered solvers
 @pytest.mark.parametrize("shift", [None, 0.3])
 @pytest.mark.parametrize("xi", [(1.0, 1.0), (0.4, 0.6)])
