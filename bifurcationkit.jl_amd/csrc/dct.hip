@@ -191,10 +191,17 @@ void blas_release(bk_ctx* ctx) {
 // -- along x: Out(rows x N) = X(rows x N) M; along y / z: Out_plane = M' X_plane, batched over the planes -- so from
 // N = 32 on it goes to rocBLAS' fp64 MFMA dgemm (the library call the design rules reserve for plain GEMMs); the
 // one-thread-per-output kernel stays for tiny extents and as a cross-check (option dct_gemm = 0).
-static int dense_axis_pass(bk_ctx* ctx, int n0, int n1, int n2, int axis, const double* M, const double* in, double* out) {
+int dense_gemm_axis_pass(bk_ctx* ctx, int n0, int n1, int n2, int axis, const double* M, const double* MT, const double* in,
+                         double* out);
+// MT = M' (row-major).  Option dct_gemm: 1 (default) the hand-written fp64-MFMA product (dense_mfma.hip), 2 rocBLAS dgemm
+// (the cross-check; rounds 1-2 ran on it), 0 the one-thread-per-output kernel.
+static int dense_axis_pass(bk_ctx* ctx, int n0, int n1, int n2, int axis, const double* M, const double* MT, const double* in,
+                           double* out) {
     const int N = axis == 0 ? n0 : (axis == 1 ? n1 : n2);
     const size_t total = (size_t)n0 * n1 * n2;
-    if (N < 32 || ctx->opt("dct_gemm", 1.0) == 0.0) {
+    const int gemm = (int)ctx->opt("dct_gemm", 1.0);
+    if (N >= 32 && gemm == 1) return dense_gemm_axis_pass(ctx, n0, n1, n2, axis, M, MT, in, out);
+    if (N < 32 || gemm == 0) {
         hipLaunchKernelGGL(dct_axis_direct, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, n0, n1, n2, axis,
                            M, in, out);
         BK_HIP(ctx, hipGetLastError());
@@ -363,7 +370,7 @@ static int dst_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out) {
     }
     auto pass = [&](int a, const double* in, double* o) -> int {
         ProfScope ps(ctx, "dct_pass", 16.0 * p->total);
-        return dense_axis_pass(ctx, n0, n1, nb, a, p->T[a], in, o);
+        return dense_axis_pass(ctx, n0, n1, nb, a, p->T[a], p->T[a], in, o);       // the sine matrix is symmetric
     };
     BK_TRY(pass(0, v, p->t1));
     BK_TRY(pass(1, p->t1, p->t2));
@@ -422,7 +429,7 @@ int dct_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out, int* dot_bl
                                 p->ndim == 3 ? p->lam[2] : nullptr, p->shift, fuse, nullptr, fuse == 2 ? dot_blocks : nullptr);
         }
         // forward: out[k] = sum_n T[k][n] in[n]  -> M[q=n][o=k] = TT ; inverse: out[n] = sum_k T[k][n] in[k] -> M = T
-        return dense_axis_pass(ctx, n0, n1, n2, a, inverse ? p->T[a] : p->TT[a], in, o);
+        return dense_axis_pass(ctx, n0, n1, n2, a, inverse ? p->T[a] : p->TT[a], inverse ? p->TT[a] : p->T[a], in, o);
     };
     // the last forward pass applies the inverse symbol while storing when it runs on the fast path
     const int last = p->ndim - 1;
@@ -632,7 +639,7 @@ static int dct_apply_dist(bk_ctx* ctx, DctPlan* p, const double* v, double* out)
         ProfScope ps(ctx, "dct_pass", 16.0 * (double)n0 * n1 * n2);
         if (use_fft && p->twid[which])
             return dct_axis_fft(ctx, n0, n1, n2, axis, inverse, p->twid[which], in, o, l0, l1, l2, p->shift, fuse, split);
-        return dense_axis_pass(ctx, n0, n1, n2, axis, inverse ? p->T[which] : p->TT[which], in, o);
+        return dense_axis_pass(ctx, n0, n1, n2, axis, inverse ? p->T[which] : p->TT[which], inverse ? p->TT[which] : p->T[which], in, o);
     };
     double *a = p->t1, *b = p->t2;
     const bool direct = p->kmap && use_fft && p->twid[1] && ctx->opt("dct_dist_direct", 1.0) != 0.0 &&

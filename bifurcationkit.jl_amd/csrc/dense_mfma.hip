@@ -102,6 +102,91 @@ __global__ void __launch_bounds__(GT) gemm_f64_kernel(GemmP P) {
                 gb.C[(size_t)(m0 + wm + i * 16 + lk + 4 * r) * P.ldc + n0 + wn + j * 16 + li] = acc[i][j][r];
 }
 
+// The same product for ANY extents (the dense DCT-II passes of the Swift-Hohenberg preconditioner on grids that are not a
+// power of two, and the sine transforms of cGL grids that do not fit the tiles above): scalar guarded loads that fill the
+// tile's overhang with zeros, guarded stores, a strided batch in blockIdx.z.  Same tiles, same MFMA schedule.
+struct GemmS {
+    int M, N, K, lda, ldb, ldc;
+    const double* A;
+    const double* B;
+    double* C;
+    size_t sA, sB, sC;
+};
+
+__global__ void __launch_bounds__(GT) gemm_f64_any_kernel(GemmS P) {
+    __shared__ __attribute__((aligned(16))) double As[2][BK][BM + PAD];
+    __shared__ __attribute__((aligned(16))) double Bs[2][BK][BN + PAD];
+    const double* A = P.A + (size_t)blockIdx.z * P.sA;
+    const double* B = P.B + (size_t)blockIdx.z * P.sB;
+    double* C = P.C + (size_t)blockIdx.z * P.sC;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int ar = tid >> 2, ak = (tid & 3) * 4;
+    const int bk = tid >> 5, bn = (tid & 31) * 2;
+    const bool arow = m0 + ar < P.M;
+    const double* Ag = A + (size_t)(arow ? m0 + ar : 0) * P.lda;
+    double ra[4], rb[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kk = k0 + ak + i;
+            ra[i] = (arow && kk < P.K) ? Ag[kk] : 0.0;
+        }
+        const int kb = k0 + bk;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + bn + j;
+            rb[j] = (kb < P.K && col < P.N) ? B[(size_t)kb * P.ldb + col] : 0.0;
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) As[buf][ak + i][ar] = ra[i];
+        Bs[buf][bk][bn] = rb[0]; Bs[buf][bk][bn + 1] = rb[1];
+    };
+    v4d acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const int li = lane & 15, lk = lane >> 4;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < P.K; k0 += BK) {
+        const bool more = k0 + BK < P.K;
+        if (more) gload(k0 + BK);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4) {
+            double a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[cur][kk + lk][wm + i * 16 + li];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = Bs[cur][kk + lk][wn + j * 16 + li];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            sstore(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm + i * 16 + lk + 4 * r, col = n0 + wn + j * 16 + li;
+                if (row < P.M && col < P.N) C[(size_t)row * P.ldc + col] = acc[i][j][r];
+            }
+}
+
 // x fold: X[rows][N] -> W[2][rows][N/2] (e, o);  unfold: W -> X
 __global__ void __launch_bounds__(256) fold_x_kernel(size_t rows, int N, const double* __restrict__ X, double* __restrict__ W) {
     const int h = N >> 1;
@@ -219,6 +304,34 @@ int dense_mfma_pass(bk_ctx* ctx, int n0, int n1, int nb, int axis, int inverse, 
         }
     }
     (void)total;
+    BK_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// One dense axis pass of the array [n2][n1][n0] (n0 fastest) with the N x N matrix M of the axis: along x
+// Out(rows x N) = X(rows x N) M, along y / z Out_plane(N x inner) = M' X_plane, batched over the planes.  MT = M' (row-major).
+int dense_gemm_axis_pass(bk_ctx* ctx, int n0, int n1, int n2, int axis, const double* M, const double* MT, const double* in,
+                         double* out) {
+    GemmS P;
+    unsigned gz = 1;
+    if (axis == 0) {
+        const size_t rows = (size_t)n1 * n2;
+        if (rows > 0x7fffffffu) return set_error(ctx, "dense_gemm_axis_pass: too many rows");
+        P.M = (int)rows; P.N = n0; P.K = n0;
+        P.A = in; P.lda = n0; P.B = M; P.ldb = n0; P.C = out; P.ldc = n0;
+        P.sA = P.sB = P.sC = 0;
+    } else {
+        const int N = axis == 1 ? n1 : n2;
+        const size_t inner = axis == 1 ? (size_t)n0 : (size_t)n0 * n1;
+        if (inner > 0x7fffffffu) return set_error(ctx, "dense_gemm_axis_pass: plane too large");
+        P.M = N; P.N = (int)inner; P.K = N;
+        P.A = MT; P.lda = N; P.B = in; P.ldb = (int)inner; P.C = out; P.ldc = (int)inner;
+        P.sA = 0; P.sB = P.sC = inner * (size_t)N;
+        gz = axis == 1 ? (unsigned)n2 : 1u;
+    }
+    const unsigned gx = (unsigned)((P.N + BN - 1) / BN), gy = (unsigned)((P.M + BM - 1) / BM);
+    if (gy > 65535u || gz > 65535u) return set_error(ctx, "dense_gemm_axis_pass: grid too large");
+    hipLaunchKernelGGL(gemm_f64_any_kernel, dim3(gx, gy, gz), dim3(GT), 0, ctx->stream, P);
     BK_HIP(ctx, hipGetLastError());
     return 0;
 }

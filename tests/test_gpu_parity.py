@@ -286,6 +286,32 @@ def test_dct_fast_path_matches_direct_and_scipy(ctx, dims):
     assert np.array_equal(W.numpy(), fast)
 
 
+@pytest.mark.parametrize("dims", [(45, 33, 50), (100, 36), (130, 70, 34), (33, 200)])
+def test_dense_transform_passes_hand_written_vs_rocblas_vs_direct(ctx, dims):
+    """Extents that are not a power of two take the dense DCT-II passes: the hand-written fp64-MFMA product with guarded
+    tile overhang (dense_mfma.hip, option dct_gemm = 1, the default) == rocBLAS dgemm (2) == the one-thread-per-output
+    kernel (0) == scipy's DCT on the CPU; odd extents, extents below / above one 128 x 64 tile, 2-D and 3-D."""
+    hip = _hip()
+    ls = tuple(np.pi * d / 32 for d in dims)
+    prob = hip.SwiftHohenberg(ctx, dims, ls)
+    P = hip.DCTPreconditioner(prob, 1.0)
+    rng = np.random.default_rng(sum(dims))
+    v = rng.standard_normal(int(np.prod(dims)))
+    V = prob.vec(v)
+    got = {}
+    try:
+        for g in (1, 2, 0):
+            ctx.set_option("dct_gemm", g)
+            got[g] = P.ldiv(V).numpy()
+    finally:
+        ctx.set_option("dct_gemm", 1)
+    ref = operators.dct_preconditioner(dims, ls, 1.0)(v)
+    scale = np.abs(ref).max()
+    for g in (1, 2, 0):
+        assert np.abs(got[g] - ref).max() <= 1e-12 * scale, (g, np.abs(got[g] - ref).max() / scale)
+    assert np.abs(got[1] - got[2]).max() <= 1e-13 * scale
+
+
 # --------------------------------------------------------------------------------------------- linear solvers
 def _sh_setup(ctx, dims, ls, seed=0):
     hip = _hip()
