@@ -5,6 +5,8 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export PYTHONPATH="$PWD"
+PART="${PART:-AB}"
+if [[ "$PART" == *A* ]]; then
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -30 > gpurun_out/r3f_pytest.log
 tail -6 gpurun_out/r3f_pytest.log | cut -c1-300
 SKIP_TESTS=1 bash scripts/gpu_profile.sh r3 > gpurun_out/r3f_profile.out 2>&1
@@ -17,7 +19,7 @@ BK_FORCE_DIST=1 timeout 300 python bench.py --steps 3 --warmup 1 --cpu-sample 0 
 OUT=gpurun_out/r3f_hostcomm8.jsonl
 : > $OUT
 BK_BENCH_HOSTCOMM=1 timeout 600 python bench.py --gpus 8 --size 256 --steps 1 --warmup 1 --cpu-sample 0 --no-steady 2> gpurun_out/r3f_hostcomm8_256.err | tail -1 >> $OUT
-BK_BENCH_HOSTCOMM=1 timeout 900 python bench.py --gpus 8 --size 512 --steps 1 --warmup 1 --cpu-sample 0 --no-steady 2> gpurun_out/r3f_hostcomm8_512.err | tail -1 >> $OUT
+[ "${HOSTCOMM512:-0}" = 1 ] && BK_BENCH_HOSTCOMM=1 timeout 900 python bench.py --gpus 8 --size 512 --steps 1 --warmup 1 --cpu-sample 0 --no-steady 2> gpurun_out/r3f_hostcomm8_512.err | tail -1 >> $OUT
 python - <<'PY'
 import json
 def show(path):
@@ -35,7 +37,24 @@ PY
 (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_c3" -- python "$OLDPWD/scripts/c3_fullsize.py" 1024 eig block > "$OLDPWD/gpurun_out/r3f_c3_prof.log" 2>&1)
 python scripts/prof_summary.py gpurun_out/prof_c3 5 2>/dev/null | head -14 | cut -c1-200 > gpurun_out/r3f_c3_eigensolve_kernel_stats.txt
 cat gpurun_out/r3f_c3_eigensolve_kernel_stats.txt | cut -c1-160
-# config 5 at full size on one GPU: two continuation steps (corrector + 15 eigenvalues + Bordered tangent per step)
+fi
+if [[ "$PART" == *B* ]]; then
+# config 5: one MINRES solve at 512^3 with the fused passes off / on (kernel families), the whole branch at 256^3 (bench.py
+# --workload branch --steps 50 ends at p_min), three steps with the reference's own eigensolver tolerance, then 512^3
+timeout 300 python scripts/micro/minres_fused_diag.py 512 2>&1 | grep -v "^$" | grep -v history > gpurun_out/r3f_minres_fused_512.txt
+cat gpurun_out/r3f_minres_fused_512.txt | cut -c1-330
+timeout 900 python bench.py --workload branch --size 256 --steps 50 2> gpurun_out/r3f_branch256.err | tail -1 > gpurun_out/r3f_branch_256_50steps.json
+timeout 600 python bench.py --workload branch --size 256 --steps 3 --eig-tol 1e-12 2>> gpurun_out/r3f_branch256.err | tail -1 > gpurun_out/r3f_branch_256_3steps_eigtol1e-12.json
+python - <<'PY'
+import json
+for f in ('gpurun_out/r3f_branch_256_50steps.json', 'gpurun_out/r3f_branch_256_3steps_eigtol1e-12.json'):
+    try:
+        d = json.load(open(f))
+        ps = d['per_step']
+        print(f.split('/')[-1], 'steps', len(ps), 's/step %.3f' % (d['ms_per_step'] / 1e3), 'init', d['config']['initialisation'], 'first/last', [(round(p['seconds'], 2), p['eig_solves'], p['eig_inner_iterations'], p['itlinear'], p['eig_converged']) for p in (ps[0], ps[-1])], 'p_end', d['param'][-1])
+    except Exception as e:
+        print(f, 'failed', e)
+PY
 [ "${SKIP_BRANCH512:-0}" = 1 ] || timeout 1500 python bench.py --workload branch --size 512 --steps 2 2> gpurun_out/r3f_branch512.err | tail -1 > gpurun_out/r3f_branch_512_2steps.json
 python - <<'PY'
 import json
@@ -45,3 +64,4 @@ try:
 except Exception as e:
     print('branch 512 failed', e)
 PY
+fi
