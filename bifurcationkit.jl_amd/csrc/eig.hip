@@ -26,6 +26,10 @@ struct ShiftedOp : bk_op {
     int apply(const double* x, const double*, double b0, double b1, double* out, double*) override {
         return J->apply(x, nullptr, b0 - b1 * sigma, b1, out, nullptr);
     }
+    // the inner MINRES / CG solves take the operator's fused Lanczos step where it has one
+    int apply_axpy_dot(const double* x, double b0, double b1, double c, const double* r, double* out, double* dot) override {
+        return J->apply_axpy_dot(x, b0 - b1 * sigma, b1, c, r, out, dot);
+    }
 };
 
 // A = du -> ls(Jshift, du)[1]   (examples/SH3d.jl:107).  The shift is folded into the operator BEFORE the
