@@ -90,6 +90,19 @@ function sh_case(name, dims, ls, l, ν, guess; newton_tol = 1e-8, branch_steps =
     c["gmres"] = Dict("converged" => ok, "numops" => it, "x" => summary_of(x))
     x, ok, it = ls_(J, r1; a₀ = 0.3, a₁ = 0.9)                   # the Pl + shift branch, src/LinearSolver.jl:268-288
     c["gmres_shift"] = Dict("a0" => 0.3, "a1" => 0.9, "converged" => ok, "numops" => it, "x" => summary_of(x))
+    # KrylovLS(:minres) / (:cg): Krylov.jl's symmetric solvers with the same factor as the "centered" preconditioner M
+    # (src/LinearSolver.jl:336-341; `ldiv = true` as in the commented line of examples/SH3d.jl:94) -- the inner solver of
+    # config 5 on the HIP side, with two of its passes fused into the stencil / transform kernels
+    try
+        kmr = KrylovLS(KrylovAlg = :minres, Pl = Pl, rtol = 1e-10, atol = 1e-13, ldiv = true)
+        x, ok, it = kmr(J, r1; a₀ = -0.1, a₁ = 1.0)
+        c["minres"] = Dict("a0" => -0.1, "a1" => 1.0, "converged" => ok, "niter" => it, "x" => summary_of(x))
+        kcg = KrylovLS(KrylovAlg = :cg, Pl = Pl, rtol = 1e-10, atol = 1e-13, ldiv = true)
+        x, ok, it = kcg(J, r1; a₀ = 2.0, a₁ = -1.0)           # -(J - 2I) is positive definite
+        c["cg"] = Dict("a0" => 2.0, "a1" => -1.0, "converged" => ok, "niter" => it, "x" => summary_of(x))
+    catch err
+        c["minres_error"] = sprint(showerror, err)
+    end
     dotp = (a, b) -> dot(a, b) / N
     bls = BorderingBLS(solver = ls_, check_precision = false)
     dX, dl, ok, its = bls(J, r2, r3, 0.4, r1, 0.3, 0.5, 0.5; dotp = dotp)

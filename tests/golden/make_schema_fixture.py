@@ -39,6 +39,10 @@ def sh_case(dims, ls, l, nu, branch_steps):
     c["gmres"] = dict(converged=bool(ok), numops=int(it), x=summary(x))
     x, ok, it = ols(J, r1, 0.3, 0.9)
     c["gmres_shift"] = dict(a0=0.3, a1=0.9, converged=bool(ok), numops=int(it), x=summary(x))
+    x, ok, it = krylov.minres_krylovjl(J, r1, -0.1, 1.0, atol=1e-13, rtol=1e-10, M=lu.solve)
+    c["minres"] = dict(a0=-0.1, a1=1.0, converged=bool(ok), niter=int(it), x=summary(x))
+    x, ok, it = krylov.cg_krylovjl(J, r1, 2.0, -1.0, atol=1e-13, rtol=1e-10, M=lu.solve)
+    c["cg"] = dict(a0=2.0, a1=-1.0, converged=bool(ok), niter=int(it), x=summary(x))
     dotp = lambda a, b: float(a @ b) / N
     dX, dl, ok, its = bordered.bordering_bls(ols, J, r2, r3, 0.4, r1, 0.3, 0.5, 0.5, check_precision=False, dotp=dotp)
     c["bordering"] = dict(converged=bool(ok), itlinear=[int(i) for i in its], dl=float(dl), dX=summary(dX))

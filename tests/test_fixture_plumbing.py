@@ -18,7 +18,7 @@ def test_consumers_run_end_to_end_on_a_schema_file(tmp_path):
     assert d["generator"] == "oracle" and {"sh3d_22", "sh2d_151x100", "cgl_41x21"} <= set(d)
     # the keys julia/gen_fixtures.jl writes per Swift-Hohenberg case
     want = {"dims", "ls", "l", "nu", "F_u0", "dF_u0_probe1", "newton", "gmres", "gmres_shift", "bordering", "matrixfree",
-            "shift_invert", "branch"}
+            "shift_invert", "branch", "minres", "cg"}
     assert want <= set(d["sh3d_22"]) and want <= set(d["sh2d_151x100"])
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_reference_fixtures.py"), "-q", "-m",
                         "not gpu", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)

@@ -95,6 +95,11 @@ def test_oracle_swift_hohenberg_matches_reference(fx, name):
     x, ok, it = ols(J, r1, 0.3, 0.9)
     assert ok == c["gmres_shift"]["converged"] and abs(it - c["gmres_shift"]["numops"]) <= 2
     close(x, c["gmres_shift"]["x"], 1e-7, "gmres shift")
+    for key, fn in (("minres", krylov.minres_krylovjl), ("cg", krylov.cg_krylovjl)):      # Krylov.jl's symmetric solvers
+        if key in c:
+            x, ok, it = fn(J, r1, c[key]["a0"], c[key]["a1"], atol=1e-13, rtol=1e-10, M=lu.solve)
+            assert ok == c[key]["converged"] and abs(it - c[key]["niter"]) <= max(2, c[key]["niter"] // 10), (key, it)
+            close(x, c[key]["x"], 1e-7, key)
     dX, dl, ok, its = bordered.bordering_bls(ols, J, r2, r3, 0.4, r1, 0.3, 0.5, 0.5, check_precision=False,
                                              dotp=lambda a, b: float(a @ b) / N)
     assert abs(dl - c["bordering"]["dl"]) <= 1e-7 * max(1.0, abs(c["bordering"]["dl"]))
@@ -150,6 +155,12 @@ def test_hip_swift_hohenberg_matches_reference(fx, ctx, name):
     x, ok, it = ls_(J, r1, 0.3, 0.9)
     assert abs(it - c["gmres_shift"]["numops"]) <= 2
     close(x.numpy(), c["gmres_shift"]["x"], 1e-7, "gmres shift")
+    for key in ("minres", "cg"):                      # the fused-pass path (3-D) / the separate passes (2-D stencil)
+        if key in c:
+            ks = hip.KrylovLSSymmetric(key, atol=1e-13, rtol=1e-10, Pl=P)
+            x, ok, it = ks(J, r1, c[key]["a0"], c[key]["a1"])
+            assert ok == c[key]["converged"] and abs(it - c[key]["niter"]) <= max(2, c[key]["niter"] // 10), (key, it)
+            close(x.numpy(), c[key]["x"], 1e-7, key)
     dX, dl, ok, its = hip.BorderingBLS(ls_, check_precision=False)(J, r2, r3, 0.4, r1, 0.3, 0.5, 0.5, dotscale=1.0 / N)
     assert abs(dl - c["bordering"]["dl"]) <= 1e-7 * max(1.0, abs(c["bordering"]["dl"]))
     close(dX.numpy(), c["bordering"]["dX"], 1e-6, "bordering")
