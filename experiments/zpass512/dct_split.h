@@ -25,18 +25,41 @@ BK_HD c2 ek_any(int k, int N, const c2* ew) {
 
 // own value Z_k, partner value Z_{N-k}: unscaled post-twiddle, times symbol(k) * c (c = forward scale * inverse scale).
 // DOT: pacc += symbol(k) |X_k|^2 with X unscaled (the caller multiplies by hs2^2 once).
-template <bool DOT, class Sym>
+// e_k from the half table when the caller knows statically which half k lies in.  In the exchange steps own element I < 4
+// is ALWAYS in the lower half (k = g + I G < N/2; k = 0 .. 3G for the rotated group-0 lane) and own element 7 - I always in
+// the upper one (k = N/2 exactly, group 0's u[4], is covered by both forms: -i conj(e_{N/2}) = e_{N/2}).
+template <bool UPPER>
+BK_HD c2 ek_half(int k, int N, const c2* ew) {
+    if (!UPPER) return ew[k];
+    const c2 t = ew[N - k];
+    c2 e; e.x = -t.y; e.y = -t.x;
+    return e;
+}
+
+template <bool DOT, bool UPPER, class Sym>
 BK_HD c2 split_post_sym(c2 own, c2 partner, int k, int N, const c2* ew, double c, Sym&& sym, c2& pacc, double wgt = 1.0) {
-    const c2 e = ek_any(k, N, ew);
+    const c2 e = ek_half<UPPER>(k, N, ew);
     c2 X = post_one(own, partner, e, 1.0);
     const c2 f = sym(k);
     const double tx = X.x * f.x, ty = X.y * f.y;          // shared by the dot and the scaling
-    if (DOT) { pacc.x = fma(tx * wgt, X.x, pacc.x); pacc.y = fma(ty * wgt, X.y, pacc.y); }
+    if (DOT) {
+        double dx = tx * X.x, dy = ty * X.y;
+#ifdef __HIP_DEVICE_COMPILE__
+        // pin the evaluation point: left alone the compiler sinks the four products and the accumulation to the end of the
+        // exchange steps and keeps their operands alive (measured: +18 VGPRs per step, 232 B of scratch at the 128 cap)
+        asm volatile("" : "+v"(dx), "+v"(dy));
+#endif
+        pacc.x = fma(dx, wgt, pacc.x); pacc.y = fma(dy, wgt, pacc.y);
+#ifdef __HIP_DEVICE_COMPILE__
+        asm volatile("" : "+v"(pacc.x), "+v"(pacc.y));
+#endif
+    }
     X.x = tx * c; X.y = ty * c;
     return X;
 }
 
-BK_HD c2 split_pre(c2 Xown, c2 Xpartner, int k, int N, const c2* ew) { return pre_one(Xown, Xpartner, ek_any(k, N, ew), 1.0, 1.0); }
+template <bool UPPER>
+BK_HD c2 split_pre(c2 Xown, c2 Xpartner, int k, int N, const c2* ew) { return pre_one(Xown, Xpartner, ek_half<UPPER>(k, N, ew), 1.0, 1.0); }
 
 // top forward radix-8 of group g: v[q] = Z_{g + q G} afterwards; w = the group's 7 twiddles (kept for the inverse)
 BK_HD void split_load_fwd(const c2* zp, int N, int g, const c2* tw, c2* v, c2* w) {
@@ -78,14 +101,14 @@ BK_HD c2 split_phase1a(const SplitRole& r, c2 a, c2 b, c2 rb, const c2* ew, doub
     c2 Pa = csel(r.self, b, rb);                          // partner of own u[I]: the other lane's u[7-I] (self-paired: own)
     if (I == 3) Pa = csel(r.sp, a, Pa);                   // k = 0 pairs with itself
     const double wgt = (I == 3 && r.sp) ? 0.5 : 1.0;    // k = 0 carries the forward scale s0, not s2
-    const c2 Xa = split_post_sym<DOT>(a, Pa, split_ki<I>(r), r.N, ew, c, sym, pacc, wgt);
+    const c2 Xa = split_post_sym<DOT, false>(a, Pa, split_ki<I>(r), r.N, ew, c, sym, pacc, wgt);
     return Xa;
 }
 template <bool DOT, int I, class Sym>
 BK_HD c2 split_phase1b(const SplitRole& r, c2 a, c2 b, c2 ra, const c2* ew, double c, Sym&& sym, c2& pacc) {
     c2 Pb = csel(r.self, a, ra);
     if (I == 3) Pb = csel(r.sp, b, Pb);                   // k = N/2 pairs with itself
-    return split_post_sym<DOT>(b, Pb, split_kj<I>(r), r.N, ew, c, sym, pacc);
+    return split_post_sym<DOT, true>(b, Pb, split_kj<I>(r), r.N, ew, c, sym, pacc);
 }
 template <bool DOT, int I, class Sym>
 BK_HD void split_phase1(const SplitRole& r, c2 a, c2 b, c2 ra, c2 rb, const c2* ew, double c, Sym&& sym, c2& pacc, c2& Xa, c2& Xb) {
@@ -101,8 +124,8 @@ BK_HD void split_phase2(const SplitRole& r, c2 Xa, c2 Xb, c2 qa, c2 qb, const c2
         Qa = csel(r.sp, zero, Qa);
         Qb = csel(r.sp, Xb, Qb);
     }
-    ua = split_pre(Xa, Qa, split_ki<I>(r), r.N, ew);
-    ub = split_pre(Xb, Qb, split_kj<I>(r), r.N, ew);
+    ua = split_pre<false>(Xa, Qa, split_ki<I>(r), r.N, ew);
+    ub = split_pre<true>(Xb, Qb, split_kj<I>(r), r.N, ew);
 }
 // register rotation of the group-0 lane (and back)
 BK_HD void split_rotate_in(bool sp, c2* v) {

@@ -67,6 +67,7 @@ template <bool DOT>
 __global__ void __launch_bounds__(NT, 4) zpass512_kernel(ZK P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double dsum[NT / 64];
+    __shared__ double lamx[LT];
     const int N = P.N, bits = P.bits, G = N >> 3;
     const int pstride = N + 1;
     c2* z = reinterpret_cast<c2*>(smem);
@@ -86,6 +87,7 @@ __global__ void __launch_bounds__(NT, 4) zpass512_kernel(ZK P) {
 
     for (int q = tid; q < N + 1; q += NT) tw[q] = reinterpret_cast<const c2*>(P.twid)[q];
     for (int q = tid; q < N; q += NT) lamk[q] = P.lam2[q];
+    if (tid < LT) lamx[tid] = 1.0 + P.lam0[x0 + tid] + P.lam1[other];       // per-line constant of the inverse symbol
     // first stage: one radix-8 group per lane, samples straight from global memory
     const int fpair = tid & (NPAIRS - 1), fg = tid >> 3;                      // pair line, first-stage group (0 .. N/8)
     c2 pf[8];
@@ -101,13 +103,6 @@ __global__ void __launch_bounds__(NT, 4) zpass512_kernel(ZK P) {
     lds_barrier();
     // merged-middle item of this lane: pair line mp, item t, half h
     const int h = tid & 1, mp = (tid >> 1) & (NPAIRS - 1), t = tid >> 4;
-    double ca, cb;
-    {
-        const int i0 = x0 + 2 * mp;
-        const double l1 = P.lam1[other];
-        ca = 1.0 + P.lam0[i0] + l1;
-        cb = 1.0 + P.lam0[i0 + 1] + l1;
-    }
     dc::fused_first(z + (size_t)fpair * pstride, N, bits, fg, [&](int r, int) { return pf[r]; });
     lds_barrier();
     auto middle = [&](int lh, int R, bool inv) {
@@ -136,6 +131,7 @@ __global__ void __launch_bounds__(NT, 4) zpass512_kernel(ZK P) {
     // ---- merged middle, one top group per lane
     const double s2 = sqrt(2.0 / N);
     const double hs2 = 0.5 * s2, cc = hs2 * ((1.0 / N) / s2);
+    const double ca = lamx[2 * mp], cb = lamx[2 * mp + 1];
     auto sym = [&](int k) {
         const double lk = lamk[k];
         const double sa = ca + lk, sb = cb + lk;
