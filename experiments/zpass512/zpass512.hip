@@ -37,7 +37,6 @@ struct ZK {
     int tiles_x, ntiles, xmap;
 };
 
-constexpr int LT = 16, NPAIRS = LT / 2, NT = 512;
 
 __device__ __forceinline__ double rcp_nr(double d) {
     double y = __builtin_amdgcn_rcp(d);
@@ -63,8 +62,11 @@ __device__ __forceinline__ double xchg1(double v) {
 }
 __device__ __forceinline__ c2 xchg(c2 v) { c2 r; r.x = xchg1(v.x); r.y = xchg1(v.y); return r; }
 
-template <bool DOT>
-__global__ void __launch_bounds__(NT, 4) zpass512_kernel(ZK P) {
+// LT lines per tile on 32 LT lanes: 16 lines = 512 lanes, two tiles (16 waves) per CU; 8 lines = 256 lanes and 45 KiB of LDS,
+// three tiles per CU (the x extent of a tile is then a 64-byte segment per plane instead of 128 bytes)
+template <int LT, bool DOT>
+__global__ void __launch_bounds__(32 * LT, LT == 16 ? 4 : 3) zpass512_kernel(ZK P) {
+    constexpr int NPAIRS = LT / 2, NT = 32 * LT, PB = (LT == 16 ? 3 : 2);      // PB = log2(NPAIRS)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double dsum[NT / 64];
     __shared__ double lamx[LT];
@@ -89,7 +91,7 @@ __global__ void __launch_bounds__(NT, 4) zpass512_kernel(ZK P) {
     for (int q = tid; q < N; q += NT) lamk[q] = P.lam2[q];
     if (tid < LT) lamx[tid] = 1.0 + P.lam0[x0 + tid] + P.lam1[other];       // per-line constant of the inverse symbol
     // first stage: one radix-8 group per lane, samples straight from global memory
-    const int fpair = tid & (NPAIRS - 1), fg = tid >> 3;                      // pair line, first-stage group (0 .. N/8)
+    const int fpair = tid & (NPAIRS - 1), fg = tid >> PB;                      // pair line, first-stage group (0 .. N/8)
     c2 pf[8];
     {
         const unsigned o = 2u * fpair;
@@ -102,7 +104,7 @@ __global__ void __launch_bounds__(NT, 4) zpass512_kernel(ZK P) {
     }
     lds_barrier();
     // merged-middle item of this lane: pair line mp, item t, half h
-    const int h = tid & 1, mp = (tid >> 1) & (NPAIRS - 1), t = tid >> 4;
+    const int h = tid & 1, mp = (tid >> 1) & (NPAIRS - 1), t = tid >> (PB + 1);
     dc::fused_first(z + (size_t)fpair * pstride, N, bits, fg, [&](int r, int) { return pf[r]; });
     lds_barrier();
     auto middle = [&](int lh, int R, bool inv) {
@@ -198,10 +200,86 @@ __global__ void __launch_bounds__(NT, 4) zpass512_kernel(ZK P) {
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
 
+
+template <int LT>
+static int run(int n0, int n1, int N, int bits, int reps, size_t total, double* din, double* dout, double* dtab, double* d0, double* d1,
+               double* d2, double shift, const std::vector<double>& hin, const std::vector<double>& l0, const std::vector<double>& l1,
+               const std::vector<double>& l2) {
+    constexpr int NPAIRS = LT / 2, NT = 32 * LT;
+    double* ddot;
+    ZK P;
+    P.n0 = n0; P.n1 = n1; P.N = N; P.bits = bits; P.in = din; P.out = dout; P.twid = dtab; P.lam0 = d0; P.lam1 = d1; P.lam2 = d2;
+    P.shift = shift; P.tiles_x = n0 / LT; P.ntiles = P.tiles_x * n1; P.xmap = 0;
+    CK(hipMalloc(&ddot, (size_t)P.ntiles * 8));
+    P.dotp = ddot;
+    CK(hipMemset(dout, 0, total * 8));
+    const size_t lds = ((size_t)NPAIRS * (N + 1) + (size_t)(N / 2) + (size_t)(N / 2 + 2)) * sizeof(c2) + (size_t)N * sizeof(double);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(zpass512_kernel<LT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(zpass512_kernel<LT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    hipLaunchKernelGGL((zpass512_kernel<LT, true>), dim3(P.ntiles), dim3(NT), lds, 0, P);
+    CK(hipDeviceSynchronize());
+    // ---- check a sample of lines against the O(N^2) orthonormal DCT-II / symbol / DCT-III on the CPU, and the dot
+    std::vector<double> hdot(P.ntiles);
+    CK(hipMemcpy(hdot.data(), ddot, (size_t)P.ntiles * 8, hipMemcpyDeviceToHost));
+    std::vector<double> C((size_t)N * N);
+    for (int k = 0; k < N; ++k)
+        for (int j = 0; j < N; ++j) C[(size_t)k * N + j] = (k == 0 ? std::sqrt(1.0 / N) : std::sqrt(2.0 / N)) * std::cos(M_PI * (2 * j + 1) * k / (2.0 * N));
+    double worst = 0.0, scale = 0.0, dot_cpu = 0.0;
+    const size_t plane = (size_t)n0 * n1;
+    const int ycheck = 3 % n1;
+    std::vector<double> col((size_t)N * LT);
+    for (int j = 0; j < N; ++j)                                         // the tile (tile_x 0, y = ycheck): LT lines
+        CK(hipMemcpy(col.data() + (size_t)j * LT, dout + (size_t)j * plane + (size_t)ycheck * n0, LT * 8, hipMemcpyDeviceToHost));
+    for (int x = 0; x < LT; ++x) {
+        std::vector<double> line(N), spec(N), back(N);
+        for (int j = 0; j < N; ++j) line[j] = hin[(size_t)j * plane + (size_t)ycheck * n0 + x];
+        for (int k = 0; k < N; ++k) { double a = 0.0; for (int j = 0; j < N; ++j) a += C[(size_t)k * N + j] * line[j]; spec[k] = a; }
+        for (int k = 0; k < N; ++k) {
+            const double sa = 1.0 + l0[x] + l1[ycheck] + l2[k];
+            const double f = 1.0 / (sa * sa + shift);
+            dot_cpu += f * spec[k] * spec[k];
+            spec[k] *= f;
+        }
+        for (int j = 0; j < N; ++j) { double a = 0.0; for (int k = 0; k < N; ++k) a += C[(size_t)k * N + j] * spec[k]; back[j] = a; }
+        for (int j = 0; j < N; ++j) {
+            const double got = col[(size_t)j * LT + x];
+            worst = std::fmax(worst, std::fabs(got - back[j])); scale = std::fmax(scale, std::fabs(back[j]));
+        }
+    }
+    const double dot_gpu = hdot[(size_t)ycheck * P.tiles_x + 0];
+    printf("LT %d check: max|gpu - cpu| = %.3e (scale %.3e), tile dot gpu %.15e cpu %.15e\n", LT, worst, scale, dot_gpu, dot_cpu);
+    const bool ok = worst <= 1e-12 * scale && std::fabs(dot_gpu - dot_cpu) <= 1e-12 * std::fabs(dot_cpu);
+    // ---- timing
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int variant = 0; variant < 4; ++variant) {
+        P.xmap = (variant & 1) && (P.ntiles % 8 == 0);
+        const bool dot = variant & 2;
+        for (int w = 0; w < 3; ++w) {
+            if (dot) hipLaunchKernelGGL((zpass512_kernel<LT, true>), dim3(P.ntiles), dim3(NT), lds, 0, P);
+            else hipLaunchKernelGGL((zpass512_kernel<LT, false>), dim3(P.ntiles), dim3(NT), lds, 0, P);
+        }
+        CK(hipEventRecord(e0, 0));
+        for (int r = 0; r < reps; ++r) {
+            if (dot) hipLaunchKernelGGL((zpass512_kernel<LT, true>), dim3(P.ntiles), dim3(NT), lds, 0, P);
+            else hipLaunchKernelGGL((zpass512_kernel<LT, false>), dim3(P.ntiles), dim3(NT), lds, 0, P);
+        }
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = 1e3 * ms / reps;
+        printf("LT %2d (%d lanes) xmap %d dot %d: %.1f us per pass, %.2f TB/s (%.3f of 8 TB/s)   [product kernel, 16 lines on 256 lanes: 608-620 us]\n", LT,
+               NT, P.xmap, (int)dot, us, 16.0 * total / (us * 1e-6) / 1e12, 16.0 * total / (us * 1e-6) / 8e12);
+    }
+    CK(hipFree(ddot));
+    return ok ? 0 : 1;
+}
+
 int main(int argc, char** argv) {
     const int n0 = argc > 1 ? atoi(argv[1]) : 512, n1 = argc > 2 ? atoi(argv[2]) : 512, reps = argc > 3 ? atoi(argv[3]) : 20;
     const int N = 512, bits = 9;
-    if (n0 % LT != 0) { fprintf(stderr, "n0 must be a multiple of %d\n", LT); return 2; }
+    if (n0 % 16 != 0) { fprintf(stderr, "n0 must be a multiple of 16\n"); return 2; }
     const size_t total = (size_t)n0 * n1 * N;
     if (total * 8 >= ((size_t)1 << 32)) { fprintf(stderr, "array must stay below 4 GiB\n"); return 2; }
     std::vector<double> hin(total), tab(2 * (N / 2) + 2 * (N / 2 + 1)), l0(n0), l1(n1), l2(N);
@@ -214,72 +292,14 @@ int main(int argc, char** argv) {
     for (int i = 0; i < n1; ++i) l1[i] = lam(i, n1, 4.9);
     for (int i = 0; i < N; ++i) l2[i] = lam(i, N, 6.5);
     const double shift = 1.0;
-    double *din, *dout, *dtab, *d0, *d1, *d2, *ddot;
+    double *din, *dout, *dtab, *d0, *d1, *d2;
     CK(hipMalloc(&din, total * 8)); CK(hipMalloc(&dout, total * 8)); CK(hipMalloc(&dtab, tab.size() * 8));
     CK(hipMalloc(&d0, n0 * 8)); CK(hipMalloc(&d1, n1 * 8)); CK(hipMalloc(&d2, N * 8));
     CK(hipMemcpy(din, hin.data(), total * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dtab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(d0, l0.data(), n0 * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d1, l1.data(), n1 * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(d2, l2.data(), N * 8, hipMemcpyHostToDevice));
-    ZK P;
-    P.n0 = n0; P.n1 = n1; P.N = N; P.bits = bits; P.in = din; P.out = dout; P.twid = dtab; P.lam0 = d0; P.lam1 = d1; P.lam2 = d2;
-    P.shift = shift; P.tiles_x = n0 / LT; P.ntiles = P.tiles_x * n1; P.xmap = 0;
-    CK(hipMalloc(&ddot, (size_t)P.ntiles * 8));
-    P.dotp = ddot;
-    const size_t lds = ((size_t)NPAIRS * (N + 1) + (size_t)(N / 2) + (size_t)(N / 2 + 2)) * sizeof(c2) + (size_t)N * sizeof(double);
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(zpass512_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(zpass512_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    hipLaunchKernelGGL(zpass512_kernel<true>, dim3(P.ntiles), dim3(NT), lds, 0, P);
-    CK(hipDeviceSynchronize());
-    // ---- check a sample of lines against the O(N^2) orthonormal DCT-II / symbol / DCT-III on the CPU, and the dot
-    std::vector<double> hout(total), hdot(P.ntiles);
-    CK(hipMemcpy(hout.data(), dout, total * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(hdot.data(), ddot, (size_t)P.ntiles * 8, hipMemcpyDeviceToHost));
-    std::vector<double> C((size_t)N * N);
-    for (int k = 0; k < N; ++k)
-        for (int j = 0; j < N; ++j) C[(size_t)k * N + j] = (k == 0 ? std::sqrt(1.0 / N) : std::sqrt(2.0 / N)) * std::cos(M_PI * (2 * j + 1) * k / (2.0 * N));
-    double worst = 0.0, scale = 0.0, dot_cpu = 0.0;
-    const size_t plane = (size_t)n0 * n1;
-    const int ycheck = 3 % n1;
-    for (int x = 0; x < LT; ++x) {                                      // the 16 lines of tile (tile_x 0, y = ycheck)
-        std::vector<double> line(N), spec(N), back(N);
-        for (int j = 0; j < N; ++j) line[j] = hin[(size_t)j * plane + (size_t)ycheck * n0 + x];
-        for (int k = 0; k < N; ++k) { double a = 0.0; for (int j = 0; j < N; ++j) a += C[(size_t)k * N + j] * line[j]; spec[k] = a; }
-        for (int k = 0; k < N; ++k) {
-            const double sa = 1.0 + l0[x] + l1[ycheck] + l2[k];
-            const double f = 1.0 / (sa * sa + shift);
-            dot_cpu += f * spec[k] * spec[k];
-            spec[k] *= f;
-        }
-        for (int j = 0; j < N; ++j) { double a = 0.0; for (int k = 0; k < N; ++k) a += C[(size_t)k * N + j] * spec[k]; back[j] = a; }
-        for (int j = 0; j < N; ++j) {
-            const double got = hout[(size_t)j * plane + (size_t)ycheck * n0 + x];
-            worst = std::fmax(worst, std::fabs(got - back[j])); scale = std::fmax(scale, std::fabs(back[j]));
-        }
-    }
-    const double dot_gpu = hdot[(size_t)ycheck * P.tiles_x + 0];
-    printf("check: max|gpu - cpu| = %.3e (scale %.3e), tile dot gpu %.15e cpu %.15e\n", worst, scale, dot_gpu, dot_cpu);
-    const bool ok = worst <= 1e-12 * scale && std::fabs(dot_gpu - dot_cpu) <= 1e-12 * std::fabs(dot_cpu);
-    // ---- timing
-    hipEvent_t e0, e1;
-    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int variant = 0; variant < 4; ++variant) {
-        P.xmap = (variant & 1) && (P.ntiles % 8 == 0);
-        const bool dot = variant & 2;
-        for (int w = 0; w < 3; ++w) {
-            if (dot) hipLaunchKernelGGL(zpass512_kernel<true>, dim3(P.ntiles), dim3(NT), lds, 0, P);
-            else hipLaunchKernelGGL(zpass512_kernel<false>, dim3(P.ntiles), dim3(NT), lds, 0, P);
-        }
-        CK(hipEventRecord(e0, 0));
-        for (int r = 0; r < reps; ++r) {
-            if (dot) hipLaunchKernelGGL(zpass512_kernel<true>, dim3(P.ntiles), dim3(NT), lds, 0, P);
-            else hipLaunchKernelGGL(zpass512_kernel<false>, dim3(P.ntiles), dim3(NT), lds, 0, P);
-        }
-        CK(hipEventRecord(e1, 0));
-        CK(hipEventSynchronize(e1));
-        float ms = 0.f;
-        CK(hipEventElapsedTime(&ms, e0, e1));
-        const double us = 1e3 * ms / reps;
-        printf("zpass512 xmap %d dot %d: %.1f us per pass, %.2f TB/s (%.3f of 8 TB/s)   [product kernel, 256 lanes: 608-620 us]\n", P.xmap, (int)dot,
-               us, 16.0 * total / (us * 1e-6) / 1e12, 16.0 * total / (us * 1e-6) / 8e12);
-    }
-    return ok ? 0 : 1;
+    int rc = 0;
+    rc |= run<16>(n0, n1, N, bits, reps, total, din, dout, dtab, d0, d1, d2, shift, hin, l0, l1, l2);
+    rc |= run<8>(n0, n1, N, bits, reps, total, din, dout, dtab, d0, d1, d2, shift, hin, l0, l1, l2);
+    return rc;
 }
