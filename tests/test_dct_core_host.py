@@ -68,3 +68,15 @@ def test_fused_roundtrip_spectral_dot_is_the_physical_dot(exe, N):
     za, zb = idct(sa * dct(a)), idct(sb * dct(b))
     assert np.abs(o[:N, 0] - za).max() < 1e-13 and np.abs(o[:N, 1] - zb).max() < 1e-13
     assert abs(o[N, 0] - a @ za) < 1e-13 * abs(a @ za) * N and abs(o[N, 1] - b @ zb) < 1e-13 * abs(b @ zb) * N
+
+
+@pytest.mark.parametrize("N", [64, 256, 512, 1024])
+def test_lane_pair_split_of_the_merged_middle_matches_fused_mid(tmp_path_factory, N):
+    """experiments/zpass512 (staged, not in the library): the merged middle split across lane pairs -- one radix-8 group per
+    lane, partners exchanged in four steps, one code path for every role -- replayed for two lanes in lockstep; it must
+    reproduce the product's fused_mid<2> (output and spectral dot).  The harness exits non-zero beyond 1e-13."""
+    out = tmp_path_factory.mktemp("split") / "host_check"
+    src = os.path.join(ROOT, "experiments", "zpass512", "host_check.cpp")
+    subprocess.run(["g++", "-O2", "-std=c++17", src, "-o", str(out)], check=True)
+    r = subprocess.run([str(out), str(N)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
