@@ -35,6 +35,7 @@ struct ZK {
     double shift;
     double* dotp;                 // per-workgroup partial sums of sum_k symbol |v^_k|^2, or NULL
     int tiles_x, ntiles, xmap;
+    int stagger;                  // > 0: the workgroups that fill the SECOND slot of every CU at launch start that many s_sleep(127) later
 };
 
 
@@ -80,6 +81,8 @@ __global__ void __launch_bounds__(32 * LT, LT == 16 ? 4 : 3) zpass512_kernel(ZK 
     const unsigned estride = (unsigned)P.n0 * (unsigned)P.n1;
     typedef double nt_d2 __attribute__((ext_vector_type(2)));
 
+    if (P.stagger > 0 && blockIdx.x < 512 && ((blockIdx.x >> 3) & 32))      // 8 XCDs x 32 CUs: slots 256..511 are each CU's second tile
+        for (int i = 0; i < P.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     const int slot = blockIdx.x;
     const int tile = P.xmap ? (slot & 7) * (P.ntiles >> 3) + (slot >> 3) : slot;
     const int x0 = (tile % P.tiles_x) * LT, other = tile / P.tiles_x;           // other = y index
@@ -201,6 +204,8 @@ __global__ void __launch_bounds__(32 * LT, LT == 16 ? 4 : 3) zpass512_kernel(ZK 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
 
 
+static bool g_stagger_only = false;
+
 template <int LT>
 static int run(int n0, int n1, int N, int bits, int reps, size_t total, double* din, double* dout, double* dtab, double* d0, double* d1,
                double* d2, double shift, const std::vector<double>& hin, const std::vector<double>& l0, const std::vector<double>& l1,
@@ -209,7 +214,7 @@ static int run(int n0, int n1, int N, int bits, int reps, size_t total, double* 
     double* ddot;
     ZK P;
     P.n0 = n0; P.n1 = n1; P.N = N; P.bits = bits; P.in = din; P.out = dout; P.twid = dtab; P.lam0 = d0; P.lam1 = d1; P.lam2 = d2;
-    P.shift = shift; P.tiles_x = n0 / LT; P.ntiles = P.tiles_x * n1; P.xmap = 0;
+    P.shift = shift; P.tiles_x = n0 / LT; P.ntiles = P.tiles_x * n1; P.xmap = 0; P.stagger = 0;
     CK(hipMalloc(&ddot, (size_t)P.ntiles * 8));
     P.dotp = ddot;
     CK(hipMemset(dout, 0, total * 8));
@@ -252,9 +257,12 @@ static int run(int n0, int n1, int N, int bits, int reps, size_t total, double* 
     // ---- timing
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int variant = 0; variant < 4; ++variant) {
-        P.xmap = (variant & 1) && (P.ntiles % 8 == 0);
-        const bool dot = variant & 2;
+    const int nvar = g_stagger_only ? 6 : 4;
+    for (int variant = 0; variant < nvar; ++variant) {
+        P.xmap = ((variant & 1) || g_stagger_only) && (P.ntiles % 8 == 0);
+        const bool dot = !g_stagger_only && (variant & 2);
+        static const int kStag[6] = {0, 1, 2, 3, 4, 6};
+        P.stagger = g_stagger_only ? kStag[variant] : 0;
         for (int w = 0; w < 3; ++w) {
             if (dot) hipLaunchKernelGGL((zpass512_kernel<LT, true>), dim3(P.ntiles), dim3(NT), lds, 0, P);
             else hipLaunchKernelGGL((zpass512_kernel<LT, false>), dim3(P.ntiles), dim3(NT), lds, 0, P);
@@ -269,8 +277,8 @@ static int run(int n0, int n1, int N, int bits, int reps, size_t total, double* 
         float ms = 0.f;
         CK(hipEventElapsedTime(&ms, e0, e1));
         const double us = 1e3 * ms / reps;
-        printf("LT %2d (%d lanes) xmap %d dot %d: %.1f us per pass, %.2f TB/s (%.3f of 8 TB/s)   [product kernel, 16 lines on 256 lanes: 608-620 us]\n", LT,
-               NT, P.xmap, (int)dot, us, 16.0 * total / (us * 1e-6) / 1e12, 16.0 * total / (us * 1e-6) / 8e12);
+        printf("LT %2d (%d lanes) stagger %d xmap %d dot %d: %.1f us per pass, %.2f TB/s (%.3f of 8 TB/s)   [product kernel, 16 lines on 256 lanes: 608-620 us]\n", LT,
+               NT, P.stagger, P.xmap, (int)dot, us, 16.0 * total / (us * 1e-6) / 1e12, 16.0 * total / (us * 1e-6) / 8e12);
     }
     CK(hipFree(ddot));
     return ok ? 0 : 1;
@@ -298,8 +306,9 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(din, hin.data(), total * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dtab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(d0, l0.data(), n0 * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d1, l1.data(), n1 * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(d2, l2.data(), N * 8, hipMemcpyHostToDevice));
+    g_stagger_only = argc > 4;                    // 4th argument: only the start-offset experiment (16-line tiles)
     int rc = 0;
     rc |= run<16>(n0, n1, N, bits, reps, total, din, dout, dtab, d0, d1, d2, shift, hin, l0, l1, l2);
-    rc |= run<8>(n0, n1, N, bits, reps, total, din, dout, dtab, d0, d1, d2, shift, hin, l0, l1, l2);
+    if (!g_stagger_only) rc |= run<8>(n0, n1, N, bits, reps, total, din, dout, dtab, d0, d1, d2, shift, hin, l0, l1, l2);
     return rc;
 }
