@@ -3,7 +3,13 @@
 #include <cmath>
 #include <cstdio>
 #include <vector>
-#include "../../bifurcationkit.jl_amd/csrc/dct_core.h"
+#ifndef BK_DCT_CORE_H
+#define BK_DCT_CORE_H "../../bifurcationkit.jl_amd/csrc/dct_core.h"
+#endif
+#include BK_DCT_CORE_H
+#ifndef BK_DCT_TWI              // table index map of the header under test (the candidate layout pads the tables: -DBK_DCT_TWI=twi)
+#define BK_DCT_TWI(j) (j)
+#endif
 using namespace bk::dctc;
 int main() {
     int inverse, N, grouped = 0, fused = 0;
@@ -18,9 +24,9 @@ int main() {
     std::vector<double> a(N), b(N);
     for (auto& x : a) if (scanf("%lf", &x) != 1) return 2;
     for (auto& x : b) if (scanf("%lf", &x) != 1) return 2;
-    std::vector<c2> tw(N / 2 > 0 ? N / 2 : 1), ew(N / 2 + 1), z(N + 16);
-    for (int j = 0; j < N / 2; ++j) { tw[j].x = std::cos(2.0 * M_PI * j / N); tw[j].y = -std::sin(2.0 * M_PI * j / N); }
-    for (int k = 0; k <= N / 2; ++k) { ew[k].x = std::cos(M_PI * k / (2.0 * N)); ew[k].y = -std::sin(M_PI * k / (2.0 * N)); }
+    std::vector<c2> tw(BK_DCT_TWI(N / 2) + 1), ew(BK_DCT_TWI(N / 2 + 1) + 1), z(N + 16);
+    for (int j = 0; j < N / 2; ++j) { tw[BK_DCT_TWI(j)].x = std::cos(2.0 * M_PI * j / N); tw[BK_DCT_TWI(j)].y = -std::sin(2.0 * M_PI * j / N); }
+    for (int k = 0; k <= N / 2; ++k) { ew[BK_DCT_TWI(k)].x = std::cos(M_PI * k / (2.0 * N)); ew[BK_DCT_TWI(k)].y = -std::sin(M_PI * k / (2.0 * N)); }
     const double s0 = std::sqrt(1.0 / N), s2 = std::sqrt(2.0 / N);
     if (fused) {
         // modes 4/5/6: the fused schedule of dct_fused_kernel (first / last radix-8 stage on registers fed from "global")

@@ -10,11 +10,16 @@ import scipy.fft as sfft
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def exe(tmp_path_factory):
-    out = tmp_path_factory.mktemp("dct") / "dct_core_check"
-    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "dct_core_check.cpp"), "-o", str(out)],
-                   check=True)
+# "product": bifurcationkit.jl_amd/csrc/dct_core.h;  "candidate": experiments/lds_conflicts/dct_core_next.h -- the same header
+# with the XOR swizzle and padded twiddle tables that the bank-conflict model prefers (staged for round 4, not in the library)
+@pytest.fixture(scope="module", params=["product", "candidate"])
+def exe(request, tmp_path_factory):
+    out = tmp_path_factory.mktemp("dct") / ("dct_core_check_" + request.param)
+    cmd = ["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "dct_core_check.cpp"), "-o", str(out)]
+    if request.param == "candidate":
+        cmd += ['-DBK_DCT_CORE_H="%s"' % os.path.join(ROOT, "experiments", "lds_conflicts", "dct_core_next.h"),
+                "-DBK_DCT_TWI(j)=bk::dctc::twi(j)"]
+    subprocess.run(cmd, check=True)
     return str(out)
 
 
