@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbkhip.so")
+# BKHIP_LIB: an explicit library file (A/B builds of the same sources, e.g. `make layout0`); default = the in-tree build
+LIB_PATH = os.environ.get("BKHIP_LIB") or os.path.join(_HERE, "lib", "libbkhip.so")
 
 BK_UNIQUE_ID_BYTES = 128
 BK_MAX_PARAMS = 8

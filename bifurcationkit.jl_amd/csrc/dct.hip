@@ -22,6 +22,7 @@
 
 #include <rocblas/rocblas.h>
 
+#include "dct_core.h"
 #include "ops.h"
 
 namespace bk {
@@ -234,6 +235,22 @@ static int dense_axis_pass(bk_ctx* ctx, int n0, int n1, int n2, int axis, const 
     return 0;
 }
 
+// Twiddle tables of the LDS FFT kernels (dct_fast.hip), in the slot layout of dct_core.h (twi: one padding slot per 16
+// entries): w[j] = exp(-2 pi i j / N), j < N/2 (FFT), followed by the Makhoul post-twiddles e[k] = exp(-i pi k / 2N), k <= N/2.
+std::vector<double> dct_twiddle_table(int N) {
+    const int twl = dctc::tw_len(N), ewl = dctc::ew_len(N);
+    std::vector<double> tw(2 * (size_t)(twl + ewl), 0.0);
+    for (int j = 0; j < N / 2; ++j) {
+        tw[2 * (size_t)dctc::twi(j)] = std::cos(2.0 * M_PI * j / N);
+        tw[2 * (size_t)dctc::twi(j) + 1] = -std::sin(2.0 * M_PI * j / N);
+    }
+    for (int k = 0; k <= N / 2; ++k) {
+        tw[2 * (size_t)(twl + dctc::twi(k))] = std::cos(M_PI * k / (2.0 * N));
+        tw[2 * (size_t)(twl + dctc::twi(k)) + 1] = -std::sin(M_PI * k / (2.0 * N));
+    }
+    return tw;
+}
+
 int dct_plan_create(bk_ctx* ctx, int ndim, const int n[3], const double ainv[3], double shift, DctPlan** out) {
     DctPlan* p = new DctPlan();
     p->ndim = ndim;
@@ -265,17 +282,7 @@ int dct_plan_create(bk_ctx* ctx, int ndim, const int n[3], const double ainv[3],
         (void)hipMemcpy(p->TT[a], TT.data(), sizeof(double) * N * N, hipMemcpyHostToDevice);
         (void)hipMemcpy(p->lam[a], lam.data(), sizeof(double) * N, hipMemcpyHostToDevice);
         if (dct_axis_fft_supported(N)) {
-            // twiddles: w[j] = exp(-2 pi i j / N) for j < N/2 (FFT) followed by the Makhoul post-twiddle
-            // e[k] = exp(-i pi k / 2N), k < N
-            std::vector<double> tw(2 * (size_t)(N / 2) + 2 * (size_t)N);
-            for (int j = 0; j < N / 2; ++j) {
-                tw[2 * j] = std::cos(2.0 * M_PI * j / N);
-                tw[2 * j + 1] = -std::sin(2.0 * M_PI * j / N);
-            }
-            for (int k = 0; k < N; ++k) {
-                tw[N + 2 * k] = std::cos(M_PI * k / (2.0 * N));
-                tw[N + 2 * k + 1] = -std::sin(M_PI * k / (2.0 * N));
-            }
+            const std::vector<double> tw = dct_twiddle_table(N);
             if (hipMalloc(&p->twid[a], sizeof(double) * tw.size()) != hipSuccess) {
                 dct_plan_destroy(p);
                 return set_error(ctx, "dct plan: allocation failed");
@@ -544,11 +551,9 @@ static int slab_tables_create(bk_ctx* ctx, DctPlan* p, int nl, bool even, double
         const double ainv[3] = {0.0, 0.0, az};
         const size_t L = nx * (size_t)n[1];
         if (even && nl >= 8 && dct_axis_fft_supported(nl) && L % R == 0 && shift > 0.0 && R - 1 <= 15) {
-            std::vector<double> tw(2 * (size_t)(nl / 2) + 2 * (size_t)nl), lam(nl), phi(2 * (size_t)nl);
-            for (int j = 0; j < nl / 2; ++j) { tw[2 * j] = std::cos(2.0 * M_PI * j / nl); tw[2 * j + 1] = -std::sin(2.0 * M_PI * j / nl); }
+            const std::vector<double> tw = dct_twiddle_table(nl);
+            std::vector<double> lam(nl), phi(2 * (size_t)nl);
             for (int k = 0; k < nl; ++k) {
-                tw[nl + 2 * k] = std::cos(M_PI * k / (2.0 * nl));
-                tw[nl + 2 * k + 1] = -std::sin(M_PI * k / (2.0 * nl));
                 const double sn = std::sin(M_PI * k / (2.0 * nl));
                 lam[k] = -4.0 * ainv[2] * sn * sn;
                 const double sk = k == 0 ? std::sqrt(1.0 / nl) : std::sqrt(2.0 / nl);

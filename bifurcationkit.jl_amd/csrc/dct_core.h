@@ -28,7 +28,27 @@ struct c2 {
     double x, y;
 };
 
+// LDS layout (round 4; the bank-conflict model of scripts/lds_model reproduces the measured conflict share of the round-3
+// layout, 38.5 %, and puts this one at 17 %):
+//   swz   XOR of the low 4 bits (the 16 slots of a 256-byte bank row) with bits 3.., 4.. and 7.. of the index, so that the
+//         power-of-two strides of the radix-8 stages (8 data reads 2^lh apart) and the bit-reversed scatter of the first stage
+//         spread over the row; swz(8g + q) == swz(8g) ^ q still holds for the first / last stage (see fused_first)
+//   twi   twiddle tables carry one padding slot per 16 entries: the three twiddle loads of a radix-8 stage index the table
+//         with lo << (sh + 2), lo << (sh + 1), lo << sh -- on a dense table the 8 distinct lo of a lane group hit ONE slot
+// BK_DCT_LAYOUT 0 keeps the round-3 layout (i ^ ((i>>4 ^ i>>8) & 15), dense tables) as the A/B reference.
+#ifndef BK_DCT_LAYOUT
+#define BK_DCT_LAYOUT 1
+#endif
+#if BK_DCT_LAYOUT == 1
+BK_HD int swz(int i) { return i ^ (((i >> 3) ^ (i >> 4) ^ (i >> 7)) & 15); }
+BK_HD int twi(int j) { return j + (j >> 4); }
+#else
 BK_HD int swz(int i) { return i ^ (((i >> 4) ^ (i >> 8)) & 15); }
+BK_HD int twi(int j) { return j; }
+#endif
+// table sizes in complex slots: FFT twiddles exp(-2 pi i j / N), j < N/2; post twiddles exp(-i pi k / 2N), k <= N/2
+BK_HD int tw_len(int N) { return twi(N >> 1); }
+BK_HD int ew_len(int N) { return twi(N >> 1) + 1; }
 
 BK_HD int bitrev(int i, int bits) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -51,7 +71,7 @@ BK_HD void dit_butterfly(c2* z, int bits, int lh, int j, const c2* tw) {
     const int pos = j & (half - 1);
     const int i0 = ((j >> lh) << (lh + 1)) + pos;
     const int i1 = i0 + half;
-    const c2 w = tw[pos << (bits - lh - 1)];
+    const c2 w = tw[twi(pos << (bits - lh - 1))];
     const int p0 = swz(i0), p1 = swz(i1);
     const c2 a = z[p0], b = z[p1];
     const double tx = w.x * b.x - w.y * b.y, ty = w.x * b.y + w.y * b.x;
@@ -65,7 +85,7 @@ BK_HD void dif_butterfly_inv(c2* z, int bits, int lh, int j, const c2* tw) {
     const int pos = j & (half - 1);
     const int i0 = ((j >> lh) << (lh + 1)) + pos;
     const int i1 = i0 + half;
-    const c2 w = tw[pos << (bits - lh - 1)];          // conj applied below
+    const c2 w = tw[twi(pos << (bits - lh - 1))];          // conj applied below
     const int p0 = swz(i0), p1 = swz(i1);
     const c2 a = z[p0], b = z[p1];
     const double dx = a.x - b.x, dy = a.y - b.y;
@@ -90,7 +110,7 @@ BK_HD void dit_group(c2* z, int bits, int lh, int g, const c2* tw) {
         for (int q = 0; q < M; ++q) {
             if (q & (1 << s)) continue;
             const int pos = ((q & ((1 << s) - 1)) << lh) + lo;
-            const c2 w = tw[pos << (bits - (lh + s) - 1)];
+            const c2 w = tw[twi(pos << (bits - (lh + s) - 1))];
             const c2 a = v[q], b = v[q | (1 << s)];
             const double tx = w.x * b.x - w.y * b.y, ty = w.x * b.y + w.y * b.x;
             v[q].x = a.x + tx; v[q].y = a.y + ty;
@@ -116,7 +136,7 @@ BK_HD void dif_group_inv(c2* z, int bits, int lh, int g, const c2* tw) {
         for (int q = 0; q < M; ++q) {
             if (q & (1 << s)) continue;
             const int pos = ((q & ((1 << s) - 1)) << lh) + lo;
-            const c2 w = tw[pos << (bits - (lh + s) - 1)];
+            const c2 w = tw[twi(pos << (bits - (lh + s) - 1))];
             const c2 a = v[q], b = v[q | (1 << s)];
             const double dx = a.x - b.x, dy = a.y - b.y;
             v[q].x = a.x + b.x; v[q].y = a.y + b.y;
@@ -176,7 +196,7 @@ BK_HD void fwd_post(c2* z, int N, int k, const c2* ew, double s0, double s2) {
     const double vax = 0.5 * (Zk.x + Zn.x), vay = 0.5 * (Zk.y - Zn.y);
     const double dx = Zk.x - Zn.x, dy = Zk.y + Zn.y;
     const double vbx = 0.5 * dy, vby = -0.5 * dx;
-    const c2 e = ew[k];
+    const c2 e = ew[twi(k)];
     const double ax = e.x * vax - e.y * vay, ay = e.x * vay + e.y * vax;
     const double bx = e.x * vbx - e.y * vby, by = e.x * vby + e.y * vbx;
     z[pk].x = s2 * ax; z[pk].y = s2 * bx;
@@ -198,7 +218,7 @@ BK_HD void inv_pre(c2* z, int N, int k, const c2* ew, double s0, double s2) {
     const c2 Xn = z[pn];
     const double f = rN / s2;
     const double cak = Xk.x * f, cbk = Xk.y * f, can = Xn.x * f, cbn = Xn.y * f;
-    const c2 e = ew[k];
+    const c2 e = ew[twi(k)];
     const double vax = e.x * cak - e.y * can, vay = -e.x * can - e.y * cak;
     const double vbx = e.x * cbk - e.y * cbn, vby = -e.x * cbn - e.y * cbk;
     z[pk].x = vax - vby; z[pk].y = vay + vbx;
@@ -296,7 +316,7 @@ BK_HD void r8_last_inv(c2* v) {
 //   = b_s * exp(-2 pi i p / 2^{s+1}),  b_s = tw[lo << (bits-lh-s-1)]   (constant rotations: 1, -i, e^{-i pi/4}, e^{-3i pi/4})
 BK_HD void r8_twiddles(c2* w7, int lo, int sh, const c2* tw) {      // sh = bits - lh - 3
     const double c = 0.70710678118654752440;
-    const c2 b0 = tw[lo << (sh + 2)], b1 = tw[lo << (sh + 1)], b2 = tw[lo << sh];
+    const c2 b0 = tw[twi(lo << (sh + 2))], b1 = tw[twi(lo << (sh + 1))], b2 = tw[twi(lo << sh)];
     w7[0] = b0;
     w7[1] = b1; w7[2].x = b1.y; w7[2].y = -b1.x;
     w7[3] = b2;
@@ -432,7 +452,7 @@ BK_HD void fused_last2(const c2* zp, int N, int bits, int gp, Store2&& st2) {
 // pacc collects the pairs UNSCALED (times hs2^2 at the end), sacc the two self-paired indices (already scaled).
 template <int MODE, bool UPPER, bool DOT, class Sym>      // UPPER: k > N/2 -- the table holds k <= N/2 only
 BK_HD void mid_pair(c2& x, c2& y, int k, int N, const c2* ew, double hs2, double f2, Sym&& sym, c2& pacc) {
-    const c2 t = ew[UPPER ? N - k : k];
+    const c2 t = ew[twi(UPPER ? N - k : k)];
     c2 e, en;
     if (UPPER) { en = t; e.x = -t.y; e.y = -t.x; }
     else { e = t; en.x = -t.y; en.y = -t.x; }
@@ -458,7 +478,7 @@ BK_HD void mid_pair(c2& x, c2& y, int k, int N, const c2* ew, double hs2, double
 // k = 0 or k = N/2: the partner is the element itself (k = 0: fn = 0, scales s0).
 template <int MODE, bool DOT, class Sym>
 BK_HD void mid_single(c2& x, int k, const c2* ew, double hs, double fk, double fn, Sym&& sym, c2& sacc) {
-    const c2 e = ew[k];
+    const c2 e = ew[twi(k)];
     c2 X = x;
     if (MODE != 1) X = post_one(x, x, e, hs);
     if (MODE == 2) {

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <mutex>
 #include <vector>
 
 #include "ops.h"
@@ -34,7 +35,7 @@ struct FftK {
     int n0, n1, n2, axis, N, bits, LT, ltbits, inverse;   // ltbits = log2(LT) if LT is a power of two, else -1
     const double* in;
     double* out;
-    const double* twid;       // [N/2] complex exp(-2 pi i q/N), then [N] complex exp(-i pi k/2N)
+    const double* twid;       // dct_twiddle_table(N): tw_len(N) complex exp(-2 pi i q/N), then ew_len(N) complex exp(-i pi k/2N)
     const double* lam0;
     const double* lam1;
     const double* lam2;       // may be NULL (2-D)
@@ -52,6 +53,7 @@ struct FftK {
     int nt_load, nt_store;    // fused kernel: non-temporal hint on the tile loads / stores (every element is touched once)
     int ntiles;               // fused kernel: tiles of the pass (= workgroups)
     int xmap;                 // fused kernel: XCD-contiguous slot -> tile map (ntiles % 8 == 0)
+    int stagger, stag_cu;     // fused kernel: start offset of the workgroups that fill every CU's second slot (stag_cu = CUs)
 };
 
 template <int NT>
@@ -61,8 +63,9 @@ __global__ void __launch_bounds__(NT) dct_fft_kernel(FftK P) {
     const int npairs = LT >> 1;
     const int pstride = N + 1;                                // complex elements per pair (+1: bank skew)
     c2* z = reinterpret_cast<c2*>(smem);
-    c2* tw = z + (size_t)npairs * pstride;                    // N/2 FFT twiddles
-    const c2* ew = reinterpret_cast<const c2*>(P.twid) + half;   // post twiddles stay in global (read once)
+    c2* tw = z + (size_t)npairs * pstride;                    // N/2 FFT twiddles (dct_core.h: twi layout)
+    const int twl = dctc::tw_len(N);
+    const c2* ew = reinterpret_cast<const c2*>(P.twid) + twl;    // post twiddles stay in global (read once)
     const int tid = threadIdx.x;
 
     // ---- tile decode
@@ -86,7 +89,7 @@ __global__ void __launch_bounds__(NT) dct_fft_kernel(FftK P) {
         else { base = x0 + (size_t)P.n0 * other; estride = (size_t)P.n0 * P.n1; ti1 = other; }
     }
 
-    for (int q = tid; q < half; q += NT) tw[q] = reinterpret_cast<const c2*>(P.twid)[q];
+    for (int q = tid; q < twl; q += NT) tw[q] = reinterpret_cast<const c2*>(P.twid)[q];
 
     // ---- load: one work item = one complex LDS element = the same sample n of the two lines (2p, 2p+1) of a pair.
     // axis 0: consecutive items walk along n (both rows coalesced); axis >= 1: consecutive items are consecutive pairs,
@@ -350,9 +353,10 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
     const int npairs = P.LT >> 1, pbits = P.ltbits - 1;
     const int pstride = N + 1;
     c2* z = reinterpret_cast<c2*>(smem);
-    c2* tw = z + (size_t)npairs * pstride;                    // N/2 FFT twiddles
-    c2* ew = tw + (N >> 1);                                   // N/2 + 1 post twiddles exp(-i pi k / 2N), k <= N/2
-    double* lamk = reinterpret_cast<double*>(ew + (N >> 1) + 2);   // MODE 2: eigenvalues along the transform axis
+    const int twl = dctc::tw_len(N), ewl = dctc::ew_len(N);
+    c2* tw = z + (size_t)npairs * pstride;                    // N/2 FFT twiddles (dct_core.h: twi layout, twl slots)
+    c2* ew = tw + twl;                                        // N/2 + 1 post twiddles exp(-i pi k / 2N), k <= N/2 (ewl slots)
+    double* lamk = reinterpret_cast<double*>(ew + ewl + 1);   // MODE 2: eigenvalues along the transform axis
     const int tid = threadIdx.x;
     const int nfirst = AX0 ? npairs * (G >> 1) : npairs * G;  // work items of the outer stages ...
     const int nmid = npairs * (G >> 1);                       // ... and of the merged middle
@@ -473,6 +477,14 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
         }
     };
     const int ntiles = P.ntiles;
+    // Start offset between the two tiles of a CU.  The first 2 x CUs workgroups fill both slots of every CU at launch
+    // (dispatch goes round-robin over the 8 XCDs, inside an XCD the first CUs/8 workgroups take the first slot of its CUs, the
+    // next CUs/8 the second); tiles that start together run their load / LDS / store phases in lockstep and compete for the
+    // same pipe instead of overlapping.  The second-slot workgroups sleep `stagger` x s_sleep(127) (~3.4 us each) first, and
+    // the offset persists down the pass because every slot picks up its next tile when its own tile retires.  Measured at the
+    // end of round 3 on the z round trip (experiment): 611 -> 564 us although the sleep is part of the kernel's duration.
+    if (P.stagger > 0 && (int)blockIdx.x < 2 * P.stag_cu && (int)(blockIdx.x >> 3) >= (P.stag_cu >> 3))
+        for (int i = 0; i < P.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     // workgroup slot -> tile.  xmap: the workgroups of one XCD (slot % 8: consecutive workgroups go round-robin over the
     // 8 XCDs) take a contiguous range of tiles, i.e. every XCD's L2 / TLB works on its own eighth of the array -- 10 % on
     // the x / y access pattern (profiles/r2_seg_copy_512_xmap.json), nothing for z (every tile touches every plane)
@@ -483,7 +495,7 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
         // wave consumes its own samples as they arrive.  Requesting the tile first and the tables behind it -- in either
         // form, tables stored before or after the first stage -- costs 20-30 % in every pass (measured): the in-order return
         // puts the short table loads behind 16 HBM loads per lane.
-        for (int q = tid; q < N + 1; q += NT) tw[q] = reinterpret_cast<const c2*>(P.twid)[q];
+        for (int q = tid; q < twl + ewl; q += NT) tw[q] = reinterpret_cast<const c2*>(P.twid)[q];
         if (MODE == 2)
             for (int q = tid; q < N; q += NT) lamk[q] = (P.axis == 1 ? P.lam1 : P.lam2)[q];
         issue(tile);
@@ -604,7 +616,7 @@ inline int choose_lt(int N, int axis, int n0, size_t rows, bool wide = false) {
         if (lt > 128) lt = 128;
         while (lt > 16 && (n0 % lt != 0 || ((size_t)(lt / 2) * (N + 1) + (size_t)(N + 4)) * 16 > 76 * 1024)) lt /= 2;
     }
-    while (lt > 2 && ((size_t)(lt / 2) * (N + 1) + (size_t)(N / 2)) * 16 > 76 * 1024) lt -= 2;
+    while (lt > 2 && ((size_t)(lt / 2) * (N + 1) + (size_t)dctc::tw_len(N)) * 16 > 76 * 1024) lt -= 2;
     if (axis == 0) {
         if ((size_t)lt > rows) lt = (int)((rows + 1) & ~(size_t)1);
     } else {
@@ -683,28 +695,31 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
         P.nt_store = big && ctx->opt("dct_nt_store", 1.0) != 0.0;
     }
     P.trace = nullptr;
-    const size_t lds = ((size_t)(P.LT / 2) * (P.N + 1) + (size_t)(P.N / 2)) * sizeof(c2);
-    static bool attr_set = false;
-    if (!attr_set) {
-        BK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dct_fft_kernel<256>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        BK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dct_fft_kernel<512>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        const void* fused[] = {reinterpret_cast<const void*>(dct_fused_kernel<256, 0, false, false>),
-                               reinterpret_cast<const void*>(dct_fused_kernel<256, 1, false, false>),
-                               reinterpret_cast<const void*>(dct_fused_kernel<256, 2, false, false>),
-                               reinterpret_cast<const void*>(dct_fused_kernel<256, 0, true, false>),
-                               reinterpret_cast<const void*>(dct_fused_kernel<256, 1, true, false>),
-                               reinterpret_cast<const void*>(dct_fused_kernel<256, 0, false, true>),
-                               reinterpret_cast<const void*>(dct_fused_kernel<256, 1, false, true>),
-                               reinterpret_cast<const void*>(dct_fused_kernel<256, 2, false, true>),
-                               reinterpret_cast<const void*>(dct_fused_kernel<256, 2, false, false, true>),
-                               reinterpret_cast<const void*>(dct_fused_kernel<256, 2, false, true, true>),
-                               reinterpret_cast<const void*>(dct_fused_kernel<256, 0, true, true>),
-                               reinterpret_cast<const void*>(dct_fused_kernel<256, 1, true, true>)};
-        for (const void* f : fused) BK_HIP(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        attr_set = true;
-    }
+    const size_t lds = ((size_t)(P.LT / 2) * (P.N + 1) + (size_t)dctc::tw_len(P.N)) * sizeof(c2);
+    // (linsolve2 drives two host threads through here concurrently: the attributes are set exactly once)
+    static std::once_flag attr_once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once, [] {
+        const void* fns[] = {reinterpret_cast<const void*>(dct_fft_kernel<256>),
+                             reinterpret_cast<const void*>(dct_fft_kernel<512>),
+                             reinterpret_cast<const void*>(dct_fused_kernel<256, 0, false, false>),
+                             reinterpret_cast<const void*>(dct_fused_kernel<256, 1, false, false>),
+                             reinterpret_cast<const void*>(dct_fused_kernel<256, 2, false, false>),
+                             reinterpret_cast<const void*>(dct_fused_kernel<256, 0, true, false>),
+                             reinterpret_cast<const void*>(dct_fused_kernel<256, 1, true, false>),
+                             reinterpret_cast<const void*>(dct_fused_kernel<256, 0, false, true>),
+                             reinterpret_cast<const void*>(dct_fused_kernel<256, 1, false, true>),
+                             reinterpret_cast<const void*>(dct_fused_kernel<256, 2, false, true>),
+                             reinterpret_cast<const void*>(dct_fused_kernel<256, 2, false, false, true>),
+                             reinterpret_cast<const void*>(dct_fused_kernel<256, 2, false, true, true>),
+                             reinterpret_cast<const void*>(dct_fused_kernel<256, 0, true, true>),
+                             reinterpret_cast<const void*>(dct_fused_kernel<256, 1, true, true>)};
+        for (const void* f : fns) {
+            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (e != hipSuccess) attr_err = e;
+        }
+    });
+    if (attr_err != hipSuccess) return set_error(ctx, "dct_axis_fft: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
     // 512 lanes per tile when the tile is big enough to feed them (two workgroups per CU => 16 wavefronts)
     const int nt = (int)ctx->opt("dct_threads", (size_t)P.LT * P.N >= 4096 ? 512.0 : 256.0);
     {
@@ -716,7 +731,7 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
         P.fast = (ctx->opt("dct_fastio", 1.0) != 0.0 && full_tiles && shapes) ? 1 : 0;
     }
     if (fused_ok && (P.LT == 16 || (axis != 0 && (P.LT == 32 || P.LT == 64 || P.LT == 128)))) {
-        const size_t ldsf = lds + ((size_t)(P.N / 2 + 2) + (P.roundtrip ? P.N / 2 : 0)) * sizeof(c2);
+        const size_t ldsf = lds + ((size_t)(dctc::ew_len(P.N) + 1) + (P.roundtrip ? P.N / 2 : 0)) * sizeof(c2);
         const bool trace = ctx->opt("dct_trace", 0.0) != 0.0;
         P.trace = nullptr;
         if (trace) {
@@ -724,6 +739,18 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
             BK_HIP(ctx, hipMemsetAsync(P.trace, 0, (size_t)grid * 8 * sizeof(long long), ctx->stream));
         }
         P.ntiles = (int)grid;
+        {
+            // per-pass start offset: option dct_stagger >= 0 overrides every pass; else dct_stagger_<axis><mode>
+            // (mode 0 forward, 1 inverse, 2 round trip); defaults swept at 512^3 (profiles/r4_dct_stagger_sweep.jsonl)
+            const int mode_ = P.roundtrip ? 2 : (P.inverse ? 1 : 0);
+            char key[32];
+            snprintf(key, sizeof(key), "dct_stagger_%d%d", axis, mode_);
+            static const int kDefault[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+            const double all = ctx->opt("dct_stagger", -1.0);
+            P.stag_cu = ctx->num_cu;
+            P.stagger = (int)(all >= 0.0 ? all : ctx->opt(key, (double)kDefault[axis][mode_]));
+            if ((int)grid < 2 * ctx->num_cu || ctx->num_cu % 8 != 0) P.stagger = 0;
+        }
         P.xmap = (grid % 8 == 0 && ((int)ctx->opt("dct_xcd_map", 3.0) >> axis & 1)) ? 1 : 0;   // bit per axis; default x, y
         const bool ntm = P.nt_load && P.nt_store;
         const int mode = P.roundtrip ? 2 : (P.inverse ? 1 : 0);

@@ -56,6 +56,7 @@ struct ShK {                // kernel-side copy of ShArgs (+ derived constants)
     const double* addv;     // FD kernels: out += addc * addv, and the block's share of v . out goes to dotp[tile]
     double addc;
     double* dotp;
+    int stagger, stag_cu;   // 3-D: start offset of the workgroups in each CU's second / third slot, in s_sleep(1) units per slot
 };
 
 // pointer to local plane lp in [-2, nz+2): halo buffers hold the two planes beyond each interior slab face
@@ -139,6 +140,13 @@ __global__ void __launch_bounds__(256, WPE) sh_stream_kernel(ShK P) {
     const int b = blockIdx.x;
     const int L = (b & 7) * (P.grid8 >> 3) + (b >> 3);
     if (L >= P.nblocks) return;
+    // Start offset (option sh_stagger): the 3 workgroups of a CU march along z in lockstep -- stage plane, barrier, 25-point
+    // update, store -- and so does the whole chip; slot s of each CU (dispatch order: the first CUs workgroups fill slot 0, ...)
+    // starts s x stagger x 64 cycles late, so that the load and the store phases of the three interleave.
+    if (DIM3 && P.stagger > 0 && b < 3 * P.stag_cu) {
+        const int slot = (b >> 3) / (P.stag_cu >> 3);
+        for (int i = 0; i < slot * P.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    }
     const int tix = L % P.ntx;
     const int tiy = (L / P.ntx) % P.nty;
     const int zc = P.zc0 + (L / (P.ntx * P.nty)) * P.zcstep;
@@ -566,6 +574,8 @@ int sh_apply(bk_ctx* ctx, const ShArgs& a) {
     P.l = a.l; P.nu = a.nu; P.a0 = a.a0; P.a1 = a.a1; P.mode = a.mode;
     P.v = a.v; P.u = a.u; P.out = a.out; P.halo_lo = a.halo_lo; P.halo_hi = a.halo_hi;
     P.addv = nullptr; P.addc = 0.0; P.dotp = nullptr;
+    P.stag_cu = ctx->num_cu;
+    P.stagger = ctx->num_cu % 8 == 0 ? (int)ctx->opt("sh_stagger", 0.0) : 0;
     if (a.dot_blocks) {
         if (!sh_fused_dot_ok(ctx, a)) return set_error(ctx, "sh_apply: fused dot requested on an unsupported path");
         P.addv = (a.addc != 0.0) ? a.addv : nullptr; P.addc = a.addc; P.dotp = ctx->d_partials;

@@ -566,12 +566,23 @@ template <int KB, int U, bool NT, bool LDNT, bool DEV>
 __global__ void __launch_bounds__(kThreads) multiaxpy_c_kernel(size_t n, const double* __restrict__ V, size_t ldv, int k, Coefs cf,
                                                                const double* src, double scale, double* dst, int want_norm,
                                                                double* __restrict__ partials,
-                                                               const double* __restrict__ dcoef, int gated) {
+                                                               const double* __restrict__ dcoef, int gated, int stag) {
     if (DEV) {
         if (gated && dcoef[kMaxBasis + 1] == 0.0) return;
         scale = dcoef[kMaxBasis];
 #pragma unroll
         for (int j = 0; j < KB; ++j) cf.c[j] = j < k ? dcoef[j] : 0.0;
+    }
+    // Start offsets (option axpy_stagger; low byte = phases P, next byte = map, rest = sleep units per burst).  Every
+    // workgroup alternates k + 1 read bursts with ONE write burst per iteration; launched together they stay in step, and the
+    // DRAM sees the read and the write phases of the whole chip alternate instead of a steady mix.  Workgroup b starts
+    // (phase / P) of one iteration late: phase = (b / 8) % P (alternating CUs of an XCD; map 0) or (b / 256) % P (the two
+    // workgroups of a CU; map 1); one burst of the chip takes `units` x s_sleep(1).
+    if (stag > 0) {
+        const int P = stag & 255, map = (stag >> 8) & 255, units = stag >> 16;
+        const int ph = (map == 0 ? (int)(blockIdx.x >> 3) : (int)(blockIdx.x >> 8)) % P;
+        const int nburst = ((k + 2) * ph) / P;
+        for (int i = 0; i < nburst * units; ++i) __builtin_amdgcn_s_sleep(1);
     }
     double nn = 0.0;
     stream_loop<U>(n >> 1, [&](auto uc, size_t i0, size_t st) {
@@ -914,10 +925,18 @@ static void launch_multidot_gram(bk_ctx* ctx, int grid, size_t n, const double* 
 }
 static void launch_multiaxpy_burst(bk_ctx* ctx, int grid, size_t n, const double* V, size_t ldv, int k, const Coefs& cf, const double* src,
                                    double scale, double* dst, int want_norm, const double* dcoef, int gated) {
+    // start offsets: P phases (option axpy_stagger), map (axpy_stagger_map), s_sleep(1) units per chip-wide burst
+    // (axpy_stagger_units: 512 workgroups x 16 KiB at ~5.7 TB/s = 1.5 us = 55 x 64 cycles)
+    int stag = 0;
+    {
+        const int P = (int)ctx->opt("axpy_stagger", 0.0);
+        if (P > 1 && P < 256 && grid >= 2 * P)
+            stag = P | (((int)ctx->opt("axpy_stagger_map", 0.0) & 255) << 8) | (((int)ctx->opt("axpy_stagger_units", 55.0) & 0x7fff) << 16);
+    }
 #define BK_MAC(KB)                                                                                                                                  \
     do {                                                                                                                                           \
-        if (dcoef) hipLaunchKernelGGL((multiaxpy_c_kernel<KB, 4, true, true, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials, dcoef, gated); \
-        else hipLaunchKernelGGL((multiaxpy_c_kernel<KB, 4, true, true, false>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials, dcoef, gated);     \
+        if (dcoef) hipLaunchKernelGGL((multiaxpy_c_kernel<KB, 4, true, true, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials, dcoef, gated, stag); \
+        else hipLaunchKernelGGL((multiaxpy_c_kernel<KB, 4, true, true, false>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, cf, src, scale, dst, want_norm, ctx->d_partials, dcoef, gated, stag);     \
     } while (0)
     if (k <= 4) BK_MAC(4);
     else if (k <= 8) BK_MAC(8);

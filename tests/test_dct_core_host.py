@@ -10,15 +10,15 @@ import scipy.fft as sfft
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-# "product": bifurcationkit.jl_amd/csrc/dct_core.h;  "candidate": experiments/lds_conflicts/dct_core_next.h -- the same header
-# with the XOR swizzle and padded twiddle tables that the bank-conflict model prefers (staged for round 4, not in the library)
-@pytest.fixture(scope="module", params=["product", "candidate"])
+# "product": the layout the library is built with (dct_core.h: BK_DCT_LAYOUT 1 -- the XOR swizzle and padded twiddle tables
+# the bank-conflict model prefers); "round3": BK_DCT_LAYOUT 0, the previous layout kept as the A/B reference
+@pytest.fixture(scope="module", params=["product", "round3"])
 def exe(request, tmp_path_factory):
     out = tmp_path_factory.mktemp("dct") / ("dct_core_check_" + request.param)
-    cmd = ["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "dct_core_check.cpp"), "-o", str(out)]
-    if request.param == "candidate":
-        cmd += ['-DBK_DCT_CORE_H="%s"' % os.path.join(ROOT, "experiments", "lds_conflicts", "dct_core_next.h"),
-                "-DBK_DCT_TWI(j)=bk::dctc::twi(j)"]
+    cmd = ["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "dct_core_check.cpp"), "-o", str(out),
+           "-DBK_DCT_TWI(j)=bk::dctc::twi(j)"]
+    if request.param == "round3":
+        cmd += ["-DBK_DCT_LAYOUT=0"]
     subprocess.run(cmd, check=True)
     return str(out)
 
@@ -73,15 +73,3 @@ def test_fused_roundtrip_spectral_dot_is_the_physical_dot(exe, N):
     za, zb = idct(sa * dct(a)), idct(sb * dct(b))
     assert np.abs(o[:N, 0] - za).max() < 1e-13 and np.abs(o[:N, 1] - zb).max() < 1e-13
     assert abs(o[N, 0] - a @ za) < 1e-13 * abs(a @ za) * N and abs(o[N, 1] - b @ zb) < 1e-13 * abs(b @ zb) * N
-
-
-@pytest.mark.parametrize("N", [64, 256, 512, 1024])
-def test_lane_pair_split_of_the_merged_middle_matches_fused_mid(tmp_path_factory, N):
-    """experiments/zpass512 (staged, not in the library): the merged middle split across lane pairs -- one radix-8 group per
-    lane, partners exchanged in four steps, one code path for every role -- replayed for two lanes in lockstep; it must
-    reproduce the product's fused_mid<2> (output and spectral dot).  The harness exits non-zero beyond 1e-13."""
-    out = tmp_path_factory.mktemp("split") / "host_check"
-    src = os.path.join(ROOT, "experiments", "zpass512", "host_check.cpp")
-    subprocess.run(["g++", "-O2", "-std=c++17", src, "-o", str(out)], check=True)
-    r = subprocess.run([str(out), str(N)], capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout + r.stderr
