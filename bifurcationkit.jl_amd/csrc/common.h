@@ -171,6 +171,10 @@ int v_multidot_gram(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, c
 // squared 2-norm of dst is returned (global).  dst may alias src.
 int v_multiaxpy(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const double* c,
                 const double* src, double scale, double* dst, double* nrm2sq);
+// block Arnoldi step (sstep.h): the two streaming passes of s Arnoldi steps at once
+bool v_block_ok(bk_ctx* ctx, size_t n, const double* V, size_t ldv);
+int v_block_dots(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int kold, int r0, int nr, double* D, double* T);
+int v_block_axpy(bk_ctx* ctx, size_t n, double* V, size_t ldv, int k, int s, const double* Cm, const double* Tm);
 // device-resident orthogonalisation step (vecops.hip): rec / coef are device buffers of kMaxBasis + 2 doubles
 // gram != NULL: the Gram-corrected single-pass step (device Gram matrix, (kMaxBasis + 1)^2 doubles, owned by the caller)
 int v_arnoldi_step_dev(bk_ctx* ctx, size_t n, double* V, size_t ldv, int k, const double* w, double eta, double orth_tol,

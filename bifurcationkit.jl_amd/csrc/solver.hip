@@ -19,6 +19,7 @@
 
 #include "dense.h"
 #include "ops.h"
+#include "sstep.h"
 
 namespace bk {
 
@@ -201,6 +202,30 @@ int arnoldi_step(bk_ctx* ctx, bk_op* A, Basis& B, int j, double* w, double* h, d
     return 0;
 }
 
+// s Arnoldi steps from V[j] as ONE block (sstep.h): p_{i+1} = A p_i straight into the basis slots j+1 .. j+s, one pass of dots
+// over the basis and the block, the coefficient algebra on the host, one update pass in place.  Against the per-step pair of
+// passes (2k + 3 vector streams per step) a block moves 2k + 3s - 1 .. 2k + 3s + 8 streams per s steps; at 512^3 the two
+// Gram-Schmidt passes were 46 % of the corrector.  On return *status = 0 and the raw Hessenberg columns j .. j+s-1 are in Hraw,
+// or *status = 1: the block was numerically rank deficient (or out of the kernels' range) and the caller repeats the steps one
+// at a time from V[j] (the measured Gram matrix stays valid up to and including column j - 1).
+int arnoldi_block(bk_ctx* ctx, bk_op* A, Basis& B, int j, int s, double* Hraw, int ldh, double op_a0, double op_a1, int* status) {
+    const size_t n = A->n;
+    const int k = j + 1, u = k - B.gram_n;
+    *status = 1;
+    if (A->ntail != 0 || !B.use_gram || u < 0 || u > sstep::kS || s < 1 || s > sstep::kS || u + s > sstep::kR || k > 32 ||
+        !v_block_ok(ctx, n, B.V, B.ld))
+        return 0;
+    for (int i = 0; i < s; ++i) BK_TRY(A->apply(B.vec(j + i), nullptr, op_a0, op_a1, B.vec(j + i + 1), nullptr));
+    double D[33 * sstep::kR], T[sstep::kTri], Cm[32 * sstep::kS], Tm[sstep::kS * sstep::kS];
+    BK_TRY(v_block_dots(ctx, n, B.V, B.ld, k - u, k - u, u + s, D, T));
+    const int st = sstep::block_coefficients(k, u, s, D, T, B.G.data(), kMaxBasis + 1, Hraw, ldh, Cm, Tm);
+    B.gram_n = st == 0 ? k : j;                      // (a refused block: column j is measured again by the single step)
+    if (st != 0) return 0;
+    BK_TRY(v_block_axpy(ctx, n, B.V, B.ld, k, s, Cm, Tm));
+    *status = 0;
+    return 0;
+}
+
 }  // namespace
 
 // Arnoldi step on a caller-owned basis (eig.hip)
@@ -265,8 +290,19 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     // host path never joins): it does not look at the rank-local length at all -- ragged z-slabs may straddle any size
     // threshold -- only at options and at the communicator kind.
     const bool rccl_ranks = ctx->comm == COMM_RCCL && ctx->nranks > 1;
+    // Block Arnoldi (round 4, option gmres_sstep = largest block, default 4 for vectors that stream from HBM, 0 = off): s
+    // operator applications, then ONE pair of Gram-Schmidt passes for the s steps (arnoldi_block, sstep.h).  The steps of a
+    // block are speculated like the device-resident chunks -- the convergence-predicted cap below applies -- and the host
+    // consumes the Hessenberg columns one at a time with the same Givens / stopping logic, so iterates and counters are those
+    // of the step-by-step run.  The decision looks at options and the GLOBAL problem only (every rank takes the same one).
+    // (ranks: always on -- a rank-local length must not decide, ragged z-slabs may straddle any threshold; a negative value = default)
+    const double sstep_opt = ctx->opt("gmres_sstep", -1.0);
+    const int sstep_max = std::min(sstep_opt < 0.0 ? ((ctx->nranks > 1 || n > ((size_t)1 << 20)) ? 4 : 0) : (int)sstep_opt, sstep::kS);
+    const bool sstep_on = sstep_max >= 1 && nt == 0 && B.use_gram && m >= 2 && v_block_ok(ctx, n, B.V, B.ld);
+    const int ldh = m + 2;
+    std::vector<double> Hraw(sstep_on ? (size_t)ldh * m : 0, 0.0);   // raw (unrotated) Hessenberg columns of the cycle
     int chunk = (int)ctx->opt("gmres_chunk", 4.0);
-    if (nt != 0 || (ctx->comm == COMM_HOST && ctx->nranks > 1) || chunk < 2 || !ctx->h_rec_dev) chunk = 1;
+    if (nt != 0 || (ctx->comm == COMM_HOST && ctx->nranks > 1) || chunk < 2 || !ctx->h_rec_dev || sstep_on) chunk = 1;
     if (chunk > kRecChunks) chunk = kRecChunks;
     // Speculation cap from the residual history (all quantities are all-reduced, i.e. identical on every rank): with the
     // last reduction factor rho = beta_k / beta_{k-1} the estimate reaches the tolerance after `need` further steps; never
@@ -274,7 +310,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     // step is rarely wasted, and when the prediction was too optimistic the next chunk simply follows.  For vectors that
     // stream from HBM a wasted step is a whole operator application; the cache-resident sizes keep the plain ramp
     // (option gmres_predict: 1 = always, 0 = never, default: HBM-sized vectors and RCCL ranks).
-    const bool predict = ctx->opt("gmres_predict", (rccl_ranks || n > ((size_t)1 << 20)) ? 1.0 : 0.0) != 0.0;
+    const bool predict = ctx->opt("gmres_predict", (rccl_ranks || sstep_on || n > ((size_t)1 << 20)) ? 1.0 : 0.0) != 0.0;
     double beta_prev = 0.0, beta_now = 0.0, tol_now = 0.0;
     double* d_coef = nullptr;
     const double* h_rec = ctx->h_rec;          // the records land in pinned, device-mapped host memory: no copy operation
@@ -290,6 +326,26 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     if (chunk > 1 && B.use_gram) BK_TRY(ws.get((size_t)(kMaxBasis + 1) * (kMaxBasis + 1), &d_gram));
     // next Hessenberg column (Arnoldi step from V[j]): from the queue of device-computed columns, else computed now
     auto next_column = [&](int j, double* hcol, double* hnext_out) -> int {
+        if (sstep_on && !cycle_on_host) {
+            if (!(q_count > 0 && j >= q_first && j < q_first + q_count)) {
+                int steps = std::min(sstep_max, m - j);
+                if (predict && steps > 1 && beta_now > 0.0) {
+                    const double rho = (beta_prev > 0.0 && beta_now < beta_prev) ? beta_now / beta_prev : 1.0;
+                    int need = 1;
+                    for (double b_ = beta_now * rho; b_ > 2.0 * tol_now && need < steps; b_ *= rho) ++need;
+                    steps = need;
+                }
+                int st = 1;
+                BK_TRY(arnoldi_block(ctx, A, B, j, steps, Hraw.data(), ldh, op_a0, op_a1, &st));
+                if (st == 0) { q_first = j; q_count = steps; }
+                else { cycle_on_host = true; q_count = 0; }      // refused: the rest of the cycle runs step by step
+            }
+            if (!cycle_on_host) {
+                for (int i = 0; i <= j; ++i) hcol[i] = Hraw[(size_t)i + (size_t)j * ldh];
+                *hnext_out = Hraw[(size_t)(j + 1) + (size_t)j * ldh];
+                return 0;
+            }
+        }
         if (chunk > 1 && !cycle_on_host) {
             if (!(q_count > 0 && j >= q_first && j < q_first + q_count)) {
                 int steps = std::min(std::min(ramp, chunk), m - j);

@@ -9,6 +9,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "sstep.h"
 
 namespace bk {
 
@@ -627,6 +628,168 @@ __global__ void __launch_bounds__(kThreads) multiaxpy_c_kernel(size_t n, const d
     }
 }
 
+// ------------------------------------------------------------------ block Arnoldi step (sstep.h; solver.hip: arnoldi_block)
+// Pass 1 of a block: the dots of up to KB basis vectors V_i with up to 8 RIGHT-HAND vectors held in registers -- the u basis
+// vectors the previous block created (their Gram columns are still unmeasured) followed by the s new block vectors; all of them
+// are consecutive basis slots starting at Rv -- and (TRI) the upper triangle of the right-hand vectors' own dots.  One visit of
+// every stream for what the single-vector step read s times.  Per workgroup: KB x 8 values [i * 8 + r], then the 36 triangle
+// values (sstep::tri order).  Unused right-hand slots (r >= nr) are never loaded and contribute exact zeros.
+template <int KB, bool TRI, int U, bool LDNT>
+__global__ void __launch_bounds__(kThreads) block_dots_kernel(size_t n, const double* __restrict__ V, size_t ldv, int kb,
+                                                              const double* __restrict__ Rv, int nr, double* __restrict__ partials) {
+    constexpr int NR = sstep::kR, NT3 = TRI ? sstep::kTri : 1;
+    double acc[KB > 0 ? KB : 1][NR], tri[NT3];
+#pragma unroll
+    for (int i = 0; i < (KB > 0 ? KB : 1); ++i)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) acc[i][r] = 0.0;
+#pragma unroll
+    for (int t = 0; t < NT3; ++t) tri[t] = 0.0;
+    stream_loop<U>(n >> 1, [&](auto uc, size_t i0, size_t st) {
+        constexpr int UU = decltype(uc)::value;
+        double2 rv[NR][UU];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (r < nr) {
+#pragma unroll
+                for (int u = 0; u < UU; ++u) rv[r][u] = ld2<LDNT>(Rv + (size_t)r * ldv, i0 + u * st);
+            } else {
+#pragma unroll
+                for (int u = 0; u < UU; ++u) rv[r][u] = make_double2(0.0, 0.0);
+            }
+        }
+        if (TRI) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int c = r; c < NR; ++c) {
+                    double a = tri[TRI ? r * NR - r * (r - 1) / 2 + (c - r) : 0];
+#pragma unroll
+                    for (int u = 0; u < UU; ++u) { a = fma(rv[r][u].x, rv[c][u].x, a); a = fma(rv[r][u].y, rv[c][u].y, a); }
+                    tri[TRI ? r * NR - r * (r - 1) / 2 + (c - r) : 0] = a;
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+            if (i < kb) {
+                double2 vv[UU];
+#pragma unroll
+                for (int u = 0; u < UU; ++u) vv[u] = ld2<LDNT>(V + (size_t)i * ldv, i0 + u * st);
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+#pragma unroll
+                    for (int u = 0; u < UU; ++u) { acc[i][r] = fma(vv[u].x, rv[r][u].x, acc[i][r]); acc[i][r] = fma(vv[u].y, rv[r][u].y, acc[i][r]); }
+            }
+        }
+    });
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        double rl[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) rl[r] = r < nr ? Rv[(size_t)r * ldv + n - 1] : 0.0;
+        if (TRI) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int c = r; c < NR; ++c) tri[TRI ? r * NR - r * (r - 1) / 2 + (c - r) : 0] = fma(rl[r], rl[c], tri[TRI ? r * NR - r * (r - 1) / 2 + (c - r) : 0]);
+        }
+#pragma unroll
+        for (int i = 0; i < KB; ++i)
+            if (i < kb) {
+                const double vl = V[(size_t)i * ldv + n - 1];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) acc[i][r] = fma(vl, rl[r], acc[i][r]);
+            }
+    }
+    constexpr int NV = KB * NR + (TRI ? sstep::kTri : 0);
+    __shared__ double sm[4][NV];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < KB; ++i)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const double s_ = wave_sum(acc[i][r]);
+            if (lane == 0) sm[wid][i * NR + r] = s_;
+        }
+    if (TRI) {
+#pragma unroll
+        for (int t = 0; t < NT3; ++t) {
+            const double s_ = wave_sum(tri[t]);
+            if (lane == 0) sm[wid][KB * NR + t] = s_;
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < NV; j += kThreads)
+        partials[(size_t)blockIdx.x * NV + j] = (sm[0][j] + sm[1][j]) + (sm[2][j] + sm[3][j]);
+}
+
+// Pass 2 of a block: the s new basis vectors in place over the block vectors,
+//   out_q = sum_{r <= q} T(r, q) P_r + sum_{i < k} C(i, q) V_i,   q < s
+// (T = R^-1 upper triangular, C = -(G^-1 Q'P) R^-1: sstep.h).  Every lane reads the s block values of its elements before it
+// writes them, so the update is safe in place; reads k + s streams, writes s.
+struct BlockCoefs {
+    double c[32][sstep::kS];
+    double t[sstep::kS][sstep::kS];
+};
+template <int KB, int U, bool LDNT>
+__global__ void __launch_bounds__(kThreads) block_axpy_kernel(size_t n, const double* V, size_t ldv, int k, double* Pv, int s,
+                                                              BlockCoefs cf) {
+    constexpr int S = sstep::kS;
+    stream_loop<U>(n >> 1, [&](auto uc, size_t i0, size_t st) {
+        constexpr int UU = decltype(uc)::value;
+        double2 acc[S][UU];
+#pragma unroll
+        for (int q = 0; q < S; ++q)
+#pragma unroll
+            for (int u = 0; u < UU; ++u) acc[q][u] = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int r = 0; r < S; ++r) {
+            if (r < s) {
+                double2 pv[UU];
+#pragma unroll
+                for (int u = 0; u < UU; ++u) pv[u] = ld2<LDNT>(Pv + (size_t)r * ldv, i0 + u * st);
+#pragma unroll
+                for (int q = r; q < S; ++q)
+#pragma unroll
+                    for (int u = 0; u < UU; ++u) { acc[q][u].x = fma(cf.t[r][q], pv[u].x, acc[q][u].x); acc[q][u].y = fma(cf.t[r][q], pv[u].y, acc[q][u].y); }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+            if (i < k) {
+                double2 vv[UU];
+#pragma unroll
+                for (int u = 0; u < UU; ++u) vv[u] = ld2<LDNT>(V + (size_t)i * ldv, i0 + u * st);
+#pragma unroll
+                for (int q = 0; q < S; ++q)
+#pragma unroll
+                    for (int u = 0; u < UU; ++u) { acc[q][u].x = fma(cf.c[i][q], vv[u].x, acc[q][u].x); acc[q][u].y = fma(cf.c[i][q], vv[u].y, acc[q][u].y); }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < S; ++q) {
+            if (q < s) {
+#pragma unroll
+                for (int u = 0; u < UU; ++u) {
+                    if (LDNT) st2nt(Pv + (size_t)q * ldv, i0 + u * st, acc[q][u]);
+                    else reinterpret_cast<double2*>(Pv + (size_t)q * ldv)[i0 + u * st] = acc[q][u];
+                }
+            }
+        }
+    });
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const size_t e = n - 1;
+        double pl[S], o[S];
+        for (int r = 0; r < S; ++r) pl[r] = r < s ? Pv[(size_t)r * ldv + e] : 0.0;
+        for (int q = 0; q < S; ++q) {
+            double v = 0.0;
+            for (int r = 0; r <= q; ++r) v = fma(cf.t[r][q], pl[r], v);
+            for (int i = 0; i < k && i < KB; ++i) v = fma(cf.c[i][q], V[(size_t)i * ldv + e], v);
+            o[q] = v;
+        }
+        for (int q = 0; q < s; ++q) Pv[(size_t)q * ldv + e] = o[q];
+    }
+}
+
 // second reduction stage into a DEVICE buffer: the same fixed summation order as reduce_stage2_kernel (context.hip), so the
 // device-resident and the host-driven Arnoldi steps produce bitwise identical projections
 __global__ void __launch_bounds__(256) reduce_stage2_dev(const double* __restrict__ partials, int nblocks, int nvals,
@@ -1011,6 +1174,70 @@ int v_multidot_gram(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, c
     BK_TRY(reduce_finish(ctx, grid, 2 * k1 + 1, 0));
     for (int j = 0; j < k1; ++j) { out[k0 + j] = ctx->h_red[j]; gram[k0 + j] = ctx->h_red[k1 + 1 + j]; }
     out[k] = ctx->h_red[k1];
+    return 0;
+}
+
+// ---- block Arnoldi step (sstep.h): pass 1 -- D[i * 8 + r] = <V_i, rhs_r> for the k_old measured basis vectors, T = the packed
+// upper triangle of the right-hand vectors' own dots; rhs_r = basis slot r0 + r, r < nr.  The first launch carries the triangle
+// and up to 4 basis vectors, every further one 8 basis vectors (register budget: 68 / 64 accumulators); the right-hand vectors are
+// re-read by every launch.  One global reduction (and host synchronisation) per launch.
+bool v_block_ok(bk_ctx* ctx, size_t n, const double* V, size_t ldv) { return n >= 2 && aligned16(V) && (ldv % 2 == 0); }
+int v_block_dots(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int kold, int r0, int nr, double* D, double* T) {
+    if (kold < 0 || kold > kMaxBasis || nr < 1 || nr > sstep::kR) return set_error(ctx, "v_block_dots: bad sizes");
+    const bool nt = nt_hint(ctx, n);
+    const int grid = nt ? burst_grid(ctx, n, "dot_blocks") : grid_for(n, 2 * 2, 512);
+    const double* Rv = V + (size_t)r0 * ldv;
+    {
+        const int kb = std::min(kold, 4);
+        {
+            ProfScope ps(ctx, "multidot", 8.0 * n * (kb + nr));
+            if (nt) hipLaunchKernelGGL((block_dots_kernel<4, true, 2, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, kb, Rv, nr, ctx->d_partials);
+            else hipLaunchKernelGGL((block_dots_kernel<4, true, 2, false>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, kb, Rv, nr, ctx->d_partials);
+            BK_HIP(ctx, hipGetLastError());
+        }
+        constexpr int NV = 4 * sstep::kR + sstep::kTri;
+        BK_TRY(reduce_finish(ctx, grid, NV, 0));
+        for (int i = 0; i < kb; ++i)
+            for (int r = 0; r < sstep::kR; ++r) D[i * sstep::kR + r] = ctx->h_red[i * sstep::kR + r];
+        for (int t = 0; t < sstep::kTri; ++t) T[t] = ctx->h_red[4 * sstep::kR + t];
+    }
+    for (int i0 = 4; i0 < kold; i0 += 8) {
+        const int kb = std::min(kold - i0, 8);
+        {
+            ProfScope ps(ctx, "multidot", 8.0 * n * (kb + nr));
+            if (nt) hipLaunchKernelGGL((block_dots_kernel<8, false, 2, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V + (size_t)i0 * ldv, ldv, kb, Rv, nr, ctx->d_partials);
+            else hipLaunchKernelGGL((block_dots_kernel<8, false, 2, false>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V + (size_t)i0 * ldv, ldv, kb, Rv, nr, ctx->d_partials);
+            BK_HIP(ctx, hipGetLastError());
+        }
+        BK_TRY(reduce_finish(ctx, grid, 8 * sstep::kR, 0));
+        for (int i = 0; i < kb; ++i)
+            for (int r = 0; r < sstep::kR; ++r) D[(i0 + i) * sstep::kR + r] = ctx->h_red[i * sstep::kR + r];
+    }
+    return 0;
+}
+
+// pass 2: basis slots k .. k + s - 1 <- the s new basis vectors (Cm: k x 4 row-major, Tm: 4 x 4 row-major upper; sstep.h)
+int v_block_axpy(bk_ctx* ctx, size_t n, double* V, size_t ldv, int k, int s, const double* Cm, const double* Tm) {
+    if (k < 1 || k > 32 || s < 1 || s > sstep::kS) return set_error(ctx, "v_block_axpy: bad sizes");
+    BlockCoefs cf;
+    for (int i = 0; i < 32; ++i)
+        for (int q = 0; q < sstep::kS; ++q) cf.c[i][q] = i < k ? Cm[i * sstep::kS + q] : 0.0;
+    for (int r = 0; r < sstep::kS; ++r)
+        for (int q = 0; q < sstep::kS; ++q) cf.t[r][q] = Tm[r * sstep::kS + q];
+    const bool nt = nt_hint(ctx, n);
+    const int grid = nt ? burst_grid(ctx, n, "axpy_burst_blocks") : grid_for(n, 2 * 2, 1024);
+    double* Pv = V + (size_t)k * ldv;
+    ProfScope ps(ctx, "multiaxpy", 8.0 * n * (k + 2 * s));
+#define BK_BAX(KB)                                                                                                                          \
+    do {                                                                                                                                    \
+        if (nt) hipLaunchKernelGGL((block_axpy_kernel<KB, 4, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, Pv, s, cf);   \
+        else hipLaunchKernelGGL((block_axpy_kernel<KB, 4, false>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, k, Pv, s, cf);     \
+    } while (0)
+    if (k <= 8) BK_BAX(8);
+    else if (k <= 16) BK_BAX(16);
+    else BK_BAX(32);
+#undef BK_BAX
+    BK_HIP(ctx, hipGetLastError());
     return 0;
 }
 

@@ -206,6 +206,157 @@ def gmres_krylovkit(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-
     return x, False, numops, beta
 
 
+def block_arnoldi_coefficients(G, H, k, u, s, Aq, Gp, pivot_tol=1e-9):
+    """Host algebra of the library's BLOCK Arnoldi step restated (csrc/sstep.h: block_coefficients).  ``G``: measured Gram
+    matrix (valid for all k basis vectors on entry), ``H``: raw Hessenberg (columns 0..k-2 valid), ``Aq`` = Q'P (k x s),
+    ``Gp`` = P'P.  Returns (C, R) with P = Q C + Q_new R, and writes columns k-1 .. k+s-2 of H; None if the block is
+    numerically rank deficient."""
+    j = k - 1
+    C = np.linalg.solve(G[:k, :k], Aq)
+    S = Gp - 0.5 * (C.T @ Aq + Aq.T @ C)
+    try:
+        R = np.linalg.cholesky(S).T
+    except np.linalg.LinAlgError:
+        return None
+    if np.any(np.diag(R) ** 2 <= pivot_tol * np.diag(Gp)):
+        return None
+    Pc = np.vstack([C, R])
+    Bc = np.zeros((k + s, s))
+    Bc[j, 0] = 1.0
+    Bc[:, 1:] = Pc[:, :s - 1]
+    rhs = Pc.copy()
+    rhs[:k] -= H[:k, :j] @ Bc[:j]
+    U = np.vstack([Bc[j:j + 1], Bc[k:k + s - 1]])
+    H[:k + s, j:j + s] = sla.solve_triangular(U, rhs.T, trans="T", lower=False).T
+    for q in range(s):
+        H[j + q + 2:k + s, j + q] = 0.0
+    return C, R
+
+
+def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, rtol=1e-12, Pl=None, block=4,
+                history=None, basis_out=None, stats=None):
+    """The library's GMRES for vectors that stream from HBM since round 4, restated (csrc/solver.hip: gmres_core with
+    arnoldi_block): KrylovKit's restarted GMRES -- same stopping rules, restart and numops bookkeeping as gmres_krylovkit
+    above -- whose Arnoldi steps are taken in BLOCKS of up to ``block``: p_1 = A q_j, .., p_s = A p_{s-1}, then ONE pass of
+    projections (Q'P, P'P and the Gram columns of the previous block's vectors) and ONE update pass for the s steps.  The
+    projection uses the MEASURED Gram matrix (C = G^-1 Q'P: the block form of GramCGS above), the new vectors come from the
+    Cholesky factor of the projected block's Gram matrix, the s Hessenberg columns from the change of basis.  The block size
+    is capped by the number of steps the residual estimate predicts to need, so no operator application is wasted in the
+    cases at hand (``stats['wasted']``); numops counts consumed steps, as the library does.  Not a reference algorithm: the
+    tests show it reproduces the reference restatement's counts, residual history and solution."""
+    if Pl is not None:
+        A_, a0_, a1_ = A, a0, a1
+        lin = lambda dx: a1_ * Pl(apply(A_, dx)) + a0_ * dx
+        return gmres_block(lin, Pl(np.asarray(b, dtype=float)), 0.0, 1.0, krylovdim=krylovdim, maxiter=maxiter, atol=atol,
+                           rtol=rtol, block=block, history=history, basis_out=basis_out, stats=stats)
+    b = np.asarray(b, dtype=float)
+    n = b.shape[0]
+    x = np.zeros(n)
+    r = b.copy()
+    numops = 1
+    beta = np.linalg.norm(r)
+    tol = max(atol, rtol * np.linalg.norm(b))
+    if stats is None:
+        stats = {}
+    stats.update(wasted=0, refused=0, blocks=[])
+    if beta < tol:
+        return x, True, numops, beta
+    m = krylovdim
+    for numiter in range(1, maxiter + 1):
+        Q = np.zeros((m + 1, n))
+        H = np.zeros((m + 2, m))
+        G = np.eye(m + 1)
+        Q[0] = r / beta
+        cs, sn, y, Rm = np.zeros(m), np.zeros(m), np.zeros(m + 1), np.zeros((m, m))
+        y[0] = beta
+        j, gram_n, k_done = 0, 0, 0
+        res, res_prev = beta, None
+        classic = False
+        while j < m and res > tol:
+            k = j + 1
+            sb = min(block, m - j)
+            if res_prev is not None and sb > 1:
+                rho = res / res_prev if res < res_prev else 1.0
+                need, bb = 1, res * rho
+                while bb > 2.0 * tol and need < sb:
+                    bb *= rho
+                    need += 1
+                sb = need
+            done = False
+            if not classic:
+                P = np.zeros((sb, n))
+                p = Q[j]
+                for i in range(sb):
+                    p = apply(A, p)
+                    P[i] = p
+                u = k - gram_n
+                Gn = Q[:k] @ Q[k - u:k].T
+                G[:k, k - u:k] = Gn
+                G[k - u:k, :k] = Gn.T
+                gram_n = k
+                out = block_arnoldi_coefficients(G, H, k, u, sb, Q[:k] @ P.T, P @ P.T)
+                if out is None:
+                    classic = True                       # refused: the rest of the cycle runs step by step (MGS2 here)
+                    stats["refused"] += 1
+                else:
+                    C, R = out
+                    Q[k:k + sb] = sla.solve_triangular(R, P - C.T @ Q[:k], trans="T", lower=False)
+                    numops += sb
+                    stats["blocks"].append(sb)
+                    done = True
+            if not done:
+                sb = 1
+                w, h = _mgs2(apply(A, Q[j]), Q, k)
+                numops += 1
+                H[:k, j] = h
+                H[k, j] = np.linalg.norm(w)
+                Q[k] = w / H[k, j]
+            for jj in range(j, j + sb):
+                col = a1 * H[:jj + 2, jj]
+                col[jj] += a0
+                for i in range(jj):
+                    t = cs[i] * col[i] + sn[i] * col[i + 1]
+                    col[i + 1] = -sn[i] * col[i] + cs[i] * col[i + 1]
+                    col[i] = t
+                cs[jj], sn[jj], col[jj] = _givens(col[jj], col[jj + 1])
+                Rm[:jj + 1, jj] = col[:jj + 1]
+                y[jj + 1] = -sn[jj] * y[jj]
+                y[jj] = cs[jj] * y[jj]
+                res_prev, res = res, abs(y[jj + 1])
+                k_done = jj + 1
+                if history is not None:
+                    history.append(res)
+                if not res > tol:
+                    stats["wasted"] += j + sb - k_done
+                    numops -= j + sb - k_done
+                    break
+            j += sb
+        k = k_done
+        yk = sla.solve_triangular(Rm[:k, :k], y[:k])
+        x = x + Q[:k].T @ yk
+        if basis_out is not None:
+            basis_out.append(Q[:k].copy())
+        beta = res
+        if beta > tol:
+            z = np.zeros(k + 1)
+            z[k] = 1.0
+            for i in range(k - 1, -1, -1):
+                t = cs[i] * z[i] - sn[i] * z[i + 1]
+                z[i + 1] = sn[i] * z[i] + cs[i] * z[i + 1]
+                z[i] = t
+            r = y[k] * (Q[:k + 1].T @ z)
+        else:
+            r = b - a0 * x - a1 * apply(A, x)
+            numops += 1
+            beta = np.linalg.norm(r)
+            if beta < tol:
+                return x, True, numops, beta
+        beta = np.linalg.norm(r)
+        if numiter < maxiter:
+            numops += 0
+    return x, False, numops, beta
+
+
 def minres_krylovjl(A, b, a0=0.0, a1=1.0, *, atol=None, rtol=None, itmax=0, M=None):
     """Krylov.jl `minres` (KrylovLS(KrylovAlg = :minres), src/LinearSolver.jl:339-341: symmetric operator v -> a0 v + a1 A v,
     "centered" SPD preconditioner M = Pl passed as a callable applying Pl^-1): Paige-Saunders MINRES, x0 = 0, stop when

@@ -412,6 +412,56 @@ def test_device_resident_arnoldi_chunks_match_host_driven_steps(ctx, flavor):
             assert np.abs(xc - x1).max() <= 1e-9 * np.abs(x1).max()
 
 
+@pytest.mark.parametrize("grid", [((20, 18, 16), (np.pi, 3.0, 2.5)), ((21, 17, 13), (np.pi, 3.0, 2.5))])
+def test_block_arnoldi_steps_match_single_steps_and_the_oracle(ctx, grid):
+    """gmres_sstep = s (default 4 for vectors that stream from HBM; forced here on small grids): s operator applications, then
+    ONE pass of projections and ONE update pass for the s Arnoldi steps (vecops.hip: block_dots_kernel / block_axpy_kernel,
+    host algebra csrc/sstep.h).  Every block size must reproduce the step-by-step run -- same counters (no speculated step is
+    consumed past convergence), same solution -- and the oracle's restatements: KrylovKit's GMRES (MGS2, numops +-1) and the
+    block algorithm itself (oracle.krylov.gmres_block).  Cases: preconditioned without / with restarts, the shift applied to the
+    Hessenberg (KrylovKit flavor) and inside the operator (IterativeSolvers flavor, a0 I + J with a large a0: the monomial
+    block's worst case), an odd number of unknowns (the kernels' tail element)."""
+    hip = _hip()
+    dims, ls = grid
+    sh, prob, rng, u = _sh_setup(ctx, dims, ls)
+    J = prob.jacobian(prob.vec(u), 0.1)
+    Jm = sh.J(u, 0.1, 1.2)
+    P = hip.DCTPreconditioner(prob, 1.0)
+    Po = operators.dct_preconditioner(dims, ls, 1.0)
+    rhs = rng.standard_normal(sh.N)
+    big = 2.0 * abs(Jm).sum(axis=1).max()
+    cases = [("kk", dict(dim=30, rtol=1e-10, atol=1e-13, maxiter=150, Pl=P), (0.0, 1.0), dict(krylovdim=30, rtol=1e-10, atol=1e-13, maxiter=150, Pl=Po)),
+             ("kk", dict(dim=7, rtol=1e-9, atol=1e-13, maxiter=150, Pl=P), (0.0, 1.0), dict(krylovdim=7, rtol=1e-9, atol=1e-13, maxiter=150, Pl=Po)),
+             ("kk", dict(dim=30, rtol=1e-10, atol=1e-13, maxiter=150, Pl=P), (0.3, 0.9), dict(krylovdim=30, rtol=1e-10, atol=1e-13, maxiter=150, Pl=Po)),
+             ("is", dict(reltol=1e-10, restart=12, maxiter=500), (big, 1.0), None)]
+    ctx.set_option("gmres_chunk", 1)
+    try:
+        for flavor, kw, (a0, a1), okw in cases:
+            ls_ = hip.GMRESKrylovKit(**kw) if flavor == "kk" else hip.GMRESIterativeSolvers(**kw)
+            out = {}
+            for s_ in (0, 1, 2, 3, 4):
+                ctx.set_option("gmres_sstep", s_)
+                ctx.set_option("orth_probe", 1)
+                x, ok, it = ls_(J, prob.vec(rhs), a0, a1)
+                out[s_] = (x.numpy(), ok, it, ctx.get_option("gmres_last_orth_defect"))
+            x0, ok0, it0, _ = out[0]
+            assert ok0
+            for s_ in (1, 2, 3, 4):
+                xs, oks, its, defect = out[s_]
+                assert oks and its == it0, (flavor, kw, s_, its, it0)
+                assert np.abs(xs - x0).max() <= 1e-9 * np.abs(x0).max(), (flavor, s_)
+                assert defect <= 1e-6, (flavor, s_, defect)
+            if okw is not None:
+                xo, oko, nopso, _ = krylov.gmres_krylovkit(Jm, rhs, a0, a1, **okw)
+                xb, okb, nopsb, _ = krylov.gmres_block(Jm, rhs, a0, a1, block=4, **okw)
+                assert oko and okb and abs(out[4][2] - nopso) <= 1 and abs(out[4][2] - nopsb) <= 1, (out[4][2], nopso, nopsb)
+                assert np.abs(out[4][0] - xo).max() <= 1e-7 * np.abs(xo).max()
+    finally:
+        ctx.set_option("gmres_chunk", 4)
+        ctx.set_option("orth_probe", 0)
+        ctx.set_option("gmres_sstep", -1)
+
+
 @pytest.mark.parametrize("chunk", [1, 4])
 def test_single_pass_gram_schmidt_policy_bounds_the_measured_orthogonality_defect(ctx, chunk):
     """The Arnoldi step takes ONE classical Gram-Schmidt pass while its running estimate of the orthogonality defect

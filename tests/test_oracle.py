@@ -486,3 +486,50 @@ def test_gram_corrected_single_pass_gram_schmidt_reproduces_mgs2():
     # control: the uncorrected single pass loses orthogonality on the shifted operator (1e-6 after 13 steps, growing by rho per
     # step) where the Gram-corrected pass stays at rounding level
     assert out["cgs1"][4] > 1e-8 > 1e3 * out["cgs_gram"][4], (out["cgs1"][4], out["cgs_gram"][4])
+
+
+def test_block_arnoldi_gmres_reproduces_the_reference_restatement():
+    """oracle.krylov.gmres_block restates the library's GMRES with BLOCK Arnoldi steps (csrc/sstep.h, solver.hip: arnoldi_block;
+    round 4): s operator applications, one pass of projections with the measured Gram matrix, one update pass, the s Hessenberg
+    columns from the change of basis.  Against the restatement of KrylovKit's GMRES (MGS2, one step at a time): the same numops
+    in every case -- no speculated operator application is wasted thanks to the convergence-predicted block size -- the same
+    residual history and solution, with restarts, with the shift applied to the Hessenberg (KrylovKit) and inside the operator,
+    and on a0 I + J with a large a0 (the monomial block's worst case: its vectors are nearly parallel)."""
+    from oracle import krylov, operators
+    dims, ls = (14, 12, 10), (np.pi, 3.0, 2.5)
+    sh = operators.SwiftHohenberg(dims, ls)
+    u = sh.guess()
+    J = sh.J(u, 0.1, 1.2)
+    Pl = operators.dct_preconditioner(dims, ls, 1.0)
+    rhs = np.random.default_rng(3).standard_normal(sh.N)
+    a0 = 2.0 * abs(J).sum(axis=1).max()
+    cases = [dict(A=J, a0=0.0, a1=1.0, Pl=Pl, krylovdim=30, rtol=1e-11),
+             dict(A=J, a0=0.0, a1=1.0, Pl=Pl, krylovdim=7, rtol=1e-10),
+             dict(A=(lambda v: a0 * v + J @ v), a0=0.0, a1=1.0, Pl=None, krylovdim=30, rtol=1e-10),
+             dict(A=J, a0=0.3, a1=0.9, Pl=Pl, krylovdim=30, rtol=1e-10)]
+    for c in cases:
+        hm = []
+        xm, okm, nm, _ = krylov.gmres_krylovkit(c["A"], rhs, c["a0"], c["a1"], krylovdim=c["krylovdim"], maxiter=60, rtol=c["rtol"],
+                                                atol=1e-14, Pl=c["Pl"], history=hm)
+        for block in (1, 2, 3, 4):
+            hb, basis, st = [], [], {}
+            xb, okb, nb, _ = krylov.gmres_block(c["A"], rhs, c["a0"], c["a1"], krylovdim=c["krylovdim"], maxiter=60, rtol=c["rtol"],
+                                                atol=1e-14, Pl=c["Pl"], block=block, history=hb, basis_out=basis, stats=st)
+            assert okm and okb and nb == nm, (c["krylovdim"], block, nb, nm)
+            assert st["wasted"] == 0 and st["refused"] == 0 and max(st["blocks"]) == block
+            k = min(len(hm), len(hb))
+            assert np.allclose(hb[:k], hm[:k], rtol=1e-3, atol=1e-13 * hm[0])
+            assert np.abs(xb - xm).max() <= 1e-11 * np.abs(xm).max()
+            defect = max(np.abs(B @ B.T - np.eye(B.shape[0])).max() for B in basis)
+            assert defect <= 1e-6, (block, defect)          # inside a block: eps * cond(projected monomial block)^2
+
+
+def test_block_arnoldi_refuses_a_closing_krylov_space():
+    """A right-hand side whose Krylov space closes inside the first block: the block is refused, the cycle falls back to single
+    steps and still returns the solution."""
+    from oracle import krylov
+    A = np.diag(np.r_[np.full(6, 2.0), np.full(6, -1.0)])
+    b = np.ones(12)
+    st = {}
+    x, ok, numops, res = krylov.gmres_block(A, b, krylovdim=10, rtol=1e-12, atol=1e-14, block=4, stats=st)
+    assert ok and st["refused"] >= 1 and np.abs(A @ x - b).max() < 1e-12
