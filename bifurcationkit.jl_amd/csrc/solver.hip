@@ -205,25 +205,25 @@ int arnoldi_step(bk_ctx* ctx, bk_op* A, Basis& B, int j, double* w, double* h, d
 // s Arnoldi steps from V[j] as ONE block (sstep.h): p_{i+1} = A p_i straight into the basis slots j+1 .. j+s, one pass of dots
 // over the basis and the block, the coefficient algebra on the host, one update pass in place.  Against the per-step pair of
 // passes (2k + 3 vector streams per step) a block moves 2k + 3s - 1 .. 2k + 3s + 8 streams per s steps; at 512^3 the two
-// Gram-Schmidt passes were 46 % of the corrector.  On return *status = 0 and the raw Hessenberg columns j .. j+s-1 are in Hraw,
-// or *status = 1: the block was numerically rank deficient (or out of the kernels' range) and the caller repeats the steps one
-// at a time from V[j] (the measured Gram matrix stays valid up to and including column j - 1).
-int arnoldi_block(bk_ctx* ctx, bk_op* A, Basis& B, int j, int s, double* Hraw, int ldh, double op_a0, double op_a1, int* status) {
+// Gram-Schmidt passes were 46 % of the corrector.  On return *s_eff <= s steps were accepted (sstep.h: the block is truncated
+// where its vectors lose independence; the trailing operator applications are then void) and the raw Hessenberg columns
+// j .. j + *s_eff - 1 are in Hraw; *s_eff = 0: nothing usable (or out of the kernels' range) -- the caller repeats the step on the
+// single-vector path from V[j] (the measured Gram matrix stays valid up to and including column j - 1).
+int arnoldi_block(bk_ctx* ctx, bk_op* A, Basis& B, int j, int s, double* Hraw, int ldh, double op_a0, double op_a1, int* s_eff,
+                  double* last_ratio) {
     const size_t n = A->n;
     const int k = j + 1, u = k - B.gram_n;
-    *status = 1;
+    *s_eff = 0;
     if (A->ntail != 0 || !B.use_gram || u < 0 || u > sstep::kS || s < 1 || s > sstep::kS || u + s > sstep::kR || k > 32 ||
         !v_block_ok(ctx, n, B.V, B.ld))
         return 0;
     for (int i = 0; i < s; ++i) BK_TRY(A->apply(B.vec(j + i), nullptr, op_a0, op_a1, B.vec(j + i + 1), nullptr));
     double D[33 * sstep::kR], T[sstep::kTri], Cm[32 * sstep::kS], Tm[sstep::kS * sstep::kS];
     BK_TRY(v_block_dots(ctx, n, B.V, B.ld, k - u, k - u, u + s, D, T));
-    const int st = sstep::block_coefficients(k, u, s, D, T, B.G.data(), kMaxBasis + 1, Hraw, ldh, Cm, Tm);
+    const int st = sstep::block_coefficients(k, u, s, D, T, B.G.data(), kMaxBasis + 1, Hraw, ldh, Cm, Tm, s_eff, last_ratio);
     B.gram_n = st == 0 ? k : j;                      // (a refused block: column j is measured again by the single step)
-    if (st != 0) return 0;
-    BK_TRY(v_block_axpy(ctx, n, B.V, B.ld, k, s, Cm, Tm));
-    *status = 0;
-    return 0;
+    if (st != 0) { *s_eff = 0; return 0; }
+    return v_block_axpy(ctx, n, B.V, B.ld, k, *s_eff, Cm, Tm);
 }
 
 }  // namespace
@@ -301,6 +301,10 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     const bool sstep_on = sstep_max >= 1 && nt == 0 && B.use_gram && m >= 2 && v_block_ok(ctx, n, B.V, B.ld);
     const int ldh = m + 2;
     std::vector<double> Hraw(sstep_on ? (size_t)ldh * m : 0, 0.0);   // raw (unrotated) Hessenberg columns of the cycle
+    // block length: starts from what the first block of the previous solve on this context achieved (the operator and the
+    // right-hand sides of a corrector's solves resemble each other), shrinks / grows with the pivots of the blocks (sstep.h)
+    int blk_cur = std::max(1, std::min(sstep_max, ctx->sstep_hint));
+    bool first_block = true;
     int chunk = (int)ctx->opt("gmres_chunk", 4.0);
     if (nt != 0 || (ctx->comm == COMM_HOST && ctx->nranks > 1) || chunk < 2 || !ctx->h_rec_dev || sstep_on) chunk = 1;
     if (chunk > kRecChunks) chunk = kRecChunks;
@@ -328,17 +332,33 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     auto next_column = [&](int j, double* hcol, double* hnext_out) -> int {
         if (sstep_on && !cycle_on_host) {
             if (!(q_count > 0 && j >= q_first && j < q_first + q_count)) {
-                int steps = std::min(sstep_max, m - j);
+                int steps = std::min(blk_cur, m - j);
+                const bool capped = steps < blk_cur;
+                bool predicted = false;
                 if (predict && steps > 1 && beta_now > 0.0) {
                     const double rho = (beta_prev > 0.0 && beta_now < beta_prev) ? beta_now / beta_prev : 1.0;
                     int need = 1;
                     for (double b_ = beta_now * rho; b_ > 2.0 * tol_now && need < steps; b_ *= rho) ++need;
+                    predicted = need < steps;
                     steps = need;
                 }
-                int st = 1;
-                BK_TRY(arnoldi_block(ctx, A, B, j, steps, Hraw.data(), ldh, op_a0, op_a1, &st));
-                if (st == 0) { q_first = j; q_count = steps; }
-                else { cycle_on_host = true; q_count = 0; }      // refused: the rest of the cycle runs step by step
+                int got = 0;
+                double ratio = 0.0;
+                BK_TRY(arnoldi_block(ctx, A, B, j, steps, Hraw.data(), ldh, op_a0, op_a1, &got, &ratio));
+                if (ctx->opt("solver_trace", 0.0) != 0.0) {      // diagnostics: operator applications of blocks / of those void
+                    ctx->opts["gmres_block_steps"] = ctx->opt("gmres_block_steps", 0.0) + steps;
+                    ctx->opts["gmres_block_void"] = ctx->opt("gmres_block_void", 0.0) + (steps - got);
+                }
+                if (got > 0) {
+                    q_first = j; q_count = got;
+                    // next block: shorter after a truncation, one step longer when the last pivot left room (sstep.h)
+                    if (got < steps) blk_cur = got;
+                    else if (!capped && !predicted && blk_cur < sstep_max && ratio >= sstep::kGrowRatio) blk_cur += 1;
+                    if (first_block) ctx->sstep_hint = (got < steps || capped || predicted) ? std::max(got, 1) : blk_cur;
+                } else {
+                    cycle_on_host = true; q_count = 0;           // refused: the rest of the cycle runs step by step
+                }
+                first_block = false;
             }
             if (!cycle_on_host) {
                 for (int i = 0; i <= j; ++i) hcol[i] = Hraw[(size_t)i + (size_t)j * ldh];

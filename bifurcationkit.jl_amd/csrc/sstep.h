@@ -19,9 +19,13 @@
 //      exactly; in coordinates of Q+ = [Q, Q_new]:  P = Q+ Pc, Pc = [C; R],  B = Q+ Bc, Bc = [e_j, Pc[:, :s-1]].  Splitting
 //      B into its components along q_0 .. q_{j-1} (where A is known: H_old) and along q_j, q_{j+1} .. q_{j+s-1} (rows U of Bc,
 //      upper triangular with U_00 = 1, U_ii = R_{i-1,i-1} > 0):   H_new U = Pc - [H_old; 0] Bc[:j, :]   =>  H_new.
-// The monomial block [A q, A^2 q, ..] is fine up to s = 4 on the preconditioned operators of this library (condition of the
-// projected block 1e2 .. 1e3, measured: oracle/krylov.py::gmres_block and tests/test_oracle.py); a block whose Cholesky pivot
-// cancels below kPivotTol of its column norm is reported (return 1) and the caller repeats those steps one at a time.
+// Conditioning.  The monomial block [A q, A^2 q, ..] loses independence at the rate GMRES converges: the part of p_q outside
+// span(Q, p_1 .. p_{q-1}) -- the Cholesky pivot -- shrinks, relative to |p_q|^2, by about the square of the residual reduction
+// per step (measured on the 512^3 corrector: 5e-3, 5e-5, 7e-7, 3e-10 down the first block), and the orthonormality INSIDE the
+// block is (rounding of the dots, ~1e-13) / (smallest pivot ratio).  So the block is TRUNCATED where the ratio falls below
+// kPivotTol: the leading s_eff columns are a valid smaller block, the trailing operator applications are discarded and the
+// caller shrinks its next blocks (solver.hip).  s_eff = 0 (w in span(Q) to working precision, or a non-positive Gram matrix):
+// return 1, the caller repeats the step on the single-vector path with its explicit cancellation branch.
 #pragma once
 
 #include <cmath>
@@ -33,7 +37,7 @@ constexpr int kS = 4;                 // largest block
 constexpr int kR = 8;                 // right-hand vectors of one block_dots launch: u unmeasured + s new, u, s <= 4
 constexpr int kTri = kR * (kR + 1) / 2;
 constexpr int kMaxK = 64;             // basis vectors
-constexpr double kPivotTol = 1e-9;    // smallest accepted (pivot^2 / column norm^2) of chol(S)
+constexpr double kPivotTol = 1e-8;    // smallest accepted (pivot^2 / column norm^2) of chol(S): in-block orthonormality ~1e-5
 
 // packed upper triangle of the kR x kR matrix of dots among the right-hand vectors, r <= c
 inline int tri(int r, int c) { return r * kR - r * (r - 1) / 2 + (c - r); }
@@ -43,10 +47,15 @@ inline int tri(int r, int c) { return r * kR - r * (r - 1) / 2 + (c - r); }
 //      T[tri(r, c)]             : <rhs_r, rhs_c>
 //      G (ldg x ldg, column-major): measured Gram matrix, valid for the first k - u vectors; completed here
 //      Hraw (ldh x *, column-major): raw Hessenberg, columns 0 .. k-2 valid (column c has c + 2 entries)
-// Out: Cm[i * kS + q] = -(C R^-1)(i, q), i < k;  Tm[r * kS + q] = R^-1(r, q) (upper);  columns k-1 .. k+s-2 of Hraw
-// Returns 0, or 1 if the block is numerically rank deficient (nothing but G was modified).
-inline int block_coefficients(int k, int u, int s, const double* D, const double* T, double* G, int ldg, double* Hraw, int ldh,
-                              double* Cm, double* Tm) {
+// Out: *s_eff <= s accepted columns (see Conditioning above); Cm[i * kS + q] = -(C R^-1)(i, q), i < k;  Tm[r * kS + q] =
+//      R^-1(r, q) (upper), both for q < *s_eff;  columns k-1 .. k+*s_eff-2 of Hraw
+// Returns 0, or 1 if not even one column is acceptable (nothing but G was modified).
+constexpr double kGrowRatio = 1e-4;   // the next block may be one step longer if the last accepted pivot ratio is above this
+inline int block_coefficients(int k, int u, int s_in, const double* D, const double* T, double* G, int ldg, double* Hraw, int ldh,
+                              double* Cm, double* Tm, int* s_eff, double* last_ratio = nullptr) {
+    int s = s_in;
+    *s_eff = 0;
+    double ratio = 1.0;
     const int ko = k - u, j = k - 1;
     if (k < 1 || k > kMaxK || u < 0 || u > kS || u > k || s < 1 || s > kS || u + s > kR) return 1;
     auto g = [&](int a, int b) -> double& { return G[(size_t)a + (size_t)b * ldg]; };
@@ -104,13 +113,20 @@ inline int block_coefficients(int k, int u, int s, const double* D, const double
             double v = S[a][b];
             for (int c = 0; c < a; ++c) v -= R[c][a] * R[c][b];
             if (a == b) {
-                if (!(v > kPivotTol * Gp[a][a])) return 1;
+                if (!(v > kPivotTol * Gp[a][a])) {          // truncate the block here
+                    if (a == 0) return 1;
+                    s = a;
+                    break;
+                }
                 R[a][a] = std::sqrt(v);
+                ratio = v / Gp[a][a];
             } else {
                 R[a][b] = v / R[a][a];
             }
         }
     }
+    *s_eff = s;
+    if (last_ratio) *last_ratio = ratio;     // pivot ratio of the last accepted column (the caller sizes its next block by it)
     // Tm = R^-1 (upper), Cm = -C R^-1
     double Ri[kS][kS] = {{0.0}};
     for (int c = 0; c < s; ++c) {

@@ -206,20 +206,29 @@ def gmres_krylovkit(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-
     return x, False, numops, beta
 
 
-def block_arnoldi_coefficients(G, H, k, u, s, Aq, Gp, pivot_tol=1e-9):
+def block_arnoldi_coefficients(G, H, k, u, s, Aq, Gp, pivot_tol=1e-8):
     """Host algebra of the library's BLOCK Arnoldi step restated (csrc/sstep.h: block_coefficients).  ``G``: measured Gram
     matrix (valid for all k basis vectors on entry), ``H``: raw Hessenberg (columns 0..k-2 valid), ``Aq`` = Q'P (k x s),
-    ``Gp`` = P'P.  Returns (C, R) with P = Q C + Q_new R, and writes columns k-1 .. k+s-2 of H; None if the block is
-    numerically rank deficient."""
+    ``Gp`` = P'P.  The block is truncated at the first Cholesky pivot below ``pivot_tol`` of its column's squared norm.
+    Returns (C, R, s_eff, ratio of the last accepted pivot) with P[:s_eff] = Q C + Q_new R, and writes columns
+    k-1 .. k+s_eff-2 of H; None if not even the first column is acceptable."""
     j = k - 1
     C = np.linalg.solve(G[:k, :k], Aq)
     S = Gp - 0.5 * (C.T @ Aq + Aq.T @ C)
-    try:
-        R = np.linalg.cholesky(S).T
-    except np.linalg.LinAlgError:
+    R = np.zeros((s, s))
+    s_eff, ratio = s, 1.0
+    for a in range(s):
+        v = S[a, a] - R[:a, a] @ R[:a, a]
+        if not v > pivot_tol * Gp[a, a]:
+            s_eff = a
+            break
+        R[a, a] = np.sqrt(v)
+        ratio = v / Gp[a, a]
+        R[a, a + 1:] = (S[a, a + 1:] - R[:a, a] @ R[:a, a + 1:]) / R[a, a]
+    if s_eff == 0:
         return None
-    if np.any(np.diag(R) ** 2 <= pivot_tol * np.diag(Gp)):
-        return None
+    s = s_eff
+    C, R = C[:, :s], R[:s, :s]
     Pc = np.vstack([C, R])
     Bc = np.zeros((k + s, s))
     Bc[j, 0] = 1.0
@@ -230,7 +239,7 @@ def block_arnoldi_coefficients(G, H, k, u, s, Aq, Gp, pivot_tol=1e-9):
     H[:k + s, j:j + s] = sla.solve_triangular(U, rhs.T, trans="T", lower=False).T
     for q in range(s):
         H[j + q + 2:k + s, j + q] = 0.0
-    return C, R
+    return C, R, s_eff, ratio
 
 
 def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, rtol=1e-12, Pl=None, block=4,
@@ -258,10 +267,11 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
     tol = max(atol, rtol * np.linalg.norm(b))
     if stats is None:
         stats = {}
-    stats.update(wasted=0, refused=0, blocks=[])
+    stats.update(wasted=0, refused=0, void=0, blocks=[])
     if beta < tol:
         return x, True, numops, beta
     m = krylovdim
+    blk_cur = block                                  # (the library starts from the previous solve's first block: ctx->sstep_hint)
     for numiter in range(1, maxiter + 1):
         Q = np.zeros((m + 1, n))
         H = np.zeros((m + 2, m))
@@ -274,13 +284,16 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
         classic = False
         while j < m and res > tol:
             k = j + 1
-            sb = min(block, m - j)
+            sb = min(blk_cur, m - j)
+            capped = sb < blk_cur
+            predicted = False
             if res_prev is not None and sb > 1:
                 rho = res / res_prev if res < res_prev else 1.0
                 need, bb = 1, res * rho
                 while bb > 2.0 * tol and need < sb:
                     bb *= rho
                     need += 1
+                predicted = need < sb
                 sb = need
             done = False
             if not classic:
@@ -293,14 +306,22 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
                 Gn = Q[:k] @ Q[k - u:k].T
                 G[:k, k - u:k] = Gn
                 G[k - u:k, :k] = Gn.T
-                gram_n = k
                 out = block_arnoldi_coefficients(G, H, k, u, sb, Q[:k] @ P.T, P @ P.T)
                 if out is None:
                     classic = True                       # refused: the rest of the cycle runs step by step (MGS2 here)
+                    gram_n = j
                     stats["refused"] += 1
+                    stats["void"] += sb
                 else:
-                    C, R = out
-                    Q[k:k + sb] = sla.solve_triangular(R, P - C.T @ Q[:k], trans="T", lower=False)
+                    C, R, got, ratio = out
+                    gram_n = k
+                    Q[k:k + got] = sla.solve_triangular(R, P[:got] - C.T @ Q[:k], trans="T", lower=False)
+                    stats["void"] += sb - got            # operator applications of a truncated block's tail
+                    if got < sb:
+                        blk_cur = got
+                    elif not capped and not predicted and blk_cur < block and ratio >= 1e-4:
+                        blk_cur += 1
+                    sb = got
                     numops += sb
                     stats["blocks"].append(sb)
                     done = True
@@ -352,8 +373,6 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
             if beta < tol:
                 return x, True, numops, beta
         beta = np.linalg.norm(r)
-        if numiter < maxiter:
-            numops += 0
     return x, False, numops, beta
 
 

@@ -6,6 +6,7 @@
 #   bench     default bench line + the driver's arguments (--gpus 1 --steps 20 --warmup 5)
 #   prof      rocprofv3 kernel stats of the bench + the two PMC passes (FETCH_SIZE / WRITE_SIZE)   [TAG, default r4]
 #   hostcomm  N ranks sharing this GPU over the host-staged communicator with the RCCL-default code path (RANKS, SIZE)
+#   ab        bench.py A/B on the same box: AB_A / AB_B = extra bench.py arguments of the two runs (e.g. "--opt gmres_sstep=0")
 #   cost      inputs of the multi-GPU cost model (bench.py --size-z slabs, slab z-solve emulation)
 # Everything lands in gpurun_out/ (scratch); summaries that are judged get copied to profiles/ by hand.
 set -u
@@ -55,6 +56,12 @@ hostcomm)
     done
     timeout 300 python bench.py --size ${SIZE:-256} --steps 2 --warmup 1 --cpu-sample 0 --no-steady 2>/dev/null | tail -1 >> $OUT
     python scripts/bench_brief.py $OUT
+    ;;
+ab)
+    timeout 600 python bench.py --steps ${AB_STEPS:-10} --warmup 3 --cpu-sample 0 ${AB_COMMON:---no-steady} ${AB_A:-} 2> gpurun_out/${TAG}_ab_a.err | tail -1 > gpurun_out/${TAG}_ab_a.json
+    timeout 600 python bench.py --steps ${AB_STEPS:-10} --warmup 3 --cpu-sample 0 ${AB_COMMON:---no-steady} ${AB_B:-} 2> gpurun_out/${TAG}_ab_b.err | tail -1 > gpurun_out/${TAG}_ab_b.json
+    tail -3 gpurun_out/${TAG}_ab_a.err gpurun_out/${TAG}_ab_b.err | cut -c1-300
+    python scripts/bench_brief.py gpurun_out/${TAG}_ab_a.json gpurun_out/${TAG}_ab_b.json
     ;;
 cost)
     bash scripts/gpu_cost_model_inputs.sh > gpurun_out/${TAG}_cost_inputs.out 2>&1

@@ -33,9 +33,11 @@ int main() {
         for (int r = 0; r < nr; ++r)
             for (int c = r; c < nr; ++c) T[tri(r, c)] = dot(rhs0 + (size_t)r * n, rhs0 + (size_t)c * n);
         double Cm[kMaxK * kS], Tm[kS * kS];
-        const int st = block_coefficients(k, u, sb, D.data(), T.data(), G.data(), ldg, H.data(), ldh, Cm, Tm);
+        int got = 0;
+        const int st = block_coefficients(k, u, sb, D.data(), T.data(), G.data(), ldg, H.data(), ldh, Cm, Tm, &got);
         gram_n = k;
         if (st != 0) { ++fails; printf("block at %d failed\n", j); return 0; }
+        if (got < sb) { printf("block at %d truncated to %d\n", j, got); return 0; }
         std::vector<double> out((size_t)sb * n, 0.0);
         for (int q = 0; q < sb; ++q)
             for (int e = 0; e < n; ++e) {

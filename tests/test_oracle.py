@@ -516,12 +516,14 @@ def test_block_arnoldi_gmres_reproduces_the_reference_restatement():
             xb, okb, nb, _ = krylov.gmres_block(c["A"], rhs, c["a0"], c["a1"], krylovdim=c["krylovdim"], maxiter=60, rtol=c["rtol"],
                                                 atol=1e-14, Pl=c["Pl"], block=block, history=hb, basis_out=basis, stats=st)
             assert okm and okb and nb == nm, (c["krylovdim"], block, nb, nm)
-            assert st["wasted"] == 0 and st["refused"] == 0 and max(st["blocks"]) == block
+            # no consumed-then-discarded step, no refused block; a block may be truncated where its vectors lose independence
+            # (its tail applications are void: at most a few per solve, the next blocks are sized accordingly)
+            assert st["wasted"] == 0 and st["refused"] == 0 and max(st["blocks"]) <= block and st["void"] <= 0.05 * nb + 3, st
             k = min(len(hm), len(hb))
             assert np.allclose(hb[:k], hm[:k], rtol=1e-3, atol=1e-13 * hm[0])
             assert np.abs(xb - xm).max() <= 1e-11 * np.abs(xm).max()
             defect = max(np.abs(B @ B.T - np.eye(B.shape[0])).max() for B in basis)
-            assert defect <= 1e-6, (block, defect)          # inside a block: eps * cond(projected monomial block)^2
+            assert defect <= 1e-5, (block, defect)          # inside a block: rounding of the dots / smallest accepted pivot ratio
 
 
 def test_block_arnoldi_refuses_a_closing_krylov_space():
