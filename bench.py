@@ -527,6 +527,12 @@ def main():
     if two_lanes and roofline is not None:
         roofline["note"] = ("two lanes: kernels of the two concurrent solves overlap, per-kernel durations (and this fraction) "
                             "are those of kernels sharing the device; compare ms_per_step")
+    # block Arnoldi: operator applications issued inside blocks over the whole run, and those void (tails of
+    # truncated blocks) -- itlinear_per_step counts consumed applications only
+    try:
+        gmres_blocks = {"operator_applications_in_blocks": ctx.get_option("gmres_block_steps"), "void": ctx.get_option("gmres_block_void")}
+    except Exception:  # noqa: BLE001
+        gmres_blocks = None
     if rank == 0:
         ms = dt / max(args.steps, 1) * 1e3
         out = {
@@ -551,7 +557,7 @@ def main():
                        "cell_corrector": {"converged": cfull["converged"], "itnewton": cfull["itnewton"],
                                           "itlinear": cfull["itlineartot"], "residuals": cfull["residuals"],
                                           "p": cfull["u"].p},
-                       "two_lanes": two_lanes,
+                       "two_lanes": two_lanes, "gmres_blocks": gmres_blocks,
                        "setup_seconds": t_setup, "sh_kernel": args.sh_kernel, "linsolver": args.linsolver,
                        "preconditioner": "none" if P is None else "dct"},
             "roofline": roofline, "inner_loop": inner, "steady_state": steady, "kernels": kernels, "comm": comm_rec,

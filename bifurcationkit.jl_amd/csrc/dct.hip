@@ -698,6 +698,18 @@ int dct_slab_emulate_tables(bk_ctx* ctx, DctPlan* p, double az) { return slab_ta
 namespace {
 struct ShDctPrecond : bk_precond {
     DctPlan* plan = nullptr;
+    const bk_problem* prob = nullptr;         // the problem whose L1 this plan diagonalises (bk_precond_sh_create)
+    bool is_l1_plus_shift(const bk_problem* pr, double* shift) const override {
+        if (!plan || plan->kind != 0 || !prob || !pr) return false;
+        if (pr != prob) {                     // (the second lane works on a copy of the problem object: compare the grids)
+            const bk_problem_desc &a = pr->desc, &b = prob->desc;
+            if (a.pde != b.pde || a.ndim != b.ndim || pr->lo != prob->lo || pr->hi != prob->hi) return false;
+            for (int d = 0; d < a.ndim; ++d)
+                if (a.n[d] != b.n[d] || a.l[d] != b.l[d]) return false;
+        }
+        *shift = plan->shift;
+        return true;
+    }
     bool shadow = false;                      // second-lane view: the tables belong to the original, only the scratch
                                               // arrays (t1, t2; fsend, frecv of the slab z-solve) are its own
     ~ShDctPrecond() override {
@@ -737,6 +749,7 @@ bk_precond* precond_lane_shadow(bk_precond* pl, bk_ctx* lane) {
     }
     ShDctPrecond* S = new ShDctPrecond();
     S->ctx = lane; S->n = P->n; S->plan = q; S->shadow = true;
+    S->prob = P->prob;
     return S;
 }
 
@@ -753,6 +766,7 @@ int bk_precond_sh_create(bk_problem* prob, double shift, bk_precond** out) {
     ShDctPrecond* P = new ShDctPrecond();
     P->ctx = ctx;
     P->n = prob->nloc;
+    P->prob = prob;
     int s = ctx->nranks > 1
                 ? dct_plan_create_dist(ctx, prob->desc.n, prob->ainv, shift, prob->lo, prob->hi, &P->plan)
                 : dct_plan_create(ctx, prob->desc.ndim, prob->desc.n, prob->ainv, shift, &P->plan);

@@ -19,6 +19,8 @@ struct ShArgs {             // Swift-Hohenberg 2-D/3-D, Neumann-ghost (mirror) b
     double ax, ay, az;      // 1/hx^2, 1/hy^2, 1/hz^2 (az = 0 in 2-D)
     double l, nu;           // parameters
     double a0, a1;          // out = a0*v + a1*( -L1 v + g(u) v )
+    double ag = 0.0;        // ag_set: out = a0*v + a1*(-L1 v) + ag*g(u) v -- the stencil part and the pointwise part scaled
+    bool ag_set = false;    //   separately (a shift folded through the preconditioner, solver.hip: ShiftPrecOp)
     int mode;               // 0: JVP, g = l + 2 nu u - 3 u^2 ; 1: residual (v == u), g = l + nu u - u^2
     const double* v;
     const double* u;        // JVP only
@@ -96,7 +98,9 @@ struct bk_problem {
     double ainv[3] = {0, 0, 0};
     double* halo_lo = nullptr;
     double* halo_hi = nullptr;
-    int apply(int mode, const double* v, const double* u, const double* params, double a0, double a1, double* out);
+    // ag != NULL (SH 2-D / 3-D only): out = a0 v + a1 (-L1 v) + *ag g(u) v
+    int apply(int mode, const double* v, const double* u, const double* params, double a0, double a1, double* out,
+              const double* ag = nullptr);
     // out = a0 v + a1 J(u) v + c r (r may be NULL), *dot = v . out, in ONE pass where the stencil kernel supports it
     // (*fused = 1), else *fused = 0 and nothing was done
     int jvp_axpy_dot(const double* v, const double* u, const double* params, double a0, double a1, double c, const double* r,
@@ -116,6 +120,13 @@ struct bk_op {              // a linear operator on (device vector [+ one host t
     // The Lanczos step of the symmetric solvers (unbordered operators): out = a0 x + a1 A x + c r (r may be NULL),
     // *dot = x . out.  Default: apply, then one fused axpy + dot pass; operators with a fused kernel override it.
     virtual int apply_axpy_dot(const double* x, double a0, double a1, double c, const double* r, double* out, double* dot);
+    // Newton-basis blocks of GMRES (solver.hip: arnoldi_block) apply (a0 - theta) x + a1 A x with a different theta per step:
+    // true if a0 != 0 costs no extra pass over the vectors
+    virtual bool shift_is_free() const { return false; }
+    // the Swift-Hohenberg Jacobian J = -L1 + diag(g(u)) with its two parts scaled separately,
+    // out = a0 x + aL (-L1 x) + ag g(u) x; returns 1 if this operator is not of that form (nothing done)
+    virtual int apply_parts(const double* x, double a0, double aL, double ag, double* out) { return 1; }
+    virtual const bk_problem* sh_problem() const { return nullptr; }
 };
 
 struct bk_precond {
@@ -126,6 +137,8 @@ struct bk_precond {
     // out = Pl \ v and *dot = v . out (out must not alias v).  Default: apply, then a dot pass; the spectral
     // preconditioner takes the dot from the spectrum (Parseval) inside its merged middle pass.
     virtual int apply_dot(const double* v, double* out, double* dot);
+    // true if this preconditioner is the exact inverse of L1 + *shift I of the problem `prob` (the spectral preconditioner)
+    virtual bool is_l1_plus_shift(const bk_problem* prob, double* shift) const { return false; }
 };
 
 namespace bk {
@@ -137,6 +150,9 @@ struct PdeJacobian : bk_op {          // J(u, params) of a bk_problem; reference
     bool adjoint = false;             // J' (cGL only; the SH Jacobians are symmetric)
     int apply(const double* x, const double* xt, double a0, double a1, double* out, double* outt) override;
     int apply_axpy_dot(const double* x, double a0, double a1, double c, const double* r, double* out, double* dot) override;
+    bool shift_is_free() const override { return true; }          // a0 is a term of the stencil kernels' store stage
+    int apply_parts(const double* x, double a0, double aL, double ag, double* out) override;
+    const bk_problem* sh_problem() const override;
 };
 
 // A preconditioner object for the second lane that shares the tables of `pl` (read-only) but has its own scratch arrays

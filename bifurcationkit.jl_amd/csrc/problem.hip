@@ -4,7 +4,7 @@
 using namespace bk;
 
 int bk_problem::apply(int mode, const double* v, const double* u, const double* params, double a0, double a1,
-                      double* out) {
+                      double* out, const double* ag) {
     const bk_problem_desc& d = desc;
     if (d.pde == BK_PDE_SH) {
         ShArgs a;
@@ -16,6 +16,7 @@ int bk_problem::apply(int mode, const double* v, const double* u, const double* 
         a.ax = ainv[0]; a.ay = ainv[1]; a.az = d.ndim == 3 ? ainv[2] : 0.0;
         a.l = params[0]; a.nu = params[1];
         a.a0 = a0; a.a1 = a1; a.mode = mode;
+        if (ag) { a.ag = *ag; a.ag_set = true; }
         a.v = v; a.u = u; a.out = out;
         a.halo_lo = halo_lo; a.halo_hi = halo_hi;
         if (ctx->nranks > 1) {
@@ -51,6 +52,7 @@ int bk_problem::apply(int mode, const double* v, const double* u, const double* 
         }
         return sh_apply(ctx, a);
     }
+    if (ag) return set_error(ctx, "bk_problem::apply: separately scaled parts are implemented for BK_PDE_SH only");
     if (d.pde == BK_PDE_CGL2D) {
         CglArgs a;
         a.nx = d.n[0]; a.ny = d.n[1];
@@ -121,6 +123,14 @@ int PdeJacobian::apply(const double* x, const double*, double a0, double a1, dou
     // the SH Jacobians are symmetric (issymmetric = true, examples/SH3d.jl:123): only cGL has a distinct adjoint
     return prob->apply(adjoint && prob->desc.pde == BK_PDE_CGL2D ? 2 : 0, x, u, params, a0, a1, out);
 }
+
+int PdeJacobian::apply_parts(const double* x, double a0, double aL, double ag, double* out) {
+    if (prob->desc.pde != BK_PDE_SH) return 1;
+    BK_TRY(prob->apply(0, x, u, params, a0, aL, out, &ag));
+    return 0;
+}
+
+const bk_problem* PdeJacobian::sh_problem() const { return prob->desc.pde == BK_PDE_SH ? prob : nullptr; }
 
 int PdeJacobian::apply_axpy_dot(const double* x, double a0, double a1, double c, const double* r, double* out, double* dot) {
     int fused = 0;

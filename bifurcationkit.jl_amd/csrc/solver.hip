@@ -205,22 +205,24 @@ int arnoldi_step(bk_ctx* ctx, bk_op* A, Basis& B, int j, double* w, double* h, d
 // s Arnoldi steps from V[j] as ONE block (sstep.h): p_{i+1} = A p_i straight into the basis slots j+1 .. j+s, one pass of dots
 // over the basis and the block, the coefficient algebra on the host, one update pass in place.  Against the per-step pair of
 // passes (2k + 3 vector streams per step) a block moves 2k + 3s - 1 .. 2k + 3s + 8 streams per s steps; at 512^3 the two
-// Gram-Schmidt passes were 46 % of the corrector.  On return *s_eff <= s steps were accepted (sstep.h: the block is truncated
+// Gram-Schmidt passes were 46 % of the corrector.  theta (optional): Newton shifts, p_{i+1} = (A - theta_i) p_i.  On return *s_eff <= s steps were accepted (sstep.h: the block is truncated
 // where its vectors lose independence; the trailing operator applications are then void) and the raw Hessenberg columns
 // j .. j + *s_eff - 1 are in Hraw; *s_eff = 0: nothing usable (or out of the kernels' range) -- the caller repeats the step on the
 // single-vector path from V[j] (the measured Gram matrix stays valid up to and including column j - 1).
 int arnoldi_block(bk_ctx* ctx, bk_op* A, Basis& B, int j, int s, double* Hraw, int ldh, double op_a0, double op_a1, int* s_eff,
-                  double* last_ratio) {
+                  double* last_ratio, const double* theta) {
     const size_t n = A->n;
     const int k = j + 1, u = k - B.gram_n;
     *s_eff = 0;
     if (A->ntail != 0 || !B.use_gram || u < 0 || u > sstep::kS || s < 1 || s > sstep::kS || u + s > sstep::kR || k > 32 ||
         !v_block_ok(ctx, n, B.V, B.ld))
         return 0;
-    for (int i = 0; i < s; ++i) BK_TRY(A->apply(B.vec(j + i), nullptr, op_a0, op_a1, B.vec(j + i + 1), nullptr));
+    // p_{i+1} = (op_a0 + op_a1 A) p_i - theta_i p_i: the shift rides in the operator's own a0 term
+    for (int i = 0; i < s; ++i)
+        BK_TRY(A->apply(B.vec(j + i), nullptr, op_a0 - (theta ? theta[i] : 0.0), op_a1, B.vec(j + i + 1), nullptr));
     double D[33 * sstep::kR], T[sstep::kTri], Cm[32 * sstep::kS], Tm[sstep::kS * sstep::kS];
     BK_TRY(v_block_dots(ctx, n, B.V, B.ld, k - u, k - u, u + s, D, T));
-    const int st = sstep::block_coefficients(k, u, s, D, T, B.G.data(), kMaxBasis + 1, Hraw, ldh, Cm, Tm, s_eff, last_ratio);
+    const int st = sstep::block_coefficients(k, u, s, D, T, B.G.data(), kMaxBasis + 1, Hraw, ldh, Cm, Tm, s_eff, last_ratio, theta);
     B.gram_n = st == 0 ? k : j;                      // (a refused block: column j is measured again by the single step)
     if (st != 0) { *s_eff = 0; return 0; }
     return v_block_axpy(ctx, n, B.V, B.ld, k, *s_eff, Cm, Tm);
@@ -305,6 +307,41 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     // right-hand sides of a corrector's solves resemble each other), shrinks / grows with the pivots of the blocks (sstep.h)
     int blk_cur = std::max(1, std::min(sstep_max, ctx->sstep_hint));
     bool first_block = true;
+    // Newton shifts of the blocks (sstep.h: Conditioning): up to kS Ritz values of the operator in Leja order, where a shift is
+    // free (bk_op::shift_is_free).  They come from the Hessenberg matrix of this solve as soon as one block exists, before that
+    // from the previous solve on this context -- correctors solve with the same operator over and over; a carried set that
+    // truncates the first block is dropped.  Any real numbers give a valid basis: the shifts only steer its conditioning.
+    const bool use_shifts = sstep_on && ctx->opt("gmres_newton", 1.0) != 0.0 && A->shift_is_free();
+    std::vector<double> shifts;
+    bool shifts_carried = false;
+    if (use_shifts && !ctx->newton_shifts.empty()) { shifts = ctx->newton_shifts; shifts_carried = true; }
+    auto ritz_shifts = [&](int kk) {              // Leja-ordered real parts of the eigenvalues of Hraw[0:kk, 0:kk]
+        if (!use_shifts || kk < 2) return;
+        dense::Mat Hm(kk, kk);
+        for (int c = 0; c < kk; ++c)
+            for (int r = 0; r < kk && r <= c + 1; ++r) Hm(r, c) = Hraw[(size_t)r + (size_t)c * ldh];
+        std::vector<dense::cplx> ev;
+        dense::CMat Y;
+        if (dense::eig_general(Hm, ev, Y) != 0) return;
+        std::vector<double> pts;
+        for (const auto& e : ev) pts.push_back(e.real());
+        std::vector<double> lj;
+        std::vector<char> used(pts.size(), 0);
+        for (int t = 0; t < sstep::kS && t < (int)pts.size(); ++t) {
+            int best = -1;
+            double bv = -1.0;
+            for (size_t i = 0; i < pts.size(); ++i) {
+                if (used[i]) continue;
+                double v = t == 0 ? std::fabs(pts[i]) : 1.0;
+                for (double q : lj) v *= std::fabs(pts[i] - q);
+                if (v > bv) { bv = v; best = (int)i; }
+            }
+            used[best] = 1;
+            lj.push_back(pts[best]);
+        }
+        shifts = lj;
+        shifts_carried = false;
+    };
     int chunk = (int)ctx->opt("gmres_chunk", 4.0);
     if (nt != 0 || (ctx->comm == COMM_HOST && ctx->nranks > 1) || chunk < 2 || !ctx->h_rec_dev || sstep_on) chunk = 1;
     if (chunk > kRecChunks) chunk = kRecChunks;
@@ -344,11 +381,14 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
                 }
                 int got = 0;
                 double ratio = 0.0;
-                BK_TRY(arnoldi_block(ctx, A, B, j, steps, Hraw.data(), ldh, op_a0, op_a1, &got, &ratio));
-                if (ctx->opt("solver_trace", 0.0) != 0.0) {      // diagnostics: operator applications of blocks / of those void
-                    ctx->opts["gmres_block_steps"] = ctx->opt("gmres_block_steps", 0.0) + steps;
-                    ctx->opts["gmres_block_void"] = ctx->opt("gmres_block_void", 0.0) + (steps - got);
-                }
+                double theta[sstep::kS] = {0.0, 0.0, 0.0, 0.0};
+                for (int i = 0; i < steps && !shifts.empty(); ++i) theta[i] = shifts[i % shifts.size()];
+                BK_TRY(arnoldi_block(ctx, A, B, j, steps, Hraw.data(), ldh, op_a0, op_a1, &got, &ratio, shifts.empty() ? nullptr : theta));
+                if (got < steps && shifts_carried) { shifts.clear(); shifts_carried = false; }     // a stale set: back to the monomial block
+                if (got > 0 && !shifts_carried && ((int)shifts.size() < sstep::kS || j + got <= 12)) ritz_shifts(j + got);
+                // diagnostics (bench.py reports them): operator applications issued by blocks / of those void (truncated tails)
+                ctx->opts["gmres_block_steps"] = ctx->opt("gmres_block_steps", 0.0) + steps;
+                ctx->opts["gmres_block_void"] = ctx->opt("gmres_block_void", 0.0) + (steps - got);
                 if (got > 0) {
                     q_first = j; q_count = got;
                     // next block: shorter after a truncation, one step longer when the last pivot left room (sstep.h)
@@ -562,6 +602,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     res->niter = kk ? numops : iters;
     res->resnorm = beta;
     ctx->gmres_last_steps = iters;
+    if (use_shifts && !shifts.empty()) ctx->newton_shifts = shifts;
     if (xt) for (int q = 0; q < nt; ++q) xt[q] = xtail[q];
     return 0;
 }
@@ -577,12 +618,28 @@ struct ShiftPrecOp : bk_op {
     double a0, a1;
     int order;
     double* tmp;
+    // order 0 with the spectral preconditioner of the SAME Swift-Hohenberg problem: a shift of the preconditioned operator can
+    // be folded into the stencil kernel (apply below), i.e. costs nothing
+    bool fold = false;
+    double pl_shift = 0.0;
+    void init_fold() {
+        fold = P && order == 0 && J->sh_problem() && P->is_l1_plus_shift(J->sh_problem(), &pl_shift) &&
+               ctx->opt("gmres_fold_shift", 1.0) != 0.0;
+    }
+    bool shift_is_free() const override { return P ? fold : J->shift_is_free(); }
     int apply(const double* x, const double*, double b0, double b1, double* out, double*) override {
         // out = b0 x + b1 * W(x)
         if (!P) return J->apply(x, nullptr, b0 + b1 * a0, b1 * a1, out, nullptr);
         if (order == 0) {
-            BK_TRY(J->apply(x, nullptr, 0.0, 1.0, tmp, nullptr));
             const double cx = b0 + b1 * a0, ct = b1 * a1;
+            if (cx != 0.0 && fold) {
+                // cx x + ct Pl^-1 J x = Pl^-1 (ct J + cx Pl) x with Pl = L1 + s I and J = -L1 + diag(g):
+                //   ct J + cx Pl = (ct - cx) (-L1) + diag(ct g + cx s)
+                // -- the SAME stencil kernel with its two parts scaled separately, then the preconditioner: no extra pass
+                BK_TRY(J->apply_parts(x, cx * pl_shift, ct - cx, ct, tmp));
+                return P->apply(tmp, out);
+            }
+            BK_TRY(J->apply(x, nullptr, 0.0, 1.0, tmp, nullptr));
             if (cx == 0.0) {                       // the common Arnoldi call (a0 = 0): Pl^-1 writes straight into out
                 BK_TRY(P->apply(tmp, out));
                 return ct == 1.0 ? 0 : v_scale(ctx, n, ct, out);
@@ -743,6 +800,7 @@ int linsolve(bk_ctx* ctx, bk_op* J, const double* rhs, double* x, double a0, dou
     ShiftPrecOp W;
     W.ctx = ctx; W.n = J->n; W.ntail = 0;
     W.J = J; W.P = pl; W.a0 = a0; W.a1 = a1; W.order = kk ? 0 : 1; W.tmp = nullptr;
+    W.init_fold();
     const double* b = rhs;
     if (pl) {
         double* prhs = nullptr;

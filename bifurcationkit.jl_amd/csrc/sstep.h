@@ -8,15 +8,16 @@
 //
 // One block, starting from an (approximately) orthonormal basis Q = [q_0 .. q_j], k = j + 1, with the raw Hessenberg columns
 // 0 .. j-1 known (A Q[:, :j] = Q H_old):
-//   1. p_1 = A q_j, p_2 = A p_1, ..., p_s = A p_{s-1}                          (s operator applications, nothing in between)
+//   1. p_1 = (A - th_0) q_j, p_2 = (A - th_1) p_1, ..., p_s = (A - th_{s-1}) p_{s-1}   (s operator applications, nothing in
+//      between; th = 0: the monomial block, th = Ritz values in Leja order: the Newton block, see Conditioning)
 //   2. ONE pass over the basis and the block (vecops.hip: block_dots_kernel):  Aq = Q'P,  Gp = P'P,  and the Gram columns
 //      Q'Q_u of the u basis vectors created by the PREVIOUS block, which nobody has measured yet
 //   3. here: C = G^-1 Aq -- the coefficients of the ORTHOGONAL projection of P onto span(Q) under the MEASURED Gram matrix G
 //      (the block analogue of round 3's Gram-corrected single pass: the defect of earlier vectors is measured and projected
 //      out, it never accumulates); S = Gp - C'Aq = (P - QC)'(P - QC); R = chol(S); Q_new = (P - Q C) R^-1
 //   4. ONE pass (block_axpy_kernel): the s new basis vectors, in place over P
-//   5. here: the s new Hessenberg columns.  With B = [q_j, p_1 .. p_{s-1}] and P = [p_1 .. p_s] the block satisfies A B = P
-//      exactly; in coordinates of Q+ = [Q, Q_new]:  P = Q+ Pc, Pc = [C; R],  B = Q+ Bc, Bc = [e_j, Pc[:, :s-1]].  Splitting
+//   5. here: the s new Hessenberg columns.  With B = [q_j, p_1 .. p_{s-1}] and P = [p_1 .. p_s] the block satisfies
+//      A B = P + B diag(th) exactly (th = 0 in what follows; the shifts add Bc diag(th) to the right-hand side); in coordinates of Q+ = [Q, Q_new]:  P = Q+ Pc, Pc = [C; R],  B = Q+ Bc, Bc = [e_j, Pc[:, :s-1]].  Splitting
 //      B into its components along q_0 .. q_{j-1} (where A is known: H_old) and along q_j, q_{j+1} .. q_{j+s-1} (rows U of Bc,
 //      upper triangular with U_00 = 1, U_ii = R_{i-1,i-1} > 0):   H_new U = Pc - [H_old; 0] Bc[:j, :]   =>  H_new.
 // Conditioning.  The monomial block [A q, A^2 q, ..] loses independence at the rate GMRES converges: the part of p_q outside
@@ -24,7 +25,9 @@
 // per step (measured on the 512^3 corrector: 5e-3, 5e-5, 7e-7, 3e-10 down the first block), and the orthonormality INSIDE the
 // block is (rounding of the dots, ~1e-13) / (smallest pivot ratio).  So the block is TRUNCATED where the ratio falls below
 // kPivotTol: the leading s_eff columns are a valid smaller block, the trailing operator applications are discarded and the
-// caller shrinks its next blocks (solver.hip).  s_eff = 0 (w in span(Q) to working precision, or a non-positive Gram matrix):
+// caller shrinks its next blocks (solver.hip).  Shifts at Ritz values of the operator (Leja order; solver.hip takes them from the
+// Hessenberg matrix at hand) remove the directions GMRES has already resolved from the block's vectors and lift the pivots by 3
+// to 6 orders (same corrector: 4e-1, 2e-2, 1e-2, 4e-4), wherever a shift costs no extra pass (bk_op::shift_is_free).  s_eff = 0 (w in span(Q) to working precision, or a non-positive Gram matrix):
 // return 1, the caller repeats the step on the single-vector path with its explicit cancellation branch.
 #pragma once
 
@@ -47,12 +50,13 @@ inline int tri(int r, int c) { return r * kR - r * (r - 1) / 2 + (c - r); }
 //      T[tri(r, c)]             : <rhs_r, rhs_c>
 //      G (ldg x ldg, column-major): measured Gram matrix, valid for the first k - u vectors; completed here
 //      Hraw (ldh x *, column-major): raw Hessenberg, columns 0 .. k-2 valid (column c has c + 2 entries)
+//      theta (optional): the s shifts of the block, p_{q+1} = (A - theta[q]) p_q
 // Out: *s_eff <= s accepted columns (see Conditioning above); Cm[i * kS + q] = -(C R^-1)(i, q), i < k;  Tm[r * kS + q] =
 //      R^-1(r, q) (upper), both for q < *s_eff;  columns k-1 .. k+*s_eff-2 of Hraw
 // Returns 0, or 1 if not even one column is acceptable (nothing but G was modified).
 constexpr double kGrowRatio = 1e-4;   // the next block may be one step longer if the last accepted pivot ratio is above this
 inline int block_coefficients(int k, int u, int s_in, const double* D, const double* T, double* G, int ldg, double* Hraw, int ldh,
-                              double* Cm, double* Tm, int* s_eff, double* last_ratio = nullptr) {
+                              double* Cm, double* Tm, int* s_eff, double* last_ratio = nullptr, const double* theta = nullptr) {
     int s = s_in;
     *s_eff = 0;
     double ratio = 1.0;
@@ -153,7 +157,7 @@ inline int block_coefficients(int k, int u, int s_in, const double* D, const dou
     double rhs[kMaxK + kS][kS];
     for (int q = 0; q < s; ++q)
         for (int a = 0; a < k + s; ++a) {
-            double v = Pc(a, q);
+            double v = Pc(a, q) + (theta ? theta[q] * Bc(a, q) : 0.0);
             if (a < k)
                 for (int c = (a > 0 ? a - 1 : 0); c < j; ++c) v -= h(a, c) * Bc(c, q);       // H_old is upper Hessenberg
             rhs[a][q] = v;

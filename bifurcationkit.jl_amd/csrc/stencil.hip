@@ -42,6 +42,7 @@ struct ShK {                // kernel-side copy of ShArgs (+ derived constants)
     int nx, ny, nz, nzg, zoff;
     double ax, ay, az, c0;
     double l, nu, a0, a1;
+    double ag;              // coefficient of the pointwise term g(u) v (= a1 unless the caller folds a shift: ShArgs::ag)
     int mode;
     const double* v;
     const double* u;
@@ -109,7 +110,7 @@ __global__ void __launch_bounds__(256) sh_gather_kernel(ShK P) {
     }
     const double uc = P.mode == 0 ? P.u[idx] : vc;
     const double g = g_of_u(P.mode, P.l, P.nu, uc);
-    P.out[idx] = P.a0 * vc + P.a1 * (g * vc - s);
+    P.out[idx] = P.ag == P.a1 ? P.a0 * vc + P.a1 * (g * vc - s) : P.a0 * vc + P.ag * (g * vc) - P.a1 * s;
 }
 
 // ------------------------------------------------------------------ streaming variant
@@ -324,7 +325,7 @@ __global__ void __launch_bounds__(256, WPE) sh_stream_kernel(ShK P) {
                     const double e1 = s * (2.0 * az) * bpl;
                     const bool own = (p >= 0 && p < P.nz);
                     const double e0 = s * (bb + 2.0 * az * az * v) +
-                                      (own ? (P.a0 + P.a1 * g_of_u(P.mode, P.l, P.nu, P.mode == 0 ? uc[r][c] : v)) * v : 0.0);
+                                      (own ? (P.a0 + P.ag * g_of_u(P.mode, P.l, P.nu, P.mode == 0 ? uc[r][c] : v)) * v : 0.0);
                     A[0] += e2; A[1] += e1; A[2] += e0; A[3] += e1; A[4] += e2;
                     // reflected ghost planes of the global z-boundaries
                     if (gp == 0) { A[2] += e1; A[3] += e2; }                    // ghost -1 carries plane 0
@@ -332,7 +333,7 @@ __global__ void __launch_bounds__(256, WPE) sh_stream_kernel(ShK P) {
                     if (gp == P.nzg - 1) { A[2] += e1; A[1] += e2; }            // ghost N carries plane N-1
                     if (gp == P.nzg - 2) { A[3] += e2; }                        // ghost N+1 carries plane N-2
                 } else {
-                    A[2] = s * bb + (P.a0 + P.a1 * g_of_u(P.mode, P.l, P.nu, P.mode == 0 ? uc[r][c] : v)) * v;
+                    A[2] = s * bb + (P.a0 + P.ag * g_of_u(P.mode, P.l, P.nu, P.mode == 0 ? uc[r][c] : v)) * v;
                 }
             }
         }
@@ -572,6 +573,7 @@ int sh_apply(bk_ctx* ctx, const ShArgs& a) {
     P.ax = a.ax; P.ay = a.ay; P.az = a.az;
     P.c0 = 1.0 - 2.0 * (a.ax + a.ay + a.az);
     P.l = a.l; P.nu = a.nu; P.a0 = a.a0; P.a1 = a.a1; P.mode = a.mode;
+    P.ag = a.ag_set ? a.ag : a.a1;
     P.v = a.v; P.u = a.u; P.out = a.out; P.halo_lo = a.halo_lo; P.halo_hi = a.halo_hi;
     P.addv = nullptr; P.addc = 0.0; P.dotp = nullptr;
     P.stag_cu = ctx->num_cu;

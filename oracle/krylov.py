@@ -206,7 +206,18 @@ def gmres_krylovkit(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-
     return x, False, numops, beta
 
 
-def block_arnoldi_coefficients(G, H, k, u, s, Aq, Gp, pivot_tol=1e-8):
+def leja_shifts(H, kk, count=4):
+    """Up to ``count`` real parts of the eigenvalues of H[:kk, :kk] in Leja order (largest modulus first, then the point that
+    maximises the product of distances to those already chosen): the Newton shifts of the library's block Arnoldi step."""
+    pts = list(np.linalg.eigvals(H[:kk, :kk]).real)
+    out = []
+    while pts and len(out) < count:
+        score = [abs(p) if not out else float(np.prod([abs(p - q) for q in out])) for p in pts]
+        out.append(pts.pop(int(np.argmax(score))))
+    return out
+
+
+def block_arnoldi_coefficients(G, H, k, u, s, Aq, Gp, pivot_tol=1e-8, theta=None):
     """Host algebra of the library's BLOCK Arnoldi step restated (csrc/sstep.h: block_coefficients).  ``G``: measured Gram
     matrix (valid for all k basis vectors on entry), ``H``: raw Hessenberg (columns 0..k-2 valid), ``Aq`` = Q'P (k x s),
     ``Gp`` = P'P.  The block is truncated at the first Cholesky pivot below ``pivot_tol`` of its column's squared norm.
@@ -234,6 +245,8 @@ def block_arnoldi_coefficients(G, H, k, u, s, Aq, Gp, pivot_tol=1e-8):
     Bc[j, 0] = 1.0
     Bc[:, 1:] = Pc[:, :s - 1]
     rhs = Pc.copy()
+    if theta is not None:
+        rhs += Bc * np.asarray(theta[:s])[None, :]       # A B = P + B diag(theta)
     rhs[:k] -= H[:k, :j] @ Bc[:j]
     U = np.vstack([Bc[j:j + 1], Bc[k:k + s - 1]])
     H[:k + s, j:j + s] = sla.solve_triangular(U, rhs.T, trans="T", lower=False).T
@@ -243,7 +256,7 @@ def block_arnoldi_coefficients(G, H, k, u, s, Aq, Gp, pivot_tol=1e-8):
 
 
 def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, rtol=1e-12, Pl=None, block=4,
-                history=None, basis_out=None, stats=None):
+                history=None, basis_out=None, stats=None, newton=True, shifts=None):
     """The library's GMRES for vectors that stream from HBM since round 4, restated (csrc/solver.hip: gmres_core with
     arnoldi_block): KrylovKit's restarted GMRES -- same stopping rules, restart and numops bookkeeping as gmres_krylovkit
     above -- whose Arnoldi steps are taken in BLOCKS of up to ``block``: p_1 = A q_j, .., p_s = A p_{s-1}, then ONE pass of
@@ -257,7 +270,8 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
         A_, a0_, a1_ = A, a0, a1
         lin = lambda dx: a1_ * Pl(apply(A_, dx)) + a0_ * dx
         return gmres_block(lin, Pl(np.asarray(b, dtype=float)), 0.0, 1.0, krylovdim=krylovdim, maxiter=maxiter, atol=atol,
-                           rtol=rtol, block=block, history=history, basis_out=basis_out, stats=stats)
+                           rtol=rtol, block=block, history=history, basis_out=basis_out, stats=stats, newton=newton,
+                           shifts=shifts)
     b = np.asarray(b, dtype=float)
     n = b.shape[0]
     x = np.zeros(n)
@@ -267,11 +281,15 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
     tol = max(atol, rtol * np.linalg.norm(b))
     if stats is None:
         stats = {}
-    stats.update(wasted=0, refused=0, void=0, blocks=[])
+    stats.update(wasted=0, refused=0, void=0, blocks=[], shifts=None)
     if beta < tol:
         return x, True, numops, beta
     m = krylovdim
     blk_cur = block                                  # (the library starts from the previous solve's first block: ctx->sstep_hint)
+    # Newton shifts p_{i+1} = (A - theta_i) p_i: Leja-ordered Ritz values, from this solve's Hessenberg as soon as a block
+    # exists; ``shifts`` = a set carried over from an earlier solve with the same operator (dropped if it truncates a block)
+    shifts = list(shifts) if (shifts and newton) else []
+    carried = bool(shifts)
     for numiter in range(1, maxiter + 1):
         Q = np.zeros((m + 1, n))
         H = np.zeros((m + 2, m))
@@ -299,14 +317,15 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
             if not classic:
                 P = np.zeros((sb, n))
                 p = Q[j]
+                theta = [shifts[i % len(shifts)] for i in range(sb)] if shifts else None
                 for i in range(sb):
-                    p = apply(A, p)
+                    p = apply(A, p) - (theta[i] * p if theta else 0.0)
                     P[i] = p
                 u = k - gram_n
                 Gn = Q[:k] @ Q[k - u:k].T
                 G[:k, k - u:k] = Gn
                 G[k - u:k, :k] = Gn.T
-                out = block_arnoldi_coefficients(G, H, k, u, sb, Q[:k] @ P.T, P @ P.T)
+                out = block_arnoldi_coefficients(G, H, k, u, sb, Q[:k] @ P.T, P @ P.T, theta=theta)
                 if out is None:
                     classic = True                       # refused: the rest of the cycle runs step by step (MGS2 here)
                     gram_n = j
@@ -317,6 +336,10 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
                     gram_n = k
                     Q[k:k + got] = sla.solve_triangular(R, P[:got] - C.T @ Q[:k], trans="T", lower=False)
                     stats["void"] += sb - got            # operator applications of a truncated block's tail
+                    if got < sb and carried:
+                        shifts, carried = [], False
+                    if newton and not carried and (len(shifts) < 4 or j + got <= 12):
+                        shifts = leja_shifts(H, j + got)
                     if got < sb:
                         blk_cur = got
                     elif not capped and not predicted and blk_cur < block and ratio >= 1e-4:
@@ -371,8 +394,10 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
             numops += 1
             beta = np.linalg.norm(r)
             if beta < tol:
+                stats["shifts"] = list(shifts)
                 return x, True, numops, beta
         beta = np.linalg.norm(r)
+    stats["shifts"] = list(shifts)
     return x, False, numops, beta
 
 

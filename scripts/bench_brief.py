@@ -17,6 +17,6 @@ for path in sys.argv[1:]:
             print(path.split("/")[-1], c.get("grid"), "ranks", d.get("n_gpus"), "ms %.2f" % d["ms_per_step"], "steps/s %.3f" % d["value"],
                   "itlin", c.get("itlinear_per_step"), "p", (c.get("full_corrector") or {}).get("p"),
                   "roof", (r.get("kernel"), round(r.get("frac", 0.0), 3), r.get("traffic")), "families (frac of 8 TB/s, ms per step)", fam,
-                  "comm", comm.get("backend"), comm.get("ranks_in_communicator"))
+                  "comm", comm.get("backend"), comm.get("ranks_in_communicator"), "blocks", c.get("gmres_blocks"))
         except Exception as e:  # noqa: BLE001
             print("unparsed", path, e, line[:200])

@@ -60,8 +60,9 @@ hostcomm)
 ab)
     timeout 600 python bench.py --steps ${AB_STEPS:-10} --warmup 3 --cpu-sample 0 ${AB_COMMON:---no-steady} ${AB_A:-} 2> gpurun_out/${TAG}_ab_a.err | tail -1 > gpurun_out/${TAG}_ab_a.json
     timeout 600 python bench.py --steps ${AB_STEPS:-10} --warmup 3 --cpu-sample 0 ${AB_COMMON:---no-steady} ${AB_B:-} 2> gpurun_out/${TAG}_ab_b.err | tail -1 > gpurun_out/${TAG}_ab_b.json
+    [ -n "${AB_C:-}" ] && timeout 600 python bench.py --steps ${AB_STEPS:-10} --warmup 3 --cpu-sample 0 ${AB_COMMON:---no-steady} ${AB_C} 2> gpurun_out/${TAG}_ab_c.err | tail -1 > gpurun_out/${TAG}_ab_c.json
     tail -3 gpurun_out/${TAG}_ab_a.err gpurun_out/${TAG}_ab_b.err | cut -c1-300
-    python scripts/bench_brief.py gpurun_out/${TAG}_ab_a.json gpurun_out/${TAG}_ab_b.json
+    python scripts/bench_brief.py gpurun_out/${TAG}_ab_a.json gpurun_out/${TAG}_ab_b.json $([ -n "${AB_C:-}" ] && echo gpurun_out/${TAG}_ab_c.json)
     ;;
 cost)
     bash scripts/gpu_cost_model_inputs.sh > gpurun_out/${TAG}_cost_inputs.out 2>&1

@@ -1,6 +1,6 @@
 // Host replay of the block Arnoldi step (bifurcationkit.jl_amd/csrc/sstep.h) on a dense matrix: the two streaming passes of
 // vecops.hip (block_dots_kernel / block_axpy_kernel) are plain loops here, the coefficient algebra is the library's header.
-// stdin: n m s, then A (n rows), then b.  stdout: status per block, then H ((m+1) x m, row-major), then Q ((m+1) x n).
+// stdin: n m s, then A (n rows), then b, then optionally ns and ns Newton shifts (used cyclically inside every block).  stdout: status per block, then H ((m+1) x m, row-major), then Q ((m+1) x n).
 #include <cstdio>
 #include <vector>
 #include "../../bifurcationkit.jl_amd/csrc/sstep.h"
@@ -11,6 +11,9 @@ int main() {
     std::vector<double> A((size_t)n * n), b(n);
     for (auto& x : A) if (scanf("%lf", &x) != 1) return 2;
     for (auto& x : b) if (scanf("%lf", &x) != 1) return 2;
+    int ns = 0;
+    std::vector<double> shifts;
+    if (scanf("%d", &ns) == 1 && ns > 0) { shifts.resize(ns); for (auto& x : shifts) if (scanf("%lf", &x) != 1) return 2; }
     const int ldg = kMaxK + 1, ldh = m + 2;
     std::vector<double> Q((size_t)(m + 1) * n, 0.0), G((size_t)ldg * ldg, 0.0), H((size_t)ldh * m, 0.0);
     double nb = 0.0;
@@ -21,10 +24,12 @@ int main() {
     int j = 0, gram_n = 0, fails = 0;
     while (j < m) {
         const int sb = s < m - j ? s : m - j, k = j + 1, u = k - gram_n, ko = k - u, nr = u + sb;
-        for (int i = 0; i < sb; ++i) {                       // p_{i+1} = A p_i into the next basis slots
+        double theta[kS] = {0.0, 0.0, 0.0, 0.0};
+        for (int i = 0; i < sb && ns > 0; ++i) theta[i] = shifts[i % ns];
+        for (int i = 0; i < sb; ++i) {                       // p_{i+1} = (A - theta_i) p_i into the next basis slots
             const double* x = &Q[(size_t)(j + i) * n];
             double* y = &Q[(size_t)(j + i + 1) * n];
-            for (int r = 0; r < n; ++r) { double v = 0.0; for (int c = 0; c < n; ++c) v += A[(size_t)r * n + c] * x[c]; y[r] = v; }
+            for (int r = 0; r < n; ++r) { double v = -theta[i] * x[r]; for (int c = 0; c < n; ++c) v += A[(size_t)r * n + c] * x[c]; y[r] = v; }
         }
         std::vector<double> D((size_t)(ko > 0 ? ko : 1) * kR, 0.0), T(kTri, 0.0);
         const double* rhs0 = &Q[(size_t)ko * n];
@@ -34,7 +39,7 @@ int main() {
             for (int c = r; c < nr; ++c) T[tri(r, c)] = dot(rhs0 + (size_t)r * n, rhs0 + (size_t)c * n);
         double Cm[kMaxK * kS], Tm[kS * kS];
         int got = 0;
-        const int st = block_coefficients(k, u, sb, D.data(), T.data(), G.data(), ldg, H.data(), ldh, Cm, Tm, &got);
+        const int st = block_coefficients(k, u, sb, D.data(), T.data(), G.data(), ldg, H.data(), ldh, Cm, Tm, &got, nullptr, ns > 0 ? theta : nullptr);
         gram_n = k;
         if (st != 0) { ++fails; printf("block at %d failed\n", j); return 0; }
         if (got < sb) { printf("block at %d truncated to %d\n", j, got); return 0; }

@@ -32,9 +32,10 @@ def _arnoldi(A, b, m):
     return V, H
 
 
-def _run(exe, A, b, m, s):
+def _run(exe, A, b, m, s, shifts=()):
     n = b.size
     inp = f"{n} {m} {s}\n" + "\n".join(" ".join(repr(float(x)) for x in row) for row in A) + "\n" + " ".join(repr(float(x)) for x in b)
+    inp += f"\n{len(shifts)} " + " ".join(repr(float(x)) for x in shifts)
     out = subprocess.run([exe], input=inp, capture_output=True, text=True, check=True).stdout.strip().split("\n")
     assert out[0] == "ok", out[0]
     H = np.array([[float(x) for x in out[1 + a].split()] for a in range(m + 1)])
@@ -70,12 +71,35 @@ def test_block_arnoldi_reproduces_the_arnoldi_process(exe, s, m):
         assert np.linalg.norm(x0 - x1) <= 1e-8 * np.linalg.norm(x0)
 
 
+def test_newton_shifts_give_the_same_hessenberg_with_a_better_conditioned_block(exe):
+    """p_{i+1} = (A - theta_i) p_i with shifts inside the spectrum: the same Arnoldi relation and the same GMRES iterates, and a
+    basis that is orthonormal to a tighter bound than the monomial block's."""
+    rng = np.random.default_rng(7)
+    n, m, s = 80, 12, 4
+    M = rng.standard_normal((n, n))
+    A = -np.eye(n) + 0.6 * (M + M.T) / np.linalg.norm(M + M.T, 2)
+    b = rng.standard_normal(n)
+    V, H0 = _arnoldi(A, b, m)
+    ev = np.sort(np.linalg.eigvalsh(H0[:m, :m] * 0.5 + H0[:m, :m].T * 0.5))
+    shifts = [ev[0], ev[-1], ev[m // 2], ev[m // 4]]
+    Hm, Qm = _run(exe, A, b, m, s)
+    Hn, Qn = _run(exe, A, b, m, s, shifts)
+    assert np.abs(A @ Qn[:m].T - Qn.T @ Hn).max() < 1e-11 and np.abs(np.tril(Hn, -2)).max() == 0.0
+    dm, dn = np.abs(Qm @ Qm.T - np.eye(m + 1)).max(), np.abs(Qn @ Qn.T - np.eye(m + 1)).max()
+    assert dn < 1e-10 and dn <= dm
+    e = np.zeros(m + 1)
+    e[0] = np.linalg.norm(b)
+    x0 = V[:m].T @ np.linalg.lstsq(H0[:m + 1, :m], e, rcond=None)[0]
+    x1 = Qn[:m].T @ np.linalg.lstsq(Hn[:m + 1, :m], e, rcond=None)[0]
+    assert np.linalg.norm(x0 - x1) <= 1e-9 * np.linalg.norm(x0)
+
+
 def test_rank_deficient_block_is_truncated(exe):
     """An operator whose Krylov space closes inside the block (A^2 b in span{b, A b}): the block must be cut after its first
     vector -- the only one that adds a direction -- not factored to the end."""
     n = 20
     A = np.diag(np.r_[np.full(10, 2.0), np.full(10, -1.0)])
     b = np.ones(n)
-    inp = f"{n} 4 4\n" + "\n".join(" ".join(repr(float(x)) for x in row) for row in A) + "\n" + " ".join(repr(float(x)) for x in b)
+    inp = f"{n} 4 4\n" + "\n".join(" ".join(repr(float(x)) for x in row) for row in A) + "\n" + " ".join(repr(float(x)) for x in b) + "\n0"
     out = subprocess.run([exe], input=inp, capture_output=True, text=True, check=True).stdout
     assert out.split("\n")[0] == "block at 0 truncated to 1"
