@@ -17,10 +17,13 @@
 //                     radix-2 Stockham FFT of the Makhoul-permuted line there; HBM traffic is one read and
 //                     one write of the array per axis.  (dct_fast.hip)
 //   spectral_scale    multiply by the inverse symbol.
+#include <dlfcn.h>
+
 #include <cmath>
+#include <mutex>
 #include <vector>
 
-#include <rocblas/rocblas.h>
+#include <rocblas/rocblas.h>   // types only: the library itself is dlopen()ed by the cross-check option (rocblas_api below)
 
 #include "dct_core.h"
 #include "ops.h"
@@ -182,8 +185,44 @@ __global__ void __launch_bounds__(256) slab_blocks_kernel(int nx, int ny, int nz
 
 }  // namespace
 
+// rocBLAS is NOT a link-time dependency of the library: its dgemm only serves the cross-check option dct_gemm = 2 (the dense
+// transform passes ran on it in rounds 1-2; the product path is dense_mfma.hip).  The five entry points are resolved with
+// dlopen("librocblas.so") the first time that option is taken; a missing library is an error of that option only.
+namespace {
+struct RocblasApi {
+    void* lib = nullptr;
+    rocblas_status (*create_handle)(rocblas_handle*) = nullptr;
+    rocblas_status (*destroy_handle)(rocblas_handle) = nullptr;
+    rocblas_status (*set_stream)(rocblas_handle, hipStream_t) = nullptr;
+    rocblas_status (*dgemm)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int, rocblas_int, const double*,
+                            const double*, rocblas_int, const double*, rocblas_int, const double*, double*, rocblas_int) = nullptr;
+    rocblas_status (*dgemm_strided_batched)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int, rocblas_int,
+                                            const double*, const double*, rocblas_int, rocblas_stride, const double*, rocblas_int,
+                                            rocblas_stride, const double*, double*, rocblas_int, rocblas_stride, rocblas_int) = nullptr;
+    bool ok = false;
+};
+RocblasApi& rocblas_api() {
+    static RocblasApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librocblas.so", "librocblas.so.5", "librocblas.so.4", "/opt/rocm/lib/librocblas.so"}) {
+            api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (api.lib) break;
+        }
+        if (!api.lib) return;
+        api.create_handle = reinterpret_cast<decltype(api.create_handle)>(dlsym(api.lib, "rocblas_create_handle"));
+        api.destroy_handle = reinterpret_cast<decltype(api.destroy_handle)>(dlsym(api.lib, "rocblas_destroy_handle"));
+        api.set_stream = reinterpret_cast<decltype(api.set_stream)>(dlsym(api.lib, "rocblas_set_stream"));
+        api.dgemm = reinterpret_cast<decltype(api.dgemm)>(dlsym(api.lib, "rocblas_dgemm"));
+        api.dgemm_strided_batched = reinterpret_cast<decltype(api.dgemm_strided_batched)>(dlsym(api.lib, "rocblas_dgemm_strided_batched"));
+        api.ok = api.create_handle && api.destroy_handle && api.set_stream && api.dgemm && api.dgemm_strided_batched;
+    });
+    return api;
+}
+}  // namespace
+
 void blas_release(bk_ctx* ctx) {
-    if (ctx->blas) (void)rocblas_destroy_handle(static_cast<rocblas_handle>(ctx->blas));
+    if (ctx->blas) (void)rocblas_api().destroy_handle(static_cast<rocblas_handle>(ctx->blas));
     ctx->blas = nullptr;
 }
 
@@ -208,26 +247,28 @@ static int dense_axis_pass(bk_ctx* ctx, int n0, int n1, int n2, int axis, const 
         BK_HIP(ctx, hipGetLastError());
         return 0;
     }
+    RocblasApi& rb = rocblas_api();
+    if (!rb.ok) return set_error(ctx, "dct_gemm = 2: librocblas.so could not be loaded (the cross-check needs it; the product path does not)");
     if (!ctx->blas) {
         rocblas_handle h = nullptr;
-        if (rocblas_create_handle(&h) != rocblas_status_success) return set_error(ctx, "rocblas_create_handle failed");
+        if (rb.create_handle(&h) != rocblas_status_success) return set_error(ctx, "rocblas_create_handle failed");
         ctx->blas = h;
     }
     rocblas_handle h = static_cast<rocblas_handle>(ctx->blas);
-    if (rocblas_set_stream(h, ctx->stream) != rocblas_status_success) return set_error(ctx, "rocblas_set_stream failed");
+    if (rb.set_stream(h, ctx->stream) != rocblas_status_success) return set_error(ctx, "rocblas_set_stream failed");
     const double one = 1.0, zero = 0.0;
     rocblas_status st;
     if (axis == 0) {
         // row-major Out(rows x N) = X M  <=>  column-major Out'(N x rows) = M' X', and the row-major M pointer read
         // column-major IS M'
         const size_t rows = total / N;
-        st = rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, N, (rocblas_int)rows, N, &one, M, N, in, N, &zero,
+        st = rb.dgemm(h, rocblas_operation_none, rocblas_operation_none, N, (rocblas_int)rows, N, &one, M, N, in, N, &zero,
                            out, N);
     } else {
         // per plane (row-major [N][inner]): Out = M' X  <=>  column-major Out'(inner x N) = X'(inner x N) M
         const size_t inner = axis == 1 ? (size_t)n0 : (size_t)n0 * n1;
         const size_t batch = axis == 1 ? (size_t)n2 : 1;
-        st = rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, (rocblas_int)inner, N, N,
+        st = rb.dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, (rocblas_int)inner, N, N,
                                            &one, in, (rocblas_int)inner, (rocblas_stride)(inner * N), M, N, 0, &zero, out,
                                            (rocblas_int)inner, (rocblas_stride)(inner * N), (rocblas_int)batch);
     }

@@ -50,3 +50,14 @@ def test_no_cpu_fallback_in_product():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_library_does_not_link_a_vendor_blas():
+    """rocBLAS only serves the cross-check option dct_gemm = 2 and is dlopen()ed there (csrc/dct.hip: rocblas_api); the product
+    library's own dependencies are the HIP runtime and RCCL."""
+    import subprocess
+    lib = os.path.join(ROOT, "bifurcationkit.jl_amd", "lib", "libbkhip.so")
+    out = subprocess.run(["readelf", "-d", lib], capture_output=True, text=True, check=True).stdout
+    needed = [l.split("[")[1].split("]")[0] for l in out.splitlines() if "NEEDED" in l]
+    assert not [n for n in needed if "blas" in n.lower()], needed
+    assert any("amdhip64" in n for n in needed) and any("rccl" in n for n in needed), needed
