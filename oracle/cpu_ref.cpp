@@ -12,8 +12,11 @@
 //   BorderingBLS (BEC, check_precision = false)             src/LinearBorderSolver.jl:88-144
 //   newton_palc, one iteration from the predictor           src/continuation/Palc.jl:187-305
 //
-// Usage: cpu_ref nx ny nz lx ly lz l nu shift ds theta u0.bin p0 u1.bin p1 [steps]
+// Usage: cpu_ref nx ny nz lx ly lz l nu shift ds theta u0.bin p0 u1.bin p1 [steps [dump_prefix]]
 //   (u0, u1: raw float64, x fastest) -> one JSON line {seconds_per_step, threads, itlinear, residuals, p}
+//   dump_prefix: also write <prefix>{xp,res,jtau,x1,x}.bin -- the predictor, F(predictor), J(predictor) tau, the solution of
+//   J x1 = F of the first bordered solve and the corrected state -- for the generic-state GPU parity test
+//   (tests/test_gpu_fullsize.py::test_generic_state_against_the_cpp_restatement).
 // The numbers are checked against the NumPy oracle (oracle/palc.py) in tests/test_oracle.py.
 #include <omp.h>
 
@@ -22,6 +25,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 typedef std::vector<double> vec;
@@ -350,7 +354,7 @@ static vec read_bin(const char* path, size_t n) {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 16) { fprintf(stderr, "usage: cpu_ref nx ny nz lx ly lz l nu shift ds theta u0.bin p0 u1.bin p1 [steps]\n"); return 2; }
+    if (argc < 16) { fprintf(stderr, "usage: cpu_ref nx ny nz lx ly lz l nu shift ds theta u0.bin p0 u1.bin p1 [steps [dump_prefix]]\n"); return 2; }
     Problem pb;
     for (int d = 0; d < 3; ++d) { pb.n[d] = atoi(argv[1 + d]); pb.l[d] = atof(argv[4 + d]); }
     const double lpar0 = atof(argv[7]);
@@ -360,6 +364,14 @@ int main(int argc, char** argv) {
     const vec u0 = read_bin(argv[12], N), u1 = read_bin(argv[14], N);
     const double p0 = atof(argv[13]), p1 = atof(argv[15]);
     const int steps = argc > 16 ? atoi(argv[16]) : 1;
+    const char* dump = argc > 17 ? argv[17] : nullptr;
+    auto write_bin = [&](const char* tag, const vec& v) {
+        if (!dump) return;
+        const std::string path = std::string(dump) + tag + ".bin";
+        FILE* f = fopen(path.c_str(), "wb");
+        if (!f || fwrite(v.data(), sizeof(double), v.size(), f) != v.size()) { fprintf(stderr, "cannot write %s\n", path.c_str()); exit(2); }
+        fclose(f);
+    };
     (void)lpar0;
     auto t_setup = std::chrono::steady_clock::now();
     {
@@ -383,7 +395,7 @@ int main(int argc, char** argv) {
     const double pp = p0 + ds * taup;
     const double eps = 1.4901161193847656e-08;
     double res0 = 0, res1 = 0, pnew = 0;
-    int itlin = 0;
+    int itlin = 0, itl[2] = {0, 0};
     vec x(N), res_f(N), dFdp(N), x1(N), dx(N);
     const double dz0 = dot(u0, tau);
     auto Nfun = [&](const vec& xx, double p) { return (theta * dot(xx, tau) / N + (1 - theta) * (p - p0) * taup - ds) - theta * dz0 / N; };
@@ -400,9 +412,18 @@ int main(int argc, char** argv) {
         Gmres g;
         g.prob = &pb; g.P = &P; g.u = &x; g.lpar = p;
         int it1 = 0, it2 = 0;
+        if (dump && s == 0) {
+            write_bin("xp", x);
+            write_bin("res", res_f);
+            vec jt(N);
+            pb.dF(x, p, tau, jt);
+            write_bin("jtau", jt);
+        }
         g.solve(res_f, x1, &it1);                                  // BEC: x1 = J^-1 R, dx = J^-1 dR  (:134-136)
+        if (dump && s == 0) write_bin("x1", x1);
         g.solve(dFdp, dx, &it2);
         itlin = it1 + it2;
+        itl[0] = it1; itl[1] = it2;
         const double xiu = theta, xip = 1 - theta;
         const double dl = (res_n - dot(tau, x1) / N * xiu) / (taup * xip - dot(tau, dx) / N * xiu);
         axpy(-dl, dx, x1);                                         // dX = x1 - dl dx
@@ -412,10 +433,11 @@ int main(int argc, char** argv) {
         res_n = Nfun(x, p);
         res1 = std::max(nrminf(res_f), std::fabs(res_n));
         pnew = p;
+        if (dump && s == 0) write_bin("x", x);
     }
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / steps;
     printf("{\"seconds_per_step\": %.6f, \"setup_seconds\": %.3f, \"threads\": %d, \"n\": %zu, \"itlinear\": %d, "
-           "\"residuals\": [%.17g, %.17g], \"p\": %.17g, \"nnz_L1\": %ld}\n",
-           dt, setup_s, omp_get_max_threads(), N, itlin, res0, res1, pnew, (long)pb.L1.ptr[pb.L1.n]);
+           "\"itlinear_each\": [%d, %d], \"residuals\": [%.17g, %.17g], \"p\": %.17g, \"p_pred\": %.17g, \"tau_p\": %.17g, \"nnz_L1\": %ld}\n",
+           dt, setup_s, omp_get_max_threads(), N, itlin, itl[0], itl[1], res0, res1, pnew, pp, taup, (long)pb.L1.ptr[pb.L1.n]);
     return 0;
 }

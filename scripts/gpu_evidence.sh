@@ -28,7 +28,7 @@ leads)
     python scripts/bench_brief.py gpurun_out/${TAG}_leads_bench_baseline.json gpurun_out/${TAG}_leads_bench_tuned.json
     ;;
 tests)
-    timeout 1800 python -m pytest tests -m gpu -q -x 2>&1 | tail -${TAILN:-30} | tee gpurun_out/${TAG}_pytest_gpu.log | cut -c1-300
+    timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -${TAILN:-30} | tee gpurun_out/${TAG}_pytest_gpu.log | cut -c1-300
     timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2 | tee gpurun_out/${TAG}_smoke.log
     ;;
 newtests)

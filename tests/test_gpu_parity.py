@@ -457,7 +457,7 @@ def test_block_arnoldi_steps_match_single_steps_and_the_oracle(ctx, grid):
             if okw is not None:
                 xo, oko, nopso, _ = krylov.gmres_krylovkit(Jm, rhs, a0, a1, **okw)
                 xb, okb, nopsb, _ = krylov.gmres_block(Jm, rhs, a0, a1, block=4, **okw)
-                assert oko and okb and abs(out[4][2] - nopso) <= max(1, nopso // 20) and abs(out[4][2] - nopsb) <= max(1, nopsb // 100), (out[4][2], nopso, nopsb)
+                assert oko and okb and abs(out[4][2] - nopso) <= max(1, nopso // 20) and abs(out[4][2] - nopsb) <= max(1, nopsb // 20), (out[4][2], nopso, nopsb)
                 assert np.abs(out[4][0] - xo).max() <= 1e-7 * np.abs(xo).max()
     finally:
         ctx.set_option("gmres_chunk", 4)
