@@ -31,7 +31,7 @@ class ProblemDesc(C.Structure):
 
 class GmresOpts(C.Structure):
     _fields_ = [("flavor", C.c_int), ("dim", C.c_int), ("maxiter", C.c_int), ("atol", C.c_double),
-                ("rtol", C.c_double)]
+                ("rtol", C.c_double), ("pr", C.c_void_p)]
 
 
 class BorderingOpts(C.Structure):

@@ -615,6 +615,8 @@ namespace {
 struct ShiftPrecOp : bk_op {
     bk_op* J;
     bk_precond* P;
+    bk_precond* Pr = nullptr;     // right preconditioner (order 1 only): the operator is v -> Pl^-1 (a0 + a1 J) Pr^-1 v
+    double* tmp2 = nullptr;
     double a0, a1;
     int order;
     double* tmp;
@@ -626,9 +628,15 @@ struct ShiftPrecOp : bk_op {
         fold = P && order == 0 && J->sh_problem() && P->is_l1_plus_shift(J->sh_problem(), &pl_shift) &&
                ctx->opt("gmres_fold_shift", 1.0) != 0.0;
     }
-    bool shift_is_free() const override { return P ? fold : J->shift_is_free(); }
+    bool shift_is_free() const override { return Pr ? false : (P ? fold : J->shift_is_free()); }
     int apply(const double* x, const double*, double b0, double b1, double* out, double*) override {
         // out = b0 x + b1 * W(x)
+        if (Pr) {
+            BK_TRY(Pr->apply(x, tmp2));
+            BK_TRY(J->apply(tmp2, nullptr, a0, a1, tmp, nullptr));
+            if (P) BK_TRY(P->apply(tmp, tmp));
+            return v_axpbyz(ctx, n, b0, x, b1, tmp, out);
+        }
         if (!P) return J->apply(x, nullptr, b0 + b1 * a0, b1 * a1, out, nullptr);
         if (order == 0) {
             const double cx = b0 + b1 * a0, ct = b1 * a1;
@@ -795,21 +803,27 @@ int linsolve(bk_ctx* ctx, bk_op* J, const double* rhs, double* x, double a0, dou
     if (o.flavor == BK_KRYLOV_MINRES) return minres_core(ctx, J, rhs, x, a0, a1, o, pl, res);
     if (o.flavor == BK_KRYLOV_CG) return cg_core(ctx, J, rhs, x, a0, a1, o, pl, res);
     const bool kk = (o.flavor == BK_GMRES_KRYLOVKIT);
+    if (kk && o.pr) return set_error(ctx, "GMRESKrylovKit has no right preconditioner (src/LinearSolver.jl:223-250): use the IterativeSolvers or Krylov.jl flavor");
     if (!pl && kk) return gmres_core(ctx, J, rhs, nullptr, x, nullptr, a0, a1, o, res);
     WsGuard ws(ctx);
     ShiftPrecOp W;
     W.ctx = ctx; W.n = J->n; W.ntail = 0;
     W.J = J; W.P = pl; W.a0 = a0; W.a1 = a1; W.order = kk ? 0 : 1; W.tmp = nullptr;
+    W.Pr = kk ? nullptr : o.pr;
     W.init_fold();
     const double* b = rhs;
+    if (pl || W.Pr) BK_TRY(ws.get(J->n, &W.tmp));
+    if (W.Pr) BK_TRY(ws.get(J->n, &W.tmp2));
     if (pl) {
         double* prhs = nullptr;
-        BK_TRY(ws.get(J->n, &W.tmp));
         BK_TRY(ws.get(J->n, &prhs));
         BK_TRY(pl->apply(rhs, prhs));            // ldiv!(similar(rhs), Pl, copy(rhs)) :278
         b = prhs;
     }
-    return gmres_core(ctx, &W, b, nullptr, x, nullptr, 0.0, 1.0, o, res);
+    BK_TRY(gmres_core(ctx, &W, b, nullptr, x, nullptr, 0.0, 1.0, o, res));
+    // right preconditioner: the iteration ran on y = Pr x; x = Pr^-1 y (IterativeSolvers update_solution!, Krylov.jl N)
+    if (W.Pr) BK_TRY(W.Pr->apply(x, x));
+    return 0;
 }
 
 // Two independent solves with the same operator and preconditioner -- the R and dF/dp solves of BorderingBLS, ls(J, rhs1,
@@ -827,7 +841,7 @@ int linsolve2(bk_ctx* ctx, bk_op* J, const double* rhs1, double* x1, const doubl
     // ranks: opt-in (two_lanes = 1) -- the lane needs its own communicator, and on RCCL that path has not seen hardware yet;
     // the decision only looks at options, the communicator and the GLOBAL problem, so every rank takes the same one
     const bool want = ctx->opt("two_lanes", (ctx->nranks == 1 && J->n <= ((size_t)1 << 24)) ? 1.0 : 0.0) != 0.0;
-    bk_ctx* lane = (want && PJ && J->ntail == 0) ? ctx_lane(ctx) : nullptr;
+    bk_ctx* lane = (want && PJ && J->ntail == 0 && !o.pr) ? ctx_lane(ctx) : nullptr;     // (a right preconditioner lives on ctx)
     bk_precond* pl2 = nullptr;
     if (lane && pl) {
         pl2 = precond_lane_shadow(pl, lane);
@@ -885,6 +899,7 @@ extern "C" {
 void bk_gmres_default_opts(bk_gmres_opts* o, int flavor) {
     if (!o) return;
     o->flavor = flavor;
+    o->pr = nullptr;
     if (flavor == BK_KRYLOV_MINRES || flavor == BK_KRYLOV_CG) {   // Krylov.jl: atol = rtol = sqrt(eps), itmax = 0 -> 2n
         o->dim = 0; o->maxiter = 0; o->atol = 1.4901161193847656e-08; o->rtol = 1.4901161193847656e-08;
     } else if (flavor == BK_GMRES_KRYLOVJL) {       // Krylov.jl gmres defaults: memory 20, atol = rtol = sqrt(eps)

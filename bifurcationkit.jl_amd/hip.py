@@ -397,6 +397,8 @@ class _GMRES:
     def _opts(self):
         o = L.GmresOpts()
         o.flavor, o.dim, o.maxiter, o.atol, o.rtol = self.flavor, self.dim, self.maxiter, self.atol, self.rtol
+        pr = getattr(self, "Pr", None)                 # right preconditioner (GMRESIterativeSolvers.Pr, KrylovLS.Pr)
+        o.pr = pr.h if pr is not None else None
         return o
 
     def _pl(self):
@@ -457,12 +459,14 @@ class GMRESKrylovKit(_GMRES):
 
 @dataclass
 class GMRESIterativeSolvers(_GMRES):
-    """Fields of src/LinearSolver.jl:149-180: reltol, abstol, restart, maxiter, Pl."""
+    """Fields of src/LinearSolver.jl:149-180: reltol, abstol, restart, maxiter, Pl, Pr (the solver iterates on
+    Pl^-1 (a0 I + a1 J) Pr^-1 y = Pl^-1 rhs and returns x = Pr^-1 y, :198-201)."""
     reltol: float = 1e-8
     abstol: float = 0.0
     restart: int = 63          # the reference default (200) allocates a 201-vector basis; capped (SURVEY App. B)
     maxiter: int = 100
     Pl: DCTPreconditioner | None = None
+    Pr: DCTPreconditioner | None = None
     flavor = L.BK_GMRES_ITERATIVESOLVERS
 
     @property
@@ -491,6 +495,7 @@ class KrylovLS(_GMRES):
     itmax: int = 2000
     restart: bool = False
     Pl: DCTPreconditioner | None = None
+    Pr: DCTPreconditioner | None = None      # Krylov.jl's right preconditioner N (src/LinearSolver.jl:343)
     flavor = L.BK_GMRES_KRYLOVJL
 
     @property

@@ -202,6 +202,11 @@ typedef struct {
     int maxiter;
     double atol;
     double rtol;
+    bk_precond* pr;  /* right preconditioner or NULL: GMRESIterativeSolvers.Pr (src/LinearSolver.jl:178,201 -- the solver iterates
+                        on Pl^-1 (a0 I + a1 J) Pr^-1 y = Pl^-1 rhs and returns x = Pr^-1 y) and KrylovLS's `N = Pr` for the
+                        non-symmetric methods (:343); an error with the KrylovKit flavor (GMRESKrylovKit has no such field,
+                        :223-250); ignored by :minres / :cg exactly as the reference does ("we only pass centered
+                        preconditioner", :339-341).  bk_gmres_default_opts sets NULL.                                      */
 } bk_gmres_opts;
 void bk_gmres_default_opts(bk_gmres_opts* o, int flavor);   /* the reference's defaults           */
 /* Solve (a0 I + a1 J) x = rhs, x0 = 0.  `pl` may be NULL.  With `pl` the KrylovKit flavor solves

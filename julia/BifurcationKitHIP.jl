@@ -34,6 +34,7 @@ struct ProblemDesc
 end
 struct GmresOpts
     flavor::Cint; dim::Cint; maxiter::Cint; atol::Cdouble; rtol::Cdouble
+    pr::Ptr{Cvoid}             # right preconditioner handle or C_NULL (bk_gmres_opts.pr)
 end
 struct BorderingOpts
     tol::Cdouble; check_precision::Cint; k::Cint
@@ -296,7 +297,7 @@ Base.@kwdef mutable struct HipGMRES{Tl} <: AbstractIterativeLinearSolver
     maxiter::Int = 100
     Pl::Tl = nothing
 end
-_opts(l::HipGMRES) = GmresOpts(Cint(0), l.dim, l.maxiter, l.atol, l.rtol)
+_opts(l::HipGMRES) = GmresOpts(Cint(0), l.dim, l.maxiter, l.atol, l.rtol, C_NULL)      # GMRESKrylovKit has no Pr
 _num(a, default) = a isa Number ? Float64(a) : default          # VI.Zero() / VI.One() defaults of the engine
 
 function (l::HipGMRES)(J::HipJacobian, rhs::HipVec; a₀ = 0.0, a₁ = 1.0, kwargs...)
@@ -324,10 +325,12 @@ Base.@kwdef mutable struct HipKrylovLS{Tl} <: AbstractIterativeLinearSolver
     itmax::Int = 0
     restart::Bool = false      # Krylov.jl: restart every `memory` steps only when true; else the basis grows (here: up to 63)
     Pl::Tl = nothing
+    Pr = nothing               # right preconditioner N = Pr of the non-symmetric methods (src/LinearSolver.jl:343)
 end
 _flavor(l::HipKrylovLS) = l.KrylovAlg == :gmres ? Cint(2) : l.KrylovAlg == :minres ? Cint(3) : l.KrylovAlg == :cg ? Cint(4) :
                           error("HipKrylovLS: KrylovAlg must be :gmres, :minres or :cg")
-_opts(l::HipKrylovLS) = GmresOpts(_flavor(l), l.restart ? l.memory : 63, l.KrylovAlg == :gmres && l.itmax == 0 ? 2000 : l.itmax, l.atol, l.rtol)
+_opts(l::HipKrylovLS) = GmresOpts(_flavor(l), l.restart ? l.memory : 63, l.KrylovAlg == :gmres && l.itmax == 0 ? 2000 : l.itmax, l.atol, l.rtol,
+                                  _plh(l.Pr))
 function (l::HipKrylovLS)(J::HipJacobian, rhs::HipVec; a₀ = 0.0, a₁ = 1.0, kwargs...)
     ctx = rhs.ctx
     x = similar(rhs)

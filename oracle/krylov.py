@@ -502,9 +502,15 @@ def cg_krylovjl(A, b, a0=0.0, a1=1.0, *, atol=None, rtol=None, itmax=0, M=None):
 
 
 def gmres_iterativesolvers(A, b, a0=0.0, a1=1.0, *, restart=200, maxiter=100, reltol=1e-8, abstol=0.0,
-                           Pl=None):
+                           Pl=None, Pr=None):
     """IterativeSolvers.gmres on v -> a0 v + a1 A v (src/LinearSolver.jl:195-201), x0 = 0.
-    ``Pl`` (optional) is a callable applying Pl^-1.  Returns (x, isconverged, iters)."""
+    ``Pl`` / ``Pr`` (optional) are callables applying Pl^-1 / Pr^-1: the iteration runs on Pl^-1 A Pr^-1 y = Pl^-1 b and the
+    solution is x = Pr^-1 y (the package's expand! / update_solution!).  Returns (x, isconverged, iters)."""
+    if Pr is not None:
+        A_, a0_, a1_ = A, a0, a1
+        y, ok, it = gmres_iterativesolvers(lambda v: axpy_op(A_, Pr(v), a0_, a1_), b, 0.0, 1.0, restart=restart, maxiter=maxiter,
+                                           reltol=reltol, abstol=abstol, Pl=Pl)
+        return Pr(y), ok, it
     b = np.asarray(b, dtype=float)
     n = b.shape[0]
     op = lambda v: axpy_op(A, v, a0, a1)
@@ -557,12 +563,18 @@ def gmres_iterativesolvers(A, b, a0=0.0, a1=1.0, *, restart=200, maxiter=100, re
 
 
 def gmres_krylovjl(A, b, a0=0.0, a1=1.0, *, memory=20, restart=False, itmax=0, atol=np.sqrt(np.finfo(float).eps),
-                   rtol=np.sqrt(np.finfo(float).eps), M=None):
+                   rtol=np.sqrt(np.finfo(float).eps), M=None, N=None):
     """Krylov.jl `gmres` as BifurcationKit's KrylovLS calls it (src/LinearSolver.jl:336-345: `krylov_solve(Val(:gmres), Jmap,
     rhs; kwargs..., M = Pl, N = Pr)`) on v -> a0 v + a1 A v, x0 = 0: left preconditioner M, modified Gram-Schmidt, Givens QR
     of the Hessenberg matrix, stop on ||M r|| <= atol + rtol ||M r0||.  `memory` is the initial basis size; with
     `restart = false` (the package default) the basis simply keeps growing, with `restart = true` the method restarts
-    every `memory` steps.  Package knowledge, not verifiable here.  Returns (x, solved, niter)."""
+    every `memory` steps.  ``N``: right preconditioner (the method solves M A N y = M b, x = N y).  Package knowledge
+    (SURVEY Appendix B), not verifiable here.  Returns (x, solved, niter)."""
+    if N is not None:
+        A_, a0_, a1_ = A, a0, a1
+        y, ok, it = gmres_krylovjl(lambda v: axpy_op(A_, N(v), a0_, a1_), b, 0.0, 1.0, memory=memory, restart=restart, itmax=itmax,
+                                   atol=atol, rtol=rtol, M=M)
+        return N(y), ok, it
     b = np.asarray(b, dtype=float)
     n = b.shape[0]
     op = lambda v: axpy_op(A, v, a0, a1)

@@ -382,6 +382,45 @@ def test_gmres_unpreconditioned_shift_and_restart(ctx):
     assert np.abs(x.numpy() - xj).max() <= 1e-7 * np.abs(xj).max()
 
 
+@pytest.mark.parametrize("dims", [(5, 4, 3), (8, 7, 6)])
+def test_right_preconditioner(ctx, dims):
+    """GMRESIterativeSolvers.Pr (src/LinearSolver.jl:178,201) and KrylovLS's N = Pr (:343) through bk_gmres_opts.pr: with
+    Pl != I != Pr the solver iterates on Pl^-1 (a0 I + a1 J) Pr^-1 y = Pl^-1 rhs and returns x = Pr^-1 y -- still the solution
+    of the unpreconditioned system (dense solve, test_linear.jl:106-169), with the iteration count of the oracle's
+    restatement; Pr alone; the KrylovKit flavor has no such field and must refuse it; :minres ignores it as the reference does."""
+    hip = _hip()
+    ls_ = (1.0, 1.2, 0.9)
+    sh, prob, rng, u = _sh_setup(ctx, dims, ls_, seed=11)
+    rhs = rng.standard_normal(sh.N)
+    Jm = sh.J(u, 0.1, 1.2)
+    J = prob.jacobian(prob.vec(u), 0.1)
+    P1, P3 = hip.DCTPreconditioner(prob, 1.0), hip.DCTPreconditioner(prob, 3.0)
+    Po1, Po3 = operators.dct_preconditioner(dims, ls_, 1.0), operators.dct_preconditioner(dims, ls_, 3.0)
+    a0, a1 = 0.4, -1.0
+    ref = np.linalg.solve(a0 * np.eye(sh.N) + a1 * Jm.toarray(), rhs)
+    full = sh.N <= 63                                     # the Krylov space can hold the whole space: exact after <= N steps
+    tol = 1e-12 if full else 1e-10
+    for Pl, Pr, Plo, Pro in ((P1, P3, Po1, Po3), (None, P3, None, Po3)):
+        x, ok, it = hip.GMRESIterativeSolvers(reltol=tol, restart=63, maxiter=4000, Pl=Pl, Pr=Pr)(J, prob.vec(rhs), a0, a1)
+        xo, oko, ito = krylov.gmres_iterativesolvers(Jm, rhs, a0, a1, restart=63, maxiter=4000, reltol=tol, Pl=Plo, Pr=Pro)
+        assert ok and oko and abs(it - ito) <= max(2, ito // 20), (it, ito)
+        assert np.abs(x.numpy() - ref).max() <= 1e-6 * np.abs(ref).max(), np.abs(x.numpy() - ref).max() / np.abs(ref).max()
+        x, ok, it = hip.KrylovLS(atol=0.0, rtol=tol, memory=63, restart=True, itmax=4000, Pl=Pl, Pr=Pr)(J, prob.vec(rhs), a0, a1)
+        xo, oko, ito = krylov.gmres_krylovjl(Jm, rhs, a0, a1, memory=63, restart=True, itmax=4000, atol=0.0, rtol=tol, M=Plo, N=Pro)
+        assert ok and oko and abs(it - ito) <= max(2, ito // 20), (it, ito)
+        assert np.abs(x.numpy() - ref).max() <= 1e-6 * np.abs(ref).max()
+    kk = hip.GMRESKrylovKit(dim=30, rtol=1e-10, Pl=P1)
+    kk.Pr = P3
+    with pytest.raises(RuntimeError, match="right preconditioner"):
+        kk(J, prob.vec(rhs))
+    # the symmetric solvers only take the centered preconditioner: Pr is ignored, as in src/LinearSolver.jl:339-341
+    sy = hip.KrylovLSSymmetric(KrylovAlg="minres", atol=0.0, rtol=1e-10, itmax=4000, Pl=P1)
+    x0, ok0, it0 = sy(J, prob.vec(rhs), 0.0, 1.0)
+    sy.Pr = P3
+    x1, ok1, it1 = sy(J, prob.vec(rhs), 0.0, 1.0)
+    assert ok0 and ok1 and it0 == it1 and np.array_equal(x0.numpy(), x1.numpy())
+
+
 @pytest.mark.parametrize("flavor", ["krylovkit", "iterativesolvers"])
 def test_device_resident_arnoldi_chunks_match_host_driven_steps(ctx, flavor):
     """gmres_chunk >= 2 (the default for cache-resident vectors): several Arnoldi steps are enqueued without a host round

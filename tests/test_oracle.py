@@ -535,3 +535,25 @@ def test_block_arnoldi_refuses_a_closing_krylov_space():
     st = {}
     x, ok, numops, res = krylov.gmres_block(A, b, krylovdim=10, rtol=1e-12, atol=1e-14, block=4, stats=st)
     assert ok and st["refused"] >= 1 and np.abs(A @ x - b).max() < 1e-12
+
+
+def test_right_preconditioner_restatements_solve_the_unpreconditioned_system():
+    """GMRESIterativeSolvers.Pr (src/LinearSolver.jl:178,201) and KrylovLS's N = Pr (:343): with Pl != I != Pr the iteration runs
+    on Pl^-1 A Pr^-1 y = Pl^-1 b and returns x = Pr^-1 y, i.e. still the solution of A x = b (mirrors
+    test/linear_solvers/test_linear.jl:106-169: every solver == J \\ rhs)."""
+    from oracle import krylov, operators
+    dims, ls = (5, 4, 3), (1.0, 1.2, 0.9)
+    sh = operators.SwiftHohenberg(dims, ls)
+    J = sh.J(sh.guess(), 0.1, 1.2).toarray()
+    Pl = operators.dct_preconditioner(dims, ls, 1.0)
+    Pr = operators.dct_preconditioner(dims, ls, 3.0)
+    rhs = np.random.default_rng(11).standard_normal(sh.N)
+    a0, a1 = 0.4, -1.0
+    ref = np.linalg.solve(a0 * np.eye(sh.N) + a1 * J, rhs)
+    x, ok, it = krylov.gmres_iterativesolvers(J, rhs, a0, a1, restart=63, maxiter=300, reltol=1e-12, Pl=Pl, Pr=Pr)
+    assert ok and it <= sh.N + 1 and np.abs(x - ref).max() <= 1e-8 * np.abs(ref).max()
+    x, ok, it = krylov.gmres_krylovjl(J, rhs, a0, a1, memory=63, restart=True, itmax=300, atol=0.0, rtol=1e-12, M=Pl, N=Pr)
+    assert ok and np.abs(x - ref).max() <= 1e-8 * np.abs(ref).max()
+    # Pr alone
+    x, ok, it = krylov.gmres_iterativesolvers(J, rhs, a0, a1, restart=63, maxiter=300, reltol=1e-12, Pr=Pr)
+    assert ok and np.abs(x - ref).max() <= 1e-8 * np.abs(ref).max()
