@@ -102,6 +102,7 @@ SIGNATURES = {
     "bk_comm_unique_id": (I, [VP]),
     "bk_ctx_create_dist": (I, [C.POINTER(VP), I, VP, I, I, VP]),
     "bk_ctx_create_hostcomm": (I, [C.POINTER(VP), I, VP, I, I, ALLREDUCE_FN, SENDRECV_FN, VP]),
+    "bk_ctx_set_lane_comm": (I, [VP, ALLREDUCE_FN, SENDRECV_FN, VP]),
     "bk_comm_info": (I, [VP, c_int_p, c_int_p, c_int_p]),
     "bk_comm_probe": (I, [VP, I, SZ, I, c_double_p]),
     "bk_ctx_destroy": (I, [VP]),

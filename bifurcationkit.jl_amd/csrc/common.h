@@ -37,6 +37,8 @@ enum CommKind { COMM_NONE = 0, COMM_RCCL = 1, COMM_HOST = 2 };
 
 }  // namespace bk
 
+struct CommProxy;                  // context.hip: proxy thread of the host-staged communicator (in-stream collectives)
+
 struct bk_ctx {
     int device = 0;
     int num_cu = 256;              // compute units of the device (persistent-kernel grids)
@@ -52,6 +54,12 @@ struct bk_ctx {
     bk_allreduce_fn h_allreduce = nullptr;
     bk_sendrecv_fn h_sendrecv = nullptr;
     void* h_user = nullptr;
+    CommProxy* proxy = nullptr;          // host-staged communicator: created with the first collective
+    // communicator of the second lane (bk_ctx_set_lane_comm): the lane's collectives are issued concurrently with the
+    // context's own and must never be matched against them
+    bk_allreduce_fn lane_allreduce = nullptr;
+    bk_sendrecv_fn lane_sendrecv = nullptr;
+    void* lane_user = nullptr;
     // reduction scratch
     double* d_partials = nullptr;   // [kRedBlocks * kMaxBasis+2]
     double* d_red = nullptr;        // [kRedSlots]
@@ -148,6 +156,11 @@ struct ProfScope {  // records a start/stop event pair on the ctx stream around 
 // op: 0 = sum, 1 = max.  On return ctx->h_red[0..nvals) holds the results (stream synchronised).
 int reduce_finish(bk_ctx* ctx, int nblocks, int nvals, int op);
 int comm_allreduce_host(bk_ctx* ctx, double* buf, int n, int op);   // small host-side all-reduce
+// all-reduce of a device buffer ENQUEUED in `stream` (ncclAllReduce on RCCL ranks, a stream-ordered hand-over to the proxy thread
+// on host-staged ranks): no host synchronisation
+int comm_allreduce_dev(bk_ctx* ctx, hipStream_t stream, double* dbuf, int n, int op);
+int ctx_sync(bk_ctx* ctx);           // hipStreamSynchronize(ctx->stream) + the error state of proxied collectives
+void proxy_destroy(bk_ctx* ctx);
 
 // ---- BLAS-1 launchers (vecops.hip) ---------------------------------------------------------
 void blas_release(bk_ctx* ctx);    // dct.hip

@@ -1,5 +1,10 @@
 // Context, workspace pool, profiling scopes, deterministic reduction finish, communicator glue.
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 
 #include "common.h"
 #include "ops.h"
@@ -112,20 +117,233 @@ __global__ void __launch_bounds__(256) reduce_stage2_kernel(const double* __rest
     }
 }
 
-int comm_allreduce_host(bk_ctx* ctx, double* buf, int n, int op) {
+}  // namespace bk
+
+// ------------------------------------------------------------------ host-staged communicator: in-stream collectives
+// The callbacks of bk_ctx_create_hostcomm work on HOST buffers.  To make the ranks of a host-staged context run the very code
+// RCCL ranks run -- collectives ENQUEUED in the stream between kernels, no host synchronisation around them: device-resident
+// Arnoldi chunks, the halo exchange on its own stream under the interior z-chunks, two lanes -- every collective becomes a
+// stream-ordered hand-over to a PROXY THREAD owned by the context (the role RCCL's own proxy threads play):
+//   stream:  copy the operand to pinned host memory -> post kernel: ready[slot] = seq -> wait kernel: spins (s_sleep) on
+//            done[slot] == seq -> copy the result back
+//   proxy:   takes the operations in the order the host enqueued them (identical on every rank), waits for ready[slot],
+//            runs the callback, sets done[slot]
+// The flags live in pinned, device-mapped (fine-grained) host memory.  The wait kernel gives up after kProxyTimeoutTicks
+// (30 s) and raises the error flag instead of hanging the device; a failing callback raises it too; ctx_sync() reports it.
+// The callbacks therefore run on a library-owned thread (include/bkhip.h says so).
+namespace {
+
+constexpr int kProxySlots = 1024;
+constexpr long long kProxyTimeoutTicks = 3000000000LL;     // wall_clock64: 100 MHz
+
+__global__ void proxy_post_kernel(unsigned long long* flag, unsigned long long seq) {
+    __threadfence_system();
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void proxy_wait_kernel(unsigned long long* flag, unsigned long long seq, int* err) {
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+        __builtin_amdgcn_s_sleep(64);
+        if (wall_clock64() - t0 > kProxyTimeoutTicks) {
+            __hip_atomic_store(err, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+    }
+    __threadfence_system();
+}
+
+struct ProxyOp {
+    unsigned long long seq = 0;
+    int kind = 0;                     // 0 all-reduce, 1 halo exchange, 2 all-to-all
+    int n = 0, op = 0;                // all-reduce
+    size_t cnt = 0;                   // halo: doubles per face
+    bool has_lo = false, has_hi = false;
+    std::vector<size_t> scount, sdispl, rcount, rdispl;   // all-to-all (staging offsets)
+};
+
+}  // namespace
+
+struct CommProxy {
+    bk_ctx* ctx = nullptr;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<ProxyOp> q;
+    bool stop = false;
+    unsigned long long seq = 0;
+    unsigned long long *ready = nullptr, *done = nullptr;        // pinned host, kProxySlots each
+    unsigned long long *ready_dev = nullptr, *done_dev = nullptr;
+    int* err = nullptr;
+    int* err_dev = nullptr;
+    double* ar = nullptr;                                        // all-reduce staging (kRedSlots)
+    double *hs = nullptr, *hr = nullptr;                         // halo staging: [lo | hi] faces
+    size_t hcap = 0;
+    double *as = nullptr, *ar2 = nullptr;                        // all-to-all staging
+    size_t acap = 0;
+
+    void run() {
+        for (;;) {
+            ProxyOp op;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || !q.empty(); });
+                if (q.empty()) return;
+                op = q.front();
+            }
+            const int slot = (int)(op.seq % kProxySlots);
+            int spins = 0;
+            while (__atomic_load_n(&ready[slot], __ATOMIC_ACQUIRE) != op.seq) {
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (stop) return;
+                }
+                if (++spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(20));
+                else std::this_thread::yield();
+            }
+            int rc = 0;
+            const int me = ctx->rank, R = ctx->nranks;
+            if (op.kind == 0) {
+                rc = ctx->h_allreduce(ctx->h_user, ar, op.n, op.op);
+            } else if (op.kind == 1) {
+                // even ranks talk to the upper neighbour first, odd ranks to the lower one (deadlock-free pairing)
+                for (int phase = 0; phase < 2 && rc == 0; ++phase) {
+                    const bool up = ((me & 1) == 0) ? (phase == 0) : (phase == 1);
+                    if (up && op.has_hi) rc = ctx->h_sendrecv(ctx->h_user, hs + op.cnt, op.cnt, me + 1, hr + op.cnt, op.cnt, me + 1);
+                    else if (!up && op.has_lo) rc = ctx->h_sendrecv(ctx->h_user, hs, op.cnt, me - 1, hr, op.cnt, me - 1);
+                }
+            } else {
+                for (int s_ = 1; s_ < R && rc == 0; ++s_) {
+                    const int dst = (me + s_) % R, src = (me - s_ + R) % R;
+                    rc = ctx->h_sendrecv(ctx->h_user, as + op.sdispl[dst], op.scount[dst], dst, ar2 + op.rdispl[src], op.rcount[src], src);
+                }
+            }
+            if (rc != 0) __atomic_store_n(err, 2, __ATOMIC_RELEASE);
+            __atomic_store_n(&done[slot], op.seq, __ATOMIC_RELEASE);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                q.pop_front();
+            }
+        }
+    }
+};
+
+namespace bk {
+
+static int proxy_get(bk_ctx* ctx, CommProxy** out) {
+    if (ctx->proxy) { *out = ctx->proxy; return 0; }
+    CommProxy* p = new CommProxy();
+    p->ctx = ctx;
+    void* d = nullptr;
+    auto pinned = [&](void** host, size_t bytes) -> hipError_t { return hipHostMalloc(host, bytes, hipHostMallocMapped | hipHostMallocCoherent); };
+    hipError_t e = pinned((void**)&p->ready, sizeof(unsigned long long) * kProxySlots);
+    if (e == hipSuccess) e = pinned((void**)&p->done, sizeof(unsigned long long) * kProxySlots);
+    if (e == hipSuccess) e = pinned((void**)&p->err, sizeof(int) * 16);
+    if (e == hipSuccess) e = pinned((void**)&p->ar, sizeof(double) * kRedSlots);
+    if (e == hipSuccess) { memset(p->ready, 0xff, sizeof(unsigned long long) * kProxySlots); memset(p->done, 0xff, sizeof(unsigned long long) * kProxySlots); p->err[0] = 0; }
+    if (e == hipSuccess) e = hipHostGetDevicePointer(&d, p->ready, 0);
+    p->ready_dev = static_cast<unsigned long long*>(d);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(&d, p->done, 0);
+    p->done_dev = static_cast<unsigned long long*>(d);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(&d, p->err, 0);
+    p->err_dev = static_cast<int*>(d);
+    if (e != hipSuccess) {
+        delete p;
+        return set_error(ctx, "host communicator: proxy allocation failed: %s", hipGetErrorString(e));
+    }
+    p->th = std::thread([p] { p->run(); });
+    ctx->proxy = p;
+    *out = p;
+    return 0;
+}
+
+void proxy_destroy(bk_ctx* ctx) {
+    CommProxy* p = ctx->proxy;
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->stop = true;
+    }
+    p->cv.notify_all();
+    if (p->th.joinable()) p->th.join();
+    for (void* h : {(void*)p->ready, (void*)p->done, (void*)p->err, (void*)p->ar, (void*)p->hs, (void*)p->hr, (void*)p->as, (void*)p->ar2})
+        if (h) (void)hipHostFree(h);
+    delete p;
+    ctx->proxy = nullptr;
+}
+
+// enqueue the hand-over of `op` on `stream`: post kernel, queue entry, wait kernel (the caller copies operands before / results after)
+static int proxy_submit(bk_ctx* ctx, CommProxy* p, hipStream_t stream, ProxyOp& op) {
+    op.seq = p->seq++;
+    const int slot = (int)(op.seq % kProxySlots);
+    hipLaunchKernelGGL(proxy_post_kernel, dim3(1), dim3(1), 0, stream, p->ready_dev + slot, op.seq);
+    BK_HIP(ctx, hipGetLastError());
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->q.push_back(op);
+    }
+    p->cv.notify_one();
+    hipLaunchKernelGGL(proxy_wait_kernel, dim3(1), dim3(1), 0, stream, p->done_dev + slot, op.seq, p->err_dev);
+    BK_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+static int proxy_grow(bk_ctx* ctx, hipStream_t stream, double** a, double** b, size_t* cap, size_t need) {
+    if (need <= *cap) return 0;
+    BK_HIP(ctx, hipStreamSynchronize(stream));           // earlier operations may still use the old buffers
+    if (ctx->comm_stream) BK_HIP(ctx, hipStreamSynchronize(ctx->comm_stream));
+    if (*a) (void)hipHostFree(*a);
+    if (*b) (void)hipHostFree(*b);
+    *a = *b = nullptr;
+    *cap = 0;
+    BK_HIP(ctx, hipHostMalloc((void**)a, need * sizeof(double), hipHostMallocDefault));
+    BK_HIP(ctx, hipHostMalloc((void**)b, need * sizeof(double), hipHostMallocDefault));
+    *cap = need;
+    return 0;
+}
+
+// In-stream all-reduce of a device buffer (n <= kRedSlots doubles), both communicator kinds: what an RCCL rank enqueues as
+// ncclAllReduce, a host-staged rank hands to its proxy thread.  No host synchronisation.
+int comm_allreduce_dev(bk_ctx* ctx, hipStream_t stream, double* dbuf, int n, int op) {
     if (ctx->comm == COMM_NONE || ctx->nranks == 1) return 0;
-    if (ctx->comm == COMM_HOST) {
-        if (ctx->h_allreduce(ctx->h_user, buf, n, op) != 0) return set_error(ctx, "host allreduce callback failed");
+    if (n > kRedSlots) return set_error(ctx, "comm_allreduce_dev: n too large");
+    if (ctx->comm == COMM_RCCL) {
+        BK_NCCL(ctx, ncclAllReduce(dbuf, dbuf, n, ncclDouble, op == 0 ? ncclSum : ncclMax, ctx->nccl, stream));
         return 0;
     }
-    // RCCL: stage through the device result buffer
+    CommProxy* p = nullptr;
+    BK_TRY(proxy_get(ctx, &p));
+    BK_HIP(ctx, hipMemcpyAsync(p->ar, dbuf, n * sizeof(double), hipMemcpyDeviceToHost, stream));
+    ProxyOp o;
+    o.kind = 0; o.n = n; o.op = op;
+    BK_TRY(proxy_submit(ctx, p, stream, o));
+    BK_HIP(ctx, hipMemcpyAsync(dbuf, p->ar, n * sizeof(double), hipMemcpyHostToDevice, stream));
+    return 0;
+}
+
+// stream synchronisation + the error state of the proxied collectives (time-out of a wait kernel, failed callback)
+int ctx_sync(bk_ctx* ctx) {
+    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->proxy) {
+        const int e = __atomic_load_n(ctx->proxy->err, __ATOMIC_ACQUIRE);
+        if (e == 1) return set_error(ctx, "host communicator: a collective timed out on the device (a peer rank never arrived)");
+        if (e == 2) return set_error(ctx, "host communicator: a callback failed");
+    }
+    return 0;
+}
+
+}  // namespace bk
+
+namespace bk {
+
+int comm_allreduce_host(bk_ctx* ctx, double* buf, int n, int op) {
+    if (ctx->comm == COMM_NONE || ctx->nranks == 1) return 0;
+    // staged through the device result buffer and the in-stream all-reduce: the same path for both communicator kinds
     if (n > kRedSlots) return set_error(ctx, "comm_allreduce_host: n too large");
     BK_HIP(ctx, hipMemcpyAsync(ctx->d_red, buf, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    BK_NCCL(ctx, ncclAllReduce(ctx->d_red, ctx->d_red, n, ncclDouble, op == 0 ? ncclSum : ncclMax, ctx->nccl,
-                               ctx->stream));
+    BK_TRY(comm_allreduce_dev(ctx, ctx->stream, ctx->d_red, n, op));
     BK_HIP(ctx, hipMemcpyAsync(buf, ctx->d_red, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return 0;
+    return ctx_sync(ctx);
 }
 
 int reduce_finish(bk_ctx* ctx, int nblocks, int nvals, int op) {
@@ -142,17 +360,9 @@ int reduce_finish(bk_ctx* ctx, int nblocks, int nvals, int op) {
     hipLaunchKernelGGL(reduce_stage2_kernel, dim3(nvals), dim3(256), 0, ctx->stream, ctx->d_partials, nblocks,
                        nvals, op, ctx->d_red);
     BK_HIP(ctx, hipGetLastError());
-    if (ctx->comm == COMM_RCCL && ctx->nranks > 1) {
-        BK_NCCL(ctx, ncclAllReduce(ctx->d_red, ctx->d_red, nvals, ncclDouble, op == 0 ? ncclSum : ncclMax,
-                                   ctx->nccl, ctx->stream));
-    }
+    BK_TRY(comm_allreduce_dev(ctx, ctx->stream, ctx->d_red, nvals, op));      // in the stream, both communicator kinds
     BK_HIP(ctx, hipMemcpyAsync(ctx->h_red, ctx->d_red, nvals * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->comm == COMM_HOST && ctx->nranks > 1) {
-        if (ctx->h_allreduce(ctx->h_user, ctx->h_red, nvals, op) != 0)
-            return set_error(ctx, "host allreduce callback failed");
-    }
-    return 0;
+    return ctx_sync(ctx);
 }
 
 // ------------------------------------------------------------------ halo exchange
@@ -180,25 +390,17 @@ int halo_exchange(bk_ctx* ctx, hipStream_t stream, const double* v, size_t plane
         BK_NCCL(ctx, ncclGroupEnd());
         return 0;
     }
-    // host-staged (test communicator)
-    std::vector<double> s_lo(has_lo ? cnt : 0), s_hi(has_hi ? cnt : 0), r_lo(has_lo ? cnt : 0), r_hi(has_hi ? cnt : 0);
-    if (has_lo) BK_HIP(ctx, hipMemcpyAsync(s_lo.data(), send_lo, cnt * 8, hipMemcpyDeviceToHost, stream));
-    if (has_hi) BK_HIP(ctx, hipMemcpyAsync(s_hi.data(), send_hi, cnt * 8, hipMemcpyDeviceToHost, stream));
-    BK_HIP(ctx, hipStreamSynchronize(stream));
-    // even ranks talk to the upper neighbour first, odd ranks to the lower one (deadlock-free pairing)
-    for (int phase = 0; phase < 2; ++phase) {
-        const bool up = ((ctx->rank & 1) == 0) ? (phase == 0) : (phase == 1);
-        if (up && has_hi) {
-            if (ctx->h_sendrecv(ctx->h_user, s_hi.data(), cnt, hi, r_hi.data(), cnt, hi) != 0)
-                return set_error(ctx, "host sendrecv callback failed");
-        } else if (!up && has_lo) {
-            if (ctx->h_sendrecv(ctx->h_user, s_lo.data(), cnt, lo, r_lo.data(), cnt, lo) != 0)
-                return set_error(ctx, "host sendrecv callback failed");
-        }
-    }
-    if (has_lo) BK_HIP(ctx, hipMemcpyAsync(halo_lo, r_lo.data(), cnt * 8, hipMemcpyHostToDevice, stream));
-    if (has_hi) BK_HIP(ctx, hipMemcpyAsync(halo_hi, r_hi.data(), cnt * 8, hipMemcpyHostToDevice, stream));
-    BK_HIP(ctx, hipStreamSynchronize(stream));
+    // host-staged communicator: stream-ordered hand-over to the proxy thread (no host synchronisation)
+    CommProxy* p = nullptr;
+    BK_TRY(proxy_get(ctx, &p));
+    BK_TRY(proxy_grow(ctx, stream, &p->hs, &p->hr, &p->hcap, 2 * cnt));
+    if (has_lo) BK_HIP(ctx, hipMemcpyAsync(p->hs, send_lo, cnt * 8, hipMemcpyDeviceToHost, stream));
+    if (has_hi) BK_HIP(ctx, hipMemcpyAsync(p->hs + cnt, send_hi, cnt * 8, hipMemcpyDeviceToHost, stream));
+    ProxyOp o;
+    o.kind = 1; o.cnt = cnt; o.has_lo = has_lo; o.has_hi = has_hi;
+    BK_TRY(proxy_submit(ctx, p, stream, o));
+    if (has_lo) BK_HIP(ctx, hipMemcpyAsync(halo_lo, p->hr, cnt * 8, hipMemcpyHostToDevice, stream));
+    if (has_hi) BK_HIP(ctx, hipMemcpyAsync(halo_hi, p->hr + cnt, cnt * 8, hipMemcpyHostToDevice, stream));
     return 0;
 }
 
@@ -221,19 +423,29 @@ int comm_alltoallv(bk_ctx* ctx, const double* sendbuf, const size_t* scount, con
         BK_NCCL(ctx, ncclGroupEnd());
         return 0;
     }
-    // host-staged test communicator: own block device-to-device, the others pairwise through the callback
+    // host-staged communicator: own block device-to-device, the others through the proxy thread, in the stream
     BK_HIP(ctx, hipMemcpyAsync(recvbuf + rdispl[me], sendbuf + sdispl[me], scount[me] * sizeof(double),
                                hipMemcpyDeviceToDevice, ctx->stream));
-    for (int s = 1; s < R; ++s) {
-        const int dst = (me + s) % R, src = (me - s + R) % R;
-        std::vector<double> sb(scount[dst]), rb(rcount[src]);
-        BK_HIP(ctx, hipMemcpyAsync(sb.data(), sendbuf + sdispl[dst], scount[dst] * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->h_sendrecv(ctx->h_user, sb.data(), sb.size(), dst, rb.data(), rb.size(), src) != 0)
-            return set_error(ctx, "host sendrecv callback failed");
-        BK_HIP(ctx, hipMemcpyAsync(recvbuf + rdispl[src], rb.data(), rcount[src] * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CommProxy* p = nullptr;
+    BK_TRY(proxy_get(ctx, &p));
+    ProxyOp o;
+    o.kind = 2;
+    o.scount.assign(scount, scount + R); o.rcount.assign(rcount, rcount + R);
+    o.sdispl.assign(R, 0); o.rdispl.assign(R, 0);
+    size_t stot = 0, rtot = 0;
+    for (int q = 0; q < R; ++q) {
+        if (q == me) continue;
+        o.sdispl[q] = stot; stot += scount[q];
+        o.rdispl[q] = rtot; rtot += rcount[q];
     }
+    BK_TRY(proxy_grow(ctx, ctx->stream, &p->as, &p->ar2, &p->acap, std::max<size_t>(std::max(stot, rtot), 1)));
+    for (int q = 0; q < R; ++q)
+        if (q != me && scount[q])
+            BK_HIP(ctx, hipMemcpyAsync(p->as + o.sdispl[q], sendbuf + sdispl[q], scount[q] * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    BK_TRY(proxy_submit(ctx, p, ctx->stream, o));
+    for (int q = 0; q < R; ++q)
+        if (q != me && rcount[q])
+            BK_HIP(ctx, hipMemcpyAsync(recvbuf + rdispl[q], p->ar2 + o.rdispl[q], rcount[q] * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     return 0;
 }
 
@@ -264,6 +476,7 @@ static int ctx_init_common(bk_ctx* ctx, int device, void* stream) {
 }
 
 bk_ctx* ctx_lane(bk_ctx* ctx) {
+    if (ctx->comm == COMM_HOST && ctx->nranks > 1 && !(ctx->lane_allreduce && ctx->lane_sendrecv)) return nullptr;   // (not an error: one lane)
     if (ctx->lane2) {
         ctx->lane2->opts = ctx->opts;                 // the lane follows the context's options
         ctx->lane2->prof = ctx->prof;
@@ -275,13 +488,15 @@ bk_ctx* ctx_lane(bk_ctx* ctx) {
         return nullptr;
     }
     bk_ctx* l = new bk_ctx();
-    if (ctx_init_common(l, ctx->device, st) != 0) {
+    // (every failure path below frees the lane, its stream included, through bk_ctx_destroy)
+    const int si = ctx_init_common(l, ctx->device, st);
+    l->stream = st;
+    l->own_stream = true;
+    if (si != 0) {
         set_error(ctx, "second lane: %s", l->err.c_str());
-        (void)hipStreamDestroy(st);
-        delete l;
+        (void)bk_ctx_destroy(l);
         return nullptr;
     }
-    l->own_stream = true;
     l->num_cu = ctx->num_cu;
     l->opts = ctx->opts;
     l->prof = ctx->prof;
@@ -301,9 +516,10 @@ bk_ctx* ctx_lane(bk_ctx* ctx) {
             return nullptr;
         }
     } else if (ctx->comm == COMM_HOST) {
-        l->h_allreduce = ctx->h_allreduce;
-        l->h_sendrecv = ctx->h_sendrecv;
-        l->h_user = reinterpret_cast<void*>(static_cast<uintptr_t>(1));
+        // the lane's callbacks were registered by the client (bk_ctx_set_lane_comm); without them there is no lane
+        l->h_allreduce = ctx->lane_allreduce;
+        l->h_sendrecv = ctx->lane_sendrecv;
+        l->h_user = ctx->lane_user;
     }
     ctx->lane2 = l;
     return l;
@@ -440,15 +656,12 @@ int bk_comm_probe(bk_ctx* ctx, int what, size_t count, int reps, double* us_per_
         const auto t0 = std::chrono::steady_clock::now();
         for (int i = 0; i < n; ++i) {
             if (what == 0) {
-                if (ctx->comm == COMM_RCCL)
-                    BK_NCCL(ctx, ncclAllReduce(ctx->d_red, ctx->d_red, count, ncclDouble, ncclSum, ctx->nccl, ctx->stream));
-                else
-                    BK_TRY(comm_allreduce_host(ctx, hbuf.data(), (int)count, 0));
+                BK_TRY(comm_allreduce_dev(ctx, ctx->stream, ctx->d_red, (int)count, 0));
             } else {
                 BK_TRY(halo_exchange(ctx, ctx->stream, v, count, 2, 1, lo, hi));
             }
         }
-        BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        BK_TRY(ctx_sync(ctx));
         if (pass == 1)
             *us_per_call = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
     }
@@ -460,6 +673,8 @@ int bk_ctx_destroy(bk_ctx* ctx) {
     if (ctx->lane2) { bk_ctx* l = ctx->lane2; ctx->lane2 = nullptr; (void)bk_ctx_destroy(l); }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
+    proxy_destroy(ctx);
     for (auto& kv : ctx->pool_all) (void)hipFree(kv.first);
     for (auto& kv : ctx->prof_entries)
         for (auto& pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -481,7 +696,17 @@ int bk_ctx_destroy(bk_ctx* ctx) {
 const char* bk_last_error(bk_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 int bk_ctx_sync(bk_ctx* ctx) {
-    BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx) return -1;
+    return ctx_sync(ctx);
+}
+
+int bk_ctx_set_lane_comm(bk_ctx* ctx, bk_allreduce_fn allreduce, bk_sendrecv_fn sendrecv, void* user) {
+    if (!ctx) return -1;
+    if (ctx->comm != COMM_HOST) return set_error(ctx, "bk_ctx_set_lane_comm: host-staged contexts only (RCCL lanes split the communicator)");
+    if (ctx->lane2) return set_error(ctx, "bk_ctx_set_lane_comm: the second lane already exists");
+    ctx->lane_allreduce = allreduce;
+    ctx->lane_sendrecv = sendrecv;
+    ctx->lane_user = user;
     return 0;
 }
 

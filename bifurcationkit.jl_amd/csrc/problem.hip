@@ -21,9 +21,9 @@ int bk_problem::apply(int mode, const double* v, const double* u, const double* 
         a.halo_lo = halo_lo; a.halo_hi = halo_hi;
         if (ctx->nranks > 1) {
             // Overlap: the halo exchange (2 planes per face) runs on its own stream while the z-chunks that read no
-            // halo plane are computed; the two face chunks follow once it has landed.  With the host-staged test
-            // communicator the exchange blocks the host, so only the split launches are exercised there.
-            const bool overlap = ctx->comm == COMM_RCCL && ctx->opt("halo_overlap", 1.0) != 0.0;
+            // halo plane are computed; the two face chunks follow once it has landed.  Both communicator kinds enqueue the
+            // exchange (ncclSend / ncclRecv group; the host-staged communicator's proxy hand-over, context.hip).
+            const bool overlap = ctx->opt("halo_overlap", 1.0) != 0.0;
             if (overlap) {
                 if (!ctx->comm_stream) {
                     BK_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));

@@ -291,7 +291,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     // The decision must be the same on every rank (a rank on the device path issues in-stream all-reduces its peer on the
     // host path never joins): it does not look at the rank-local length at all -- ragged z-slabs may straddle any size
     // threshold -- only at options and at the communicator kind.
-    const bool rccl_ranks = ctx->comm == COMM_RCCL && ctx->nranks > 1;
+    const bool rccl_ranks = ctx->nranks > 1;        // (both communicator kinds enqueue their collectives in the stream)
     // Block Arnoldi (round 4, option gmres_sstep = largest block, default 4 for vectors that stream from HBM, 0 = off): s
     // operator applications, then ONE pair of Gram-Schmidt passes for the s steps (arnoldi_block, sstep.h).  The steps of a
     // block are speculated like the device-resident chunks -- the convergence-predicted cap below applies -- and the host
@@ -343,7 +343,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
         shifts_carried = false;
     };
     int chunk = (int)ctx->opt("gmres_chunk", 4.0);
-    if (nt != 0 || (ctx->comm == COMM_HOST && ctx->nranks > 1) || chunk < 2 || !ctx->h_rec_dev || sstep_on) chunk = 1;
+    if (nt != 0 || chunk < 2 || !ctx->h_rec_dev || sstep_on) chunk = 1;
     if (chunk > kRecChunks) chunk = kRecChunks;
     // Speculation cap from the residual history (all quantities are all-reduced, i.e. identical on every rank): with the
     // last reduction factor rho = beta_k / beta_{k-1} the estimate reaches the tolerance after `need` further steps; never
@@ -429,7 +429,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
                     BK_TRY(v_arnoldi_step_dev(ctx, n, B.V, B.ld, j + s2 + 1, w, eta, B.orth_tol,
                                               ctx->h_rec_dev + (size_t)s2 * (kMaxBasis + 2), d_coef, gstep ? d_gram : nullptr));
                 }
-                BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                BK_TRY(ctx_sync(ctx));
                 q_first = j; q_count = steps;
             }
             const double* rec = h_rec + (size_t)(j - q_first) * (kMaxBasis + 2);

@@ -1294,7 +1294,6 @@ int v_multiaxpy(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const
 int v_arnoldi_step_dev(bk_ctx* ctx, size_t n, double* V, size_t ldv, int k, const double* w, double eta, double orth_tol,
                        double* rec, double* coef, double* gram) {
     if (k < 1 || k > kMaxBasis - 1) return set_error(ctx, "v_arnoldi_step_dev: k=%d out of range", k);
-    if (ctx->comm == COMM_HOST && ctx->nranks > 1) return set_error(ctx, "v_arnoldi_step_dev: needs a device-side all-reduce");
     const bool vec = aligned16(V) && aligned16(w) && (ldv % 2 == 0);
     const int grid = grid_for(n, vec ? 2 : 1, kRedBlocks);
     double* dst = V + (size_t)k * ldv;
@@ -1345,7 +1344,7 @@ int v_arnoldi_step_dev(bk_ctx* ctx, size_t n, double* V, size_t ldv, int k, cons
         else BK_MA_DEV(64);
 #undef BK_MA_DEV
     };
-    const bool rccl = ctx->comm == COMM_RCCL && ctx->nranks > 1;
+    // ranks: the small all-reduce is ENQUEUED (ncclAllReduce, or the host-staged communicator's proxy hand-over)
     if (gram) {
         // Gram-corrected single pass: multidot with the Gram column, coefficients, ONE multiaxpy -- no second pass
         if (k > kBurstMax || !v_multidot_gram_ok(ctx, n, V, ldv, k, w)) return set_error(ctx, "v_arnoldi_step_dev: gram step out of range");
@@ -1357,7 +1356,7 @@ int v_arnoldi_step_dev(bk_ctx* ctx, size_t n, double* V, size_t ldv, int k, cons
                                (const double*)nullptr);
             BK_HIP(ctx, hipGetLastError());
         }
-        if (rccl) BK_NCCL(ctx, ncclAllReduce(ctx->d_red, ctx->d_red, 2 * k + 1, ncclDouble, ncclSum, ctx->nccl, ctx->stream));
+        BK_TRY(comm_allreduce_dev(ctx, ctx->stream, ctx->d_red, 2 * k + 1, 0));
         hipLaunchKernelGGL(arnoldi_gram_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_red, k, gram, rec, coef);
         {
             ProfScope ps(ctx, "multiaxpy", 8.0 * n * (k + 2));
@@ -1371,17 +1370,17 @@ int v_arnoldi_step_dev(bk_ctx* ctx, size_t n, double* V, size_t ldv, int k, cons
         dots(w, nullptr);
         BK_HIP(ctx, hipGetLastError());
     }
-    if (rccl) BK_NCCL(ctx, ncclAllReduce(ctx->d_red, ctx->d_red, k + 1, ncclDouble, ncclSum, ctx->nccl, ctx->stream));
+    BK_TRY(comm_allreduce_dev(ctx, ctx->stream, ctx->d_red, k + 1, 0));
     hipLaunchKernelGGL(arnoldi_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_red, k, eta * eta, orth_tol, rec, coef);
     {
         ProfScope ps(ctx, "multiaxpy", 8.0 * n * (k + 2));
         axpys(w, 0);
         BK_HIP(ctx, hipGetLastError());
     }
-    // DGKS second pass, gated on the device (kernels return at once when the first pass kept >= eta of ||w||).  With RCCL
-    // ranks the small all-reduce runs unconditionally (every rank takes the same decision from the same reduced numbers).
+    // DGKS second pass, gated on the device (kernels return at once when the first pass kept >= eta of ||w||).  On ranks
+    // the small all-reduce runs unconditionally (every rank takes the same decision from the same reduced numbers).
     dots(dst, gate);
-    if (rccl) BK_NCCL(ctx, ncclAllReduce(ctx->d_red, ctx->d_red, k + 1, ncclDouble, ncclSum, ctx->nccl, ctx->stream));
+    BK_TRY(comm_allreduce_dev(ctx, ctx->stream, ctx->d_red, k + 1, 0));
     hipLaunchKernelGGL(arnoldi_coef2_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_red, k, rec, coef);
     axpys(dst, 1);
     BK_HIP(ctx, hipGetLastError());

@@ -35,7 +35,8 @@ def _ptr(t):
 
 class Context:
     """``bk_ctx``: one per process / GPU.  ``comm`` = None | ("rccl", rank, nranks, id_bytes) |
-    ("host", rank, nranks, allreduce, sendrecv)."""
+    ("host", rank, nranks, allreduce, sendrecv[, lane_user]) -- ``lane_user`` (optional): the `user` value under which the SAME
+    callbacks serve the second lane's communicator (bk_ctx_set_lane_comm; hostcomm.py: a second gloo group)."""
 
     def __init__(self, device: int = 0, comm=None):
         if not torch.cuda.is_available():
@@ -56,11 +57,13 @@ class Context:
             st = self.lib.bk_ctx_create_dist(C.byref(h), device, C.c_void_p(stream), rank, nranks, buf)
             self.rank, self.nranks = rank, nranks
         elif comm[0] == "host":
-            _, rank, nranks, allreduce, sendrecv = comm
+            _, rank, nranks, allreduce, sendrecv = comm[:5]
             ar = L.ALLREDUCE_FN(allreduce)
             sr = L.SENDRECV_FN(sendrecv)
             self._keep += [ar, sr]
             st = self.lib.bk_ctx_create_hostcomm(C.byref(h), device, C.c_void_p(stream), rank, nranks, ar, sr, None)
+            if st == 0 and len(comm) > 5 and comm[5] is not None:
+                st = self.lib.bk_ctx_set_lane_comm(h, ar, sr, C.c_void_p(int(comm[5])))
             self.rank, self.nranks = rank, nranks
         else:
             raise ValueError(comm)

@@ -10,8 +10,9 @@ import torch
 import torch.distributed as dist
 
 
-# Lane of the calling context (bk_ctx::h_user: NULL for the context itself, 1 for its second lane, which a library thread
-# drives concurrently): each lane has its own gloo group, so that the two threads' collectives cannot be matched crosswise.
+# `user` of the callbacks: NULL for the context's own communicator, 1 for the communicator registered for its second lane
+# (bk_ctx_set_lane_comm; comm_tuple below passes lane_user = 1).  Each has its own gloo group: the two are driven by two
+# library-owned proxy threads concurrently and their collectives must never be matched crosswise.
 _groups = {}
 
 
@@ -57,7 +58,7 @@ def comm_tuple():
     creates the gloo group of the second lane."""
     if 1 not in _groups and dist.get_world_size() > 1:
         _groups[1] = dist.new_group(backend="gloo")
-    return ("host", dist.get_rank(), dist.get_world_size(), allreduce, sendrecv)
+    return ("host", dist.get_rank(), dist.get_world_size(), allreduce, sendrecv, 1 if 1 in _groups else None)
 
 
 def slab(n, rank, nranks):

@@ -57,6 +57,16 @@ typedef int (*bk_sendrecv_fn)(void* user, const double* sendbuf, size_t nsend, i
                               double* recvbuf, size_t nrecv, int src);
 int bk_ctx_create_hostcomm(bk_ctx** ctx, int device, void* stream, int rank, int nranks,
                            bk_allreduce_fn allreduce, bk_sendrecv_fn sendrecv, void* user);
+/* THREADING of the callbacks.  A host-staged context ENQUEUES its collectives in the stream like an RCCL context does
+ * (device-resident Arnoldi chunks, halo exchange under the interior z-chunks): each one is a stream-ordered hand-over to a
+ * proxy thread the library owns, and the callbacks run ON THAT THREAD, never on the caller's (a Julia client needs
+ * @cfunction callbacks that may be entered from a foreign thread: Julia >= 1.9).  `user` is passed through untouched.
+ * Second lane (option two_lanes, solver: ls(J, rhs1, rhs2) with both solves in flight): its collectives are issued
+ * concurrently with the context's own and must never be matched against them, so it needs a communicator of its own:
+ * register one with bk_ctx_set_lane_comm (same callback types, its own `user`; e.g. a second gloo / MPI group).  Without
+ * a registered lane communicator a host-staged context simply runs one lane.  RCCL contexts split their communicator
+ * themselves (ncclCommSplit).  No reference counterpart.                                                              */
+int bk_ctx_set_lane_comm(bk_ctx* ctx, bk_allreduce_fn allreduce, bk_sendrecv_fn sendrecv, void* user);
 /* What the communicator of this context is: *kind 0 = none, 1 = RCCL, 2 = host-staged test communicator; *rank /
  * *nranks as the communicator itself reports them (RCCL: ncclCommUserRank / ncclCommCount -- the number of ranks RCCL
  * actually connected, bench.py prints it next to a multi-GPU number).  No reference counterpart.                    */

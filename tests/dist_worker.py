@@ -229,7 +229,7 @@ def main_gpu(rank, world):
     print(f"rank {rank}: gpu distributed checks OK", flush=True)
 
 
-def slab_checks(ctx, hip, rank, world, tag):
+def slab_checks(ctx, hip, rank, world, tag, only=None):
     """The core of the distributed path against the 1-rank result, on grids whose z extent does not divide evenly
     (ragged slabs), with slabs as thin as the 2-plane halo allows, and on a power-of-two grid (fused FFT passes + the
     all-to-all block layout): JVP (all split-launch variants), preconditioner, GMRES, bordered solve."""
@@ -239,6 +239,8 @@ def slab_checks(ctx, hip, rank, world, tag):
              ((32, 32, 16 * world), (2.0, 2.0, 0.6 * world))]                        # equal 16-plane slabs: the slab z-solve
                                                                                      # (power-of-two world sizes), else transposes
     for ci, (dims, ls) in enumerate(cases):
+        if only is not None and ci not in only:
+            continue
         N = int(np.prod(dims))
         rng = np.random.default_rng(10 + ci)
         u, v, r = 0.5 * rng.standard_normal(N), rng.standard_normal(N), rng.standard_normal(N)
@@ -305,16 +307,67 @@ def slab_checks(ctx, hip, rank, world, tag):
             c1.close()
 
 
+# option variants every communicator kind runs on top of its defaults (block Arnoldi steps with the in-stream all-reduce inside
+# reduce_finish, halo exchange on the second stream under the interior z-chunks, slab z-solve): two lanes; single Arnoldi steps as
+# device-resident chunks (all-reduce enqueued between the kernels, one host synchronisation per chunk) and host-driven; the halo
+# exchange in line; the transposed preconditioner; the two-pass Gram-Schmidt
+VARIANTS = [(("two_lanes", 1),), (("gmres_sstep", 0),), (("gmres_sstep", 0), ("two_lanes", 1)), (("gmres_sstep", 0), ("gmres_chunk", 1)),
+            (("halo_overlap", 0),), (("dct_dist_slab", 0),), (("gmres_sstep", 0), ("gmres_gram", 0))]
+DEFAULTS = {"two_lanes": 0, "gmres_sstep": -1, "gmres_chunk": 4, "halo_overlap": 1, "dct_dist_slab": 1, "gmres_gram": 1}
+
+
 def main_gpu_many(rank, world):
-    """world ranks on cuda:0 through the host-staged communicator (ragged and thin slabs)."""
+    """world ranks on cuda:0 through the host-staged communicator (ragged and thin slabs).  Since round 4 that communicator
+    ENQUEUES its collectives like RCCL does (proxy thread, csrc/context.hip), so these ranks execute the code path the RCCL
+    ranks of a multi-GPU node execute -- defaults first, then the same option variants as main_rccl."""
     from bk_amd import hip
     ctx = hip.Context(0, hostcomm.comm_tuple())
     slab_checks(ctx, hip, rank, world, f"hostcomm x{world}")
-    # the two right-hand sides of the bordered solve on two lanes: the second lane has its own communicator (here: its own
-    # gloo group, driven from the library's thread), halo planes and preconditioner scratch
-    ctx.set_option("two_lanes", 1)
-    slab_checks(ctx, hip, rank, world, f"hostcomm x{world} two lanes")
+    for var in VARIANTS:
+        for key, val in var:
+            ctx.set_option(key, val)
+        slab_checks(ctx, hip, rank, world, f"hostcomm x{world} {var}", only=(0, 3) if var != (("two_lanes", 1),) else None)
+        for key, _ in var:
+            ctx.set_option(key, DEFAULTS[key])
     ctx.close()
+    print(f"rank {rank}: gpu distributed checks OK", flush=True)
+
+
+def main_gpu_ragged(rank, world):
+    """A multi-million-unknown ragged split (128 x 128 x 129 on 2 ranks: 65 + 64 planes) with the default options, against the
+    1-rank run: the block Arnoldi path at a size where it is also the single-rank default."""
+    from bk_amd import hip
+    dims, ls = (128, 128, 129), (np.pi * 4, np.pi * 4, np.pi * 129 / 32)
+    N = int(np.prod(dims))
+    rng = np.random.default_rng(3)
+    u, v, r = 0.5 * rng.standard_normal(N), rng.standard_normal(N), rng.standard_normal(N)
+    B = hip.BorderedArray
+    tn = np.sqrt(np.dot(v, v) / N * 0.5 + 0.3 * 0.3 * 0.5)
+
+    def run(ctx_):
+        prob = hip.SwiftHohenberg(ctx_, dims, ls)
+        U = prob.vec(u)
+        P = hip.DCTPreconditioner(prob, 1.0)
+        lsol = hip.GMRESKrylovKit(dim=30, rtol=1e-9, atol=1e-12, maxiter=150, Pl=P)
+        Z0, T = B(U, 0.1), B(prob.vec(v / tn), 0.3 / tn)
+        sc = hip.newton_palc_native(prob, Z0, T, Z0.copy().add_(T, -0.01), -0.01, 0.5, hip.BorderingBLS(lsol, check_precision=False),
+                                    tol=0.0, max_iterations=1, norm_inf=True)
+        return prob, sc
+
+    ctx = hip.Context(0, hostcomm.comm_tuple())
+    prob, sc = run(ctx)
+    assert prob.slab == hostcomm.slab(dims[2], rank, world)
+    xs = gather_slabs(sc["u"].u.numpy(), rank, world)
+    ctx.close()
+    if rank == 0:
+        c1 = hip.Context(0)
+        _, s1 = run(c1)
+        assert abs(sc["u"].p - s1["u"].p) <= 1e-12 * max(1.0, abs(s1["u"].p)), (sc["u"].p, s1["u"].p)
+        assert sc["itlineartot"] == s1["itlineartot"], (sc["itlineartot"], s1["itlineartot"])
+        assert abs(sc["residuals"][1] - s1["residuals"][1]) <= 1e-9 * s1["residuals"][0]
+        x1 = s1["u"].u.numpy()
+        assert np.abs(xs - x1).max() <= 1e-9 * np.abs(x1).max()
+        c1.close()
     print(f"rank {rank}: gpu distributed checks OK", flush=True)
 
 
@@ -328,14 +381,14 @@ def main_rccl(rank, world):
     ctx = hip.Context(rank, ("rccl", rank, world, idt[0]))
     kind, crank, cranks = ctx.comm_info()
     assert kind == "rccl" and crank == rank and cranks == world, (kind, crank, cranks)      # what ncclCommCount reports
-    # default options: device-resident Arnoldi chunks with the in-stream all-reduce of the 2k + 1 projections / Gram
-    # column, halo exchange on the second stream under the interior z-chunks, slab z-solve where the slabs allow it
-    slab_checks(ctx, hip, rank, world, f"rccl x{world}")
-    # and the host-driven variants of the same paths (one all-reduce + host synchronisation per Arnoldi step, halo
-    # exchange in line, transposed preconditioner)
-    for key, val in (("two_lanes", 1), ("gmres_chunk", 1), ("halo_overlap", 0), ("dct_dist_slab", 0), ("gmres_gram", 0)):
-        ctx.set_option(key, val)
-        slab_checks(ctx, hip, rank, world, f"rccl x{world} {key}={val}")
+    # default options: block Arnoldi steps (all-reduce of a block's projections enqueued inside reduce_finish), halo exchange on
+    # the second stream under the interior z-chunks, slab z-solve where the slabs allow it; then the variants
+    for var in VARIANTS:
+        for key, val in var:
+            ctx.set_option(key, val)
+        slab_checks(ctx, hip, rank, world, f"rccl x{world} {var}")
+        for key, _ in var:
+            ctx.set_option(key, DEFAULTS[key])
     ctx.close()
     print(f"rank {rank}: gpu distributed checks OK", flush=True)
 
@@ -345,6 +398,6 @@ if __name__ == "__main__":
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        dict(cpu=main_cpu, gpu=main_gpu, gpu_many=main_gpu_many, rccl=main_rccl)[mode](rank, world)
+        dict(cpu=main_cpu, gpu=main_gpu, gpu_many=main_gpu_many, gpu_ragged=main_gpu_ragged, rccl=main_rccl)[mode](rank, world)
     finally:
         dist.destroy_process_group()

@@ -54,8 +54,17 @@ def test_two_ranks_share_one_gpu_host_communicator():
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [3, 4])
 def test_ragged_and_thin_slabs_host_communicator(world):
-    """3 and 4 ranks on one GPU: z extents that do not divide evenly, slabs of 2-3 planes (every z-chunk is a face chunk)."""
+    """3 and 4 ranks on one GPU: z extents that do not divide evenly, slabs of 2-3 planes (every z-chunk is a face chunk).  The
+    host-staged communicator enqueues its collectives in the stream (proxy thread) since round 4: the ranks run the RCCL ranks'
+    code path -- block Arnoldi / device-resident chunks with in-stream all-reduces, halo exchange on the second stream, two
+    lanes with their own communicator -- with the defaults and with every variant switched (tests/dist_worker.py: VARIANTS)."""
     _run("gpu_many", world)
+
+
+@pytest.mark.gpu
+def test_ragged_multi_million_unknown_slabs_host_communicator():
+    """128 x 128 x 129 on 2 ranks (65 + 64 planes), default options = the code path RCCL ranks run, vs 1 rank."""
+    _run("gpu_ragged", 2)
 
 
 @pytest.mark.gpu
