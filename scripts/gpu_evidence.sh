@@ -28,11 +28,14 @@ leads)
     python scripts/bench_brief.py gpurun_out/${TAG}_leads_bench_baseline.json gpurun_out/${TAG}_leads_bench_tuned.json
     ;;
 tests)
-    timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -${TAILN:-30} | tee gpurun_out/${TAG}_pytest_gpu.log | cut -c1-300
+    timeout 1500 python -m pytest tests -m gpu -q --timeout=400 --durations=12 > gpurun_out/${TAG}_pytest_gpu.log 2>&1
+    tail -${TAILN:-45} gpurun_out/${TAG}_pytest_gpu.log | cut -c1-300
     timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2 | tee gpurun_out/${TAG}_smoke.log
     ;;
 newtests)
-    timeout 1200 python -m pytest tests -m gpu -q -k "${TESTS_K}" 2>&1 | tail -${TAILN:-40} | tee gpurun_out/${TAG}_pytest_new.log | cut -c1-400
+    # every test under its own clock (pytest-timeout), slowest tests listed, the whole log kept
+    timeout ${TESTS_LIMIT:-900} python -m pytest tests -m gpu -q -x --timeout=${TEST_TIMEOUT:-240} --durations=8 -k "${TESTS_K}" > gpurun_out/${TAG}_pytest_new.log 2>&1
+    tail -${TAILN:-40} gpurun_out/${TAG}_pytest_new.log | cut -c1-400
     ;;
 bench)
     timeout 900 python bench.py 2> gpurun_out/${TAG}_bench.err | tail -1 > gpurun_out/${TAG}_bench_512_1gpu.json

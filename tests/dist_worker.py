@@ -323,7 +323,9 @@ def main_gpu_many(rank, world):
     from bk_amd import hip
     ctx = hip.Context(0, hostcomm.comm_tuple())
     slab_checks(ctx, hip, rank, world, f"hostcomm x{world}")
-    for var in VARIANTS:
+    # (every collective is a Python / gloo round trip here: the variants run on the power-of-two world only, on the ragged
+    # grid and on the slab-z-solve grid; two lanes on every grid, as in round 3)
+    for var in VARIANTS if world == 4 else VARIANTS[:1]:
         for key, val in var:
             ctx.set_option(key, val)
         slab_checks(ctx, hip, rank, world, f"hostcomm x{world} {var}", only=(0, 3) if var != (("two_lanes", 1),) else None)

@@ -18,7 +18,7 @@ def _free_port():
     return p
 
 
-def _run(mode, world=2, timeout=600):
+def _run(mode, world=2, timeout=300):
     port = _free_port()
     procs = []
     for r in range(world):
