@@ -319,5 +319,8 @@ def test_generic_state_against_the_cpp_restatement(ctx, dims, tmp_path):
     dl = abs(ref["p"] - ref["p_pred"])
     assert abs(sg["u"].p - ref["p"]) <= 1e-6 * max(dl, 1e-12) + 1e-12, (sg["u"].p, ref["p"], dl)
     assert abs(sg["itlineartot"] - ref["itlinear"]) <= 4, (sg["itlineartot"], ref["itlinear"])
+    # the corrected state carries dl * J^-1 dF/dp, and the literal quotient (F(x, p + eps) - F(x, p)) / eps carries the rounding
+    # noise of F divided by eps = 1.5e-8: ~4 eps_mach |F|_inf / eps = 4e-3 absolute on this white-noise state (|F|_inf = 7e4), a
+    # different realisation on each side -- hence 1e-4 relative here, where the solves above agree to 1e-7
     xref = load("x")
-    assert np.abs(sg["u"].u.numpy() - xref).max() <= 1e-6 * np.abs(xref).max()
+    assert np.abs(sg["u"].u.numpy() - xref).max() <= 1e-4 * np.abs(xref).max()
