@@ -244,7 +244,7 @@ def test_generic_engine_with_literal_and_routed_dfdp(ctx):
     assert sum(literal.itlinear[2:]) >= 2.5 * sum(routed.itlinear[2:]), (literal.itlinear, routed.itlinear)
 
 
-@pytest.mark.parametrize("dims", [(256, 128, 128), (128, 128, 128)])
+@pytest.mark.parametrize("dims", [(256, 128, 128), (100, 90, 66)])
 def test_generic_state_against_the_cpp_restatement(ctx, dims, tmp_path):
     """VERDICT r3 Weak 1 / Next 3: multi-million-unknown parity on a GENERIC state -- white noise, no symmetry, nothing the
     even-reflection tiling could hide -- against oracle/cpu_ref.cpp, the C++/OpenMP restatement of the reference's own CSR
@@ -252,7 +252,8 @@ def test_generic_state_against_the_cpp_restatement(ctx, dims, tmp_path):
     directly, vector by vector: the residual F at the secant predictor, the Jacobian-vector product J tau, the iterate of the
     preconditioned GMRES solve J x1 = F (and its true residual through the HIP operator), then one whole newton_palc iteration
     (residual history, corrected parameter, operator applications per solve).  Mirrors test/linear_solvers/test_linear.jl:
-    106-169 in spirit (every solver == J \\ rhs) at 4.2 M and 2.1 M unknowns."""
+    106-169 in spirit (every solver == J \\ rhs) at 4.2 M unknowns (LDS-FFT transform passes, block Arnoldi steps) and at
+    0.6 M unknowns with extents that are no powers of two (dense fp64-MFMA transform passes)."""
     import json
     import subprocess
     import torch
