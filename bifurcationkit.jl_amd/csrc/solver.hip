@@ -297,15 +297,20 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     // block are speculated like the device-resident chunks -- the convergence-predicted cap below applies -- and the host
     // consumes the Hessenberg columns one at a time with the same Givens / stopping logic, so iterates and counters are those
     // of the step-by-step run.  The decision looks at options and the GLOBAL problem only (every rank takes the same one).
-    // (ranks: always on -- a rank-local length must not decide, ragged z-slabs may straddle any threshold; a negative value = default)
+    // On at every size (a negative value = the default, 4): for vectors that stream from HBM it halves the Gram-Schmidt traffic,
+    // for cache-resident ones it replaces ~8 dependent launches per step by ~5 and one host synchronisation per block (C2, SH2d
+    // 512^2: 51.6 -> 39.2 us per operator application, profiles/r4_c2_block_ab.jsonl).  No rank-local quantity decides.
     const double sstep_opt = ctx->opt("gmres_sstep", -1.0);
-    const int sstep_max = std::min(sstep_opt < 0.0 ? ((ctx->nranks > 1 || n > ((size_t)1 << 20)) ? 4 : 0) : (int)sstep_opt, sstep::kS);
+    const int sstep_max = std::min(sstep_opt < 0.0 ? 4 : (int)sstep_opt, sstep::kS);
     const bool sstep_on = sstep_max >= 1 && nt == 0 && B.use_gram && m >= 2 && v_block_ok(ctx, n, B.V, B.ld);
     const int ldh = m + 2;
     std::vector<double> Hraw(sstep_on ? (size_t)ldh * m : 0, 0.0);   // raw (unrotated) Hessenberg columns of the cycle
     // block length: starts from what the first block of the previous solve on this context achieved (the operator and the
     // right-hand sides of a corrector's solves resemble each other), shrinks / grows with the pivots of the blocks (sstep.h)
-    int blk_cur = std::max(1, std::min(sstep_max, ctx->sstep_hint));
+    // (a solve whose predecessor needed <= 2 steps -- config 3 with the exact block preconditioner converges in ONE -- starts with
+    // single steps and grows from there, as the device-resident chunks do)
+    int blk_cur = ctx->gmres_last_steps <= 2 ? 1 : std::max(1, std::min(sstep_max, ctx->sstep_hint));
+    const bool ramping = ctx->gmres_last_steps <= 2;
     bool first_block = true;
     // Newton shifts of the blocks (sstep.h: Conditioning): up to kS Ritz values of the operator in Leja order, where a shift is
     // free (bk_op::shift_is_free).  They come from the Hessenberg matrix of this solve as soon as one block exists, before that
@@ -394,7 +399,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
                     // next block: shorter after a truncation, one step longer when the last pivot left room (sstep.h)
                     if (got < steps) blk_cur = got;
                     else if (!capped && !predicted && blk_cur < sstep_max && ratio >= sstep::kGrowRatio) blk_cur += 1;
-                    if (first_block) ctx->sstep_hint = (got < steps || capped || predicted) ? std::max(got, 1) : blk_cur;
+                    if (first_block && !ramping) ctx->sstep_hint = (got < steps || capped || predicted) ? std::max(got, 1) : blk_cur;
                 } else {
                     cycle_on_host = true; q_count = 0;           // refused: the rest of the cycle runs step by step
                 }

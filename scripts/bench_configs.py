@@ -16,6 +16,10 @@ import torch  # noqa: E402
 from bk_amd import hip  # noqa: E402
 
 ctx = hip.Context(0)
+for kv in os.environ.get("BK_OPTS", "").split(","):                        # library options, "key=value,key=value"
+    if "=" in kv:
+        ctx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
+ONLY = os.environ.get("BK_ONLY", "")                                       # "c2": stop after config 2
 if os.environ.get("BK_GMRES_CHUNK"):
     ctx.set_option("gmres_chunk", float(os.environ["BK_GMRES_CHUNK"]))      # 1: host-driven Arnoldi steps; >= 2: device-resident chunks
 
@@ -64,6 +68,8 @@ print(json.dumps(dict(config="C2 SH2d 512x512 PALC corrector iteration", ms_per_
                       itlinear=r["itlineartot"], ms_per_operator_application=dt * 1e3 / max(1, r["itlineartot"]),
                       jvp_us=tj * 1e6, jvp_gbs=24.0 * prob.nglobal / tj / 1e9, residuals=r["residuals"])))
 
+if ONLY == "c2":
+    sys.exit(0)
 # ---- C3
 dims3, ls3 = (1024, 1024), (np.pi * 1024 / 41, (np.pi / 2) * 1024 / 21)
 p3 = hip.CGL2d(ctx, dims3, ls3, r=0.5)

@@ -438,10 +438,12 @@ def test_device_resident_arnoldi_chunks_match_host_driven_steps(ctx, flavor):
         out = {}
         for chunk in (1, 2, 4, 8):
             ctx.set_option("gmres_chunk", chunk)
+            ctx.set_option("gmres_sstep", 0)               # single Arnoldi steps (the default since round 4 is the block step)
             try:
                 x, ok, it = ls(J, rhs, -0.5, 1.0)          # J - 0.5 I: definite, well conditioned with Pl
             finally:
                 ctx.set_option("gmres_chunk", 4)
+                ctx.set_option("gmres_sstep", -1)
             out[chunk] = (x.numpy(), ok, it)
         x1, ok1, it1 = out[1]
         assert ok1
@@ -524,6 +526,7 @@ def test_single_pass_gram_schmidt_policy_bounds_the_measured_orthogonality_defec
     its, defects = {}, {}
     ctx.set_option("orth_probe", 1)
     ctx.set_option("gmres_chunk", chunk)
+    ctx.set_option("gmres_sstep", 0)                       # the single-step policy is the subject here
     try:
         for tol in (1e-12, 1e-8, 1e-5, 1e-3):
             ctx.set_option("orth_tol", tol)
@@ -540,6 +543,7 @@ def test_single_pass_gram_schmidt_policy_bounds_the_measured_orthogonality_defec
         ctx.set_option("orth_probe", 0)
         ctx.set_option("orth_tol", 1e-8)
         ctx.set_option("gmres_chunk", 4)
+        ctx.set_option("gmres_sstep", -1)
     # relaxing the tolerance up to 1e-5 does not cost iterations (numops of the 1e-12 run = always-two-passes reference)
     assert abs(its[1e-8] - its[1e-12]) <= 1 and abs(its[1e-5] - its[1e-12]) <= 1, its
     assert its[1e-3] <= its[1e-12] + 3, its
