@@ -35,7 +35,7 @@ class GmresOpts(C.Structure):
 
 
 class BorderingOpts(C.Structure):
-    _fields_ = [("tol", C.c_double), ("check_precision", C.c_int), ("k", C.c_int)]
+    _fields_ = [("tol", C.c_double), ("check_precision", C.c_int), ("k", C.c_int), ("kind", C.c_int)]
 
 
 class EigOpts(C.Structure):

@@ -1039,6 +1039,22 @@ struct BorderedMapOp : bk_op {
     }
 };
 
+// MatrixFreeBLS (src/LinearBorderSolver.jl:424-437): ONE GMRES on the (N + 1) operator MatrixFreeBLSmap over BorderedArray(u, p)
+int bls_matrixfree(bk_ctx* ctx, bk_op* J, const double* dR, const double* dzu, double dzp, const double* R, double n, double xiu,
+                   double xip, bool has_shift, double shift, double dotscale, const bk_gmres_opts& ls, double* dX, double* dl,
+                   int* converged, int* itlinear) {
+    if (ls.flavor >= BK_KRYLOV_MINRES) return set_error(ctx, "bk_bls_matrixfree: the bordered operator is not symmetric (use a GMRES flavor)");
+    BorderedMapOp M;
+    M.ctx = ctx; M.n = J->n; M.ntail = 1;
+    M.J = J; M.a[0] = dR; M.bvec[0] = dzu; M.bscale = xiu * dotscale; M.c[0] = dzp * xip;
+    M.has_shift = has_shift; M.shift = shift;
+    GmresResult r;
+    BK_TRY(gmres_core(ctx, &M, R, &n, dX, dl, 0.0, 1.0, ls, &r));
+    if (converged) *converged = r.converged;
+    if (itlinear) *itlinear = r.niter;
+    return 0;
+}
+
 }  // namespace bk
 
 extern "C" {
@@ -1059,16 +1075,7 @@ int bk_bls_matrixfree(bk_ctx* ctx, bk_op* J, const double* dR, const double* dzu
                       const bk_gmres_opts* lsopts, double* dX, double* dl, int* converged, int* itlinear) {
     if (!ctx || !J || !dR || !dzu || !R || !lsopts || !dX || !dl) return -1;
     if (dX == R || dX == dR || dX == dzu) return set_error(ctx, "bk_bls_matrixfree: dX must be a fresh buffer");
-    if (lsopts->flavor >= BK_KRYLOV_MINRES) return set_error(ctx, "bk_bls_matrixfree: the bordered operator is not symmetric (use a GMRES flavor)");
-    BorderedMapOp M;
-    M.ctx = ctx; M.n = J->n; M.ntail = 1;
-    M.J = J; M.a[0] = dR; M.bvec[0] = dzu; M.bscale = xiu * dotscale; M.c[0] = dzp * xip;
-    M.has_shift = has_shift != 0; M.shift = shift;
-    GmresResult r;
-    BK_TRY(gmres_core(ctx, &M, R, &n, dX, dl, 0.0, 1.0, *lsopts, &r));
-    if (converged) *converged = r.converged;
-    if (itlinear) *itlinear = r.niter;
-    return 0;
+    return bls_matrixfree(ctx, J, dR, dzu, dzp, R, n, xiu, xip, has_shift != 0, shift, dotscale, *lsopts, dX, dl, converged, itlinear);
 }
 
 // solve_bls_block(::BorderingBLS, J, b::NTuple{M}, c::NTuple{M}, d::Matrix, rhst, rhsb), src/LinearBorderSolver.jl:173-206:
@@ -1263,8 +1270,15 @@ int bk_newton_palc(bk_ctx* ctx, bk_problem* prob, double* x, double* p, const do
         BK_TRY(bk_jacobian(prob, x, par, nparams, &J));
         double up = 0.0;
         int cv = 0, it[2] = {0, 0};
-        int s = bls_bordering(ctx, J, dFdp, tauu, taup, res_f, res_n, theta, 1.0 - theta, false, 0.0, dotscale, *bo,
+        int s;
+        if (bo->kind == 1) {                                  // MatrixFreeBLS: one GMRES on the (N + 1) operator, no preconditioner
+            int itm = 0;
+            s = bls_matrixfree(ctx, J, dFdp, tauu, taup, res_f, res_n, theta, 1.0 - theta, false, 0.0, dotscale, *lsopts, u, &up, &cv, &itm);
+            it[0] = itm; it[1] = 0;
+        } else {
+            s = bls_bordering(ctx, J, dFdp, tauu, taup, res_f, res_n, theta, 1.0 - theta, false, 0.0, dotscale, *bo,
                               *lsopts, pl, u, &up, &cv, it);
+        }
         bk_op_destroy(J);
         if (s != 0) return s;
         itlin += it[0] + it[1];

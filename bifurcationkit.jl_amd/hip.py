@@ -936,14 +936,17 @@ def newton_native(prob: _PdeProblem, x0: HipVec, p: float, ls: _GMRES, tol=1e-12
 def newton_palc_native(prob: _PdeProblem, z0: BorderedArray, tau: BorderedArray, z_pred: BorderedArray, ds, theta,
                        bls: BorderingBLS, tol=1e-12, max_iterations=25, p_min=-math.inf, p_max=math.inf,
                        norm_inf=False, linesearch=False, alpha=1.0, alphamin=1e-3, callback=None):
-    """newton_palc (src/continuation/Palc.jl:187-305) with BorderingBLS as one library call."""
+    """newton_palc (src/continuation/Palc.jl:187-305) as one library call, with BorderingBLS or MatrixFreeBLS."""
     ctx = prob.ctx
     x = z_pred.u.copy()
     p = C.c_double(z_pred.p)
     pv = prob._pvec(z_pred.p)
     arr = (C.c_double * len(pv))(*pv)
     no = newton_opts(tol, max_iterations, norm_inf, linesearch, alpha, alphamin, callback)
-    bo = L.BorderingOpts(bls.tol, 1 if bls.check_precision else 0, bls.k)
+    if isinstance(bls, MatrixFreeBLS):                     # bk_bordering_opts.kind = 1: one GMRES on the (N + 1) operator per iteration
+        bo = L.BorderingOpts(0.0, 0, 1, 1)
+    else:
+        bo = L.BorderingOpts(bls.tol, 1 if bls.check_precision else 0, bls.k, 0)
     lo = bls.solver._opts()
     res = L.NewtonResult()
     big = 1.7e308

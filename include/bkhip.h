@@ -240,6 +240,10 @@ typedef struct {
     double tol;            /* BorderingBLS.tol             (:63)                                  */
     int check_precision;   /* BorderingBLS.check_precision (:66)                                  */
     int k;                 /* BorderingBLS.k               (:69)                                  */
+    int kind;              /* which bordered solver the correctors (bk_newton_palc, bk_cont_*) use: 0 = BorderingBLS (the
+                              fields above), 1 = MatrixFreeBLS (:326-335,424-437: ONE GMRES on the (N+1) operator; tol,
+                              check_precision, k and the preconditioner are not used by it, as in the reference).
+                              bk_bls_bordering itself ignores the field.                                           */
 } bk_bordering_opts;
 int bk_bls_bordering(bk_ctx* ctx, bk_op* J, const double* dR, const double* dzu, double dzp,
                      const double* R, double n, double xiu, double xip, int has_shift,

@@ -38,6 +38,7 @@ struct GmresOpts
 end
 struct BorderingOpts
     tol::Cdouble; check_precision::Cint; k::Cint
+    kind::Cint                 # correctors: 0 = BorderingBLS, 1 = MatrixFreeBLS (bk_bordering_opts.kind)
 end
 struct EigOpts
     sigma::Cdouble; krylovdim::Cint; maxiter::Cint; tol::Cdouble; hermitian::Cint; seed::Culonglong
@@ -392,7 +393,7 @@ function (lbs::HipBorderingBLS)(J::HipJacobian, dR::HipVec, dzu::HipVec, dzp::T,
     ctx = R.ctx
     dX = similar(R)
     dl, cv, it = Ref{Cdouble}(0), Ref{Cint}(0), zeros(Cint, 2)
-    bo = BorderingOpts(lbs.tol, lbs.check_precision, lbs.k)
+    bo = BorderingOpts(lbs.tol, lbs.check_precision, lbs.k, 0)
     check(ctx, ccall((:bk_bls_bordering, libbkhip[]), Cint,
         (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Cdouble, Cdouble, Cdouble, Cint, Cdouble, Cdouble,
          Ref{BorderingOpts}, Ref{GmresOpts}, Ptr{Cvoid}, Ptr{Cdouble}, Ref{Cdouble}, Ref{Cint}, Ptr{Cint}),
@@ -510,9 +511,11 @@ function _newton_cb(user::Ptr{Cvoid}, x::Ptr{Cdouble}, fx::Ptr{Cdouble}, res::Cd
 end
 
 # newton_palc(iter, state, dotθ; normN, callback, kwargs...): src/continuation/Palc.jl:187-305 as ONE library call
-# (bk_newton_palc: cancellation-free dF/dp, Jacobian handle, BorderingBLS, update, clamping, line search :254-281, callback
-# veto :235,294-297) whenever the bordered solver is the device BorderingBLS with the standard DotTheta; any other
-# combination (MatrixFreeBLS, a custom dotθ) takes the engine's generic loop with only the quotient routed.
+# (bk_newton_palc: cancellation-free dF/dp, Jacobian handle, the bordered solve, update, clamping, line search :254-281,
+# callback veto :235,294-297) for every combination the library covers: HipBorderingBLS or HipMatrixFreeBLS (bk_bordering_opts.
+# kind) around any device linear solver, the standard DotTheta, norm or norminf.  Anything else (a custom dotθ or norm) is
+# handed back to the engine's own method with `invoke` -- nothing of Palc.jl is restated here -- at the price of the engine's
+# two-residual dF/dp quotient (DESIGN.md section 7).
 function BK.newton_palc(iter::HipContIterable, state::BK.AbstractContinuationState, dotθ = BK.getdot(iter);
                         normN = LinearAlgebra.norm, callback = BK.cb_default, kwargs...)
     prob = iter.prob
@@ -528,10 +531,12 @@ function BK.newton_palc(iter::HipContIterable, state::BK.AbstractContinuationSta
     (; tol, max_iterations, verbose, α, αmin, linesearch) = contparams.newton_options
     (; p_min, p_max) = contparams
     lbs = BK.get_bordered_linsolver(iter)
-    native = lbs isa HipBorderingBLS{<:HipGMRES} && dotθ isa BK.DotTheta && dotθ.dot isa BK.NormalisedDot &&
-             (normN === LinearAlgebra.norm || normN === BK.norminf)
+    native = (lbs isa HipBorderingBLS || lbs isa HipMatrixFreeBLS) && !isnothing(lbs.solver) && dotθ isa BK.DotTheta &&
+             dotθ.dot isa BK.NormalisedDot && (normN === LinearAlgebra.norm || normN === BK.norminf)
     if !native
-        return _newton_palc_generic(iter, state, dotθ; normN, callback, kwargs...)
+        @warn "BifurcationKitHIP: newton_palc falls back to the engine's generic loop (two-residual dF/dp)" maxlog = 1
+        return invoke(BK.newton_palc, Tuple{BK.ContIterable, BK.AbstractContinuationState, Any}, iter, state, dotθ;
+                      normN, callback, kwargs...)
     end
     x = BK._copy(z_pred.u)
     p = Ref{Cdouble}(z_pred.p)
@@ -541,7 +546,7 @@ function BK.newton_palc(iter::HipContIterable, state::BK.AbstractContinuationSta
            @cfunction(_newton_cb, Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cint, Cint, Cdouble, Ptr{Cdouble}, Cdouble, Cint))
     no = NewtonOpts(tol, max_iterations, normN === BK.norminf ? 1 : 0, linesearch ? 1 : 0, α, αmin, 0.0, cfun,
                     callback === BK.cb_default ? C_NULL : pointer_from_objref(box))
-    bo = BorderingOpts(lbs.tol, lbs.check_precision, lbs.k)
+    bo = lbs isa HipMatrixFreeBLS ? BorderingOpts(0.0, 0, 1, 1) : BorderingOpts(lbs.tol, lbs.check_precision, lbs.k, 0)
     res = Ref(NewtonResult())
     GC.@preserve box begin
         check(ctx, ccall((:bk_newton_palc, libbkhip[]), Cint,
@@ -555,77 +560,6 @@ function BK.newton_palc(iter::HipContIterable, state::BK.AbstractContinuationSta
     residuals = Float64[r.residuals[i] for i in 1:(r.itnewton + 1)]
     verbose && foreach(i -> BK.print_nonlinear_step(i - 1, residuals[i]), eachindex(residuals))
     return BK.NonLinearSolution(BK.BorderedArray(x, p[]), prob, residuals, r.converged == 1, Int(r.itnewton), Int(r.itlinear))
-end
-
-# the engine's loop, line by line (Palc.jl:187-305), with the two-residual quotient replaced by residual_dparam
-function _newton_palc_generic(iter, state, dotθ; normN = LinearAlgebra.norm, callback = BK.cb_default, kwargs...)
-    prob = iter.prob
-    hp = hipproblem(prob)
-    par = BK.getparams(prob)
-    ϵ = BK.getdelta(prob)
-    paramlens = BK.getlens(iter)
-    ipar = _ipar(par, paramlens)
-    contparams = BK.getcontparams(iter)
-    𝒯 = eltype(iter)
-    θ = BK.getθ(iter)
-    z0 = BK.getsolution(state)
-    τ0 = state.τ
-    (; z_pred, ds) = state
-    (; tol, max_iterations, verbose, α, αmin, linesearch) = contparams.newton_options
-    (; p_min, p_max) = contparams
-    linsolver = BK.get_bordered_linsolver(iter)
-    α0 = α
-    N(u, _p) = BK.arc_length_eq(dotθ, u, z0.u, _p - z0.p, τ0.u, τ0.p, θ, ds)
-    normAC(resf, resn) = max(normN(resf), abs(resn))
-    x = BK._copy(z_pred.u)
-    p = z_pred.p
-    x_pred = BK._copy(x)
-    res_f = BK.residual(prob, x, BK.set(par, paramlens, p)); res_n = N(x, p)
-    res = normAC(res_f, res_n)
-    residuals = [res]
-    step = 0
-    itlineartot = 0
-    line_step = true
-    compute = callback((; x, res_f, residual = res, step, contparams, z0, p, residuals, options = (; linsolver)); fromNewton = false, kwargs...)
-    while (step < max_iterations) && (res > tol) && line_step && compute
-        dFdp = residual_dparam(hp, x, BK.set(par, paramlens, p), ipar; eps = ϵ)          # Palc.jl:239-240, routed
-        J = BK.jacobian(prob, x, BK.set(par, paramlens, p))
-        u, up, flag, itlinear = BK.solve_bls_palc(linsolver, iter, state, J, dFdp, res_f, res_n)
-        ~flag && @debug "[newton_palc] Linear solver did not converge."
-        itlineartot += sum(itlinear)
-        if linesearch
-            line_step = false
-            while !line_step && (α > αmin)
-                x_pred = VI.add!(BK._copyto!(x_pred, x), u, -α)
-                p_pred = p - α * up
-                BK._copyto!(res_f, BK.residual(prob, x_pred, BK.set(par, paramlens, p_pred)))
-                res_n = N(x_pred, p_pred)
-                res = normAC(res_f, res_n)
-                if res < residuals[end]
-                    if (res < residuals[end] / 4) && (α < 1)
-                        α *= 2
-                    end
-                    line_step = true
-                    BK._copyto!(x, x_pred)
-                    p = clamp(p_pred, p_min, p_max)
-                else
-                    α /= 2
-                end
-            end
-            α = α0
-        else
-            x = BK.minus!!(x, u)
-            p = clamp(p - up, p_min, p_max)
-            BK._copyto!(res_f, BK.residual(prob, x, BK.set(par, paramlens, p)))
-            res_n = N(x, p); res = normAC(res_f, res_n)
-        end
-        push!(residuals, res)
-        step += 1
-        verbose && BK.print_nonlinear_step(step, res, itlinear)
-        compute = callback((; x, res_f, J, residual = res, step, itlinear, contparams, z0, p, residuals, options = (; linsolver)); fromNewton = false, kwargs...)
-    end
-    flag = (residuals[end] < tol) & callback((; x, res_f, residual = res, step, contparams, p, residuals, options = (; linsolver)); fromNewton = false, kwargs...)
-    return BK.NonLinearSolution(BK.BorderedArray(x, p), prob, residuals, flag, step, itlineartot)
 end
 
 # ------------------------------------------------------------------------------------------------ eigensolver
