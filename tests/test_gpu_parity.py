@@ -1000,6 +1000,38 @@ def test_continuation_reaches_the_parameter_bound_with_the_natural_corrector(ctx
     assert np.abs(sh.F(bn.sol[-1].numpy(), 0.108, 1.2)).max() < 1e-9              # a solution AT the boundary
 
 
+def test_newton_palc_with_matrixfree_bls_is_one_library_call(ctx):
+    """bk_bordering_opts.kind = 1: the native corrector with MatrixFreeBLS (src/LinearBorderSolver.jl:424-437: one GMRES on the
+    (N + 1) operator per Newton iteration) against the Python mirror of the engine loop driving hip.MatrixFreeBLS call by call,
+    and against the BorderingBLS corrector (same Newton iterates up to the linear tolerance)."""
+    hip = _hip()
+    from bk_amd import continuation as Cn
+    dims, ls_ = (12, 12, 12), (np.pi,) * 3
+    sh, prob, rng, u = _sh_setup(ctx, dims, ls_)
+    oprob = palc.Problem(lambda x, p: sh.F(x, p, 1.2), lambda x, p: (lambda dx: sh.dF(x, p, 1.2, dx)))
+    ols = _oracle_ls(sh)
+    s0 = palc.newton(oprob, u, 0.1, ols, tol=1e-10, max_iterations=30, normN=palc.norminf)
+    s1 = palc.newton(oprob, s0["u"], 0.1 - 0.01 / 150, ols, tol=1e-10, max_iterations=30, normN=palc.norminf)
+    z0, z1 = (s0["u"], 0.1), (s1["u"], 0.1 - 0.01 / 150)
+    ds = -0.01
+    tau = palc.secant_tangent(z1, z0, ds, 0.5)
+    zp = palc.add_tangent(z0, tau, ds)
+    B = hip.BorderedArray
+    gz0, gtau, gzp = B(prob.vec(z0[0]), z0[1]), B(prob.vec(tau[0]), tau[1]), B(prob.vec(zp[0]), zp[1])
+    mfls = hip.GMRESKrylovKit(dim=60, rtol=1e-10, atol=1e-13, maxiter=300)          # MatrixFreeBLS is unpreconditioned
+    mf = hip.MatrixFreeBLS(mfls)
+    sn = hip.newton_palc_native(prob, gz0, gtau, gzp, ds, 0.5, mf, tol=1e-9, max_iterations=14, norm_inf=True)
+    sm = Cn.newton_palc(prob, gz0, gtau, gzp, ds, 0.5, mf, Cn.NewtonPar(tol=1e-9, max_iterations=14, linsolver=mfls), normN=Cn.norminf)
+    assert sn["converged"] and sm.converged and sn["itnewton"] == sm.itnewton
+    assert abs(sn["u"].p - sm.u.p) <= 1e-9 and abs(sn["itlineartot"] - sm.itlinear) <= 2 * sn["itnewton"]
+    for a, b in zip(sn["residuals"], sm.residuals):
+        assert abs(a - b) <= 1e-6 * max(a, 1e-3)
+    P = hip.DCTPreconditioner(prob, 0.0)
+    bls = hip.BorderingBLS(hip.GMRESKrylovKit(dim=30, rtol=1e-10, atol=1e-13, maxiter=150, Pl=P), check_precision=False)
+    sb = hip.newton_palc_native(prob, gz0, gtau, gzp, ds, 0.5, bls, tol=1e-9, max_iterations=14, norm_inf=True)
+    assert sb["converged"] and sb["itnewton"] == sn["itnewton"] and abs(sb["u"].p - sn["u"].p) <= 1e-8
+
+
 def test_newton_palc_linesearch_and_callbacks_match_oracle(ctx):
     """newton_palc with linesearch = true (Palc.jl:254-281) and the callback veto (Palc.jl:235,294-297; cbMaxNorm
     src/Newton.jl:156-159): the native one-call corrector, the Python mirror and the oracle take the same accept / halve /
