@@ -81,8 +81,7 @@ struct bk_ctx {
     // one entry per Krylov iteration (the solver's own residual estimate); a negative entry -(k+1) opens solve k
     std::vector<double> hist;
     int hist_solves = 0;
-    std::vector<double> newton_shifts; // Leja-ordered Ritz values of the last GMRES solve (shifts of the next solve's first blocks)
-    int sstep_hint = 4;               // block length the first block of the previous GMRES solve achieved (solver.hip: gmres_core)
+    std::vector<double> newton_shifts; // option gmres_newton_carry: Leja-ordered Ritz values of the last GMRES solve (solver.hip)
     int gmres_last_steps = 1 << 20;   // Arnoldi steps of the previous GMRES solve (speculation ramp of the device-resident chunks)
     const double* eig_x0 = nullptr;   // one-shot start vector of the next eigensolve (bk_eig_set_start_vector)
     // second execution lane (context.hip: ctx_lane): an independent context on the same device -- own non-blocking stream,

@@ -305,21 +305,25 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     const bool sstep_on = sstep_max >= 1 && nt == 0 && B.use_gram && m >= 2 && v_block_ok(ctx, n, B.V, B.ld);
     const int ldh = m + 2;
     std::vector<double> Hraw(sstep_on ? (size_t)ldh * m : 0, 0.0);   // raw (unrotated) Hessenberg columns of the cycle
-    // block length: starts from what the first block of the previous solve on this context achieved (the operator and the
-    // right-hand sides of a corrector's solves resemble each other), shrinks / grows with the pivots of the blocks (sstep.h)
-    // (a solve whose predecessor needed <= 2 steps -- config 3 with the exact block preconditioner converges in ONE -- starts with
-    // single steps and grows from there, as the device-resident chunks do)
-    int blk_cur = ctx->gmres_last_steps <= 2 ? 1 : std::max(1, std::min(sstep_max, ctx->sstep_hint));
-    const bool ramping = ctx->gmres_last_steps <= 2;
-    bool first_block = true;
+    // Block length.  A solve does NOT depend on the solves before it (results are reproducible whatever the call sequence; the
+    // two lanes of linsolve2 reproduce the sequential calls bitwise): its first block is monomial and at most kMonomialMax = 3
+    // long -- down a monomial block the pivots fall by ~1e-2 per vector (sstep.h), three stay above the truncation threshold --,
+    // the later ones take Newton shifts from the Hessenberg matrix at hand and may be sstep_max long; a truncated block
+    // shrinks the next ones, a comfortable last pivot lets them grow again.  The one thing carried over is the ramp of the
+    // device-resident chunks: a solve whose predecessor needed <= 2 steps (config 3 with the exact block preconditioner
+    // converges in ONE) starts with single steps -- block boundaries move, iterates and counters do not.
+    constexpr int kMonomialMax = 3;
+    int blk_cur = ctx->gmres_last_steps <= 2 ? 1 : sstep_max;
     // Newton shifts of the blocks (sstep.h: Conditioning): up to kS Ritz values of the operator in Leja order, where a shift is
-    // free (bk_op::shift_is_free).  They come from the Hessenberg matrix of this solve as soon as one block exists, before that
-    // from the previous solve on this context -- correctors solve with the same operator over and over; a carried set that
-    // truncates the first block is dropped.  Any real numbers give a valid basis: the shifts only steer its conditioning.
+    // free (bk_op::shift_is_free), from the Hessenberg matrix of THIS solve as soon as one block exists.  (Option
+    // gmres_newton_carry = 1 also starts from the previous solve's set -- correctors solve with the same operator family again
+    // and again: 2 % at 512^3 -- at the price of solves that depend on the context's history; a carried set that truncates a
+    // block is dropped.  Any real numbers give a valid basis: the shifts only steer its conditioning.)
     const bool use_shifts = sstep_on && ctx->opt("gmres_newton", 1.0) != 0.0 && A->shift_is_free();
+    const bool carry = use_shifts && ctx->opt("gmres_newton_carry", 0.0) != 0.0;
     std::vector<double> shifts;
     bool shifts_carried = false;
-    if (use_shifts && !ctx->newton_shifts.empty()) { shifts = ctx->newton_shifts; shifts_carried = true; }
+    if (carry && !ctx->newton_shifts.empty()) { shifts = ctx->newton_shifts; shifts_carried = true; }
     auto ritz_shifts = [&](int kk) {              // Leja-ordered real parts of the eigenvalues of Hraw[0:kk, 0:kk]
         if (!use_shifts || kk < 2) return;
         dense::Mat Hm(kk, kk);
@@ -374,7 +378,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     auto next_column = [&](int j, double* hcol, double* hnext_out) -> int {
         if (sstep_on && !cycle_on_host) {
             if (!(q_count > 0 && j >= q_first && j < q_first + q_count)) {
-                int steps = std::min(blk_cur, m - j);
+                int steps = std::min(std::min(blk_cur, shifts.empty() ? kMonomialMax : sstep_max), m - j);
                 const bool capped = steps < blk_cur;
                 bool predicted = false;
                 if (predict && steps > 1 && beta_now > 0.0) {
@@ -399,11 +403,9 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
                     // next block: shorter after a truncation, one step longer when the last pivot left room (sstep.h)
                     if (got < steps) blk_cur = got;
                     else if (!capped && !predicted && blk_cur < sstep_max && ratio >= sstep::kGrowRatio) blk_cur += 1;
-                    if (first_block && !ramping) ctx->sstep_hint = (got < steps || capped || predicted) ? std::max(got, 1) : blk_cur;
                 } else {
                     cycle_on_host = true; q_count = 0;           // refused: the rest of the cycle runs step by step
                 }
-                first_block = false;
             }
             if (!cycle_on_host) {
                 for (int i = 0; i <= j; ++i) hcol[i] = Hraw[(size_t)i + (size_t)j * ldh];
@@ -607,7 +609,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     res->niter = kk ? numops : iters;
     res->resnorm = beta;
     ctx->gmres_last_steps = iters;
-    if (use_shifts && !shifts.empty()) ctx->newton_shifts = shifts;
+    if (carry && !shifts.empty()) ctx->newton_shifts = shifts;
     if (xt) for (int q = 0; q < nt; ++q) xt[q] = xtail[q];
     return 0;
 }
@@ -852,10 +854,21 @@ int linsolve2(bk_ctx* ctx, bk_op* J, const double* rhs1, double* x1, const doubl
         pl2 = precond_lane_shadow(pl, lane);
         if (!pl2) lane = nullptr;
     }
+    // both solves start from the context's state as it is on entry (speculation ramp, carried shifts), whichever way they run,
+    // and the first solve's is what the context keeps: the two lanes reproduce the sequential calls bitwise
+    const int entry_steps = ctx->gmres_last_steps;
+    const std::vector<double> entry_shifts = ctx->newton_shifts;
     if (!lane) {
         BK_TRY(linsolve(ctx, J, rhs1, x1, a0, a1, o, pl, r1));
-        return linsolve(ctx, J, rhs2, x2, a0, a1, o, pl, r2);
+        const int keep_steps = ctx->gmres_last_steps;
+        const std::vector<double> keep_shifts = ctx->newton_shifts;
+        ctx->gmres_last_steps = entry_steps; ctx->newton_shifts = entry_shifts;
+        const int s2 = linsolve(ctx, J, rhs2, x2, a0, a1, o, pl, r2);
+        ctx->gmres_last_steps = keep_steps; ctx->newton_shifts = keep_shifts;
+        return s2;
     }
+    lane->gmres_last_steps = entry_steps;
+    lane->newton_shifts = entry_shifts;
     bk_problem prob2 = *PJ->prob;              // the problem on the lane, with its own halo planes on ranks
     prob2.ctx = lane;
     prob2.halo_lo = prob2.halo_hi = nullptr;

@@ -285,7 +285,7 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
     if beta < tol:
         return x, True, numops, beta
     m = krylovdim
-    blk_cur = block                                  # (the library starts from the previous solve's first block: ctx->sstep_hint)
+    blk_cur = block
     # Newton shifts p_{i+1} = (A - theta_i) p_i: Leja-ordered Ritz values, from this solve's Hessenberg as soon as a block
     # exists; ``shifts`` = a set carried over from an earlier solve with the same operator (dropped if it truncates a block)
     shifts = list(shifts) if (shifts and newton) else []
@@ -302,7 +302,7 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
         classic = False
         while j < m and res > tol:
             k = j + 1
-            sb = min(blk_cur, m - j)
+            sb = min(blk_cur, block if shifts else min(block, 3), m - j)     # monomial blocks: at most 3 (csrc/solver.hip: kMonomialMax)
             capped = sb < blk_cur
             predicted = False
             if res_prev is not None and sb > 1:
