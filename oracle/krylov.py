@@ -256,7 +256,7 @@ def block_arnoldi_coefficients(G, H, k, u, s, Aq, Gp, pivot_tol=1e-8, theta=None
 
 
 def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, rtol=1e-12, Pl=None, block=4,
-                history=None, basis_out=None, stats=None, newton=True, shifts=None):
+                history=None, basis_out=None, stats=None, newton=True, shifts=None, keep_shifts=False):
     """The library's GMRES for vectors that stream from HBM since round 4, restated (csrc/solver.hip: gmres_core with
     arnoldi_block): KrylovKit's restarted GMRES -- same stopping rules, restart and numops bookkeeping as gmres_krylovkit
     above -- whose Arnoldi steps are taken in BLOCKS of up to ``block``: p_1 = A q_j, .., p_s = A p_{s-1}, then ONE pass of
@@ -271,7 +271,7 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
         lin = lambda dx: a1_ * Pl(apply(A_, dx)) + a0_ * dx
         return gmres_block(lin, Pl(np.asarray(b, dtype=float)), 0.0, 1.0, krylovdim=krylovdim, maxiter=maxiter, atol=atol,
                            rtol=rtol, block=block, history=history, basis_out=basis_out, stats=stats, newton=newton,
-                           shifts=shifts)
+                           shifts=shifts, keep_shifts=keep_shifts)
     b = np.asarray(b, dtype=float)
     n = b.shape[0]
     x = np.zeros(n)
@@ -287,9 +287,11 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
     m = krylovdim
     blk_cur = block
     # Newton shifts p_{i+1} = (A - theta_i) p_i: Leja-ordered Ritz values, from this solve's Hessenberg as soon as a block
-    # exists; ``shifts`` = a set carried over from an earlier solve with the same operator (dropped if it truncates a block)
+    # exists; ``shifts`` = the set of the FIRST block (the library: the accumulation point of the preconditioned operator's
+    # spectrum, bk_op::accumulation_point), replaced by Ritz values after it unless ``keep_shifts`` (then kept until it
+    # truncates a block: the library's option gmres_newton_carry)
     shifts = list(shifts) if (shifts and newton) else []
-    carried = bool(shifts)
+    carried = bool(shifts) and keep_shifts
     for numiter in range(1, maxiter + 1):
         Q = np.zeros((m + 1, n))
         H = np.zeros((m + 2, m))
