@@ -123,9 +123,6 @@ struct bk_op {              // a linear operator on (device vector [+ one host t
     // Newton-basis blocks of GMRES (solver.hip: arnoldi_block) apply (a0 - theta) x + a1 A x with a different theta per step:
     // true if a0 != 0 costs no extra pass over the vectors
     virtual bool shift_is_free() const { return false; }
-    // the point the operator's spectrum accumulates at, if its structure tells (the preconditioned Swift-Hohenberg operator
-    // a0 + a1 Pl^-1 J = (a0 - a1) I + a1 Pl^-1 (s I + diag g): a0 - a1): the shift of a solve's FIRST block
-    virtual bool accumulation_point(double* c) const { return false; }
     // the Swift-Hohenberg Jacobian J = -L1 + diag(g(u)) with its two parts scaled separately,
     // out = a0 x + aL (-L1 x) + ag g(u) x; returns 1 if this operator is not of that form (nothing done)
     virtual int apply_parts(const double* x, double a0, double aL, double ag, double* out) { return 1; }

@@ -287,9 +287,9 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
     m = krylovdim
     blk_cur = block
     # Newton shifts p_{i+1} = (A - theta_i) p_i: Leja-ordered Ritz values, from this solve's Hessenberg as soon as a block
-    # exists; ``shifts`` = the set of the FIRST block (the library: the accumulation point of the preconditioned operator's
-    # spectrum, bk_op::accumulation_point), replaced by Ritz values after it unless ``keep_shifts`` (then kept until it
-    # truncates a block: the library's option gmres_newton_carry)
+    # exists; ``shifts`` = a set for the FIRST block (none in the library by default: monomial, at most 3 long), replaced by
+    # Ritz values after it unless ``keep_shifts`` (then kept until it truncates a block: the library's option
+    # gmres_newton_carry, which starts from the previous solve's set)
     shifts = list(shifts) if (shifts and newton) else []
     carried = bool(shifts) and keep_shifts
     for numiter in range(1, maxiter + 1):
