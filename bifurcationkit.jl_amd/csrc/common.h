@@ -20,6 +20,7 @@ namespace bk {
 constexpr int kMaxBasis = 64;      // largest Krylov dimension + 1 the fused kernels are built for
 constexpr int kRedSlots = 256;     // doubles in the reduction result buffers
 constexpr int kRedBlocks = 1024;   // blocks of a reduction kernel (stage 1); stage 2 is one block
+constexpr double kCancelTol = 1e-8;   // Pythagorean norm b^2 = |w|^2 - |h|^2 is trusted while b^2 > kCancelTol |w|^2 (host and device Arnoldi steps)
 constexpr int kRecChunks = 16;     // most speculative Arnoldi steps per synchronisation (option gmres_chunk)
 
 struct Coefs {                     // by-value kernel argument: coefficients of a fused multi-axpy

@@ -17,6 +17,8 @@
 #include <cmath>
 #include <vector>
 
+#include <algorithm>
+
 #include "ops.h"
 
 namespace bk {
@@ -304,7 +306,7 @@ int dense_mfma_pass(bk_ctx* ctx, int n0, int n1, int nb, int axis, int inverse, 
         }
     }
     (void)total;
-    BK_HIP(ctx, hipGetLastError());
+    BK_HIP(ctx, hipGetLastError());        // (launch errors are sticky until read: one check covers the fold / gemm / unfold launches above)
     return 0;
 }
 
@@ -329,10 +331,25 @@ int dense_gemm_axis_pass(bk_ctx* ctx, int n0, int n1, int n2, int axis, const do
         P.sA = 0; P.sB = P.sC = inner * (size_t)N;
         gz = axis == 1 ? (unsigned)n2 : 1u;
     }
-    const unsigned gx = (unsigned)((P.N + BN - 1) / BN), gy = (unsigned)((P.M + BM - 1) / BM);
-    if (gy > 65535u || gz > 65535u) return set_error(ctx, "dense_gemm_axis_pass: grid too large");
-    hipLaunchKernelGGL(gemm_f64_any_kernel, dim3(gx, gy, gz), dim3(GT), 0, ctx->stream, P);
-    BK_HIP(ctx, hipGetLastError());
+    // grid y (row tiles) and z (planes) are 16-bit launch dimensions: longer extents go in slices of 65535 (the
+    // rocBLAS path this kernel replaced took such shapes; an error here would have been a regression)
+    const unsigned gx = (unsigned)((P.N + BN - 1) / BN);
+    const size_t gy_all = ((size_t)P.M + BM - 1) / BM;
+    const int M_all = P.M;
+    const double *A0 = P.A, *B0 = P.B;
+    double* C0 = P.C;
+    for (unsigned z0 = 0; z0 < gz; z0 += 65535u) {
+        const unsigned gzc = std::min(gz - z0, 65535u);
+        for (size_t y0 = 0; y0 < gy_all; y0 += 65535) {
+            const unsigned gyc = (unsigned)std::min<size_t>(gy_all - y0, 65535);
+            P.M = (int)std::min<size_t>((size_t)M_all - y0 * BM, (size_t)gyc * BM);
+            P.A = A0 + y0 * BM * (size_t)P.lda + (size_t)z0 * P.sA;
+            P.B = B0 + (size_t)z0 * P.sB;
+            P.C = C0 + y0 * BM * (size_t)P.ldc + (size_t)z0 * P.sC;
+            hipLaunchKernelGGL(gemm_f64_any_kernel, dim3(gx, gyc, gzc), dim3(GT), 0, ctx->stream, P);
+            BK_HIP(ctx, hipGetLastError());
+        }
+    }
     return 0;
 }
 

@@ -156,7 +156,9 @@ struct PdeJacobian : bk_op {          // J(u, params) of a bk_problem; reference
 };
 
 // A preconditioner object for the second lane that shares the tables of `pl` (read-only) but has its own scratch arrays
-// and runs on `lane`; NULL when `pl` is of a kind that cannot be shared (distributed plans).  Delete it after the solve.
+// (t1, t2; the face buffers of a distributed plan's slab z-solve) and runs on `lane` -- distributed plans included: the lane
+// has its own communicator (ncclCommSplit / bk_ctx_set_lane_comm); NULL for preconditioners of another kind.  Delete it after
+// the solve.
 bk_precond* precond_lane_shadow(bk_precond* pl, bk_ctx* lane);
 
 // GMRES core on an operator (solver.hip)

@@ -84,7 +84,7 @@ int arnoldi_step(bk_ctx* ctx, bk_op* A, Basis& B, int j, double* w, double* h, d
     BK_TRY(A->apply(B.vec(j), nt ? B.tail(j) : nullptr, op_a0, op_a1, w, wt));
     const int k = j + 1;
     double hh[kMaxBasis + 1], c[kMaxBasis];
-    // ---- Gram-corrected single pass (option gmres_gram, default on; GMRES only -- the eigensolver keeps two passes).
+    // ---- Gram-corrected single pass (option gmres_gram, default on; the eigensolver's outer Arnoldi takes it too: eig_gram).
     // The multidot pass also measures g = V'v_j, the Gram column of the newest vector (no extra traffic: v_j is one of the
     // streams).  With G known, the coefficients of the ORTHOGONAL projection of w onto span(V) are c = G^-1 (V'w) -- for the
     // nearly orthonormal V at hand c = a - E a + E E a, E = G - I -- and w - V c is orthogonal to every v_i up to the
@@ -117,7 +117,7 @@ int arnoldi_step(bk_ctx* ctx, bk_op* A, Basis& B, int j, double* w, double* h, d
             proj += c[i] * hh[i];
         }
         const double b2 = ww - proj;
-        if (b2 > 1e-8 * ww) {
+        if (b2 > kCancelTol * ww) {
             const double be = std::sqrt(b2);
             double cm[kMaxBasis];
             for (int i = 0; i < k; ++i) { h[i] = c[i]; cm[i] = -c[i]; }
@@ -145,7 +145,7 @@ int arnoldi_step(bk_ctx* ctx, bk_op* A, Basis& B, int j, double* w, double* h, d
     double hsq = 0.0;
     for (int i = 0; i < k; ++i) { h[i] = hh[i]; hsq += hh[i] * hh[i]; c[i] = -hh[i]; }
     const double b2 = ww - hsq;                 // Pythagoras: ||w - V h||^2, relative error ~ eps * ww / b2
-    if (b2 > 1e-8 * ww) {
+    if (b2 > kCancelTol * ww) {
         // pass B with the normalisation folded in: v_{k} = (w - V h) / sqrt(b2)
         const double be = std::sqrt(b2);
         BK_TRY(v_multiaxpy(ctx, n, B.V, B.ld, k, c, w, 1.0 / be, B.vec(k), nullptr));
@@ -241,7 +241,7 @@ int arnoldi_step_public(bk_ctx* ctx, bk_op* A, double* V, size_t ld, std::vector
     B.nt = A->ntail;
     B.t.swap(tails);
     if (G && gram_n) { B.use_gram = true; B.G.swap(*G); B.gram_n = *gram_n; }
-    const int s = arnoldi_step(ctx, A, B, j, w, h, beta, 0.0, 1.0, 2.0);      // eigensolver fallback: always two passes
+    const int s = arnoldi_step(ctx, A, B, j, w, h, beta, 0.0, 1.0, 2.0);      // (eta = 2: a step that cannot take the Gram pass takes two passes)
     if (G && gram_n) { B.G.swap(*G); *gram_n = B.gram_n; }
     B.t.swap(tails);
     return s;

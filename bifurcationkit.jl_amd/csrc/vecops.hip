@@ -823,7 +823,7 @@ __global__ void arnoldi_coef_kernel(const double* __restrict__ hw, int k, double
     double hsq = 0.0;
     for (int i = 0; i < k; ++i) { const double h = hw[i]; hsq += h * h; rec[i] = h; coef[i] = -h; }
     const double b2 = ww - hsq;
-    const bool ok = ww > 0.0 && b2 > 1e-8 * ww;
+    const bool ok = ww > 0.0 && b2 > kCancelTol * ww;
     const double be = ok ? sqrt(b2) : 1.0;
     rec[kMaxBasis] = ok ? be : 0.0;
     rec[kMaxBasis + 1] = ok ? 0.0 : 1.0;
@@ -847,7 +847,7 @@ __global__ void arnoldi_coef2_kernel(const double* __restrict__ hw, int k, doubl
     double ssq = 0.0;
     for (int i = 0; i < k; ++i) { const double s_ = hw[i]; ssq += s_ * s_; coef[i] = -s_; rec[i] += be * s_; }
     const double n2 = vv - ssq;
-    const bool ok = n2 > 1e-8 * vv;
+    const bool ok = n2 > kCancelTol * vv;
     const double cn = ok ? sqrt(n2) : 1.0;
     coef[kMaxBasis] = 1.0 / cn;
     rec[kMaxBasis] = ok ? be * cn : 0.0;
@@ -883,7 +883,7 @@ __global__ void __launch_bounds__(64) arnoldi_gram_coef_kernel(const double* __r
     const double pr = __shfl(proj, 0, 64);
     const double ww = hw[k];
     const double b2 = ww - pr;
-    const bool ok = ww > 0.0 && b2 > 1e-8 * ww;
+    const bool ok = ww > 0.0 && b2 > kCancelTol * ww;
     const double be = ok ? sqrt(b2) : 1.0;
     if (on) { rec[i] = ci; coef[i] = -ci; }
     if (i == 0) {
@@ -1347,6 +1347,8 @@ int v_arnoldi_step_dev(bk_ctx* ctx, size_t n, double* V, size_t ldv, int k, cons
     // ranks: the small all-reduce is ENQUEUED (ncclAllReduce, or the host-staged communicator's proxy hand-over)
     if (gram) {
         // Gram-corrected single pass: multidot with the Gram column, coefficients, ONE multiaxpy -- no second pass
+        // (the caller, gmres_core, only passes `gram` for k <= 32 and operands v_multidot_gram_ok accepts; anything else is a
+        // programming error of the library, not a property of the data)
         if (k > kBurstMax || !v_multidot_gram_ok(ctx, n, V, ldv, k, w)) return set_error(ctx, "v_arnoldi_step_dev: gram step out of range");
         const int gg = nt_hint(ctx, n) ? burst_grid(ctx, n, "dot_blocks") : grid_for(n, 2 * 4, 512);
         {
