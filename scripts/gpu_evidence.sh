@@ -7,6 +7,7 @@
 #   prof      rocprofv3 kernel stats of the bench + the two PMC passes (FETCH_SIZE / WRITE_SIZE)   [TAG, default r4]
 #   hostcomm  N ranks sharing this GPU over the host-staged communicator with the RCCL-default code path (RANKS, SIZE)
 #   ab        bench.py A/B on the same box: AB_A / AB_B = extra bench.py arguments of the two runs (e.g. "--opt gmres_sstep=0")
+#   sq        one SQ-counter pass over a bench step (LDS bank-conflict share, stall breakdown per kernel)
 #   cost      inputs of the multi-GPU cost model (bench.py --size-z slabs, slab z-solve emulation)
 # Everything lands in gpurun_out/ (scratch); summaries that are judged get copied to profiles/ by hand.
 set -u
@@ -66,6 +67,9 @@ ab)
     [ -n "${AB_C:-}" ] && timeout 600 python bench.py --steps ${AB_STEPS:-10} --warmup 3 --cpu-sample 0 ${AB_COMMON:---no-steady} ${AB_C} 2> gpurun_out/${TAG}_ab_c.err | tail -1 > gpurun_out/${TAG}_ab_c.json
     tail -3 gpurun_out/${TAG}_ab_a.err gpurun_out/${TAG}_ab_b.err | cut -c1-300
     python scripts/bench_brief.py gpurun_out/${TAG}_ab_a.json gpurun_out/${TAG}_ab_b.json $([ -n "${AB_C:-}" ] && echo gpurun_out/${TAG}_ab_c.json)
+    ;;
+sq)
+    bash scripts/gpu_sq_counters.sh ${TAG} 2>&1 | tail -14 | cut -c1-200
     ;;
 cost)
     bash scripts/gpu_cost_model_inputs.sh > gpurun_out/${TAG}_cost_inputs.out 2>&1
