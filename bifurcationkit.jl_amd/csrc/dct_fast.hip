@@ -483,7 +483,12 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
     // same pipe instead of overlapping.  The second-slot workgroups sleep `stagger` x s_sleep(127) (~3.4 us each) first, and
     // the offset persists down the pass because every slot picks up its next tile when its own tile retires.  Measured at the
     // end of round 3 on the z round trip (experiment): 611 -> 564 us although the sleep is part of the kernel's duration.
-    if (P.stagger > 0 && (int)blockIdx.x < 2 * P.stag_cu && (int)(blockIdx.x >> 3) >= (P.stag_cu >> 3))
+    // (Not in the inverse kernels, MODE 1.  Measured per pass at 512^3 with the offset at 0, i.e. the branch never taken
+    // (profiles/r4_dct_pass_variants.txt): with these two lines in the prologue of EVERY instantiation the y inverse pass takes
+    // 483 us instead of 375 -- it then waits on memory for 64 % of its wave cycles instead of 39 % -- while its neighbours in
+    // the stream, the z round trip and the y forward pass, run 632 / 347 instead of 655 / 376 us; with the lines only in the
+    // forward / round-trip kernels all five are back at round 3's durations.  The sum is what counts: 2173 vs 2130 us.)
+    if (MODE != 1 && P.stagger > 0 && (int)blockIdx.x < 2 * P.stag_cu && (int)(blockIdx.x >> 3) >= (P.stag_cu >> 3))
         for (int i = 0; i < P.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     // workgroup slot -> tile.  xmap: the workgroups of one XCD (slot % 8: consecutive workgroups go round-robin over the
     // 8 XCDs) take a contiguous range of tiles, i.e. every XCD's L2 / TLB works on its own eighth of the array -- 10 % on
