@@ -51,7 +51,7 @@ prof)
     cd "$R"
     python scripts/prof_summary.py gpurun_out/prof_${TAG} 300 > gpurun_out/${TAG}_rocprofv3_kernel_stats_bench512.txt 2>&1
     head -18 gpurun_out/${TAG}_rocprofv3_kernel_stats_bench512.txt | cut -c1-170
-    python scripts/pmc_summary.py gpurun_out/pmc_fetch_${TAG} gpurun_out/pmc_write_${TAG} gpurun_out/${TAG}_pmc_hbm_traffic | cut -c1-150
+    python scripts/pmc_summary.py gpurun_out/pmc_fetch_${TAG} gpurun_out/pmc_write_${TAG} gpurun_out/${TAG} | cut -c1-150
     ;;
 hostcomm)
     OUT=gpurun_out/${TAG}_hostcomm_ranks.jsonl
