@@ -209,8 +209,14 @@ int arnoldi_step(bk_ctx* ctx, bk_op* A, Basis& B, int j, double* w, double* h, d
 // where its vectors lose independence; the trailing operator applications are then void) and the raw Hessenberg columns
 // j .. j + *s_eff - 1 are in Hraw; *s_eff = 0: nothing usable (or out of the kernels' range) -- the caller repeats the step on the
 // single-vector path from V[j] (the measured Gram matrix stays valid up to and including column j - 1).
+struct PendingBlock {              // a block whose update pass (pass 2) has not run yet: slots k .. k+s-1 still hold the raw P
+    bool active = false;
+    int k = 0, s = 0;
+    double Cm[32 * sstep::kS], Tm[sstep::kS * sstep::kS];
+};
+
 int arnoldi_block(bk_ctx* ctx, bk_op* A, Basis& B, int j, int s, double* Hraw, int ldh, double op_a0, double op_a1, int* s_eff,
-                  double* last_ratio, const double* theta) {
+                  double* last_ratio, const double* theta, PendingBlock* defer = nullptr) {
     const size_t n = A->n;
     const int k = j + 1, u = k - B.gram_n;
     *s_eff = 0;
@@ -220,12 +226,17 @@ int arnoldi_block(bk_ctx* ctx, bk_op* A, Basis& B, int j, int s, double* Hraw, i
     // p_{i+1} = (op_a0 + op_a1 A) p_i - theta_i p_i: the shift rides in the operator's own a0 term
     for (int i = 0; i < s; ++i)
         BK_TRY(A->apply(B.vec(j + i), nullptr, op_a0 - (theta ? theta[i] : 0.0), op_a1, B.vec(j + i + 1), nullptr));
-    double D[33 * sstep::kR], T[sstep::kTri], Cm[32 * sstep::kS], Tm[sstep::kS * sstep::kS];
+    double D[33 * sstep::kR], T[sstep::kTri];
+    PendingBlock local;
+    PendingBlock* pb = defer ? defer : &local;
     BK_TRY(v_block_dots(ctx, n, B.V, B.ld, k - u, k - u, u + s, D, T));
-    const int st = sstep::block_coefficients(k, u, s, D, T, B.G.data(), kMaxBasis + 1, Hraw, ldh, Cm, Tm, s_eff, last_ratio, theta);
+    const int st = sstep::block_coefficients(k, u, s, D, T, B.G.data(), kMaxBasis + 1, Hraw, ldh, pb->Cm, pb->Tm, s_eff, last_ratio, theta);
     B.gram_n = st == 0 ? k : j;                      // (a refused block: column j is measured again by the single step)
     if (st != 0) { *s_eff = 0; return 0; }
-    return v_block_axpy(ctx, n, B.V, B.ld, k, *s_eff, Cm, Tm);
+    // deferred: the Hessenberg columns are complete without the update pass; the caller runs it when the new vectors are needed
+    // explicitly -- or folds it into the solution update if the solve ends inside this block (gmres_core)
+    if (defer) { pb->active = true; pb->k = k; pb->s = *s_eff; return 0; }
+    return v_block_axpy(ctx, n, B.V, B.ld, k, *s_eff, pb->Cm, pb->Tm);
 }
 
 }  // namespace
@@ -378,7 +389,19 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     bool dev_gram = false, cycle_on_host = false;
     if (chunk > 1 && B.use_gram) BK_TRY(ws.get((size_t)(kMaxBasis + 1) * (kMaxBasis + 1), &d_gram));
     // next Hessenberg column (Arnoldi step from V[j]): from the queue of device-computed columns, else computed now
+    // The update pass of a block (Q_new = (P - QC) R^-1, k + 2s vector streams) is DEFERRED: the block's Hessenberg columns
+    // do not need it.  It runs when the new vectors are needed explicitly -- the next block, a restart's residual -- and is
+    // folded into the solution update when the solve ends inside the block: x = Q y_old + Q_new y_new =
+    // Q (y_old - C R^-1 y_new) + P (R^-1 y_new), ONE multiaxpy over [Q, P] instead of the update pass plus a multiaxpy over
+    // [Q, Q_new] (the last block of every solve: ~13 % of the Gram-Schmidt traffic of a 12-step solve).
+    PendingBlock pend;
+    auto flush_pending = [&]() -> int {
+        if (!pend.active) return 0;
+        pend.active = false;
+        return v_block_axpy(ctx, n, B.V, B.ld, pend.k, pend.s, pend.Cm, pend.Tm);
+    };
     auto next_column = [&](int j, double* hcol, double* hnext_out) -> int {
+        if (!(q_count > 0 && j >= q_first && j < q_first + q_count)) BK_TRY(flush_pending());   // new work starts from explicit vectors
         if (sstep_on && !cycle_on_host) {
             if (!(q_count > 0 && j >= q_first && j < q_first + q_count)) {
                 int steps = std::min(std::min(blk_cur, shifts.empty() ? kMonomialMax : sstep_max), m - j);
@@ -395,7 +418,8 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
                 double ratio = 0.0;
                 double theta[sstep::kS] = {0.0, 0.0, 0.0, 0.0};
                 for (int i = 0; i < steps && !shifts.empty(); ++i) theta[i] = shifts[i % shifts.size()];
-                BK_TRY(arnoldi_block(ctx, A, B, j, steps, Hraw.data(), ldh, op_a0, op_a1, &got, &ratio, shifts.empty() ? nullptr : theta));
+                BK_TRY(arnoldi_block(ctx, A, B, j, steps, Hraw.data(), ldh, op_a0, op_a1, &got, &ratio, shifts.empty() ? nullptr : theta,
+                                     ctx->opt("gmres_defer_update", 1.0) != 0.0 ? &pend : nullptr));
                 if (got < steps && shifts_carried) { shifts.clear(); shifts_carried = false; }     // a stale set: back to the monomial block
                 if (got > 0 && !shifts_carried && ((int)shifts.size() < sstep::kS || j + got <= 12)) ritz_shifts(j + got);
                 // diagnostics (bench.py reports them): operator applications issued by blocks / of those void (truncated tails)
@@ -499,6 +523,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
         cycle_on_host = false;
         if (chunk > 1) BK_HIP(ctx, hipMemsetAsync(d_coef + kMaxBasis + 2, 0, sizeof(double), ctx->stream));
         q_count = 0;                           // a new cycle: nothing speculative carries over
+        pend.active = false;                   // (a deferred update of the finished cycle is void with its basis)
         beta_prev = 0.0; beta_now = beta; tol_now = tol;
         BK_TRY(next_column(0, h.data(), &hnext));
         numops += 1;
@@ -541,6 +566,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
             numops += 1;
         }
         if (ctx->opt("orth_probe", 0.0) != 0.0 && nt == 0) {
+            BK_TRY(flush_pending());
             // diagnostics (tests): the MEASURED orthogonality defect max |V'V - I| of this cycle's basis V[0..k] next to the
             // running estimate the single-pass policy steers by -- options gmres_last_orth_defect / gmres_last_orth_estimate
             double worst = 0.0, row[kMaxBasis + 1];
@@ -565,7 +591,24 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
             for (int j = i + 1; j < k; ++j) s -= Rat(i, j) * yk[j];
             yk[i] = s / Rat(i, i);
         }
-        BK_TRY(v_multiaxpy(ctx, n, B.V, B.ld, k, yk.data(), x_zero ? nullptr : x, 1.0, x, nullptr));
+        if (pend.active && k > pend.k) {
+            // the solve (or the cycle) ends inside the deferred block: c of its vectors carry solution coefficients
+            const int c = k - pend.k;
+            std::vector<double> cf(k, 0.0);
+            for (int i = 0; i < pend.k; ++i) {
+                double v = yk[i];
+                for (int q = 0; q < c; ++q) v += pend.Cm[i * sstep::kS + q] * yk[pend.k + q];
+                cf[i] = v;
+            }
+            for (int rr_ = 0; rr_ < c; ++rr_) {
+                double v = 0.0;
+                for (int q = rr_; q < c; ++q) v += pend.Tm[rr_ * sstep::kS + q] * yk[pend.k + q];
+                cf[pend.k + rr_] = v;
+            }
+            BK_TRY(v_multiaxpy(ctx, n, B.V, B.ld, k, cf.data(), x_zero ? nullptr : x, 1.0, x, nullptr));
+        } else {
+            BK_TRY(v_multiaxpy(ctx, n, B.V, B.ld, k, yk.data(), x_zero ? nullptr : x, 1.0, x, nullptr));
+        }
         x_zero = false;
         for (int q = 0; q < nt; ++q) for (int i = 0; i < k; ++i) xtail[q] += yk[i] * B.tail(i)[q];
 
@@ -580,6 +623,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
                     z[i] = t;
                 }
                 for (int i = 0; i <= k; ++i) z[i] *= y[k];
+                BK_TRY(flush_pending());           // the residual vector needs V[0..k] explicitly
                 BK_TRY(v_multiaxpy(ctx, n, B.V, B.ld, k + 1, z.data(), nullptr, 1.0, r, nullptr));
                 for (int q = 0; q < nt; ++q) { rt[q] = 0.0; for (int i = 0; i <= k; ++i) rt[q] += z[i] * B.tail(i)[q]; }
             } else {
