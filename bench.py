@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--sh-kernel", type=int, default=1)
     ap.add_argument("--dgks-eta", type=float, default=None)
     ap.add_argument("--opt", action="append", default=[], help="library tuning option key=value (experiments)")
+    ap.add_argument("--trace", action="store_true", help="after the timed region, repeat the step once with the solver trace on and "
+                                                         "report the residual history of its linear solves (config.trace)")
     ap.add_argument("--workload", default="corrector", choices=["corrector", "branch"],
                     help="corrector: the BASELINE metric (PALC corrector steps/s); branch: BASELINE config 5 -- --steps native "
                          "continuation steps (corrector + 15 eigenvalues + Bordered tangent + predictor per step)")
@@ -336,10 +338,6 @@ def main():
     ctx.set_option("sh_kernel", args.sh_kernel)
     if args.dgks_eta is not None:
         ctx.set_option("dgks_eta", args.dgks_eta)
-    for kv in args.opt:
-        k_, v_ = kv.split("=")
-        ctx.set_option(k_, float(v_))
-
     n = args.size
     nzz = args.size_z or n
     tiles = tiles_for(n, nzz)
@@ -349,6 +347,11 @@ def main():
     t_setup = time.perf_counter()
     ctx_cell = ctx if world == 1 else hip.Context(local)
     cprob, cls_, c0, c1 = cell_branch_points(ctx_cell, hip, args.shift, ds)
+    # experiment options apply from here on: the two cell solutions above -- the INPUT of the timed step, whose secant amplifies
+    # their last digits to ~1e-6 of the tangent -- are the same for every option set, so that an A/B compares the same step
+    for kv in args.opt:
+        k_, v_ = kv.split("=")
+        ctx.set_option(k_, float(v_))
     prob = hip.SwiftHohenberg(ctx, (n, n, nzz), big_l, l=0.1, nu=1.2)
     P = None if args.no_precond else hip.DCTPreconditioner(prob, args.shift)
     ls = hip.GMRESKrylovKit(dim=30, rtol=1e-9, atol=1e-12, maxiter=150, Pl=P)       # SH3d.jl:93
@@ -421,6 +424,14 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if hostcomm_mode else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    trace_rec = None
+    if args.trace:
+        ctx.set_option("solver_trace", 1)
+        ctx.solver_history()
+        tl = one_step()
+        trace_rec = {"itlinear": tl["itlineartot"], "histories": ctx.solver_history()}
+        ctx.set_option("solver_trace", 0)
 
     # ---- steady state: the corrector of a RUNNING branch (state, Bordered tangent and step size after two native
     # continuation steps), run to convergence -- next to the first-corrector headline (Weak 2)
@@ -557,7 +568,7 @@ def main():
                        "cell_corrector": {"converged": cfull["converged"], "itnewton": cfull["itnewton"],
                                           "itlinear": cfull["itlineartot"], "residuals": cfull["residuals"],
                                           "p": cfull["u"].p},
-                       "two_lanes": two_lanes, "gmres_blocks": gmres_blocks,
+                       "two_lanes": two_lanes, "gmres_blocks": gmres_blocks, "trace": trace_rec,
                        "setup_seconds": t_setup, "sh_kernel": args.sh_kernel, "linsolver": args.linsolver,
                        "preconditioner": "none" if P is None else "dct"},
             "roofline": roofline, "inner_loop": inner, "steady_state": steady, "kernels": kernels, "comm": comm_rec,
