@@ -256,7 +256,7 @@ def block_arnoldi_coefficients(G, H, k, u, s, Aq, Gp, pivot_tol=1e-8, theta=None
 
 
 def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, rtol=1e-12, Pl=None, block=4,
-                history=None, basis_out=None, stats=None, newton=True, shifts=None, keep_shifts=False):
+                history=None, basis_out=None, stats=None, newton=True, shifts=None, keep_shifts=False, defer=True):
     """The library's GMRES for vectors that stream from HBM since round 4, restated (csrc/solver.hip: gmres_core with
     arnoldi_block): KrylovKit's restarted GMRES -- same stopping rules, restart and numops bookkeeping as gmres_krylovkit
     above -- whose Arnoldi steps are taken in BLOCKS of up to ``block``: p_1 = A q_j, .., p_s = A p_{s-1}, then ONE pass of
@@ -264,14 +264,17 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
     projection uses the MEASURED Gram matrix (C = G^-1 Q'P: the block form of GramCGS above), the new vectors come from the
     Cholesky factor of the projected block's Gram matrix, the s Hessenberg columns from the change of basis.  The block size
     is capped by the number of steps the residual estimate predicts to need, so no operator application is wasted in the
-    cases at hand (``stats['wasted']``); numops counts consumed steps, as the library does.  Not a reference algorithm: the
-    tests show it reproduces the reference restatement's counts, residual history and solution."""
+    cases at hand (``stats['wasted']``); numops counts consumed steps, as the library does.  ``defer``: the update pass of a
+    block (Q_new = R^-T (P - C'Q)) waits until the new vectors are needed explicitly -- the next block, a restart's residual
+    -- and a solve that ends inside the block folds it into the solution update, x += Q (y_old - C R^-1 y_new) + P (R^-1
+    y_new) (csrc/solver.hip: PendingBlock; ``stats['folded']`` counts those).  Not a reference algorithm: the tests show it
+    reproduces the reference restatement's counts, residual history and solution."""
     if Pl is not None:
         A_, a0_, a1_ = A, a0, a1
         lin = lambda dx: a1_ * Pl(apply(A_, dx)) + a0_ * dx
         return gmres_block(lin, Pl(np.asarray(b, dtype=float)), 0.0, 1.0, krylovdim=krylovdim, maxiter=maxiter, atol=atol,
                            rtol=rtol, block=block, history=history, basis_out=basis_out, stats=stats, newton=newton,
-                           shifts=shifts, keep_shifts=keep_shifts)
+                           shifts=shifts, keep_shifts=keep_shifts, defer=defer)
     b = np.asarray(b, dtype=float)
     n = b.shape[0]
     x = np.zeros(n)
@@ -281,7 +284,7 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
     tol = max(atol, rtol * np.linalg.norm(b))
     if stats is None:
         stats = {}
-    stats.update(wasted=0, refused=0, void=0, blocks=[], shifts=None)
+    stats.update(wasted=0, refused=0, void=0, blocks=[], shifts=None, folded=0)
     if beta < tol:
         return x, True, numops, beta
     m = krylovdim
@@ -302,8 +305,18 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
         j, gram_n, k_done = 0, 0, 0
         res, res_prev = beta, None
         classic = False
+        pend = None                                      # (k, got, C, R, P) of a block whose update pass has not run
+
+        def flush():
+            nonlocal pend
+            if pend is not None:
+                k0, g, C0, R0, P0 = pend
+                Q[k0:k0 + g] = sla.solve_triangular(R0, P0[:g] - C0.T @ Q[:k0], trans="T", lower=False)
+                pend = None
+
         while j < m and res > tol:
             k = j + 1
+            flush()
             sb = min(blk_cur, block if shifts else min(block, 3), m - j)     # monomial blocks: at most 3 (csrc/solver.hip: kMonomialMax)
             capped = sb < blk_cur
             predicted = False
@@ -336,7 +349,9 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
                 else:
                     C, R, got, ratio = out
                     gram_n = k
-                    Q[k:k + got] = sla.solve_triangular(R, P[:got] - C.T @ Q[:k], trans="T", lower=False)
+                    pend = (k, got, C, R, P)
+                    if not defer:
+                        flush()
                     stats["void"] += sb - got            # operator applications of a truncated block's tail
                     if got < sb and carried:
                         shifts, carried = [], False
@@ -379,7 +394,15 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
             j += sb
         k = k_done
         yk = sla.solve_triangular(Rm[:k, :k], y[:k])
-        x = x + Q[:k].T @ yk
+        if pend is not None and k > pend[0]:
+            k0, g, C0, R0, P0 = pend
+            c = k - k0
+            tnew = sla.solve_triangular(R0[:c, :c], yk[k0:k], lower=False)        # R^-1 y_new (leading c x c block)
+            x = x + Q[:k0].T @ (yk[:k0] - C0[:, :c] @ tnew) + P0[:c].T @ tnew
+            stats["folded"] += 1
+        else:
+            x = x + Q[:k].T @ yk
+        flush()
         if basis_out is not None:
             basis_out.append(Q[:k].copy())
         beta = res

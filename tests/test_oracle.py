@@ -524,6 +524,14 @@ def test_block_arnoldi_gmres_reproduces_the_reference_restatement():
             assert np.abs(xb - xm).max() <= 1e-11 * np.abs(xm).max()
             defect = max(np.abs(B @ B.T - np.eye(B.shape[0])).max() for B in basis)
             assert defect <= 1e-5, (block, defect)          # inside a block: rounding of the dots / smallest accepted pivot ratio
+            # the deferred update pass (default; solver.hip: PendingBlock) against the update pass right after every block: the
+            # same iterates -- a solve that ends inside a block folds the pass into the solution update
+            st2 = {}
+            xd, okd, nd, _ = krylov.gmres_block(c["A"], rhs, c["a0"], c["a1"], krylovdim=c["krylovdim"], maxiter=60, rtol=c["rtol"],
+                                                atol=1e-14, Pl=c["Pl"], block=block, stats=st2, defer=False)
+            assert okd and nd == nb and st2["folded"] == 0 and st2["blocks"] == st["blocks"]
+            # (a last block of ONE step has nothing to fold: its new vector carries no solution coefficient and is never formed)
+            assert (st["folded"] >= 1 or st["blocks"][-1] == 1) and np.abs(xd - xb).max() <= 1e-13 * np.abs(xb).max(), (block, st)
 
 
 def test_block_arnoldi_refuses_a_closing_krylov_space():
