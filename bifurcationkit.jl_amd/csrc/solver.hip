@@ -593,18 +593,8 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
         }
         if (pend.active && k > pend.k) {
             // the solve (or the cycle) ends inside the deferred block: c of its vectors carry solution coefficients
-            const int c = k - pend.k;
             std::vector<double> cf(k, 0.0);
-            for (int i = 0; i < pend.k; ++i) {
-                double v = yk[i];
-                for (int q = 0; q < c; ++q) v += pend.Cm[i * sstep::kS + q] * yk[pend.k + q];
-                cf[i] = v;
-            }
-            for (int rr_ = 0; rr_ < c; ++rr_) {
-                double v = 0.0;
-                for (int q = rr_; q < c; ++q) v += pend.Tm[rr_ * sstep::kS + q] * yk[pend.k + q];
-                cf[pend.k + rr_] = v;
-            }
+            sstep::fold_solution_coefficients(pend.k, k - pend.k, pend.Cm, pend.Tm, yk.data(), cf.data());
             BK_TRY(v_multiaxpy(ctx, n, B.V, B.ld, k, cf.data(), x_zero ? nullptr : x, 1.0, x, nullptr));
         } else {
             BK_TRY(v_multiaxpy(ctx, n, B.V, B.ld, k, yk.data(), x_zero ? nullptr : x, 1.0, x, nullptr));

@@ -176,5 +176,23 @@ inline int block_coefficients(int k, int u, int s_in, const double* D, const dou
     return 0;
 }
 
+// Solution update through a block whose update pass has not run (solver.hip: PendingBlock).  The basis is [Q (k0 vectors), Q_new]
+// with Q_new = Q Cm + P Tm still unformed (slots k0 .. hold the raw P); the solution takes coefficients yk[0 .. k0 + c) with c <=
+// s_eff of the block's vectors:  sum_i yk[i] q_i + sum_q yk[k0 + q] qnew_q  =  sum_i cf[i] q_i + sum_r cf[k0 + r] p_r,
+//   cf[i] = yk[i] + sum_{q < c} Cm(i, q) yk[k0 + q],   cf[k0 + r] = sum_{r <= q < c} Tm(r, q) yk[k0 + q]     (Tm upper triangular:
+// the first c columns of Q_new only involve p_0 .. p_{c-1}).  ONE multiaxpy over [Q, P] replaces the update pass + the multiaxpy.
+inline void fold_solution_coefficients(int k0, int c, const double* Cm, const double* Tm, const double* yk, double* cf) {
+    for (int i = 0; i < k0; ++i) {
+        double v = yk[i];
+        for (int q = 0; q < c; ++q) v += Cm[i * kS + q] * yk[k0 + q];
+        cf[i] = v;
+    }
+    for (int r = 0; r < c; ++r) {
+        double v = 0.0;
+        for (int q = r; q < c; ++q) v += Tm[r * kS + q] * yk[k0 + q];
+        cf[k0 + r] = v;
+    }
+}
+
 }  // namespace sstep
 }  // namespace bk

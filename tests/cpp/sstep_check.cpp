@@ -1,6 +1,6 @@
 // Host replay of the block Arnoldi step (bifurcationkit.jl_amd/csrc/sstep.h) on a dense matrix: the two streaming passes of
 // vecops.hip (block_dots_kernel / block_axpy_kernel) are plain loops here, the coefficient algebra is the library's header.
-// stdin: n m s, then A (n rows), then b, then optionally ns and ns Newton shifts (used cyclically inside every block).  stdout: status per block, then H ((m+1) x m, row-major), then Q ((m+1) x n).
+// stdin: n m s, then A (n rows), then b, then optionally ns and ns Newton shifts (used cyclically inside every block).  stdout: status per block ("ok <defect of the folded solution update>"), then H ((m+1) x m, row-major), then Q ((m+1) x n).
 #include <cstdio>
 #include <vector>
 #include "../../bifurcationkit.jl_amd/csrc/sstep.h"
@@ -22,6 +22,7 @@ int main() {
     for (int i = 0; i < n; ++i) Q[i] = b[i] / nb;
     auto dot = [&](const double* x, const double* y) { double v = 0.0; for (int i = 0; i < n; ++i) v += x[i] * y[i]; return v; };
     int j = 0, gram_n = 0, fails = 0;
+    double fold_defect = 0.0;
     while (j < m) {
         const int sb = s < m - j ? s : m - j, k = j + 1, u = k - gram_n, ko = k - u, nr = u + sb;
         double theta[kS] = {0.0, 0.0, 0.0, 0.0};
@@ -51,11 +52,28 @@ int main() {
                 for (int i = 0; i < k; ++i) v += Cm[i * kS + q] * Q[(size_t)i * n + e];
                 out[(size_t)q * n + e] = v;
             }
+        if (j + sb >= m) {
+            // the last block: a solution update with coefficients on c = 1 .. sb of its vectors, once through the explicit new
+            // vectors and once through fold_solution_coefficients on [Q, P] (the deferred update pass of solver.hip)
+            for (int c = 1; c <= sb; ++c) {
+                std::vector<double> yk(k + c), cf(k + c);
+                for (int i = 0; i < k + c; ++i) yk[i] = ((i % 3) - 0.8) / (1.0 + 0.3 * i);
+                fold_solution_coefficients(k, c, Cm, Tm, yk.data(), cf.data());
+                double worst = 0.0, big = 0.0;
+                for (int e = 0; e < n; ++e) {
+                    double a = 0.0, f = 0.0;
+                    for (int i = 0; i < k; ++i) { a += yk[i] * Q[(size_t)i * n + e]; f += cf[i] * Q[(size_t)i * n + e]; }
+                    for (int q = 0; q < c; ++q) { a += yk[k + q] * out[(size_t)q * n + e]; f += cf[k + q] * Q[(size_t)(k + q) * n + e]; }
+                    worst = std::fmax(worst, std::fabs(a - f)); big = std::fmax(big, std::fabs(a));
+                }
+                fold_defect = std::fmax(fold_defect, worst / big);
+            }
+        }
         for (int q = 0; q < sb; ++q)
             for (int e = 0; e < n; ++e) Q[(size_t)(k + q) * n + e] = out[(size_t)q * n + e];
         j += sb;
     }
-    printf("ok\n");
+    printf("ok %.3e\n", fold_defect);
     for (int a = 0; a <= m; ++a) { for (int c = 0; c < m; ++c) printf("%.17g ", H[(size_t)a + (size_t)c * ldh]); printf("\n"); }
     for (int a = 0; a <= m; ++a) { for (int e = 0; e < n; ++e) printf("%.17g ", Q[(size_t)a * n + e]); printf("\n"); }
     return 0;

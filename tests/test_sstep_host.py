@@ -37,7 +37,10 @@ def _run(exe, A, b, m, s, shifts=()):
     inp = f"{n} {m} {s}\n" + "\n".join(" ".join(repr(float(x)) for x in row) for row in A) + "\n" + " ".join(repr(float(x)) for x in b)
     inp += f"\n{len(shifts)} " + " ".join(repr(float(x)) for x in shifts)
     out = subprocess.run([exe], input=inp, capture_output=True, text=True, check=True).stdout.strip().split("\n")
-    assert out[0] == "ok", out[0]
+    assert out[0].split()[0] == "ok", out[0]
+    # the solution update folded through the last block's unformed vectors (sstep.h: fold_solution_coefficients; the deferred update
+    # pass of solver.hip) equals the update through the explicit vectors
+    assert float(out[0].split()[1]) < 1e-13, out[0]
     H = np.array([[float(x) for x in out[1 + a].split()] for a in range(m + 1)])
     Q = np.array([[float(x) for x in out[2 + m + a].split()] for a in range(m + 1)])
     return H, Q
