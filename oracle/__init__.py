@@ -12,6 +12,14 @@ reference ``file:line`` it follows (paths relative to ``/root/reference``).
 
 Parity status ("pinned" = checked against something the reference itself
 holds):
+  * Newton / PALC corrector / MatrixBLS / Secant and Bordered tangents /
+    step-size control / eigenvalue-count detection / bisection / both-sides
+    merge (palc.py, bordered.py, bifurcations.py): pinned by the known answers
+    the reference's own tests assert at rtol sqrt(eps) -- special points of
+    test/hopf_codim_2/COModel.jl:31-34, bisection intervals of lorenz84.jl:63-66,
+    the fold of test/fold_codim_2/codim2.jl:54-55, the bifurcation points and
+    kernel dimensions of test/continuation/test_bif_detection.jl:62-98
+    (tests/golden/reference_known_answers.json, tests/test_reference_known_answers.py).
   * dense/eigen plumbing: pinned by the literal 5x5 golden eigen-decomposition
     of ``test/linear_solvers/test_linear.jl:595-614`` (tests/golden/eig5x5.json)
     and by the reference tests' own identities (solver == dense ``\\``).

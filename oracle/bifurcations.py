@@ -31,7 +31,7 @@ class ContPar:
     eta: float = 150.0
     nev: int = 3
     tol_stability: float = 1e-10
-    tol: float = 1e-10
+    tol: float = 1e-12                     # NewtonPar.tol, src/Newton.jl:19
     max_iterations: int = 25
     tangent: str = "secant"
     dsmin_bisection: float = 1e-16
@@ -199,7 +199,9 @@ def bifurcation_type(S: ContState):
 
 def continuation(prob, x0, p0, *, ls, bls, eig, cp: ContPar, normC=palc.norm2, detect_bifurcation_level=3):
     """continuation! (Continuation.jl:349-456, 505-600) with eigenvalues every step and bisection of detected bifurcations.
-    Returns dict(param, n_unstable, ds, itnewton, specialpoint=[dict(type, status, interval, param, step, n_unstable)])."""
+    Returns dict(param, n_unstable, ds, itnewton, specialpoint=[dict(type, status, interval, param, step, n_unstable, x)]).
+    Pinned to reference-held known answers (special-point parameters and bisection intervals asserted by the reference's own
+    tests to its default isapprox tolerance) in tests/test_reference_known_answers.py."""
     kw = dict(tol=cp.tol, max_iterations=cp.max_iterations, normN=normC)
     s0 = palc.newton(prob, x0, p0, ls, **kw)
     assert s0["converged"]
@@ -227,7 +229,7 @@ def continuation(prob, x0, p0, *, ls, bls, eig, cp: ContPar, normC=palc.norm2, d
                     tp = bifurcation_type(st)
                     if tp != "none":
                         out["specialpoint"].append(dict(type=tp, status=status, interval=interval, param=st.z[1], step=st.step,
-                                                        n_unstable=st.n_unstable))
+                                                        n_unstable=st.n_unstable, x=st.z[0].copy()))
             out["param"].append(st.z[1]); out["n_unstable"].append(st.n_unstable[0]); out["ds"].append(st.ds)
             out["itnewton"].append(st.itnewton)
         nxt = step_fn(st)
