@@ -16,9 +16,17 @@ import torch  # noqa: E402
 from bk_amd import hip  # noqa: E402
 
 ctx = hip.Context(0)
-for kv in os.environ.get("BK_OPTS", "").split(","):                        # library options, "key=value,key=value"
-    if "=" in kv:
-        ctx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
+
+
+def apply_opts():
+    """Library options of an experiment, BK_OPTS="key=value,key=value".  Applied AFTER the cell solves that define the input of the
+    timed step (their last digits move with solver options, and the secant of two close solutions amplifies them), so that every
+    option set times the same step."""
+    for kv in os.environ.get("BK_OPTS", "").split(","):
+        if "=" in kv:
+            ctx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
+
+
 ONLY = os.environ.get("BK_ONLY", "")                                       # "c2": stop after config 2
 if os.environ.get("BK_GMRES_CHUNK"):
     ctx.set_option("gmres_chunk", float(os.environ["BK_GMRES_CHUNK"]))      # 1: host-driven Arnoldi steps; >= 2: device-resident chunks
@@ -47,6 +55,7 @@ ds, theta = -0.001, 0.5
 c0 = hip.newton_native(cprob, u0c, -0.1, cls_, tol=5e-9, max_iterations=40, norm_inf=True)
 c1 = hip.newton_native(cprob, c0["u"], -0.1 + ds / 150, cls_, tol=5e-9, max_iterations=20, norm_inf=True)
 assert c0["converged"] and c1["converged"]
+apply_opts()
 idx = [np.concatenate([np.arange(nc) if c % 2 == 0 else np.arange(nc)[::-1] for c in range(T)]) for nc, T in zip(cell, tiles)]
 tile = lambda a: np.ascontiguousarray(a.reshape(cell[1], cell[0])[np.ix_(idx[1], idx[0])]).reshape(-1)
 dims, ls_ = (512, 512), (16 * np.pi, 8 * np.pi / np.sqrt(3))
