@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU-box runs of round 4, one script, parts selected by name:   bash scripts/gpu_evidence.sh <part> [<part> ...]
 #   leads     start-offset / LDS-layout sweep of the hot kernels (both layouts), then bench.py with the winning options
-#   tests     pytest -m gpu + smoke
+#   tests     pytest -m gpu + smoke   (6 min serial; `-n 3 --dist loadfile` was tried: ~5 min, tests/test_gpu_parity.py keeps one worker busy)
 #   newtests  only the tests added this round (TESTS_K = pytest -k expression)
 #   bench     default bench line + the driver's arguments (--gpus 1 --steps 20 --warmup 5)
 #   prof      rocprofv3 kernel stats of the bench + the two PMC passes (FETCH_SIZE / WRITE_SIZE)   [TAG, default r4]
