@@ -544,6 +544,8 @@ def main():
         gmres_blocks = {"operator_applications_in_blocks": ctx.get_option("gmres_block_steps"), "void": ctx.get_option("gmres_block_void")}
     except Exception:  # noqa: BLE001
         gmres_blocks = None
+    sf_opt = [float(kv.split("=")[1]) for kv in args.opt if kv.startswith("gmres_stencil_free=")]
+    stencil_free = bool((sf_opt[-1] if sf_opt else 1.0) != 0.0) and P is not None and args.linsolver == "gmres"
     if rank == 0:
         ms = dt / max(args.steps, 1) * 1e3
         out = {
@@ -569,6 +571,12 @@ def main():
                                           "itlinear": cfull["itlineartot"], "residuals": cfull["residuals"],
                                           "p": cfull["u"].p},
                        "two_lanes": two_lanes, "gmres_blocks": gmres_blocks, "trace": trace_rec,
+                       "arnoldi_operator": ("stencil-free: Pl^-1 J = -I + Pl^-1 diag(g(u) + shift) for Pl = L1 + shift I (exact; "
+                                            "src/LinearSolver.jl:270-277 `_linmap` rearranged) -- the pointwise factor rides in the "
+                                            "x-forward transform pass, -I is a Hessenberg shift, the stencil kernel runs only in the "
+                                            "residuals and in each solve's explicit residual check (--opt gmres_stencil_free=0: the "
+                                            "literal chain stencil -> Pl^-1)") if stencil_free else "literal chain: stencil kernel, then Pl^-1",
+                       "jvp_calls_per_step": (kernels["jvp"]["calls"] / max(args.steps, 1)) if "jvp" in kernels else 0,
                        "setup_seconds": t_setup, "sh_kernel": args.sh_kernel, "linsolver": args.linsolver,
                        "preconditioner": "none" if P is None else "dct"},
             "roofline": roofline, "inner_loop": inner, "steady_state": steady, "kernels": kernels, "comm": comm_rec,

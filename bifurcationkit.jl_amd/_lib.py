@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # BKHIP_LIB: an explicit library file (A/B builds of the same sources, e.g. `make layout0`); default = the in-tree build
 LIB_PATH = os.environ.get("BKHIP_LIB") or os.path.join(_HERE, "lib", "libbkhip.so")
 
+BK_ABI_VERSION = 5          # include/bkhip.h: layout version of the option structs mirrored below
 BK_UNIQUE_ID_BYTES = 128
 BK_MAX_PARAMS = 8
 BK_MAX_NEWTON_ITER = 64
@@ -98,6 +99,7 @@ SZ = C.c_size_t
 # name -> (restype, argtypes): every symbol include/bkhip.h declares
 SIGNATURES = {
     "bk_version": (I, []),
+    "bk_abi_version": (I, []),
     "bk_ctx_create": (I, [C.POINTER(VP), I, VP]),
     "bk_comm_unique_id": (I, [VP]),
     "bk_ctx_create_dist": (I, [C.POINTER(VP), I, VP, I, I, VP]),
@@ -141,6 +143,7 @@ SIGNATURES = {
     "bk_precond_cgl_create": (I, [VP, D, D, C.POINTER(VP)]),
     "bk_precond_destroy": (I, [VP]),
     "bk_precond_apply": (I, [VP, VP, VP]),
+    "bk_precond_op_apply": (I, [VP, VP, VP, VP, D, D, VP, c_int_p]),
     "bk_gmres_default_opts": (None, [C.POINTER(GmresOpts), I]),
     "bk_gmres": (I, [VP, VP, VP, VP, D, D, C.POINTER(GmresOpts), VP, c_int_p, c_int_p, c_double_p]),
     "bk_gmres2": (I, [VP, VP, VP, VP, VP, VP, D, D, C.POINTER(GmresOpts), VP, c_int_p, c_int_p]),
@@ -204,6 +207,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
+    if lib.bk_abi_version() != BK_ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: option-struct layout version {lib.bk_abi_version()}, this binding was written for "
+                          f"{BK_ABI_VERSION} (include/bkhip.h: BK_ABI_VERSION)")
     _lib = lib
     return lib
 

@@ -20,6 +20,10 @@ namespace bk {
 constexpr int kMaxBasis = 64;      // largest Krylov dimension + 1 the fused kernels are built for
 constexpr int kRedSlots = 256;     // doubles in the reduction result buffers
 constexpr int kRedBlocks = 1024;   // blocks of a reduction kernel (stage 1); stage 2 is one block
+// values per workgroup the stage-1 kernels may leave in d_partials: multidot kMaxBasis + 2, the Gram variant 2 * 32 + 1, block_dots
+// 4 * 8 + 36 = 68 (vecops.hip: static_asserts at the launch sites); every launcher checks grid * values against kPartialDoubles
+constexpr int kPartialVals = 72;
+constexpr size_t kPartialDoubles = (size_t)kRedBlocks * kPartialVals;
 constexpr double kCancelTol = 1e-8;   // Pythagorean norm b^2 = |w|^2 - |h|^2 is trusted while b^2 > kCancelTol |w|^2 (host and device Arnoldi steps)
 constexpr int kRecChunks = 16;     // most speculative Arnoldi steps per synchronisation (option gmres_chunk)
 
@@ -62,7 +66,7 @@ struct bk_ctx {
     bk_sendrecv_fn lane_sendrecv = nullptr;
     void* lane_user = nullptr;
     // reduction scratch
-    double* d_partials = nullptr;   // [kRedBlocks * kMaxBasis+2]
+    double* d_partials = nullptr;   // [kPartialDoubles]
     double* d_red = nullptr;        // [kRedSlots]
     double* h_red = nullptr;        // pinned [kRedSlots]
     double* h_red_dev = nullptr;    // its device-side address (mapped): single-rank reductions land in it directly
@@ -170,6 +174,8 @@ int v_scale(bk_ctx* ctx, size_t n, double a, double* x);
 int v_axpby(bk_ctx* ctx, size_t n, double a, const double* x, double b, double* y);
 // z = a x + b y (z may alias x or y)
 int v_axpbyz(bk_ctx* ctx, size_t n, double a, const double* x, double b, const double* y, double* z);
+// z = x .* (A + u (B + C u))   (z may alias x)
+int v_pw_scale(bk_ctx* ctx, size_t n, const double* x, const double* u, double A, double B, double C, double* z);
 int v_dot(bk_ctx* ctx, size_t n, const double* x, const double* y, double* out);
 int v_dot2(bk_ctx* ctx, size_t n, const double* x, const double* y1, const double* y2, double* out2);
 int v_nrm2(bk_ctx* ctx, size_t n, const double* x, double* out);

@@ -296,8 +296,10 @@ static int proxy_grow(bk_ctx* ctx, hipStream_t stream, double** a, double** b, s
     if (*b) (void)hipHostFree(*b);
     *a = *b = nullptr;
     *cap = 0;
-    BK_HIP(ctx, hipHostMalloc((void**)a, need * sizeof(double), hipHostMallocDefault));
-    BK_HIP(ctx, hipHostMalloc((void**)b, need * sizeof(double), hipHostMallocDefault));
+    // (coherent like the flags and the all-reduce staging buffer: the proxy thread reads what a stream-ordered copy wrote and the
+    // stream reads what the proxy wrote, with no host synchronisation in between -- ADVICE r4)
+    BK_HIP(ctx, hipHostMalloc((void**)a, need * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    BK_HIP(ctx, hipHostMalloc((void**)b, need * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
     *cap = need;
     return 0;
 }
@@ -348,6 +350,8 @@ int comm_allreduce_host(bk_ctx* ctx, double* buf, int n, int op) {
 
 int reduce_finish(bk_ctx* ctx, int nblocks, int nvals, int op) {
     if (nvals > kRedSlots) return set_error(ctx, "reduce_finish: too many values");
+    // (after the fact for this launch, but loud: a stage-1 grid that would not fit d_partials is a bug of its launcher)
+    if ((size_t)nblocks * (size_t)nvals > kPartialDoubles) return set_error(ctx, "reduce_finish: %d x %d partial sums exceed d_partials", nblocks, nvals);
     if (ctx->nranks == 1 && ctx->h_red_dev) {
         // single rank: the second stage writes straight into the pinned, device-mapped host buffer -- no copy
         // operation, the host only waits for the stream
@@ -460,7 +464,7 @@ static int ctx_init_common(bk_ctx* ctx, int device, void* stream) {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->num_cu = cus;
     }
-    BK_HIP(ctx, hipMalloc(&ctx->d_partials, sizeof(double) * kRedBlocks * (kMaxBasis + 2)));
+    BK_HIP(ctx, hipMalloc(&ctx->d_partials, sizeof(double) * kPartialDoubles));
     BK_HIP(ctx, hipMalloc(&ctx->d_red, sizeof(double) * kRedSlots));
     BK_HIP(ctx, hipHostMalloc(&ctx->h_red, sizeof(double) * kRedSlots, hipHostMallocMapped));
     {

@@ -458,11 +458,11 @@ void dct_plan_destroy(DctPlan* p) {
     delete p;
 }
 
-static int dct_apply_slab(bk_ctx* ctx, DctPlan* p, const double* v, double* out);
+static int dct_apply_slab(bk_ctx* ctx, DctPlan* p, const double* v, double* out, const DctFuse* fz = nullptr);
 
-int dct_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out, int* dot_blocks) {
+int dct_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out, int* dot_blocks, const DctFuse* fz) {
     if (dot_blocks) *dot_blocks = 0;
-    if (p->slab_ok) return dct_apply_slab(ctx, p, v, out);      // cost-model emulation (option dct_slab_emulate), timing only
+    if (p->slab_ok) return dct_apply_slab(ctx, p, v, out, fz);      // cost-model emulation (option dct_slab_emulate), timing only
     const int n0 = p->n[0], n1 = p->n[1], n2 = p->n[2];
     const unsigned grid = (unsigned)((p->total + 255) / 256);
     const bool use_fft = ctx->opt("dct_fft", 1.0) != 0.0;
@@ -471,11 +471,14 @@ int dct_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out, int* dot_bl
     double* bufs[2] = {p->t1, p->t2};
     int cur = 0;
     auto axis_pass = [&](int a, int inverse, const double* in, double* o, int fuse) -> int {
-        ProfScope ps(ctx, "dct_pass", 16.0 * p->total);          // one read + one write of the array per axis pass
+        // the fused pointwise work (DctFuse) rides in the first pass (input side: in == v) and the last one (output side: o == out)
+        const DctFuse* f = (fz && a == 0 && ((!inverse && in == v && fz->u) || (inverse && o == out && fz->xadd))) ? fz : nullptr;
+        ProfScope ps(ctx, "dct_pass", (f ? 24.0 : 16.0) * p->total);   // one read + one write of the array per axis pass (+ the fused stream)
         if (use_fft && p->twid[a]) {
             return dct_axis_fft(ctx, n0, n1, n2, a, inverse, p->twid[a], in, o, p->lam[0], p->lam[1],
-                                p->ndim == 3 ? p->lam[2] : nullptr, p->shift, fuse, nullptr, fuse == 2 ? dot_blocks : nullptr);
+                                p->ndim == 3 ? p->lam[2] : nullptr, p->shift, fuse, nullptr, fuse == 2 ? dot_blocks : nullptr, f);
         }
+        if (f) return set_error(ctx, "dct_apply: fused pointwise work on a dense transform pass");
         // forward: out[k] = sum_n T[k][n] in[n]  -> M[q=n][o=k] = TT ; inverse: out[n] = sum_k T[k][n] in[k] -> M = T
         return dense_axis_pass(ctx, n0, n1, n2, a, inverse ? p->T[a] : p->TT[a], inverse ? p->TT[a] : p->T[a], in, o);
     };
@@ -627,12 +630,13 @@ static int slab_tables_create(bk_ctx* ctx, DctPlan* p, int nl, bool even, double
 // Slab path of the distributed apply (dct_slab.hip): x, y passes on the z-slab; B^-1 = the fused z pass of length nl on the
 // slab; face data to the line owners, the capacitance solves, the corrections back; B^-1 again on the corrected right-hand
 // side; inverse y, x.  Two small all-to-alls (4 doubles per line each way) instead of two transposes of the array.
-static int dct_apply_slab(bk_ctx* ctx, DctPlan* p, const double* v, double* out) {
+static int dct_apply_slab(bk_ctx* ctx, DctPlan* p, const double* v, double* out, const DctFuse* fz) {
     const int nx = p->n[0], ny = p->n[1], nl = p->nl;
     const double n3 = (double)nx * ny * nl;
     auto pass = [&](int axis, int inverse, const double* tw, const double* in, double* o, int fuse, const double* l2) -> int {
-        ProfScope ps(ctx, "dct_pass", 16.0 * n3);
-        return dct_axis_fft(ctx, nx, ny, nl, axis, inverse, tw, in, o, p->lam[0], p->lam[1], l2, p->shift, fuse, nullptr);
+        const DctFuse* f = (fz && axis == 0 && ((!inverse && in == v && fz->u) || (inverse && o == out && fz->xadd))) ? fz : nullptr;
+        ProfScope ps(ctx, "dct_pass", (f ? 24.0 : 16.0) * n3);
+        return dct_axis_fft(ctx, nx, ny, nl, axis, inverse, tw, in, o, p->lam[0], p->lam[1], l2, p->shift, fuse, nullptr, nullptr, f);
     };
     SlabK K;
     K.nx = nx; K.ny = ny; K.nl = nl; K.R = p->R; K.rank = p->rank;
@@ -670,9 +674,9 @@ static int dct_apply_slab(bk_ctx* ctx, DctPlan* p, const double* v, double* out)
 // (forward, symbol, inverse) runs on it directly as an axis-2 pass; all-to-all back; inverse y and x passes.  With a
 // uniform y split and the fused y kernel the forward y pass writes the block layout itself and the inverse y pass reads
 // it (DctSplit), so no pack / unpack kernel runs at all; otherwise slab_blocks_kernel packs / unpacks.
-static int dct_apply_dist(bk_ctx* ctx, DctPlan* p, const double* v, double* out) {
+static int dct_apply_dist(bk_ctx* ctx, DctPlan* p, const double* v, double* out, const DctFuse* fz = nullptr) {
     if (p->slab_ok && ctx->opt("dct_fft", 1.0) != 0.0 && p->twid[0] && p->twid[1] && ctx->opt("dct_dist_slab", 1.0) != 0.0)
-        return dct_apply_slab(ctx, p, v, out);
+        return dct_apply_slab(ctx, p, v, out, fz);
     const int nx = p->n[0], ny = p->n[1], nz = p->n[2];
     const int nzl = p->zhi - p->zlo, nyl = p->yhi - p->ylo;
     const size_t loc_z = (size_t)nx * ny * nzl, loc_y = (size_t)nx * nyl * nz;
@@ -682,9 +686,11 @@ static int dct_apply_dist(bk_ctx* ctx, DctPlan* p, const double* v, double* out)
     auto pass = [&](int n0, int n1, int n2, int axis, int which, int inverse, const double* in, double* o, int fuse,
                     const double* l0, const double* l1, const double* l2, const DctSplit* split) -> int {
         // `which` = index of the global axis being transformed (selects tables)
-        ProfScope ps(ctx, "dct_pass", 16.0 * (double)n0 * n1 * n2);
+        const DctFuse* f = (fz && which == 0 && ((!inverse && in == v && fz->u) || (inverse && o == out && fz->xadd))) ? fz : nullptr;
+        ProfScope ps(ctx, "dct_pass", (f ? 24.0 : 16.0) * (double)n0 * n1 * n2);
         if (use_fft && p->twid[which])
-            return dct_axis_fft(ctx, n0, n1, n2, axis, inverse, p->twid[which], in, o, l0, l1, l2, p->shift, fuse, split);
+            return dct_axis_fft(ctx, n0, n1, n2, axis, inverse, p->twid[which], in, o, l0, l1, l2, p->shift, fuse, split, nullptr, f);
+        if (f) return set_error(ctx, "dct_apply_dist: fused pointwise work on a dense transform pass");
         return dense_axis_pass(ctx, n0, n1, n2, axis, inverse ? p->T[which] : p->TT[which], inverse ? p->TT[which] : p->T[which], in, o);
     };
     double *a = p->t1, *b = p->t2;
@@ -739,15 +745,17 @@ int dct_slab_emulate_tables(bk_ctx* ctx, DctPlan* p, double az) { return slab_ta
 namespace {
 struct ShDctPrecond : bk_precond {
     DctPlan* plan = nullptr;
-    const bk_problem* prob = nullptr;         // the problem whose L1 this plan diagonalises (bk_precond_sh_create)
+    // the grid whose L1 this plan diagonalises, by VALUE (bk_precond_sh_create): the problem object may be destroyed or its
+    // address reused while the preconditioner lives on
+    bool has_grid = false;
+    bk_problem_desc grid{};
+    int grid_lo = 0, grid_hi = 0;
     bool is_l1_plus_shift(const bk_problem* pr, double* shift) const override {
-        if (!plan || plan->kind != 0 || !prob || !pr) return false;
-        if (pr != prob) {                     // (the second lane works on a copy of the problem object: compare the grids)
-            const bk_problem_desc &a = pr->desc, &b = prob->desc;
-            if (a.pde != b.pde || a.ndim != b.ndim || pr->lo != prob->lo || pr->hi != prob->hi) return false;
-            for (int d = 0; d < a.ndim; ++d)
-                if (a.n[d] != b.n[d] || a.l[d] != b.l[d]) return false;
-        }
+        if (!plan || plan->kind != 0 || !has_grid || !pr) return false;
+        const bk_problem_desc &a = pr->desc, &b = grid;
+        if (a.pde != b.pde || a.ndim != b.ndim || pr->lo != grid_lo || pr->hi != grid_hi) return false;
+        for (int d = 0; d < a.ndim; ++d)
+            if (a.n[d] != b.n[d] || a.l[d] != b.l[d]) return false;
         *shift = plan->shift;
         return true;
     }
@@ -760,6 +768,23 @@ struct ShDctPrecond : bk_precond {
     int apply(const double* v, double* out) override {
         if (plan->kind >= 1) return dst_apply(ctx, plan, v, out);
         return plan->dist ? dct_apply_dist(ctx, plan, v, out) : dct_apply(ctx, plan, v, out);
+    }
+    // the x passes of this plan run as the fused LDS kernel on these buffers: the pointwise work of apply_pw can ride in them
+    bool pw_fused_ok(const double* x, const double* u, const double* out) const override {
+        if (!plan || plan->kind != 0 || plan->ndim < 2 || !plan->twid[0] || ctx->opt("dct_fft", 1.0) == 0.0) return false;
+        if (((uintptr_t)x | (uintptr_t)u | (uintptr_t)out) & 15) return false;
+        const int nzl = plan->dist ? plan->zhi - plan->zlo : (plan->slab_ok ? plan->nl : plan->n[2]);
+        return dct_axis_fused_ok(ctx, plan->n[0], plan->n[1], nzl, 0, x, plan->t1, 0) &&
+               dct_axis_fused_ok(ctx, plan->n[0], plan->n[1], nzl, 0, plan->t2, const_cast<double*>(out), 0);
+    }
+    int apply_pw(const double* x, const DctFuse& d, double cx, double ct, double* out) override {
+        if (!pw_fused_ok(x, d.u, out) || ctx->opt("dct_fuse_pw", 1.0) == 0.0) return bk_precond::apply_pw(x, d, cx, ct, out);
+        DctFuse f = d;
+        f.xadd = nullptr; f.cx = 0.0; f.ct = 1.0;
+        const bool scale_after = cx == 0.0 && ct != 1.0;              // (rare: no x term but a scale -- not worth a kernel variant)
+        if (cx != 0.0) { f.xadd = x; f.cx = cx; f.ct = ct; }
+        BK_TRY(plan->dist ? dct_apply_dist(ctx, plan, x, out, &f) : dct_apply(ctx, plan, x, out, nullptr, &f));
+        return scale_after ? v_scale(ctx, n, ct, out) : 0;
     }
     int apply_dot(const double* v, double* out, double* dot) override {
         if (plan->kind >= 1 || plan->dist || plan->ndim < 2 || ctx->nranks != 1) return bk_precond::apply_dot(v, out, dot);
@@ -790,7 +815,7 @@ bk_precond* precond_lane_shadow(bk_precond* pl, bk_ctx* lane) {
     }
     ShDctPrecond* S = new ShDctPrecond();
     S->ctx = lane; S->n = P->n; S->plan = q; S->shadow = true;
-    S->prob = P->prob;
+    S->has_grid = P->has_grid; S->grid = P->grid; S->grid_lo = P->grid_lo; S->grid_hi = P->grid_hi;
     return S;
 }
 
@@ -807,7 +832,7 @@ int bk_precond_sh_create(bk_problem* prob, double shift, bk_precond** out) {
     ShDctPrecond* P = new ShDctPrecond();
     P->ctx = ctx;
     P->n = prob->nloc;
-    P->prob = prob;
+    P->has_grid = true; P->grid = prob->desc; P->grid_lo = prob->lo; P->grid_hi = prob->hi;
     int s = ctx->nranks > 1
                 ? dct_plan_create_dist(ctx, prob->desc.n, prob->ainv, shift, prob->lo, prob->hi, &P->plan)
                 : dct_plan_create(ctx, prob->desc.ndim, prob->desc.n, prob->ainv, shift, &P->plan);

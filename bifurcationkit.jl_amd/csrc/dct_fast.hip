@@ -54,6 +54,10 @@ struct FftK {
     int ntiles;               // fused kernel: tiles of the pass (= workgroups)
     int xmap;                 // fused kernel: XCD-contiguous slot -> tile map (ntiles % 8 == 0)
     int stagger, stag_cu;     // fused kernel: start offset of the workgroups that fill every CU's second slot (stag_cu = CUs)
+    // FZ kernels (x passes, ops.h: DctFuse): forward -- every sample is multiplied by fzA + u (fzB + fzC u), u = fz_v at the
+    // sample's own index; inverse -- the stored value is fz_ct * result + fz_cx * fz_v[same index]
+    const double* fz_v;
+    double fzA, fzB, fzC, fz_cx, fz_ct;
 };
 
 template <int NT>
@@ -345,8 +349,11 @@ __device__ __forceinline__ void lds_barrier() {
 // it lived in this file up to commit 96342eb.)  NTM: non-temporal tile loads / stores (every element is touched once).
 // DOT (MODE 2): the per-tile partial sum of sum_k symbol(k) |v^_k|^2 -- by Parseval (orthonormal transforms on every axis)
 // the dot product v . (M^-1 v) of this tile's lines -- goes to P.dotp[workgroup]; costs no memory traffic.
-template <int NT, int MODE, bool AX0, bool NTM, bool DOT = false>   // MODE 0: forward, 1: inverse, 2: forward - symbol - inverse (AX0: 0 / 1 only)
+// FZ (AX0 only): the pointwise work of the stencil-free preconditioned operator rides in the x passes (ops.h: DctFuse) -- one more
+// 8 B/point read stream in the pass, same tile pipeline.
+template <int NT, int MODE, bool AX0, bool NTM, bool DOT = false, bool FZ = false>   // MODE 0: forward, 1: inverse, 2: forward - symbol - inverse (AX0: 0 / 1 only)
 __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
+    static_assert(!FZ || (AX0 && MODE != 2), "FZ: x passes only");
     __shared__ double dsum[NT / 64];
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int N = P.N, bits = P.bits, G = N >> 3;
@@ -428,6 +435,7 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
     // first-stage samples held in registers: (AX0) the 8 + 8 sample pairs of this lane's item, line a in pfa / line b in
     // pfb; (axis >= 1) the 8 samples of item tid in pfa and of item tid + NT in pfb
     c2 pfa[8], pfb[8];
+    c2 qfa[FZ ? 8 : 1], qfb[FZ ? 8 : 1];     // FZ: the second stream's values at the same indices (u forward, x inverse)
     // (the host launches this kernel only when nfirst <= NT (AX0) / 2 NT, so the two register sets cover the tile)
     const bool act0 = tid < nfirst, act1 = !AX0 && tid + NT < nfirst;
     auto issue = [&](int tile) {
@@ -465,6 +473,16 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
                 pfb[2 * r] = ld16(row + lstride + m * (gp + G * r));
                 pfa[2 * r + 1] = ld16(row + m * (gq + G * r));
                 pfb[2 * r + 1] = ld16(row + lstride + m * (gq + G * r));
+            }
+            if (FZ) {
+                const double* urow = P.fz_v + tile_base(tile) + (act0 ? (size_t)(2 * (tid >> hbits)) * lstride : (size_t)0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    qfa[2 * r] = ld16(urow + m * (gp + G * r));
+                    qfb[2 * r] = ld16(urow + lstride + m * (gp + G * r));
+                    qfa[2 * r + 1] = ld16(urow + m * (gq + G * r));
+                    qfb[2 * r + 1] = ld16(urow + lstride + m * (gq + G * r));
+                }
             }
         } else {
             const unsigned o = 2u * (tid & (npairs - 1));
@@ -526,6 +544,11 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
                     dctc::fused_first2(z + (size_t)(tid >> hbits) * pstride, N, bits, tid & ((1 << hbits) - 1),
                                        [&](int s, int, double& ea, double& oa, double& eb, double& ob) {
                                            ea = pfa[s].x; oa = pfa[s].y; eb = pfb[s].x; ob = pfb[s].y;
+                                           if (FZ) {
+                                               const int t = FZ ? s : 0;
+                                               auto d = [&](double u) { return P.fzA + u * (P.fzB + P.fzC * u); };
+                                               ea *= d(qfa[t].x); oa *= d(qfa[t].y); eb *= d(qfb[t].x); ob *= d(qfb[t].y);
+                                           }
                                        });
             } else {
                 c2* zp = z + (size_t)(tid & (npairs - 1)) * pstride;
@@ -548,6 +571,20 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
                 const int pr = AX0 ? tid >> hbits : tid & (npairs - 1), t = AX0 ? tid & ((1 << hbits) - 1) : tid >> pbits;
                 dctc::fused_mid<1, false>(z + (size_t)pr * pstride, N, t, tw, ew, s0, s2,
                                           [&](int slot, int) { return slot < 8 ? pfa[slot & 7] : pfb[slot & 7]; }, nost, nosym, dtot);
+            }
+            if (FZ) {
+                // the values this lane's last stage will be added to, requested now: they travel while the inverse middle stages run
+                // (same indices as the forward pass's samples: item tid owns the groups gp and G - 1 - gp of its pair of rows)
+                const int gp = tid & ((1 << hbits) - 1), gq = (G - 1) - gp;
+                const double* xrow = P.fz_v + tile_base(tile) + (act0 ? (size_t)(2 * (tid >> hbits)) * lstride : (size_t)0);
+                const int m = act0 ? 2 : 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    qfa[2 * r] = ld16(xrow + m * (gp + G * r));
+                    qfb[2 * r] = ld16(xrow + lstride + m * (gp + G * r));
+                    qfa[2 * r + 1] = ld16(xrow + m * (gq + G * r));
+                    qfb[2 * r + 1] = ld16(xrow + lstride + m * (gq + G * r));
+                }
             }
         } else
         for (int w = tid; w < nmid; w += NT) {
@@ -594,8 +631,15 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
             if (AX0) {
                 const int pr = w >> hbits;
                 double* row = gout + (size_t)(2 * pr) * lstride;
+                int slot = 0;       // (st2 is called in the order the samples were requested: fully unrolled, a compile-time index)
                 dctc::fused_last2(z + (size_t)pr * pstride, N, bits, w & ((1 << hbits) - 1),
                                   [&](int j, double ea, double oa, double eb, double ob) {
+                                      if (FZ) {
+                                          const int t = FZ ? slot : 0;
+                                          ea = P.fz_ct * ea + P.fz_cx * qfa[t].x; oa = P.fz_ct * oa + P.fz_cx * qfa[t].y;
+                                          eb = P.fz_ct * eb + P.fz_cx * qfb[t].x; ob = P.fz_ct * ob + P.fz_cx * qfb[t].y;
+                                          ++slot;
+                                      }
                                       st16(row + 2 * j, ea, oa);
                                       st16(row + lstride + 2 * j, eb, ob);
                                   });
@@ -656,9 +700,19 @@ bool dct_axis_fused_ok(bk_ctx* ctx, int n0, int n1, int n2, int axis, const doub
 
 int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, const double* twid, const double* in,
                  double* out, const double* lam0, const double* lam1, const double* lam2, double shift,
-                 int fuse_scale, const DctSplit* split, int* dot_blocks) {
+                 int fuse_scale, const DctSplit* split, int* dot_blocks, const DctFuse* fz) {
     FftK P;
     P.dotp = nullptr;
+    P.fz_v = nullptr; P.fzA = 1.0; P.fzB = P.fzC = 0.0; P.fz_cx = 0.0; P.fz_ct = 1.0;
+    // the pointwise work this pass is asked to take in: the factor on a forward pass, the axpy on an inverse one
+    const bool want_fz = fz && (inverse ? fz->xadd != nullptr : fz->u != nullptr);
+    if (want_fz) {
+        if (axis != 0 || fuse_scale != 0 || split || !dct_axis_fused_ok(ctx, n0, n1, n2, 0, in, out, 0) ||
+            (((uintptr_t)(inverse ? fz->xadd : fz->u)) & 15) != 0)
+            return set_error(ctx, "dct_axis_fft: fused pointwise work needs the fused x-axis kernel (pw_fused_ok)");
+        if (inverse) { P.fz_v = fz->xadd; P.fz_cx = fz->cx; P.fz_ct = fz->ct; }
+        else { P.fz_v = fz->u; P.fzA = fz->A; P.fzB = fz->B; P.fzC = fz->C; }
+    }
     if (dot_blocks) *dot_blocks = 0;
     P.kmap = nullptr; P.split_plane = 0; P.split = 0;
     if (split) {
@@ -718,7 +772,11 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
                              reinterpret_cast<const void*>(dct_fused_kernel<256, 2, false, false, true>),
                              reinterpret_cast<const void*>(dct_fused_kernel<256, 2, false, true, true>),
                              reinterpret_cast<const void*>(dct_fused_kernel<256, 0, true, true>),
-                             reinterpret_cast<const void*>(dct_fused_kernel<256, 1, true, true>)};
+                             reinterpret_cast<const void*>(dct_fused_kernel<256, 1, true, true>),
+                             reinterpret_cast<const void*>(dct_fused_kernel<256, 0, true, false, false, true>),
+                             reinterpret_cast<const void*>(dct_fused_kernel<256, 1, true, false, false, true>),
+                             reinterpret_cast<const void*>(dct_fused_kernel<256, 0, true, true, false, true>),
+                             reinterpret_cast<const void*>(dct_fused_kernel<256, 1, true, true, false, true>)};
         for (const void* f : fns) {
             const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             if (e != hipSuccess) attr_err = e;
@@ -760,10 +818,14 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
         const bool ntm = P.nt_load && P.nt_store;
         const int mode = P.roundtrip ? 2 : (P.inverse ? 1 : 0);
 #define BK_DCT_LAUNCH(M, A, T) hipLaunchKernelGGL((dct_fused_kernel<256, M, A, T>), dim3(grid), dim3(256), ldsf, ctx->stream, P)
-        if (axis == 0) {
+#define BK_DCT_LAUNCH_FZ(M, T) hipLaunchKernelGGL((dct_fused_kernel<256, M, true, T, false, true>), dim3(grid), dim3(256), ldsf, ctx->stream, P)
+        if (axis == 0 && want_fz) {
+            if (mode == 1) { if (ntm) BK_DCT_LAUNCH_FZ(1, true); else BK_DCT_LAUNCH_FZ(1, false); }
+            else { if (ntm) BK_DCT_LAUNCH_FZ(0, true); else BK_DCT_LAUNCH_FZ(0, false); }
+        } else if (axis == 0) {
             if (mode == 1) { if (ntm) BK_DCT_LAUNCH(1, true, true); else BK_DCT_LAUNCH(1, true, false); }
             else { if (ntm) BK_DCT_LAUNCH(0, true, true); else BK_DCT_LAUNCH(0, true, false); }
-        } else if (mode == 2 && dot_blocks && grid <= (unsigned)kRedBlocks * (kMaxBasis + 2) && ctx->opt("dct_fused_dot", 1.0) != 0.0) {
+        } else if (mode == 2 && dot_blocks && (size_t)grid <= kPartialDoubles && ctx->opt("dct_fused_dot", 1.0) != 0.0) {
             P.dotp = ctx->d_partials;
             if (ntm) hipLaunchKernelGGL((dct_fused_kernel<256, 2, false, true, true>), dim3(grid), dim3(256), ldsf, ctx->stream, P);
             else hipLaunchKernelGGL((dct_fused_kernel<256, 2, false, false, true>), dim3(grid), dim3(256), ldsf, ctx->stream, P);
@@ -772,6 +834,7 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
         else if (mode == 1) { if (ntm) BK_DCT_LAUNCH(1, false, true); else BK_DCT_LAUNCH(1, false, false); }
         else { if (ntm) BK_DCT_LAUNCH(0, false, true); else BK_DCT_LAUNCH(0, false, false); }
 #undef BK_DCT_LAUNCH
+#undef BK_DCT_LAUNCH_FZ
         BK_HIP(ctx, hipGetLastError());
         if (trace) {
             // phase durations (wall_clock64 ticks of 10 ns) averaged over the tiles: stamps 0 start, 1 first stage done,

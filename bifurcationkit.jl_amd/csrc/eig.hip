@@ -30,6 +30,18 @@ struct ShiftedOp : bk_op {
     int apply_axpy_dot(const double* x, double b0, double b1, double c, const double* r, double* out, double* dot) override {
         return J->apply_axpy_dot(x, b0 - b1 * sigma, b1, c, r, out, dot);
     }
+    // still a Swift-Hohenberg Jacobian, J - sigma I = -L1 + diag(g - sigma): the preconditioned inner solves of ShiftInvert take the
+    // folded shift / the stencil-free Arnoldi step of solver.hip (ShiftPrecOp) like the corrector's solves do
+    bool shift_is_free() const override { return J->shift_is_free(); }
+    const bk_problem* sh_problem() const override { return J->sh_problem(); }
+    bool sh_state(const double** u, double* l, double* nu) const override {
+        if (!J->sh_state(u, l, nu)) return false;
+        *l -= sigma;                       // g(u) = l + 2 nu u - 3 u^2: the shift is a shift of l
+        return true;
+    }
+    int apply_parts(const double* x, double a0, double aL, double ag, double* out) override {
+        return J->apply_parts(x, a0 - ag * sigma, aL, ag, out);
+    }
 };
 
 // A = du -> ls(Jshift, du)[1]   (examples/SH3d.jl:107).  The shift is folded into the operator BEFORE the

@@ -72,7 +72,16 @@ void dct_plan_destroy(DctPlan* p);
 // dot_blocks (optional): when the merged middle pass runs as the fused LDS kernel it also leaves the per-tile partial sums
 // of v . out (= sum over the spectrum of symbol * |v^|^2: the transforms are orthonormal) in ctx->d_partials and their count
 // in *dot_blocks; 0 = not available on this path
-int dct_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out, int* dot_blocks = nullptr);
+// Pointwise work fused into the FIRST and LAST pass of one preconditioner application (the stencil-free Arnoldi step of
+// solver.hip: Pl^-1 J = -I + Pl^-1 diag(g(u) + s)): the x-forward pass reads in[i] * (A + u[i] (B + C u[i])) -- one extra 8 B/point
+// stream -- and the x-inverse pass stores ct * result[i] + cx * xadd[i] (one more, only when xadd != NULL).
+struct DctFuse {
+    const double* u = nullptr;
+    double A = 1.0, B = 0.0, C = 0.0;
+    const double* xadd = nullptr;
+    double cx = 0.0, ct = 1.0;
+};
+int dct_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out, int* dot_blocks = nullptr, const DctFuse* fz = nullptr);
 // axis pass of the LDS FFT kernels (dct_fast.hip).  fuse_scale 0: plain, 1: forward + inverse symbol, 2: forward,
 // symbol, inverse in one pass.  split (distributed plan, y passes only): the output (forward) / input (inverse) side
 // uses the all-to-all block layout: element (x, k, other) at kmap[k] + other * plane + x.
@@ -82,7 +91,7 @@ struct DctSplit {
 };
 int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, const double* twid, const double* in,
                  double* out, const double* symx, const double* symy, const double* symz, double shift, int fuse_scale,
-                 const DctSplit* split = nullptr, int* dot_blocks = nullptr);
+                 const DctSplit* split = nullptr, int* dot_blocks = nullptr, const DctFuse* fz = nullptr);
 bool dct_axis_fft_supported(int n);
 bool dct_axis_fused_ok(bk_ctx* ctx, int n0, int n1, int n2, int axis, const double* in, const double* out, int fuse_scale);
 
@@ -127,6 +136,17 @@ struct bk_op {              // a linear operator on (device vector [+ one host t
     // out = a0 x + aL (-L1 x) + ag g(u) x; returns 1 if this operator is not of that form (nothing done)
     virtual int apply_parts(const double* x, double a0, double aL, double ag, double* out) { return 1; }
     virtual const bk_problem* sh_problem() const { return nullptr; }
+    // ... and the state it is linearised at: g(u) = l + 2 nu u - 3 u^2 (false: not a Swift-Hohenberg Jacobian)
+    virtual bool sh_state(const double** u, double* l, double* nu) const { return false; }
+    // The explicit residual of a solve, r = b - (a0 + a1 A) x (KrylovKit: "to ensure that no numerical errors have accumulated";
+    // restarts of the other flavors).  Operators that run their Arnoldi steps on an algebraically rearranged form (solver.hip:
+    // ShiftPrecOp in stencil-free mode) evaluate THIS through the original operator chain, so the check stays independent.
+    virtual int apply_check(const double* x, const double* xt, double a0, double a1, double* out, double* outt) {
+        return apply(x, xt, a0, a1, out, outt);
+    }
+    // true: GMRES builds its Krylov space on A itself and applies (alpha0, alpha1) to the Hessenberg matrix whatever the flavor
+    // (the space of alpha0 + alpha1 A is the space of A; the iterates are the same) -- for operators whose shift costs a stream
+    virtual bool hessenberg_shift() const { return false; }
 };
 
 struct bk_precond {
@@ -139,6 +159,10 @@ struct bk_precond {
     virtual int apply_dot(const double* v, double* out, double* dot);
     // true if this preconditioner is the exact inverse of L1 + *shift I of the problem `prob` (the spectral preconditioner)
     virtual bool is_l1_plus_shift(const bk_problem* prob, double* shift) const { return false; }
+    // out = cx x + ct Pl \ (d .* x), d_i = A + u_i (B + C u_i)   (out must not alias x unless pw_fused_ok)
+    // Default: a pointwise pass, apply, an axpby; the spectral preconditioner fuses both into its first / last transform pass.
+    virtual int apply_pw(const double* x, const bk::DctFuse& d, double cx, double ct, double* out);
+    virtual bool pw_fused_ok(const double* x, const double* u, const double* out) const { return false; }
 };
 
 namespace bk {
@@ -153,6 +177,7 @@ struct PdeJacobian : bk_op {          // J(u, params) of a bk_problem; reference
     bool shift_is_free() const override { return true; }          // a0 is a term of the stencil kernels' store stage
     int apply_parts(const double* x, double a0, double aL, double ag, double* out) override;
     const bk_problem* sh_problem() const override;
+    bool sh_state(const double** u_, double* l, double* nu) const override;
 };
 
 // A preconditioner object for the second lane that shares the tables of `pl` (read-only) but has its own scratch arrays

@@ -145,6 +145,28 @@ int bk_op::apply_axpy_dot(const double* x, double a0, double a1, double c, const
     return v_axpy_dot(ctx, n, c, r, out, x, dot);
 }
 
+int bk_precond::apply_pw(const double* x, const bk::DctFuse& d, double cx, double ct, double* out) {
+    // the separate passes: t = d .* x ; t = Pl \ t ; out = cx x + ct t
+    if (cx == 0.0) {
+        BK_TRY(v_pw_scale(ctx, n, x, d.u, d.A, d.B, d.C, out));
+        BK_TRY(apply(out, out));
+        return ct == 1.0 ? 0 : v_scale(ctx, n, ct, out);
+    }
+    if (out == x) return set_error(ctx, "apply_pw: out must not alias x");
+    WsGuard ws(ctx);
+    double* t = nullptr;
+    BK_TRY(ws.get(n, &t));
+    BK_TRY(v_pw_scale(ctx, n, x, d.u, d.A, d.B, d.C, t));
+    BK_TRY(apply(t, t));
+    return v_axpbyz(ctx, n, cx, x, ct, t, out);
+}
+
+bool PdeJacobian::sh_state(const double** u_, double* l, double* nu) const {
+    if (prob->desc.pde != BK_PDE_SH) return false;
+    *u_ = u; *l = params[0]; *nu = params[1];
+    return true;
+}
+
 int bk_precond::apply_dot(const double* v, double* out, double* dot) {
     BK_TRY(apply(v, out));
     return v_dot(ctx, n, v, out, dot);

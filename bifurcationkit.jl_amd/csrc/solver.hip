@@ -268,8 +268,11 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     const bool kk = (o.flavor == BK_GMRES_KRYLOVKIT);
     // KrylovKit builds the Krylov space on A and applies (alpha0, alpha1) to the Hessenberg matrix;
     // IterativeSolvers iterates on the shifted operator itself.
-    const double op_a0 = kk ? 0.0 : alpha0, op_a1 = kk ? 1.0 : alpha1;
-    const double s0 = kk ? alpha0 : 0.0, s1 = kk ? alpha1 : 1.0;
+    // (operators that ask for it -- bk_op::hessenberg_shift -- get KrylovKit's arrangement in every flavor: same space, same
+    // iterates, and the shift costs no stream)
+    const bool hs = kk || A->hessenberg_shift();
+    const double op_a0 = hs ? 0.0 : alpha0, op_a1 = hs ? 1.0 : alpha1;
+    const double s0 = hs ? alpha0 : 0.0, s1 = hs ? alpha1 : 1.0;
     VecOps vo{ctx, n, nt};
     // DGKS threshold: re-orthogonalise only when the remainder keeps less than eta of the norm.  One CGS pass leaves
     // |V'v| <= ~eps/eta, so eta = 0.1 still gives orthogonality ~2e-15 while skipping the second pass on operators
@@ -619,7 +622,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
             } else {
                 // explicit residual r = b - (a0 + a1 A) x, "to ensure that no numerical errors have accumulated"
                 double wt[BK_MAX_BORDER] = {0.0};
-                BK_TRY(A->apply(x, nt ? xtail : nullptr, alpha0, alpha1, w, wt));
+                BK_TRY(A->apply_check(x, nt ? xtail : nullptr, alpha0, alpha1, w, wt));
                 numops += 1;
                 BK_TRY(v_axpbyz(ctx, n, 1.0, b, -1.0, w, r));
                 for (int q = 0; q < nt; ++q) rt[q] = bt[q] - wt[q];
@@ -635,7 +638,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
             if (beta <= tol) { res->converged = 1; break; }
             if (stop || iters >= o.maxiter) break;
             double wt[BK_MAX_BORDER] = {0.0};
-            BK_TRY(A->apply(x, nt ? xtail : nullptr, alpha0, alpha1, w, wt));
+            BK_TRY(A->apply_check(x, nt ? xtail : nullptr, alpha0, alpha1, w, wt));
             BK_TRY(v_axpbyz(ctx, n, 1.0, b, -1.0, w, r));
             for (int q = 0; q < nt; ++q) rt[q] = bt[q] - wt[q];
             BK_TRY(vo.nrm2(r, rt, &beta));
@@ -656,6 +659,19 @@ namespace {
 // v -> a0 v + a1 Pl^-1 (J v)   (order 0: KrylovKit branch, src/LinearSolver.jl:270-277)
 // v -> Pl^-1 (a0 v + a1 J v)   (order 1: IterativeSolvers `Pl`, :198-201)
 // v -> a0 v + a1 J v           (no preconditioner; used by the IterativeSolvers flavor)
+//
+// Stencil-free mode (round 5; option gmres_stencil_free, default on where the transform kernels can take the pointwise work in).
+// With the spectral preconditioner of the SAME Swift-Hohenberg problem, Pl = L1 + s I and J = -L1 + diag g(u), so
+//     Pl^-1 J = Pl^-1 (-(Pl - s I) + diag g) = -I + T,           T = Pl^-1 diag(g + s)                       (order 0)
+//     Pl^-1 (a0 + a1 J) = -a1 I + T',                             T' = Pl^-1 diag(a0 + a1 s + a1 g)           (order 1)
+// exactly: the 25-point stencil drops out of the preconditioned operator.  The Arnoldi process then runs on T (T'): ONE
+// preconditioner application whose first transform pass multiplies its input by the pointwise factor on the fly (one more
+// 8 B/point stream, bk_precond::apply_pw) -- no stencil kernel, no intermediate vector, and on ranks no halo exchange inside GMRES.
+// The identity part is a shift of the Hessenberg matrix (bk_op::hessenberg_shift: the Krylov space of alpha0 + alpha1 T is the
+// space of T, the iterates are the same), so it costs nothing; a Newton shift of a block step rides in the last transform pass
+// (one more 8 B/point stream).  What the Arnoldi vectors lose is the O(1) component along v_j that Gram-Schmidt had to cancel
+// (w = Pl^-1 J v = -v + T v): T v is formed without that cancellation.  The explicit residual checks of a solve (apply_check)
+// still go through the stencil kernel and the plain preconditioner, so every solve verifies the identity on its own solution.
 struct ShiftPrecOp : bk_op {
     bk_op* J;
     bk_precond* P;
@@ -668,37 +684,64 @@ struct ShiftPrecOp : bk_op {
     // be folded into the stencil kernel (apply below), i.e. costs nothing
     bool fold = false;
     double pl_shift = 0.0;
+    // stencil-free mode: apply() is b0 x + b1 T x; (alpha0, alpha1) of the solve are in t_alpha0 / t_alpha1 (linsolve hands them
+    // to gmres_core instead of (0, 1))
+    bool tmode = false;
+    DctFuse pw;
+    double t_alpha0 = 0.0, t_alpha1 = 1.0;
     void init_fold() {
-        fold = P && order == 0 && J->sh_problem() && P->is_l1_plus_shift(J->sh_problem(), &pl_shift) &&
-               ctx->opt("gmres_fold_shift", 1.0) != 0.0;
+        const bool same = P && J->sh_problem() && P->is_l1_plus_shift(J->sh_problem(), &pl_shift);
+        fold = same && order == 0 && ctx->opt("gmres_fold_shift", 1.0) != 0.0;
+        // 1 (default): where the x passes run as the fused LDS kernel; 2: everywhere (separate pointwise pass: tests); 0: off
+        const double sf = ctx->opt("gmres_stencil_free", 1.0);
+        const double* u = nullptr;
+        double l = 0.0, nu = 0.0;
+        tmode = same && !Pr && sf != 0.0 && J->sh_state(&u, &l, &nu) && (sf == 2.0 || P->pw_fused_ok(u, u, u));
+        if (ctx->nranks > 1 && same && !Pr && sf == 1.0) {
+            // every rank must take the same form (the chain exchanges halos inside GMRES, the stencil-free form does not): the
+            // local test looks at this rank's slab and buffers, so agree on it
+            double no = tmode ? 0.0 : 1.0;
+            if (comm_allreduce_host(ctx, &no, 1, 1) != 0) no = 1.0;
+            tmode = no == 0.0;
+        }
+        if (!tmode) return;
+        // g(u) = l + 2 nu u - 3 u^2 (examples/SH3d.jl:50-53); factor = c0 + cg g = A + u (B + C u)
+        const double cg = order == 0 ? 1.0 : a1, c0 = order == 0 ? pl_shift : a0 + a1 * pl_shift;
+        pw.u = u; pw.A = c0 + cg * l; pw.B = 2.0 * nu * cg; pw.C = -3.0 * cg;
+        t_alpha0 = order == 0 ? a0 - a1 : -a1;
+        t_alpha1 = order == 0 ? a1 : 1.0;
     }
-    bool shift_is_free() const override { return Pr ? false : (P ? fold : J->shift_is_free()); }
+    bool shift_is_free() const override { return Pr ? false : (P ? (fold || tmode) : J->shift_is_free()); }
+    bool hessenberg_shift() const override { return tmode; }
     int apply(const double* x, const double*, double b0, double b1, double* out, double*) override {
         // out = b0 x + b1 * W(x)
-        if (Pr) {
-            BK_TRY(Pr->apply(x, tmp2));
-            BK_TRY(J->apply(tmp2, nullptr, a0, a1, tmp, nullptr));
-            if (P) BK_TRY(P->apply(tmp, tmp));
-            return v_axpbyz(ctx, n, b0, x, b1, tmp, out);
+        if (tmode) return P->apply_pw(x, pw, b0, b1, out);      // W = T (T'): see above
+        return apply_chain(x, b0, b1, out);
+    }
+    int apply_check(const double* x, const double*, double c0, double c1, double* out, double*) override {
+        if (!tmode) return apply_chain(x, c0, c1, out);
+        // c0 x + c1 T x through the stencil: T = I + Pl^-1 J (order 0), T' = a1 I + Pl^-1 (a0 + a1 J) (order 1)
+        return order == 0 ? chain_order0(x, c0 + c1, c1, out) : chain_order1(x, c0 + c1 * a1, c1, out);
+    }
+    // out = cx x + ct Pl^-1 J x
+    int chain_order0(const double* x, double cx, double ct, double* out) {
+        if (cx != 0.0 && fold) {
+            // cx x + ct Pl^-1 J x = Pl^-1 (ct J + cx Pl) x with Pl = L1 + s I and J = -L1 + diag(g):
+            //   ct J + cx Pl = (ct - cx) (-L1) + diag(ct g + cx s)
+            // -- the SAME stencil kernel with its two parts scaled separately, then the preconditioner: no extra pass
+            BK_TRY(J->apply_parts(x, cx * pl_shift, ct - cx, ct, tmp));
+            return P->apply(tmp, out);
         }
-        if (!P) return J->apply(x, nullptr, b0 + b1 * a0, b1 * a1, out, nullptr);
-        if (order == 0) {
-            const double cx = b0 + b1 * a0, ct = b1 * a1;
-            if (cx != 0.0 && fold) {
-                // cx x + ct Pl^-1 J x = Pl^-1 (ct J + cx Pl) x with Pl = L1 + s I and J = -L1 + diag(g):
-                //   ct J + cx Pl = (ct - cx) (-L1) + diag(ct g + cx s)
-                // -- the SAME stencil kernel with its two parts scaled separately, then the preconditioner: no extra pass
-                BK_TRY(J->apply_parts(x, cx * pl_shift, ct - cx, ct, tmp));
-                return P->apply(tmp, out);
-            }
-            BK_TRY(J->apply(x, nullptr, 0.0, 1.0, tmp, nullptr));
-            if (cx == 0.0) {                       // the common Arnoldi call (a0 = 0): Pl^-1 writes straight into out
-                BK_TRY(P->apply(tmp, out));
-                return ct == 1.0 ? 0 : v_scale(ctx, n, ct, out);
-            }
-            BK_TRY(P->apply(tmp, tmp));
-            return v_axpbyz(ctx, n, cx, x, ct, tmp, out);
+        BK_TRY(J->apply(x, nullptr, 0.0, 1.0, tmp, nullptr));
+        if (cx == 0.0) {                       // the common Arnoldi call (a0 = 0): Pl^-1 writes straight into out
+            BK_TRY(P->apply(tmp, out));
+            return ct == 1.0 ? 0 : v_scale(ctx, n, ct, out);
         }
+        BK_TRY(P->apply(tmp, tmp));
+        return v_axpbyz(ctx, n, cx, x, ct, tmp, out);
+    }
+    // out = b0 x + b1 Pl^-1 (a0 x + a1 J x)
+    int chain_order1(const double* x, double b0, double b1, double* out) {
         BK_TRY(J->apply(x, nullptr, a0, a1, tmp, nullptr));
         if (b0 == 0.0) {
             BK_TRY(P->apply(tmp, out));
@@ -706,6 +749,17 @@ struct ShiftPrecOp : bk_op {
         }
         BK_TRY(P->apply(tmp, tmp));
         return v_axpbyz(ctx, n, b0, x, b1, tmp, out);
+    }
+    int apply_chain(const double* x, double b0, double b1, double* out) {
+        if (Pr) {
+            BK_TRY(Pr->apply(x, tmp2));
+            BK_TRY(J->apply(tmp2, nullptr, a0, a1, tmp, nullptr));
+            if (P) BK_TRY(P->apply(tmp, tmp));
+            return v_axpbyz(ctx, n, b0, x, b1, tmp, out);
+        }
+        if (!P) return J->apply(x, nullptr, b0 + b1 * a0, b1 * a1, out, nullptr);
+        if (order == 0) return chain_order0(x, b0 + b1 * a0, b1 * a1, out);
+        return chain_order1(x, b0, b1, out);
     }
 };
 
@@ -864,7 +918,8 @@ int linsolve(bk_ctx* ctx, bk_op* J, const double* rhs, double* x, double a0, dou
         BK_TRY(pl->apply(rhs, prhs));            // ldiv!(similar(rhs), Pl, copy(rhs)) :278
         b = prhs;
     }
-    BK_TRY(gmres_core(ctx, &W, b, nullptr, x, nullptr, 0.0, 1.0, o, res));
+    // (stencil-free mode: W applies T, and the identity part of the operator is the solve's (alpha0, alpha1))
+    BK_TRY(gmres_core(ctx, &W, b, nullptr, x, nullptr, W.tmode ? W.t_alpha0 : 0.0, W.tmode ? W.t_alpha1 : 1.0, o, res));
     // right preconditioner: the iteration ran on y = Pr x; x = Pr^-1 y (IterativeSolvers update_solution!, Krylov.jl N)
     if (W.Pr) BK_TRY(W.Pr->apply(x, x));
     return 0;
@@ -977,6 +1032,23 @@ int bk_gmres(bk_ctx* ctx, bk_op* J, const double* rhs, double* x, double a0, dou
     if (resnorm) *resnorm = r.resnorm;
     return 0;
 }
+
+int bk_precond_op_apply(bk_ctx* ctx, bk_precond* pl, bk_op* J, const double* x, double a0, double a1, double* out, int* stencil_free) {
+    if (!ctx || !pl || !J || !x || !out) return -1;
+    if (J->ntail != 0) return set_error(ctx, "bk_precond_op_apply: operator must be unbordered");
+    if (out == x) return set_error(ctx, "bk_precond_op_apply: out must not alias x");
+    WsGuard ws(ctx);
+    ShiftPrecOp W;
+    W.ctx = ctx; W.n = J->n; W.ntail = 0;
+    W.J = J; W.P = pl; W.a0 = a0; W.a1 = a1; W.order = 0; W.tmp = nullptr;
+    W.init_fold();
+    BK_TRY(ws.get(J->n, &W.tmp));
+    if (stencil_free) *stencil_free = W.tmode ? 1 : 0;
+    // tmode: W.apply(b0, b1) = b0 x + b1 T x and a0 + a1 Pl^-1 J = (a0 - a1) + a1 T; else the chain a0 x + a1 Pl^-1 (J x)
+    return W.tmode ? W.apply(x, nullptr, W.t_alpha0, W.t_alpha1, out, nullptr) : W.apply(x, nullptr, 0.0, 1.0, out, nullptr);
+}
+
+int bk_abi_version(void) { return BK_ABI_VERSION; }
 
 int bk_gmres2(bk_ctx* ctx, bk_op* J, const double* rhs1, const double* rhs2, double* x1, double* x2, double a0,
               double a1, const bk_gmres_opts* opts, bk_precond* pl, int* converged, int niter[2]) {

@@ -561,7 +561,7 @@ bool sh_fused_dot_ok(bk_ctx* ctx, const ShArgs& a) {
     const int tiles = ((a.nx + TX - 1) / TX) * ((a.ny + TY - 1) / TY);
     const int zchunk = sh_zchunk_of(ctx, a, tiles);
     const long nblocks = (long)tiles * ((a.nz + zchunk - 1) / zchunk);
-    return nblocks <= (long)kRedBlocks * (kMaxBasis + 2) && (!a.addv || (((uintptr_t)a.addv & 15) == 0));
+    return nblocks <= (long)kPartialDoubles && (!a.addv || (((uintptr_t)a.addv & 15) == 0));
 }
 
 int sh_apply(bk_ctx* ctx, const ShArgs& a) {

@@ -151,6 +151,17 @@ __global__ void __launch_bounds__(kThreads) axpbyz_kernel(size_t n, double a, co
     }
 }
 
+// z = x .* (A + u (B + C u)): the pointwise factor of the stencil-free preconditioned operator where the transform pass cannot
+// take it in (dense transforms, tiny grids; solver.hip: ShiftPrecOp, bk_precond::apply_pw)
+__global__ void __launch_bounds__(kThreads) pw_scale_kernel(size_t n, const double* __restrict__ x, const double* __restrict__ u,
+                                                            double A, double B, double C, double* z) {
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        const double ui = u[i];
+        z[i] = x[i] * (A + ui * (B + C * ui));
+    }
+}
+
 // splitmix64-based uniform [0,1): deterministic in (seed, global index)
 __global__ void __launch_bounds__(kThreads) fill_random_kernel(size_t n, size_t goff, unsigned long long seed,
                                                                double* __restrict__ x) {
@@ -952,6 +963,14 @@ int v_axpbyz(bk_ctx* ctx, size_t n, double a, const double* x, double b, const d
     return 0;
 }
 
+int v_pw_scale(bk_ctx* ctx, size_t n, const double* x, const double* u, double A, double B, double C, double* z) {
+    if (n == 0) return 0;
+    ProfScope ps(ctx, "blas1", 24.0 * n);
+    hipLaunchKernelGGL(pw_scale_kernel, dim3(grid_for(n, 1, 4096)), dim3(kThreads), 0, ctx->stream, n, x, u, A, B, C, z);
+    BK_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
 int v_axpby(bk_ctx* ctx, size_t n, double a, const double* x, double b, double* y) {
     return v_axpbyz(ctx, n, a, x, b, y, y);
 }
@@ -1196,6 +1215,7 @@ int v_block_dots(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int kold, i
             BK_HIP(ctx, hipGetLastError());
         }
         constexpr int NV = 4 * sstep::kR + sstep::kTri;
+        static_assert(NV <= kPartialVals && 8 * sstep::kR <= kPartialVals && kMaxBasis + 2 <= kPartialVals, "d_partials too small");
         BK_TRY(reduce_finish(ctx, grid, NV, 0));
         for (int i = 0; i < kb; ++i)
             for (int r = 0; r < sstep::kR; ++r) D[i * sstep::kR + r] = ctx->h_red[i * sstep::kR + r];

