@@ -592,12 +592,14 @@ def main():
                 cb = {"value": scaled, "unit": "steps/s", "cores": 1, "kind": "port", "sample": note_np +
                       "; CPU restatement of the reference path (assembled sparse L1, MGS2 GMRES, DCT preconditioner), not Julia"}
                 try:                                  # second baseline, SURVEY 8(d)(ii): C++/OpenMP on all host cores
-                    cc = cpu_baseline_cpp((args.cpu_sample + 1,) * 3, args.shift)
+                    # (sample: BASELINE config 4's own size, 256^3, for the default --cpu-sample 3: 4 x 8 x 8 cells; ~10 s per step on 16 threads)
+                    cs1 = args.cpu_sample + 1
+                    cc = cpu_baseline_cpp((cs1, 2 * cs1, 2 * cs1), args.shift)
                     scaled_c = (1.0 / cc["seconds_per_step"]) * (cc["n"] / prob.nglobal)
                     cb = {"value": scaled_c, "unit": "steps/s", "cores": cc["threads"], "kind": "port",
                           "numpy_1thread_value": scaled,
                           "sample": f"C++/OpenMP restatement of the reference's CSR formulation (oracle/cpu_ref.cpp: assembled "
-                                    f"L1 = A*A with {cc['nnz_L1']} nonzeros, SpMV, MGS2 GMRES(30), Bordering, dense-DCT "
+                                    f"L1 = A*A with {cc['nnz_L1']} nonzeros, SpMV, MGS2 GMRES(30), Bordering, FFT-based DCT "
                                     f"preconditioner) on {cc['threads']} threads: 1 corrector step on SH3d {cc['dims']} "
                                     f"({cc['n']} unknowns, {cc['itlinear']} operator applications) took "
                                     f"{cc['seconds_per_step']:.2f} s, scaled by the unknowns ratio to {n}^3; " + note_np +

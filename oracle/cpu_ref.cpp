@@ -12,11 +12,18 @@
 //   BorderingBLS (BEC, check_precision = false)             src/LinearBorderSolver.jl:88-144
 //   newton_palc, one iteration from the predictor           src/continuation/Palc.jl:187-305
 //
-// Usage: cpu_ref nx ny nz lx ly lz l nu shift ds theta u0.bin p0 u1.bin p1 [steps [dump_prefix]]
+// Usage: cpu_ref nx ny nz lx ly lz l nu shift ds theta u0.bin p0 u1.bin p1 [steps [dump_prefix [mode]]]
 //   (u0, u1: raw float64, x fastest) -> one JSON line {seconds_per_step, threads, itlinear, residuals, p}
 //   dump_prefix: also write <prefix>{xp,res,jtau,x1,x}.bin -- the predictor, F(predictor), J(predictor) tau, the solution of
 //   J x1 = F of the first bordered solve and the corrected state -- for the generic-state GPU parity test
 //   (tests/test_gpu_fullsize.py::test_generic_state_against_the_cpp_restatement).
+//   mode (default "assembled"):
+//     "factored"  L1 v is applied as A (A v) with the 7-point CSR matrix A = I + Lap instead of the assembled product L1 = A*A
+//                 (the same operator -- examples/SH3d.jl:85 forms L1 as that matrix product -- at 7 instead of 25 stored entries
+//                 per row: 11 GB instead of 40+ GB at 512^3); everything else as above
+//     "apply"     factored, and NO solves: for the 512^3 parity test (tests/test_gpu_fullsize.py).  Writes xp, res, jtau as above,
+//                 reads <prefix>v.bin and writes plv = Pl^-1 v, reads <prefix>x1g.bin (a solution of J x1 = F(predictor) computed
+//                 elsewhere) and reports the TRUE preconditioned residual |Pl^-1 (J x1g - F)| / |Pl^-1 F| in the JSON line
 // The numbers are checked against the NumPy oracle (oracle/palc.py) in tests/test_oracle.py.
 #include <omp.h>
 
@@ -83,43 +90,44 @@ static Csr assemble_A(const int n[3], const double l[3]) {
     return A;
 }
 
-// C = A * A (row-wise sparse product with a dense marker per thread)
+// C = A * A, row by row: a row of A has <= 7 entries, so a row of the product gathers <= 49 (column, value) pairs; they are sorted by
+// column and merged in a fixed-size buffer (two passes: count, then fill -- no per-row allocations: 16.7 M rows take seconds)
 static Csr spgemm(const Csr& A) {
     Csr C;
     C.n = A.n;
     C.ptr.assign(A.n + 1, 0);
-    std::vector<std::vector<int>> rc(A.n);
-    std::vector<std::vector<double>> rv(A.n);
-#pragma omp parallel
-    {
-        std::vector<int> mark(A.n, -1);
-        std::vector<int> cols;
-        std::vector<double> acc;
-#pragma omp for schedule(static)
-        for (int i = 0; i < A.n; ++i) {
-            cols.clear(); acc.clear();
-            for (long k = A.ptr[i]; k < A.ptr[i + 1]; ++k) {
-                const int j = A.col[k];
-                const double v = A.val[k];
-                for (long q = A.ptr[j]; q < A.ptr[j + 1]; ++q) {
-                    const int c = A.col[q];
-                    if (mark[c] < 0) { mark[c] = (int)cols.size(); cols.push_back(c); acc.push_back(v * A.val[q]); }
-                    else acc[mark[c]] += v * A.val[q];
-                }
+    auto row = [&](int i, int* cols, double* vals) -> int {
+        int m = 0;
+        for (long k = A.ptr[i]; k < A.ptr[i + 1]; ++k) {
+            const int j = A.col[k];
+            const double v = A.val[k];
+            for (long q = A.ptr[j]; q < A.ptr[j + 1]; ++q) {
+                const int c = A.col[q];
+                const double p = v * A.val[q];
+                int t = m;                                   // insertion into the sorted prefix; equal columns accumulate
+                while (t > 0 && cols[t - 1] > c) --t;
+                if (t > 0 && cols[t - 1] == c) { vals[t - 1] += p; continue; }
+                for (int s = m; s > t; --s) { cols[s] = cols[s - 1]; vals[s] = vals[s - 1]; }
+                cols[t] = c; vals[t] = p;
+                ++m;
             }
-            std::vector<int> order(cols.size());
-            for (size_t t = 0; t < order.size(); ++t) order[t] = (int)t;
-            std::sort(order.begin(), order.end(), [&](int x, int y) { return cols[x] < cols[y]; });
-            rc[i].resize(cols.size()); rv[i].resize(cols.size());
-            for (size_t t = 0; t < order.size(); ++t) { rc[i][t] = cols[order[t]]; rv[i][t] = acc[order[t]]; }
-            for (int c : cols) mark[c] = -1;
         }
+        return m;
+    };
+    std::vector<int> cnt(A.n);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < A.n; ++i) {
+        int cols[64]; double vals[64];
+        cnt[i] = row(i, cols, vals);
     }
-    for (int i = 0; i < A.n; ++i) C.ptr[i + 1] = C.ptr[i] + (long)rc[i].size();
+    for (int i = 0; i < A.n; ++i) C.ptr[i + 1] = C.ptr[i] + cnt[i];
     C.col.resize(C.ptr[A.n]); C.val.resize(C.ptr[A.n]);
 #pragma omp parallel for schedule(static)
-    for (int i = 0; i < A.n; ++i)
-        for (size_t t = 0; t < rc[i].size(); ++t) { C.col[C.ptr[i] + t] = rc[i][t]; C.val[C.ptr[i] + t] = rv[i][t]; }
+    for (int i = 0; i < A.n; ++i) {
+        int cols[64]; double vals[64];
+        const int m = row(i, cols, vals);
+        for (int t = 0; t < m; ++t) { C.col[C.ptr[i] + t] = cols[t]; C.val[C.ptr[i] + t] = vals[t]; }
+    }
     return C;
 }
 
@@ -144,16 +152,23 @@ static void axpy(double a, const vec& x, vec& y) {
 struct Problem {
     int n[3];
     double l[3];
-    Csr L1;
+    Csr L1;                     // assembled A*A (mode "assembled") ...
+    Csr A;                      // ... or its factor, applied twice (modes "factored" / "apply")
+    bool factored = false;
     double nu;
-    mutable vec tmp;
+    mutable vec tmp, tmp2;
+    void mulL1(const vec& x, vec& y) const {
+        if (!factored) { L1.mul(x, y); return; }
+        A.mul(x, tmp2);
+        A.mul(tmp2, y);
+    }
     void F(const vec& u, double lpar, vec& out) const {           // SH3d.jl:44-47
-        L1.mul(u, tmp);
+        mulL1(u, tmp);
 #pragma omp parallel for schedule(static)
         for (long i = 0; i < (long)u.size(); ++i) out[i] = -tmp[i] + lpar * u[i] + nu * u[i] * u[i] - u[i] * u[i] * u[i];
     }
     void dF(const vec& u, double lpar, const vec& du, vec& out) const {     // SH3d.jl:50-53
-        L1.mul(du, tmp);
+        mulL1(du, tmp);
 #pragma omp parallel for schedule(static)
         for (long i = 0; i < (long)u.size(); ++i) out[i] = -tmp[i] + (lpar + 2.0 * nu * u[i] - 3.0 * u[i] * u[i]) * du[i];
     }
@@ -167,6 +182,7 @@ struct Precond {
     mutable vec a, b;
     void init(const int n_[3], const double l[3], double s) {
         shift = s;
+        dense_only = getenv("CPU_REF_DENSE_DCT") != nullptr;
         for (int d = 0; d < 3; ++d) {
             n[d] = n_[d];
             const int N = n[d];
@@ -229,15 +245,113 @@ struct Precond {
                 }
             }
     }
+    // Power-of-two extents: the same orthonormal DCT-II / DCT-III through an N-point complex FFT of the Makhoul-permuted line
+    // (v_n = x_2n, v_{N-1-n} = x_{2n+1}; C_k = Re(w_k V_k), w_k = exp(-i pi k / 2N); inverse: V_k = conj(w_k) (C_k - i C_{N-k})),
+    // LB lines at a time so that the butterflies vectorise across lines: O(N log N) instead of the O(N^2) dense sweep -- at 256^3 /
+    // 512^3 the dense form is ~30x the work of everything else in this file.  `fast_ok` selects it per axis; CPU_REF_DENSE_DCT=1
+    // forces the dense form (the two are compared by the selftest mode, tests/test_oracle.py).
+    static constexpr int LB = 32;
+    bool dense_only = false;
+    bool fast_ok(int d) const { const int N = n[d]; return !dense_only && N >= 8 && (N & (N - 1)) == 0; }
+    void axis_fast(int d, bool inverse, const vec& in, vec& out) const {
+        const int N = n[d];
+        int bits = 0;
+        while ((1 << bits) < N) ++bits;
+        const long total = (long)n[0] * n[1] * n[2];
+        const long inner = d == 0 ? 1 : (d == 1 ? n[0] : (long)n[0] * n[1]);      // stride of the transform index
+        const long outer = total / (inner * N);
+        // lines: (o, i) -> base o * N * inner + i (d >= 1), or line index * N (d == 0); blocks of LB lines with consecutive i
+        const long nlines = total / N;
+        const long nblocks = (nlines + LB - 1) / LB;
+        std::vector<double> wr(N / 2), wi(N / 2), er(N), ei(N);
+        for (int k = 0; k < N / 2; ++k) { wr[k] = std::cos(2.0 * M_PI * k / N); wi[k] = -std::sin(2.0 * M_PI * k / N); }
+        for (int k = 0; k < N; ++k) { er[k] = std::cos(M_PI * k / (2.0 * N)); ei[k] = -std::sin(M_PI * k / (2.0 * N)); }
+        std::vector<int> rev(N);
+        for (int i = 0; i < N; ++i) { int r = 0; for (int b = 0; b < bits; ++b) r |= ((i >> b) & 1) << (bits - 1 - b); rev[i] = r; }
+        const double s0 = std::sqrt(1.0 / N), s2 = std::sqrt(2.0 / N);
+        (void)outer;
+#pragma omp parallel
+        {
+            std::vector<double> re((size_t)N * LB), im((size_t)N * LB), c((size_t)(N + 1) * LB);
+#pragma omp for schedule(static)
+            for (long blk = 0; blk < nblocks; ++blk) {
+                const long l0 = blk * LB;
+                const int L = (int)std::min<long>(LB, nlines - l0);
+                // element (line l, index j) lives at addr(l) + j * inner
+                long addr[LB];
+                for (int l = 0; l < L; ++l) {
+                    const long ln = l0 + l;
+                    addr[l] = d == 0 ? ln * N : (ln / inner) * N * inner + (ln % inner);
+                }
+                if (!inverse) {
+                    for (int j = 0; j < N; ++j) {                 // Makhoul permutation straight into bit-reversed order
+                        const int m = (j & 1) ? N - 1 - (j >> 1) : (j >> 1);
+                        double* r = &re[(size_t)rev[m] * LB];
+                        double* q = &im[(size_t)rev[m] * LB];
+                        for (int l = 0; l < L; ++l) { r[l] = in[addr[l] + (long)j * inner]; q[l] = 0.0; }
+                    }
+                } else {
+                    for (int k = 0; k < N; ++k) {
+                        const double sk = 1.0 / (k == 0 ? s0 : s2);
+                        double* ck = &c[(size_t)k * LB];
+                        for (int l = 0; l < L; ++l) ck[l] = in[addr[l] + (long)k * inner] * sk;
+                    }
+                    for (int l = 0; l < L; ++l) c[(size_t)N * LB + l] = 0.0;
+                    for (int k = 0; k < N; ++k) {                 // V_k = conj(w_k) (C_k - i C_{N-k})
+                        const double* ck = &c[(size_t)k * LB];
+                        const double* cn = &c[(size_t)(N - k) * LB];
+                        double* r = &re[(size_t)rev[k] * LB];
+                        double* q = &im[(size_t)rev[k] * LB];
+                        const double a_ = er[k], b_ = -ei[k];     // conj(w_k) = a_ + i b_
+                        for (int l = 0; l < L; ++l) { r[l] = a_ * ck[l] + b_ * cn[l]; q[l] = b_ * ck[l] - a_ * cn[l]; }
+                    }
+                }
+                // radix-2 decimation in time on bit-reversed input; inverse: conjugate twiddles
+                for (int sb = 0; sb < bits; ++sb) {
+                    const int half = 1 << sb, step = N >> (sb + 1);
+                    for (int g = 0; g < N; g += 2 * half)
+                        for (int t = 0; t < half; ++t) {
+                            const double tr = wr[(size_t)t * step], ti = inverse ? -wi[(size_t)t * step] : wi[(size_t)t * step];
+                            double* ar = &re[(size_t)(g + t) * LB]; double* ai = &im[(size_t)(g + t) * LB];
+                            double* br = &re[(size_t)(g + t + half) * LB]; double* bi = &im[(size_t)(g + t + half) * LB];
+                            for (int l = 0; l < LB; ++l) {
+                                const double xr = tr * br[l] - ti * bi[l], xi = tr * bi[l] + ti * br[l];
+                                br[l] = ar[l] - xr; bi[l] = ai[l] - xi;
+                                ar[l] += xr; ai[l] += xi;
+                            }
+                        }
+                }
+                if (!inverse) {
+                    for (int k = 0; k < N; ++k) {                 // X_k = s_k Re(w_k V_k)
+                        const double sk = k == 0 ? s0 : s2;
+                        const double* r = &re[(size_t)k * LB];
+                        const double* q = &im[(size_t)k * LB];
+                        for (int l = 0; l < L; ++l) out[addr[l] + (long)k * inner] = sk * (er[k] * r[l] - ei[k] * q[l]);
+                    }
+                } else {
+                    const double invN = 1.0 / N;
+                    for (int m = 0; m < N; ++m) {                 // x_2n = v_n, x_{2n+1} = v_{N-1-n}
+                        const int j = m < N / 2 ? 2 * m : 2 * (N - 1 - m) + 1;
+                        const double* r = &re[(size_t)m * LB];
+                        for (int l = 0; l < L; ++l) out[addr[l] + (long)j * inner] = r[l] * invN;
+                    }
+                }
+            }
+        }
+    }
+    void axis_any(int d, bool inverse, const vec& in, vec& out) const {
+        if (fast_ok(d)) axis_fast(d, inverse, in, out);
+        else axis(d, inverse, in, out);
+    }
     void apply(const vec& v, vec& out) const {
-        axis(0, false, v, a); axis(1, false, a, b); axis(2, false, b, a);
+        axis_any(0, false, v, a); axis_any(1, false, a, b); axis_any(2, false, b, a);
 #pragma omp parallel for schedule(static)
         for (long i = 0; i < (long)a.size(); ++i) {
             const int ix = (int)(i % n[0]), iy = (int)((i / n[0]) % n[1]), iz = (int)(i / ((long)n[0] * n[1]));
             const double sy = 1.0 + lam[0][ix] + lam[1][iy] + lam[2][iz];
             a[i] /= sy * sy + shift;
         }
-        axis(2, true, a, b); axis(1, true, b, a); axis(0, true, a, out);
+        axis_any(2, true, a, b); axis_any(1, true, b, a); axis_any(0, true, a, out);
     }
 };
 
@@ -365,6 +479,24 @@ int main(int argc, char** argv) {
     const double p0 = atof(argv[13]), p1 = atof(argv[15]);
     const int steps = argc > 16 ? atoi(argv[16]) : 1;
     const char* dump = argc > 17 ? argv[17] : nullptr;
+    const std::string mode = argc > 18 ? argv[18] : "assembled";
+    if (mode == "selftest") {
+        // fast (FFT) vs dense transform passes of the preconditioner on this grid: max |difference| of Pl^-1 u0, relative
+        Precond Pf, Pd;
+        Pf.init(pb.n, pb.l, shift);
+        Pd.init(pb.n, pb.l, shift);
+        Pd.dense_only = true;
+        vec a_(N), b_(N);
+        Pf.apply(u0, a_);
+        Pd.apply(u0, b_);
+        double dmax = 0.0;
+        for (size_t i = 0; i < N; ++i) dmax = std::max(dmax, std::fabs(a_[i] - b_[i]));
+        printf("{\"mode\": \"selftest\", \"fast_axes\": [%d, %d, %d], \"dct_fast_vs_dense_rel\": %.3e}\n", (int)Pf.fast_ok(0), (int)Pf.fast_ok(1),
+               (int)Pf.fast_ok(2), dmax / nrminf(b_));
+        return 0;
+    }
+    if (mode != "assembled" && mode != "factored" && mode != "apply") { fprintf(stderr, "unknown mode %s\n", mode.c_str()); return 2; }
+    pb.factored = mode != "assembled";
     auto write_bin = [&](const char* tag, const vec& v) {
         if (!dump) return;
         const std::string path = std::string(dump) + tag + ".bin";
@@ -374,7 +506,10 @@ int main(int argc, char** argv) {
     };
     (void)lpar0;
     auto t_setup = std::chrono::steady_clock::now();
-    {
+    if (pb.factored) {
+        pb.A = assemble_A(pb.n, pb.l);
+        pb.tmp2.resize(N);
+    } else {
         Csr A = assemble_A(pb.n, pb.l);
         pb.L1 = spgemm(A);                                         // L1 = A*A, SH3d.jl:85
     }
@@ -399,6 +534,37 @@ int main(int argc, char** argv) {
     vec x(N), res_f(N), dFdp(N), x1(N), dx(N);
     const double dz0 = dot(u0, tau);
     auto Nfun = [&](const vec& xx, double p) { return (theta * dot(xx, tau) / N + (1 - theta) * (p - p0) * taup - ds) - theta * dz0 / N; };
+    if (mode == "apply") {
+        if (!dump) { fprintf(stderr, "mode apply needs a dump prefix\n"); return 2; }
+        x = xp;
+        pb.F(x, pp, res_f);
+        write_bin("xp", x);
+        write_bin("res", res_f);
+        vec t(N), w(N);
+        pb.dF(x, pp, tau, t);
+        write_bin("jtau", t);
+        {
+            const vec v = read_bin((std::string(dump) + "v.bin").c_str(), N);
+            P.apply(v, w);
+            write_bin("plv", w);
+        }
+        double rel = -1.0, nb = 0.0;
+        {
+            const vec xg = read_bin((std::string(dump) + "x1g.bin").c_str(), N);
+            pb.dF(x, pp, xg, t);                                   // J x1g
+#pragma omp parallel for schedule(static)
+            for (long i = 0; i < (long)N; ++i) t[i] -= res_f[i];
+            P.apply(t, w);
+            const double nr = nrm2(w);
+            P.apply(res_f, w);
+            nb = nrm2(w);
+            rel = nr / nb;
+        }
+        printf("{\"mode\": \"apply\", \"threads\": %d, \"n\": %zu, \"setup_seconds\": %.3f, \"residual_inf\": %.17g, \"p_pred\": %.17g, "
+               "\"tau_p\": %.17g, \"true_residual_rel\": %.17g, \"norm_pl_rhs\": %.17g, \"nnz_A\": %ld}\n",
+               omp_get_max_threads(), N, setup_s, std::max(nrminf(res_f), std::fabs(Nfun(x, pp))), pp, taup, rel, nb, (long)pb.A.ptr[pb.A.n]);
+        return 0;
+    }
     auto t0 = std::chrono::steady_clock::now();
     for (int s = 0; s < steps; ++s) {                              // newton_palc, one iteration (Palc.jl:237-295)
         x = xp;
@@ -438,6 +604,6 @@ int main(int argc, char** argv) {
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / steps;
     printf("{\"seconds_per_step\": %.6f, \"setup_seconds\": %.3f, \"threads\": %d, \"n\": %zu, \"itlinear\": %d, "
            "\"itlinear_each\": [%d, %d], \"residuals\": [%.17g, %.17g], \"p\": %.17g, \"p_pred\": %.17g, \"tau_p\": %.17g, \"nnz_L1\": %ld}\n",
-           dt, setup_s, omp_get_max_threads(), N, itlin, itl[0], itl[1], res0, res1, pnew, pp, taup, (long)pb.L1.ptr[pb.L1.n]);
+           dt, setup_s, omp_get_max_threads(), N, itlin, itl[0], itl[1], res0, res1, pnew, pp, taup, (long)(pb.factored ? pb.A.ptr[pb.A.n] : pb.L1.ptr[pb.L1.n]));
     return 0;
 }

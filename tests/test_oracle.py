@@ -327,6 +327,23 @@ def test_cpu_ref_cpp_matches_numpy_oracle(tmp_path):
     assert abs(out["residuals"][0] - ref["residuals"][0]) <= 1e-9 * ref["residuals"][0]
     assert abs(out["itlinear"] - ref["itlinear"]) <= 2
     assert out["residuals"][1] < 1e-9 and ref["residuals"][1] < 1e-9
+    # round 5: the modes the full-size GPU parity tests use.  "factored" applies L1 v as A (A v) with the 7-point factor (the same
+    # operator; what fits the host at 512^3), "selftest" compares the FFT-based transform passes (power-of-two extents) with the dense
+    # ones -- here on the cell, whose extents are all powers of two, so the run above already went through the FFT passes
+    args = [exe, *map(str, bench.CELL), *map(repr, bench.CELL_L), "0.1", "1.2", "1.0", repr(ds), "0.5", f0, "0.1", f1, repr(0.1 + ds / 150.0), "1",
+            str(tmp_path / "d_")]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    fac = json.loads(subprocess.run(args + ["factored"], capture_output=True, text=True, check=True, env=env).stdout.strip().splitlines()[-1])
+    # (the literal quotient (F(x, p + eps) - F(x, p)) / eps carries the stencil's rounding noise / eps: the two forms of L1 v round
+    # differently, and the correction dl = p_pred - p follows to ~1e-6 relative -- DESIGN section 7)
+    assert fac["itlinear_each"] == out["itlinear_each"] and abs(fac["p"] - out["p"]) <= 1e-5 * abs(out["p_pred"] - out["p"]) + 1e-13
+    # (the predictor residual is O(ds^2) = 5.6e-6: the two forms agree to the absolute rounding floor of one stencil evaluation)
+    floor = 8 * np.finfo(float).eps * (1.0 + 12.0 / (2 * bench.CELL_L[0] / bench.CELL[0]) ** 2) ** 2 * 1.5
+    assert abs(fac["residuals"][0] - out["residuals"][0]) <= floor and fac["nnz_L1"] <= 7 * fac["n"]
+    st = json.loads(subprocess.run(args + ["selftest"], capture_output=True, text=True, check=True, env=env).stdout.strip().splitlines()[-1])
+    assert st["fast_axes"] == [1, 1, 1] and st["dct_fast_vs_dense_rel"] <= 1e-13, st
+    den = json.loads(subprocess.run(args, capture_output=True, text=True, check=True, env=dict(env, CPU_REF_DENSE_DCT="1")).stdout.strip().splitlines()[-1])
+    assert den["itlinear_each"] == out["itlinear_each"] and abs(den["p"] - out["p"]) <= 1e-5 * abs(out["p_pred"] - out["p"]) + 1e-13
 
 
 def test_bordered_solver_complex_shift():
