@@ -179,6 +179,8 @@ int v_pw_scale(bk_ctx* ctx, size_t n, const double* x, const double* u, double A
 int v_dot(bk_ctx* ctx, size_t n, const double* x, const double* y, double* out);
 int v_dot2(bk_ctx* ctx, size_t n, const double* x, const double* y1, const double* y2, double* out2);
 int v_nrm2(bk_ctx* ctx, size_t n, const double* x, double* out);
+// *out = |x - y|_2 (global), nothing written
+int v_diff_nrm2(bk_ctx* ctx, size_t n, const double* x, const double* y, double* out);
 int v_axpy_dot(bk_ctx* ctx, size_t n, double c, const double* r, double* y, const double* z, double* out);
 int v_minres_update(bk_ctx* ctx, size_t n, double cz, const double* z, double c1, const double* w1, double c2, const double* w2,
                     double* w, double phi, double* x);

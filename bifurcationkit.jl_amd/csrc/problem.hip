@@ -78,16 +78,25 @@ int bk_problem::jvp_axpy_dot(const double* v, const double* u, const double* par
                              const double* r, double* out, double* dot, int* fused) {
     *fused = 0;
     const bk_problem_desc& d = desc;
-    if (d.pde != BK_PDE_SH || d.ndim != 3 || ctx->nranks != 1) return 0;
+    if (d.pde != BK_PDE_SH || d.ndim != 3) return 0;
+    // ranks (round 5): the same fused kernel over the slab with the halo planes in place -- the exchange runs in line first (this
+    // launch covers every z-chunk, there is nothing to overlap it with), the per-tile partial sums are all-reduced by reduce_finish
+    const bool ranks = ctx->nranks > 1;
+    // (slabs of at least 8 planes, every rank alike: the decision must not differ between ranks -- d.n[2] / nranks is global)
+    if (ranks && (ctx->opt("jvp_fused_dot_ranks", 1.0) == 0.0 || !halo_lo || !halo_hi || d.n[2] / ctx->nranks < 8)) return 0;
     ShArgs a;
     a.nx = d.n[0]; a.ny = d.n[1]; a.nz = hi - lo; a.nzg = d.n[2]; a.zoff = lo;
     a.ax = ainv[0]; a.ay = ainv[1]; a.az = ainv[2];
     a.l = params[0]; a.nu = params[1];
     a.a0 = a0; a.a1 = a1; a.mode = 0;
     a.v = v; a.u = u; a.out = out;
-    a.halo_lo = nullptr; a.halo_hi = nullptr;
+    a.halo_lo = ranks ? halo_lo : nullptr; a.halo_hi = ranks ? halo_hi : nullptr;
     a.addv = r; a.addc = r ? c : 0.0;
     if (!sh_fused_dot_ok(ctx, a)) return 0;
+    if (ranks) {
+        ProfScope ps(ctx, "halo", 32.0 * plane * 2);
+        BK_TRY(halo_exchange(ctx, ctx->stream, v, plane, a.nz, 2, halo_lo, halo_hi));
+    }
     int nb = 0;
     a.dot_blocks = &nb;
     BK_TRY(sh_apply(ctx, a));

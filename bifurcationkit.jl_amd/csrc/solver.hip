@@ -624,10 +624,13 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
                 double wt[BK_MAX_BORDER] = {0.0};
                 BK_TRY(A->apply_check(x, nt ? xtail : nullptr, alpha0, alpha1, w, wt));
                 numops += 1;
-                BK_TRY(v_axpbyz(ctx, n, 1.0, b, -1.0, w, r));
                 for (int q = 0; q < nt; ++q) rt[q] = bt[q] - wt[q];
-                BK_TRY(vo.nrm2(r, rt, &beta));
+                // the norm first, from b and w as they are (two read streams); the residual VECTOR is only formed when the check fails
+                // and another cycle has to start from it
+                BK_TRY(v_diff_nrm2(ctx, n, b, w, &beta));
+                if (nt) { double s_ = beta * beta; for (int q = 0; q < nt; ++q) s_ += rt[q] * rt[q]; beta = std::sqrt(s_); }
                 if (beta < tol) { res->converged = 1; break; }
+                BK_TRY(v_axpbyz(ctx, n, 1.0, b, -1.0, w, r));
             }
             if (numiter < max_cycles) {
                 BK_TRY(vo.nrm2(r, rt, &beta));

@@ -549,14 +549,15 @@ int pde_dparam(bk_ctx* ctx, int pde, int ipar, size_t npts, double c, const doub
     return 0;
 }
 
-// the fused Lanczos step needs the 3-D streaming kernel over the whole (single-rank) array and one partial sum per tile
+// the fused Lanczos step needs the 3-D streaming kernel over the whole local array (a rank's slab with its halo planes exchanged) and one
+// partial sum per tile
 static int sh_zchunk_of(bk_ctx* ctx, const ShArgs& a, int tiles) {
     int zchunk = (int)ctx->opt("sh_zchunk", 0.0);
     if (zchunk <= 0) zchunk = sh_plan_zchunk(a.nz, tiles, 3L * (ctx->num_cu > 0 ? ctx->num_cu : 256), a.part != 0);
     return zchunk > a.nz ? a.nz : zchunk;
 }
 bool sh_fused_dot_ok(bk_ctx* ctx, const ShArgs& a) {
-    if (a.az == 0.0 || a.mode != 0 || a.part != 0 || ctx->nranks != 1 || a.halo_lo || a.halo_hi) return false;
+    if (a.az == 0.0 || a.mode != 0 || a.part != 0) return false;      // (slabs of a multi-rank run: the halo planes must be in place)
     if ((int)ctx->opt("sh_kernel", 1.0) == 0 || ctx->opt("jvp_fused_dot", 1.0) == 0.0) return false;
     const int tiles = ((a.nx + TX - 1) / TX) * ((a.ny + TY - 1) / TY);
     const int zchunk = sh_zchunk_of(ctx, a, tiles);

@@ -228,6 +228,37 @@ __global__ void __launch_bounds__(kThreads) dot_kernel(size_t n, const double* _
     }
 }
 
+// |x - y|^2 without materialising the difference: the explicit residual check of a converged solve (solver.hip: gmres_core) only
+// needs the NORM of b - (a0 + a1 A) x -- two read streams instead of a write plus a read-back (the vector is formed only when the
+// check fails and a new cycle starts from it)
+template <int VEC, bool NTH = false>
+__global__ void __launch_bounds__(kThreads) diff_nrm2_kernel(size_t n, const double* __restrict__ x, const double* __restrict__ y,
+                                                             double* __restrict__ partials) {
+    double s0 = 0.0;
+    if (VEC == 2) {
+        stream_loop<4>(n >> 1, [&](auto uc, size_t i0, size_t st) {
+            constexpr int UU = decltype(uc)::value;
+            double2 xv[UU], yv[UU];
+#pragma unroll
+            for (int u = 0; u < UU; ++u) { xv[u] = ld2<NTH>(x, i0 + u * st); yv[u] = ld2<NTH>(y, i0 + u * st); }
+#pragma unroll
+            for (int u = 0; u < UU; ++u) {
+                const double dx = xv[u].x - yv[u].x, dy = xv[u].y - yv[u].y;
+                s0 = fma(dx, dx, s0); s0 = fma(dy, dy, s0);
+            }
+        });
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) { const double d = x[n - 1] - y[n - 1]; s0 = fma(d, d, s0); }
+    } else {
+        const size_t stride = (size_t)gridDim.x * kThreads;
+        for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) { const double d = x[i] - y[i]; s0 = fma(d, d, s0); }
+    }
+    __shared__ double sm[4];
+    s0 = wave_sum(s0);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s0;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
 // ------------------------------------------------------------------ fused MINRES passes (solver.hip: minres_core)
 // y <- y + c r (has_r), partial of z . y (after the update): the Lanczos three-term update and its alpha in one pass.
 template <int VEC, bool NTH = false>
@@ -645,10 +676,13 @@ __global__ void __launch_bounds__(kThreads) multiaxpy_c_kernel(size_t n, const d
 // are consecutive basis slots starting at Rv -- and (TRI) the upper triangle of the right-hand vectors' own dots.  One visit of
 // every stream for what the single-vector step read s times.  Per workgroup: KB x 8 values [i * 8 + r], then the 36 triangle
 // values (sstep::tri order).  Unused right-hand slots (r >= nr) are never loaded and contribute exact zeros.
-template <int KB, bool TRI, int U, bool LDNT>
+// NRT = right-hand slots of this instantiation (8, or 5 for the usual LAST block of a solve -- one step plus the previous block's four
+// unmeasured vectors -- which then fits 8 basis vectors AND the triangle into one launch: 55 accumulators); per workgroup KB x NRT
+// values [i * NRT + r], then the NRT (NRT + 1) / 2 triangle values in row order.
+template <int KB, bool TRI, int U, bool LDNT, int NRT = sstep::kR>
 __global__ void __launch_bounds__(kThreads) block_dots_kernel(size_t n, const double* __restrict__ V, size_t ldv, int kb,
                                                               const double* __restrict__ Rv, int nr, double* __restrict__ partials) {
-    constexpr int NR = sstep::kR, NT3 = TRI ? sstep::kTri : 1;
+    constexpr int NR = NRT, NT3 = TRI ? NRT * (NRT + 1) / 2 : 1;
     double acc[KB > 0 ? KB : 1][NR], tri[NT3];
 #pragma unroll
     for (int i = 0; i < (KB > 0 ? KB : 1); ++i)
@@ -711,7 +745,7 @@ __global__ void __launch_bounds__(kThreads) block_dots_kernel(size_t n, const do
                 for (int r = 0; r < NR; ++r) acc[i][r] = fma(vl, rl[r], acc[i][r]);
             }
     }
-    constexpr int NV = KB * NR + (TRI ? sstep::kTri : 0);
+    constexpr int NV = KB * NR + (TRI ? NR * (NR + 1) / 2 : 0);
     __shared__ double sm[4][NV];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
@@ -1014,6 +1048,21 @@ int v_dot2(bk_ctx* ctx, size_t n, const double* x, const double* y1, const doubl
     return dot_launch(ctx, n, x, y1, y2, 2, out2);
 }
 
+int v_diff_nrm2(bk_ctx* ctx, size_t n, const double* x, const double* y, double* out) {
+    const bool vec = aligned16(x) && aligned16(y);
+    const int grid = grid_for(n, vec ? 2 : 1, kRedBlocks);
+    {
+        ProfScope ps(ctx, "blas1", 16.0 * n);
+        if (vec && nt_hint(ctx, n)) hipLaunchKernelGGL((diff_nrm2_kernel<2, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, x, y, ctx->d_partials);
+        else if (vec) hipLaunchKernelGGL((diff_nrm2_kernel<2>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, x, y, ctx->d_partials);
+        else hipLaunchKernelGGL((diff_nrm2_kernel<1>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, x, y, ctx->d_partials);
+        BK_HIP(ctx, hipGetLastError());
+    }
+    BK_TRY(reduce_finish(ctx, grid, 1, 0));
+    *out = sqrt(ctx->h_red[0]);
+    return 0;
+}
+
 int v_nrm2(bk_ctx* ctx, size_t n, const double* x, double* out) {
     double s = 0.0;
     BK_TRY(dot_launch(ctx, n, x, x, nullptr, 1, &s));
@@ -1206,7 +1255,27 @@ int v_block_dots(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int kold, i
     const bool nt = nt_hint(ctx, n);
     const int grid = nt ? burst_grid(ctx, n, "dot_blocks") : grid_for(n, 2 * 2, 512);
     const double* Rv = V + (size_t)r0 * ldv;
-    {
+    int done = 0;                        // measured basis vectors covered by the first launch (the one that carries the triangle)
+    constexpr int NR5 = 5;
+    if (nr <= NR5 && kold > 4 && ctx->opt("block_dots_nr5", 1.0) != 0.0) {
+        // few right-hand vectors (a solve's last block is usually ONE step: s = 1, u <= 4): 8 basis vectors and the triangle in one launch
+        const int kb = std::min(kold, 8);
+        constexpr int NV = 8 * NR5 + NR5 * (NR5 + 1) / 2;
+        static_assert(NV <= kPartialVals, "d_partials too small");
+        {
+            ProfScope ps(ctx, "multidot", 8.0 * n * (kb + nr));
+            if (nt) hipLaunchKernelGGL((block_dots_kernel<8, true, 2, true, NR5>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, kb, Rv, nr, ctx->d_partials);
+            else hipLaunchKernelGGL((block_dots_kernel<8, true, 2, false, NR5>), dim3(grid), dim3(kThreads), 0, ctx->stream, n, V, ldv, kb, Rv, nr, ctx->d_partials);
+            BK_HIP(ctx, hipGetLastError());
+        }
+        BK_TRY(reduce_finish(ctx, grid, NV, 0));
+        for (int i = 0; i < kb; ++i)
+            for (int r = 0; r < sstep::kR; ++r) D[i * sstep::kR + r] = r < NR5 ? ctx->h_red[i * NR5 + r] : 0.0;
+        for (int t = 0; t < sstep::kTri; ++t) T[t] = 0.0;
+        for (int r = 0, t = 0; r < NR5; ++r)
+            for (int c = r; c < NR5; ++c, ++t) T[sstep::tri(r, c)] = ctx->h_red[8 * NR5 + t];
+        done = kb;
+    } else {
         const int kb = std::min(kold, 4);
         {
             ProfScope ps(ctx, "multidot", 8.0 * n * (kb + nr));
@@ -1220,8 +1289,9 @@ int v_block_dots(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int kold, i
         for (int i = 0; i < kb; ++i)
             for (int r = 0; r < sstep::kR; ++r) D[i * sstep::kR + r] = ctx->h_red[i * sstep::kR + r];
         for (int t = 0; t < sstep::kTri; ++t) T[t] = ctx->h_red[4 * sstep::kR + t];
+        done = kb;
     }
-    for (int i0 = 4; i0 < kold; i0 += 8) {
+    for (int i0 = done; i0 < kold; i0 += 8) {
         const int kb = std::min(kold - i0, 8);
         {
             ProfScope ps(ctx, "multidot", 8.0 * n * (kb + nr));

@@ -22,3 +22,16 @@ def ctx():
     c = hip.Context(0)
     yield c
     c.close()
+
+
+def probe(name, value, bound, tight=None, **kw):
+    """Assert ``value <= bound`` and, on the GPU box (gpurun_out/ exists), log the measured value next to the bound in force and a
+    candidate tighter bound to gpurun_out/tolerance_probe.jsonl -- the record the tolerances of the parity tests are set from
+    (profiles/r5_tolerance_probe.jsonl: every bound carries its measured margin)."""
+    import json
+    d = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "tolerance_probe.jsonl"), "a") as f:
+            f.write(json.dumps(dict(name=name, value=float(value), bound=float(bound), tight=None if tight is None else float(tight),
+                                    holds_tight=None if tight is None else bool(value <= tight), **kw)) + "\n")
+    assert value <= bound, (name, value, bound, kw)

@@ -229,6 +229,14 @@ def main_gpu(rank, world):
     print(f"rank {rank}: gpu distributed checks OK", flush=True)
 
 
+def _has_opt(ctx, key):
+    try:
+        ctx.get_option(key)
+        return True
+    except Exception:  # noqa: BLE001
+        return False
+
+
 def slab_checks(ctx, hip, rank, world, tag, only=None):
     """The core of the distributed path against the 1-rank result, on grids whose z extent does not divide evenly
     (ragged slabs), with slabs as thin as the 2-plane halo allows, and on a power-of-two grid (fused FFT passes + the
@@ -236,8 +244,12 @@ def slab_checks(ctx, hip, rank, world, tag, only=None):
     cases = [((16, 12, 4 * world + 2 if world > 2 else 20), (2.0, 1.5, 2.5)),      # ragged: some ranks own one plane more
              ((8, 6, 2 * world + 1), (1.0, 1.5, 2.0)),                               # thin: 2 or 3 planes per rank
              ((32, 64, 64), (2.0, 3.0, 2.5)),                                        # power of two: fused DCT passes
-             ((32, 32, 16 * world), (2.0, 2.0, 0.6 * world))]                        # equal 16-plane slabs: the slab z-solve
+             ((32, 32, 16 * world), (2.0, 2.0, 0.6 * world)),                        # equal 16-plane slabs: the slab z-solve
                                                                                      # (power-of-two world sizes), else transposes
+             # round 5: x extents >= 64 -- the x transform passes run as the fused LDS kernel, so the solvers take the STENCIL-FREE
+             # Arnoldi step (Pl^-1 J = -I + Pl^-1 diag(g + s): no halo exchange inside GMRES) -- on the slab z-solve and on ragged slabs
+             ((64, 64, 16 * world), (4.0, 4.0, 1.0 * world)),
+             ((64, 32, 4 * world + 2), (4.0, 2.0, 2.5))]
     for ci, (dims, ls) in enumerate(cases):
         if only is not None and ci not in only:
             continue
@@ -259,6 +271,15 @@ def slab_checks(ctx, hip, rank, world, tag, only=None):
         lsol = hip.GMRESKrylovKit(dim=30, rtol=1e-10, atol=1e-13, maxiter=100, Pl=P)
         x, ok, it = lsol(J, Rv)
         out["x"], out["ok"], out["it"] = gather_slabs(x.numpy(), rank, world), ok, it
+        # which form of the preconditioned operator the solvers' Arnoldi steps take here (the same on every rank), and its value
+        wl, out["stencil_free"] = P.linmap(J, V, 0.3, 0.9)
+        out["linmap"] = gather_slabs(wl.numpy(), rank, world)
+        if dims[0] >= 64:
+            assert out["stencil_free"] == (ctx.get_option("gmres_stencil_free") != 0.0 if _has_opt(ctx, "gmres_stencil_free") else True), (tag, dims)
+        # KrylovLS(:minres) with M = Pl on J - 0.5 I (definite): the fused Lanczos step runs on slabs of >= 8 planes (halo exchange
+        # in line, per-tile partial sums all-reduced)
+        xm, okm, itm = hip.KrylovLSSymmetric(KrylovAlg="minres", atol=0.0, rtol=1e-10, itmax=400, Pl=P)(J, Rv, -0.5, 1.0)
+        out["xm"], out["okm"], out["itm"] = gather_slabs(xm.numpy(), rank, world), okm, itm
         dX, dl, okb, itb = hip.BorderingBLS(lsol, check_precision=False)(J, V, U, 0.3, Rv, 0.7, 0.5, 0.5, dotscale=1.0 / N)
         out["dX"], out["dl"] = gather_slabs(dX.numpy(), rank, world), dl
         # one PALC corrector iteration (newton_palc, Palc.jl:237-295) as ONE library call: the bench's step on slabs
@@ -292,6 +313,13 @@ def slab_checks(ctx, hip, rank, world, tag, only=None):
             x1, ok1, it1 = l1(J1, R1)
             assert out["ok"] and ok1 and abs(out["it"] - it1) <= 1, (tag, dims, out["it"], it1)
             assert np.allclose(out["x"], x1.numpy(), rtol=1e-7, atol=1e-9 * np.abs(x1.numpy()).max())
+            c1.set_option("gmres_stencil_free", 0)                   # the literal chain on one rank is the reference of both forms
+            wl1, sf1 = P1.linmap(J1, V1, 0.3, 0.9)
+            c1.set_option("gmres_stencil_free", 1)
+            assert not sf1 and np.abs(out["linmap"] - wl1.numpy()).max() <= 1e-11 * np.abs(wl1.numpy()).max(), (tag, dims, out["stencil_free"])
+            xm1, okm1, itm1 = hip.KrylovLSSymmetric(KrylovAlg="minres", atol=0.0, rtol=1e-10, itmax=400, Pl=P1)(J1, R1, -0.5, 1.0)
+            assert out["okm"] and okm1 and abs(out["itm"] - itm1) <= 1, (tag, dims, out["itm"], itm1)
+            assert np.allclose(out["xm"], xm1.numpy(), rtol=1e-6, atol=1e-8 * np.abs(xm1.numpy()).max()), (tag, dims)
             dX1, dl1, _, _ = hip.BorderingBLS(l1, check_precision=False)(J1, V1, U1, 0.3, R1, 0.7, 0.5, 0.5, dotscale=1.0 / N)
             assert np.isclose(out["dl"], dl1, rtol=1e-7)
             assert np.allclose(out["dX"], dX1.numpy(), rtol=1e-6, atol=1e-8 * np.abs(dX1.numpy()).max())
@@ -312,8 +340,10 @@ def slab_checks(ctx, hip, rank, world, tag, only=None):
 # device-resident chunks (all-reduce enqueued between the kernels, one host synchronisation per chunk) and host-driven; the halo
 # exchange in line; the transposed preconditioner; the two-pass Gram-Schmidt
 VARIANTS = [(("two_lanes", 1),), (("gmres_sstep", 0),), (("gmres_sstep", 0), ("two_lanes", 1)), (("gmres_sstep", 0), ("gmres_chunk", 1)),
-            (("halo_overlap", 0),), (("dct_dist_slab", 0),), (("gmres_sstep", 0), ("gmres_gram", 0))]
-DEFAULTS = {"two_lanes": 0, "gmres_sstep": -1, "gmres_chunk": 4, "halo_overlap": 1, "dct_dist_slab": 1, "gmres_gram": 1}
+            (("halo_overlap", 0),), (("dct_dist_slab", 0),), (("gmres_sstep", 0), ("gmres_gram", 0)),
+            (("gmres_stencil_free", 0), ("jvp_fused_dot_ranks", 0)), (("gmres_stencil_free", 2),)]
+DEFAULTS = {"two_lanes": 0, "gmres_sstep": -1, "gmres_chunk": 4, "halo_overlap": 1, "dct_dist_slab": 1, "gmres_gram": 1,
+            "gmres_stencil_free": 1, "jvp_fused_dot_ranks": 1}
 
 
 def main_gpu_many(rank, world):
@@ -328,7 +358,9 @@ def main_gpu_many(rank, world):
     for var in VARIANTS if world == 4 else VARIANTS[:1]:
         for key, val in var:
             ctx.set_option(key, val)
-        slab_checks(ctx, hip, rank, world, f"hostcomm x{world} {var}", only=(0, 3) if var != (("two_lanes", 1),) else None)
+        sf_var = any(k == "gmres_stencil_free" for k, _ in var)           # (those only matter where the stencil-free step can run)
+        slab_checks(ctx, hip, rank, world, f"hostcomm x{world} {var}",
+                    only=(4,) if sf_var else ((0, 3) if var != (("two_lanes", 1),) else None))
         for key, _ in var:
             ctx.set_option(key, DEFAULTS[key])
     ctx.close()

@@ -366,7 +366,9 @@ def test_generic_state_against_the_cpp_restatement(ctx, dims, amp, tmp_path):
         assert abs(res.norminf() - ref["residuals"][0]) <= 1e-12 * ref["residuals"][0]
         del rref
         J = prob.jacobian(ZP.u, ZP.p)
-        jt = J(T.u).numpy()
+        # (the two sides normalise the tangent with differently ordered sums: tau agrees to a few eps RELATIVE, and |J tau| is
+        # |L1|_inf ~ 1e5 times |tau| on white noise -- so that scale difference is removed exactly before the floor applies)
+        jt = J(T.u).numpy() * (ref["tau_p"] / T.p)
         jref = load("jtau")
         assert np.abs(jt - jref).max() <= floor * np.abs(T.u.numpy()).max(), np.abs(jt - jref).max()
         del jt, jref
@@ -474,28 +476,33 @@ def test_c5_512_operator_preconditioner_and_solve_against_the_cpp_restatement(ct
         t_ = _phase("cpu_ref_512_apply", t_, setup_s=ref["setup_seconds"], threads=ref["threads"])
         assert ref["n"] == N
         load = lambda tag: np.fromfile(pre + tag + ".bin")
-        assert abs(T.p - ref["tau_p"]) <= 1e-12 * abs(ref["tau_p"]) and abs(ZP.p - ref["p_pred"]) <= 1e-15
+        # every comparison is evaluated (and logged) before any is asserted: one run of this test reports all of them
+        chk = {}
+        chk["tau_p"] = (abs(T.p - ref["tau_p"]), 1e-12 * abs(ref["tau_p"]))
+        chk["p_pred"] = (abs(ZP.p - ref["p_pred"]), 1e-15)
         xp = load("xp")
         xpmax = np.abs(xp).max()
-        assert np.abs(ZP.u.numpy() - xp).max() <= 1e-15 * xpmax
+        chk["predictor"] = (np.abs(ZP.u.numpy() - xp).max(), 1e-15 * xpmax)
         del xp
         h = math.pi / 16
         floor = 8 * np.finfo(float).eps * (1.0 + 12.0 / h ** 2) ** 2
         rref = load("res")
-        d = np.abs(res.numpy() - rref).max()
-        assert d <= floor * xpmax, d
-        assert abs(res.norminf() - ref["residual_inf"]) <= 1e-12 * ref["residual_inf"]
+        chk["residual"] = (np.abs(res.numpy() - rref).max(), floor * xpmax)
+        chk["residual_inf"] = (abs(res.norminf() - ref["residual_inf"]), 1e-12 * ref["residual_inf"])
         del rref
         jref = load("jtau")
-        d = np.abs(J(T.u).numpy() - jref).max()
-        assert d <= floor * T.u.norminf(), d
+        # (scale difference of the two tangent normalisations removed exactly: see the 256^3 test)
+        chk["J_tau"] = (np.abs(J(T.u).numpy() * (ref["tau_p"] / T.p) - jref).max(), floor * T.u.norminf())
         del jref
         pref = load("plv")
-        d = np.abs(P.ldiv(V).numpy() - pref).max()
-        assert d <= 1e-13 * np.abs(pref).max(), d / np.abs(pref).max()       # five orthonormal transform passes + the symbol
+        chk["Pl_inv_v"] = (np.abs(P.ldiv(V).numpy() - pref).max(), 1e-13 * np.abs(pref).max())   # five orthonormal passes + the symbol
         del pref
         # the HIP solver's solution under the CPU side's own operator and preconditioner
-        assert ref["true_residual_rel"] <= 2e-9, ref
+        chk["true_residual_rel"] = (ref["true_residual_rel"], 2e-9)
+        chk = {k: (float(a), float(b)) for k, (a, b) in chk.items()}
+        _phase("checks_512", t_, **{k: {"value": a, "bound": b} for k, (a, b) in chk.items()})
+        bad = {k: v for k, v in chk.items() if not v[0] <= v[1]}
+        assert not bad, bad
         _phase("compare_512", t_, true_residual_rel=ref["true_residual_rel"])
     finally:
         if work != str(tmp_path):
