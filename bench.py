@@ -541,7 +541,9 @@ def main():
     # block Arnoldi: operator applications issued inside blocks over the whole run, and those void (tails of
     # truncated blocks) -- itlinear_per_step counts consumed applications only
     try:
-        gmres_blocks = {"operator_applications_in_blocks": ctx.get_option("gmres_block_steps"), "void": ctx.get_option("gmres_block_void")}
+        gmres_blocks = {"operator_applications_in_blocks": ctx.get_option("gmres_block_steps"),
+                        "truncated_tails": ctx.get_option("gmres_block_truncated"),
+                        "speculated_past_convergence": ctx.get_option("gmres_block_unconsumed")}
     except Exception:  # noqa: BLE001
         gmres_blocks = None
     sf_opt = [float(kv.split("=")[1]) for kv in args.opt if kv.startswith("gmres_stencil_free=")]

@@ -176,6 +176,16 @@ struct CommProxy {
     unsigned long long *ready_dev = nullptr, *done_dev = nullptr;
     int* err = nullptr;
     int* err_dev = nullptr;
+    // INVARIANT of the three staging buffers (single instances, not per-slot): two operations that use the same buffer are never in
+    // flight at once, because every use is totally ordered by stream dependencies --
+    //   ar        all-reduces are only ever enqueued on the context's compute stream (reduce_finish, comm_allreduce_host, the
+    //             device-resident Arnoldi step): one stream, program order;
+    //   hs / hr   a halo exchange runs on comm_stream under the interior z-chunks (comm_stream waits for ev_ready of the compute stream,
+    //             the compute stream waits for ev_halo before the face chunks) or in line on the compute stream (halo_overlap = 0, the
+    //             fused Lanczos step): the next exchange, on either stream, is enqueued behind that wait;
+    //   as / ar2  all-to-alls are only enqueued on the compute stream (the distributed preconditioner).
+    // The second lane is a separate context with its own proxy and buffers.  A new call site on another stream breaks this: give it its
+    // own buffers (or index the buffers by slot).
     double* ar = nullptr;                                        // all-reduce staging (kRedSlots)
     double *hs = nullptr, *hr = nullptr;                         // halo staging: [lo | hi] faces
     size_t hcap = 0;

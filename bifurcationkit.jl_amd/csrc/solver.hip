@@ -397,6 +397,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     // folded into the solution update when the solve ends inside the block: x = Q y_old + Q_new y_new =
     // Q (y_old - C R^-1 y_new) + P (R^-1 y_new), ONE multiaxpy over [Q, P] instead of the update pass plus a multiaxpy over
     // [Q, Q_new] (the last block of every solve: ~13 % of the Gram-Schmidt traffic of a 12-step solve).
+    int blk_accepted = 0, blk_consumed = 0;         // diagnostics: block steps accepted by the host algebra / handed to the Givens logic
     PendingBlock pend;
     auto flush_pending = [&]() -> int {
         if (!pend.active) return 0;
@@ -426,8 +427,11 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
                 if (got < steps && shifts_carried) { shifts.clear(); shifts_carried = false; }     // a stale set: back to the monomial block
                 if (got > 0 && !shifts_carried && ((int)shifts.size() < sstep::kS || j + got <= 12)) ritz_shifts(j + got);
                 // diagnostics (bench.py reports them): operator applications issued by blocks / of those void (truncated tails)
+                // ("truncated": tails of blocks cut at a small pivot; "unconsumed", counted at the end of the solve: accepted steps the
+                // host never needed because the solve converged earlier in the block -- speculation past convergence)
                 ctx->opts["gmres_block_steps"] = ctx->opt("gmres_block_steps", 0.0) + steps;
-                ctx->opts["gmres_block_void"] = ctx->opt("gmres_block_void", 0.0) + (steps - got);
+                ctx->opts["gmres_block_truncated"] = ctx->opt("gmres_block_truncated", 0.0) + (steps - got);
+                blk_accepted += got;
                 if (got > 0) {
                     q_first = j; q_count = got;
                     // next block: shorter after a truncation, one step longer when the last pivot left room (sstep.h)
@@ -440,6 +444,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
             if (!cycle_on_host) {
                 for (int i = 0; i <= j; ++i) hcol[i] = Hraw[(size_t)i + (size_t)j * ldh];
                 *hnext_out = Hraw[(size_t)(j + 1) + (size_t)j * ldh];
+                blk_consumed += 1;
                 return 0;
             }
         }
@@ -651,6 +656,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     }
     res->niter = kk ? numops : iters;
     res->resnorm = beta;
+    if (sstep_on) ctx->opts["gmres_block_unconsumed"] = ctx->opt("gmres_block_unconsumed", 0.0) + (blk_accepted - blk_consumed);
     ctx->gmres_last_steps = iters;
     if (carry && !shifts.empty()) ctx->newton_shifts = shifts;
     if (xt) for (int q = 0; q < nt; ++q) xt[q] = xtail[q];

@@ -316,7 +316,9 @@ def slab_checks(ctx, hip, rank, world, tag, only=None):
             c1.set_option("gmres_stencil_free", 0)                   # the literal chain on one rank is the reference of both forms
             wl1, sf1 = P1.linmap(J1, V1, 0.3, 0.9)
             c1.set_option("gmres_stencil_free", 1)
-            assert not sf1 and np.abs(out["linmap"] - wl1.numpy()).max() <= 1e-11 * np.abs(wl1.numpy()).max(), (tag, dims, out["stencil_free"])
+            # (|J v| is ~|L1|_inf |v| and the slab z-solve reproduces Pl^-1 to 1e-11 of its input: 1e-9 of the result)
+            dlm = np.abs(out["linmap"] - wl1.numpy()).max() / np.abs(wl1.numpy()).max()
+            assert not sf1 and dlm <= 1e-9, (tag, dims, out["stencil_free"], dlm)
             xm1, okm1, itm1 = hip.KrylovLSSymmetric(KrylovAlg="minres", atol=0.0, rtol=1e-10, itmax=400, Pl=P1)(J1, R1, -0.5, 1.0)
             assert out["okm"] and okm1 and abs(out["itm"] - itm1) <= 1, (tag, dims, out["itm"], itm1)
             assert np.allclose(out["xm"], xm1.numpy(), rtol=1e-6, atol=1e-8 * np.abs(xm1.numpy()).max()), (tag, dims)

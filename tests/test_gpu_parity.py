@@ -493,12 +493,16 @@ def test_block_arnoldi_steps_match_single_steps_and_the_oracle(ctx, grid):
                 # few per cent apart: every cycle starts from a residual that differs at rounding level, and restarted GMRES
                 # amplifies that; the oracle's restatement of the block algorithm shows the same counts, e.g. 867 vs 836)
                 from conftest import probe
-                probe("block vs single steps: count", abs(its - it0), max(1, it0 // 20), max(1, it0 // 50), flavor=flavor, s=s_, it0=it0, its=its,
-                      dim=kw.get("dim", kw.get("restart")))
+                # one cycle: the SAME count (+-1 where a stopping test sits within rounding of its threshold); many restart cycles
+                # drift apart by a few per cent (round 5 probe, profiles/r5_tolerance_probe.jsonl: 30 of 32 cases within 2 %)
+                cyc = kw.get("dim", kw.get("restart"))
+                probe("block vs single steps: count", abs(its - it0), 1 if it0 <= cyc + 2 else max(1, it0 // 20), max(1, it0 // 50),
+                      flavor=flavor, s=s_, it0=it0, its=its, dim=cyc)
                 assert oks
                 assert np.abs(xs - x0).max() <= 1e-9 * np.abs(x0).max(), (flavor, s_)
-                # in-block orthonormality: dot rounding / smallest accepted pivot ratio
-                probe("block Arnoldi basis defect", defect, 1e-4, 1e-6, flavor=flavor, s=s_, dim=kw.get("dim", kw.get("restart")), shift=(a0, a1))
+                # in-block orthonormality = dot rounding / smallest accepted pivot ratio.  Round 4 allowed 1e-4 here; measured in round 5
+                # over every case of this test: <= 1.7e-10 (profiles/r5_tolerance_probe.jsonl) -- the bound is two orders above that
+                probe("block Arnoldi basis defect", defect, 1e-8, 1e-9, flavor=flavor, s=s_, dim=cyc, shift=(a0, a1))
             if okw is not None:
                 xo, oko, nopso, _ = krylov.gmres_krylovkit(Jm, rhs, a0, a1, **okw)
                 xb, okb, nopsb, _ = krylov.gmres_block(Jm, rhs, a0, a1, block=4, **okw)
