@@ -668,6 +668,11 @@ def run_branch_workload(args, ctx, hip, Cn, prob, P, ls, u0, branch_setup, barri
                                    f"{args.eig_inner} rtol {args.eig_inner_rtol:g}, thick start {args.eig_thick}) + Bordered tangent + "
                                    f"predictor per step",
                        "grid": [n, n, n], "tiles": list(tiles), "parallelism": f"z-slabs x{world}",
+                       "eig_settings_note": ("the reference example asks for tol 1e-12, maxiter 20, krylovdim 45 (examples/SH3d.jl:109); on the tiled "
+                                             "domain the wanted eigenvalues sit in a dense band (relative gaps 1e-3 in 1/(lambda - sigma)) and "
+                                             "Krylov-Schur stops at the restart limit with eig_converged = false there (run with --eig-tol 1e-12 to "
+                                             "see it: per_step[].eig_converged); 1e-8 is the tolerance it reaches within 20 restarts"),
+                       "all_eigensolves_converged": all(p_["eig_converged"] for p_ in per) and bool(init.get("eig_converged", True)),
                        "initialisation": init, "setup_seconds": t_setup},
             "per_step": per, "param": br.param, "n_unstable": br.n_unstable}))
 
