@@ -58,8 +58,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=512, help="grid points per axis (BASELINE metric: 512)")
     ap.add_argument("--size-z", type=int, default=0, help="z extent if different from --size (cost-model runs: the z-slab one of "
                                                           "8 ranks owns, e.g. --size 512 --size-z 64 --opt dct_slab_emulate=8)")
@@ -531,14 +531,14 @@ def main():
                         frac=k["gbs"] / HBM_PEAK_GBS, traffic=traffic, traffic_source=tsrc, avg_ms=k["avg_ms"],
                         calls=k["calls"], alg_bytes_per_launch=k["alg_gb_per_call"] * 1e9)
 
-    # two lanes: the two solves of the bordered system run concurrently where a single solve does not saturate
+    # two lanes (docs/history.md 8c): the two solves of the bordered system run concurrently where a single solve does not saturate
     # HBM (default: one rank, vectors <= 128 MiB -- not the 512^3 headline); the per-kernel event timings then overlap
     tl_opt = [float(kv.split("=")[1]) for kv in args.opt if kv.startswith("two_lanes=")]
     two_lanes = bool(tl_opt[-1] != 0.0) if tl_opt else bool(world == 1 and prob.nlocal <= (1 << 24))
     if two_lanes and roofline is not None:
         roofline["note"] = ("two lanes: kernels of the two concurrent solves overlap, per-kernel durations (and this fraction) "
                             "are those of kernels sharing the device; compare ms_per_step")
-    # block Arnoldi (DESIGN 4c): operator applications issued inside blocks over the whole run, and those void (tails of
+    # block Arnoldi (DESIGN 4): operator applications issued inside blocks over the whole run, and those void (tails of
     # truncated blocks) -- itlinear_per_step counts consumed applications only
     try:
         gmres_blocks = {"operator_applications_in_blocks": ctx.get_option("gmres_block_steps"),

@@ -345,7 +345,7 @@ __device__ __forceinline__ void lds_barrier() {
 // One tile per workgroup.  The tile's global loads (first-stage samples; MODE 1: the spectral pairs of the merged
 // middle) are requested into registers before the twiddle tables are staged, so that the two latencies overlap.
 // (A persistent variant -- two workgroups per CU walking over the tiles with the next tile's samples prefetched across
-// the LDS phases -- was measured 5-12 % slower in every pass, also with only 2 tiles per workgroup: DESIGN.md section 4;
+// the LDS phases -- was measured 5-12 % slower in every pass, also with only 2 tiles per workgroup: docs/history.md section 4;
 // it lived in this file up to commit 96342eb.)  NTM: non-temporal tile loads / stores (every element is touched once).
 // DOT (MODE 2): the per-tile partial sum of sum_k symbol(k) |v^_k|^2 -- by Parseval (orthonormal transforms on every axis)
 // the dot product v . (M^-1 v) of this tile's lines -- goes to P.dotp[workgroup]; costs no memory traffic.

@@ -8,7 +8,7 @@
 #     julia --project=<env with BifurcationKit> julia/gen_fixtures.jl        # writes tests/golden/julia_fixtures.json
 #
 # There is no Julia in the build container of this repository: this script has NOT been executed there.  Until someone
-# runs it, tests/test_reference_fixtures.py skips and the oracle stays "parity unpinned" (DESIGN.md section 2).
+# runs it, tests/test_reference_fixtures.py skips and the oracle stays "parity unpinned" (DESIGN.md section 1).
 #
 # Inputs are closed-form (no RNG, no input files): probe(k, N)[i] = sin(a_k i) + 0.5 cos(b_k i + 0.1), i = 1..N -- the
 # Python side (tests/test_reference_fixtures.py: probe) builds the same vectors with i = index0 + 1.  Vectors are not

@@ -35,7 +35,7 @@ for R, nz in ((2, 256), (4, 128), (8, 64)):
     t_red = n_red * LAT
     t_T = t_local + t_a2a_T + t_red
     t_S = t_local + applies * (e1 - e0) + t_a2a_S + t_red
-    # two lanes: the two right-hand sides of the bordered solve in flight at once, each lane with its own
+    # two lanes (docs/history.md 8c): the two right-hand sides of the bordered solve in flight at once, each lane with its own
     # communicator -- measured local step with two lanes; ASSUMED: half of the collective time of one solve hides behind the
     # other solve's kernels (the second z round trip is real work and stays)
     two = None

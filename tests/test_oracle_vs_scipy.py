@@ -4,7 +4,7 @@ restarted GMRES with modified Gram-Schmidt + Givens (Saad & Schultz), Paige-Saun
 the same Fortran ARPACK that `Arpack.jl` (`EigArpack`, src/EigSolver.jl:67-102) wraps.  On the PDE operators of the hot path
 the iterates of two correct implementations of one algorithm coincide: residual histories to rounding, iteration counts
 exactly (+-1 where a stopping test sits on its threshold), ARPACK's eigenvalues to its tolerance.  This does not pin the Julia
-packages themselves (no Julia here: parity stays "unpinned", DESIGN.md section 2); it pins the restatements to the published
+packages themselves (no Julia here: parity stays "unpinned", DESIGN.md section 1); it pins the restatements to the published
 algorithms those packages implement."""
 import numpy as np
 import pytest
