@@ -2,8 +2,10 @@
 #
 # Runs the REAL BifurcationKit.jl (+ KrylovKit / Arpack, whatever versions the environment resolves; they are written
 # into the fixture) on the three problems of this repository's hot path and dumps what the reference computes at the
-# plugin boundary: residuals / JVPs, GMRESKrylovKit solves (incl. the Pl + shift branch), BorderingBLS and MatrixFreeBLS
-# solves, Newton and newton_palc histories along a short PALC branch, shift-invert eigenvalues.
+# plugin boundary: residuals / JVPs, GMRESKrylovKit solves (incl. the Pl + shift branch), GMRESIterativeSolvers with Pl and Pr,
+# KrylovLS(:minres / :cg), BorderingBLS and MatrixFreeBLS solves, Newton and newton_palc histories along a short PALC branch (with
+# BorderingBLS and with MatrixFreeBLS as the corrector's bordered solver), shift-invert eigenvalues.  The `numops` / `niter` counters
+# are what the consumers hold the HIP solvers to for EVERY block size of its Arnoldi process (gmres_sstep = 0 and 4).
 #
 #     julia --project=<env with BifurcationKit> julia/gen_fixtures.jl        # writes tests/golden/julia_fixtures.json
 #
@@ -110,6 +112,17 @@ function sh_case(name, dims, ls, l, ν, guess; newton_tol = 1e-8, branch_steps =
     mf = MatrixFreeBLS(GMRESKrylovKit(verbose = 0, rtol = 1e-9, maxiter = 150))
     dX, dl, ok, its = mf(J, r2, r3, 0.4, r1, 0.3, 0.5, 0.5; dotp = dotp)
     c["matrixfree"] = Dict("converged" => ok, "itlinear" => sum(its), "dl" => dl, "dX" => summary_of(dX))
+    # GMRESIterativeSolvers with a left AND a right preconditioner (src/LinearSolver.jl:178,198-201): the iteration runs on
+    # Pl^-1 (a0 + a1 J) Pr^-1 y = Pl^-1 rhs, x = Pr^-1 y.  Pl = lu(L1 + I), Pr = lu(L1 + 1e5 I) (bk_gmres_opts.pr on the HIP side; the
+    # large shift keeps Pl^-1 A Pr^-1 well conditioned -- 20-30 iterations -- while Pr still is a genuine, non-scalar operator)
+    try
+        lsis = GMRESIterativeSolvers(reltol = 1e-10, restart = 63, maxiter = 4000, N = N, Pl = lu(L1 + I), Pr = lu(L1 + 1e5I))
+        x, ok, it = lsis(J, r1; a₀ = 0.4, a₁ = -1.0)
+        c["gmres_is_pr"] = Dict("a0" => 0.4, "a1" => -1.0, "reltol" => 1e-10, "restart" => 63, "pl_shift" => 1.0, "pr_shift" => 1e5,
+                                "converged" => ok, "niter" => it, "x" => summary_of(x))
+    catch err
+        c["gmres_is_pr_error"] = sprint(showerror, err)
+    end
     # shift-invert eigenvalues the way the example's user-defined eigensolver does it (sigma = 0.1, KrylovKit.eigsolve)
     σ = 0.1
     A = dx -> ls_(v -> J(v) .- σ .* v, dx)[1]
@@ -124,6 +137,16 @@ function sh_case(name, dims, ls, l, ν, guess; newton_tol = 1e-8, branch_steps =
     br = continuation(probb, PALC(tangent = Bordered(), bls = BorderingBLS(solver = ls_, check_precision = false)), optc;
                       normC = x -> norm(x, Inf), verbosity = 0)
     c["branch"] = Dict("param" => br.param, "itnewton" => br.itnewton, "itlinear" => br.itlinear, "ds" => br.ds)
+    # the same branch with MatrixFreeBLS as the corrector's bordered solver (src/LinearBorderSolver.jl:424-437: one unpreconditioned
+    # GMRES on the (N + 1) operator per Newton iteration) -- bk_bordering_opts.kind = 1 on the HIP side, one library call per corrector
+    try
+        mfc = MatrixFreeBLS(GMRESKrylovKit(verbose = 0, dim = 60, rtol = 1e-10, atol = 1e-13, maxiter = 300))
+        optm = ContinuationPar(optc; max_steps = 2)
+        brm = continuation(probb, PALC(tangent = Bordered(), bls = mfc), optm; normC = x -> norm(x, Inf), verbosity = 0)
+        c["branch_matrixfree"] = Dict("param" => brm.param, "itnewton" => brm.itnewton, "itlinear" => brm.itlinear)
+    catch err
+        c["branch_matrixfree_error"] = sprint(showerror, err)
+    end
     out[name] = c
 end
 

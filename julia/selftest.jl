@@ -16,6 +16,7 @@ const H = BifurcationKitHIP
 length(ARGS) >= 1 && (H.libbkhip[] = ARGS[1])
 
 @testset "struct layouts match include/bkhip.h" begin
+    @test ccall((:bk_abi_version, H.libbkhip[]), Cint, ()) == H.BK_ABI_VERSION        # the library's layout version (round 5)
     @test sizeof(H.GmresOpts) == 40 && fieldoffset(H.GmresOpts, 6) == 32            # flavor dim maxiter | atol rtol | pr
     @test sizeof(H.BorderingOpts) == 24 && fieldoffset(H.BorderingOpts, 4) == 16      # tol | check_precision k kind (+pad)
     @test sizeof(H.ProblemDesc) == 48

@@ -52,6 +52,10 @@ def sh_case(dims, ls, l, nu, branch_steps):
     A = sp.bmat([[Jm, sp.csc_matrix(r2[:, None])], [sp.csc_matrix(0.5 * r3[None, :] / N), sp.csc_matrix([[0.5 * 0.4]])]]).tocsc()
     sol = spla.spsolve(A, np.concatenate([r1, [0.3]]))
     c["matrixfree"] = dict(converged=True, itlinear=0, dl=float(sol[-1]), dX=summary(sol[:-1]))
+    lu1, lu3 = spla.splu((sh.L1 + sp.identity(N)).tocsc()), spla.splu((sh.L1 + 1e5 * sp.identity(N)).tocsc())
+    x, ok, it = krylov.gmres_iterativesolvers(J, r1, 0.4, -1.0, restart=63, maxiter=4000, reltol=1e-10, Pl=lu1.solve, Pr=lu3.solve)
+    c["gmres_is_pr"] = dict(a0=0.4, a1=-1.0, reltol=1e-10, restart=63, pl_shift=1.0, pr_shift=1e5, converged=bool(ok), niter=int(it),
+                            x=summary(x))
     sigma = 0.1
     near = spla.eigsh(Jm, k=6, sigma=sigma, which="LM", tol=1e-12, return_eigenvectors=False)
     c["shift_invert"] = dict(sigma=sigma, converged=6, numops=0, vals=[float(v) for v in np.sort(near)[::-1]])
@@ -60,6 +64,8 @@ def sh_case(dims, ls, l, nu, branch_steps):
                            dsmax=0.005, p_min=-0.1, p_max=0.15, max_steps=branch_steps, tol=1e-9, max_iterations=15)
     c["branch"] = dict(param=[float(p) for p in br.param], itnewton=[int(i) for i in br.itnewton],
                        itlinear=[int(i) for i in br.itlinear], ds=[float(d) for d in br.ds])
+    # (the MatrixFreeBLS branch is the same curve: only the GPU consumer reads it, against the native corrector)
+    c["branch_matrixfree"] = dict(param=c["branch"]["param"][:3], itnewton=c["branch"]["itnewton"][:3], itlinear=[0, 0, 0])
     return c
 
 

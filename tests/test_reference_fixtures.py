@@ -100,6 +100,15 @@ def test_oracle_swift_hohenberg_matches_reference(fx, name):
             x, ok, it = fn(J, r1, c[key]["a0"], c[key]["a1"], atol=1e-13, rtol=1e-10, M=lu.solve)
             assert ok == c[key]["converged"] and abs(it - c[key]["niter"]) <= max(2, c[key]["niter"] // 10), (key, it)
             close(x, c[key]["x"], 1e-7, key)
+    if "gmres_is_pr" in c:                                     # GMRESIterativeSolvers with Pl and Pr (src/LinearSolver.jl:178,198-201)
+        import scipy.sparse as sp
+        g = c["gmres_is_pr"]
+        lu1 = spla.splu((sh.L1 + g["pl_shift"] * sp.identity(N)).tocsc())
+        lu3 = spla.splu((sh.L1 + g["pr_shift"] * sp.identity(N)).tocsc())
+        x, ok, it = krylov.gmres_iterativesolvers(J, r1, g["a0"], g["a1"], restart=g["restart"], maxiter=4000, reltol=g["reltol"],
+                                                  Pl=lu1.solve, Pr=lu3.solve)
+        assert ok == g["converged"] and abs(it - g["niter"]) <= max(2, g["niter"] // 20), (it, g["niter"])
+        close(x, g["x"], 1e-7, "gmres Pl + Pr")
     dX, dl, ok, its = bordered.bordering_bls(ols, J, r2, r3, 0.4, r1, 0.3, 0.5, 0.5, check_precision=False,
                                              dotp=lambda a, b: float(a @ b) / N)
     assert abs(dl - c["bordering"]["dl"]) <= 1e-7 * max(1.0, abs(c["bordering"]["dl"]))
@@ -149,12 +158,28 @@ def test_hip_swift_hohenberg_matches_reference(fx, ctx, name):
     close(sn["u"].numpy(), rn["u"], 1e-7, "newton u")
     J = prob.jacobian(sn["u"], l)
     r1, r2, r3 = (prob.vec(probe(k, N)) for k in (1, 2, 3))
-    x, ok, it = ls_(J, r1)
-    assert ok == c["gmres"]["converged"] and abs(it - c["gmres"]["numops"]) <= 2
-    close(x.numpy(), c["gmres"]["x"], 1e-7, "gmres")
-    x, ok, it = ls_(J, r1, 0.3, 0.9)
-    assert abs(it - c["gmres_shift"]["numops"]) <= 2
-    close(x.numpy(), c["gmres_shift"]["x"], 1e-7, "gmres shift")
+    # KrylovKit's numops, whatever the block size of the library's Arnoldi process (single steps, blocks of 4) and whichever form of
+    # the preconditioned operator it iterates on (stencil-free forced / the literal chain): the counter is the reference's, not ours
+    for sstep, sfree in ((-1, 1), (0, 1), (4, 2), (4, 0)):
+        ctx.set_option("gmres_sstep", sstep)
+        ctx.set_option("gmres_stencil_free", sfree)
+        try:
+            x, ok, it = ls_(J, r1)
+            assert ok == c["gmres"]["converged"] and abs(it - c["gmres"]["numops"]) <= 2, (sstep, sfree, it, c["gmres"]["numops"])
+            close(x.numpy(), c["gmres"]["x"], 1e-7, "gmres")
+            x, ok, it = ls_(J, r1, 0.3, 0.9)
+            assert abs(it - c["gmres_shift"]["numops"]) <= 2, (sstep, sfree, it, c["gmres_shift"]["numops"])
+            close(x.numpy(), c["gmres_shift"]["x"], 1e-7, "gmres shift")
+        finally:
+            ctx.set_option("gmres_sstep", -1)
+            ctx.set_option("gmres_stencil_free", 1)
+    if "gmres_is_pr" in c:                            # GMRESIterativeSolvers with Pl and Pr: bk_gmres_opts.pr
+        g = c["gmres_is_pr"]
+        lis = hip.GMRESIterativeSolvers(reltol=g["reltol"], restart=g["restart"], maxiter=4000,
+                                        Pl=hip.DCTPreconditioner(prob, g["pl_shift"]), Pr=hip.DCTPreconditioner(prob, g["pr_shift"]))
+        x, ok, it = lis(J, r1, g["a0"], g["a1"])
+        assert ok == g["converged"] and abs(it - g["niter"]) <= max(2, g["niter"] // 20), (it, g["niter"])
+        close(x.numpy(), g["x"], 1e-7, "gmres Pl + Pr")
     for key in ("minres", "cg"):                      # the fused-pass path (3-D) / the separate passes (2-D stencil)
         if key in c:
             ks = hip.KrylovLSSymmetric(key, atol=1e-13, rtol=1e-10, Pl=P)
@@ -180,6 +205,14 @@ def test_hip_swift_hohenberg_matches_reference(fx, ctx, name):
     br = Cn.continuation_native(prob, sn["u"], l, alg, cp, normC=Cn.norminf)
     assert np.allclose(br.param, c["branch"]["param"], rtol=0, atol=1e-8)
     assert all(abs(a - b) <= 1 for a, b in zip(br.itnewton, c["branch"]["itnewton"]))
+    if "branch_matrixfree" in c:                      # the corrector with MatrixFreeBLS: bk_bordering_opts.kind = 1, one call per corrector
+        bm = c["branch_matrixfree"]
+        mfc = hip.MatrixFreeBLS(hip.GMRESKrylovKit(dim=60, rtol=1e-10, atol=1e-13, maxiter=300))
+        cpm = Cn.ContinuationPar(ds=-0.001, dsmin=1e-4, dsmax=0.005, p_min=-0.1, p_max=0.15, max_steps=len(bm["param"]) - 1,
+                                 detect_bifurcation=0, newton_options=Cn.NewtonPar(tol=1e-9, max_iterations=15, linsolver=ls_))
+        brm = Cn.continuation(prob, sn["u"], l, Cn.PALC(tangent="bordered", theta=0.5, bls=mfc), cpm, normC=Cn.norminf)
+        assert np.allclose(brm.param, bm["param"], rtol=0, atol=1e-8)
+        assert all(abs(a - b) <= 1 for a, b in zip(brm.itnewton, bm["itnewton"]))
 
 
 @pytest.mark.gpu
