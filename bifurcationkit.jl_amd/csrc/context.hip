@@ -128,24 +128,28 @@ __global__ void __launch_bounds__(256) reduce_stage2_kernel(const double* __rest
 //            done[slot] == seq -> copy the result back
 //   proxy:   takes the operations in the order the host enqueued them (identical on every rank), waits for ready[slot],
 //            runs the callback, sets done[slot]
-// The flags live in pinned, device-mapped (fine-grained) host memory.  The wait kernel gives up after kProxyTimeoutTicks
+// The flags live in pinned, device-mapped (fine-grained) host memory.  The wait kernel gives up after "hostcomm_timeout_s"
 // (30 s) and raises the error flag instead of hanging the device; a failing callback raises it too; ctx_sync() reports it.
 // The callbacks therefore run on a library-owned thread (include/bkhip.h says so).
 namespace {
 
 constexpr int kProxySlots = 1024;
-constexpr long long kProxyTimeoutTicks = 3000000000LL;     // wall_clock64: 100 MHz
+constexpr long long kProxyTicksPerSecond = 100000000LL;     // wall_clock64: 100 MHz
+// The wait kernel's time-out is the context option "hostcomm_timeout_s" (default 30): a callback that legitimately takes longer (a
+// Python callback waiting for the GIL behind a long host-side computation) needs a larger value.  A time-out or a failed callback is
+// FATAL for the context: the error flag is sticky (ctx_sync keeps reporting it), the stream has continued with stale data and the
+// proxy threads of the ranks are no longer in step -- destroy the context on every rank and create a new one.
 
 __global__ void proxy_post_kernel(unsigned long long* flag, unsigned long long seq) {
     __threadfence_system();
     __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__global__ void proxy_wait_kernel(unsigned long long* flag, unsigned long long seq, int* err) {
+__global__ void proxy_wait_kernel(unsigned long long* flag, unsigned long long seq, int* err, long long timeout_ticks) {
     const long long t0 = wall_clock64();
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
         __builtin_amdgcn_s_sleep(64);
-        if (wall_clock64() - t0 > kProxyTimeoutTicks) {
+        if (wall_clock64() - t0 > timeout_ticks) {
             __hip_atomic_store(err, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
         }
@@ -293,7 +297,9 @@ static int proxy_submit(bk_ctx* ctx, CommProxy* p, hipStream_t stream, ProxyOp& 
         p->q.push_back(op);
     }
     p->cv.notify_one();
-    hipLaunchKernelGGL(proxy_wait_kernel, dim3(1), dim3(1), 0, stream, p->done_dev + slot, op.seq, p->err_dev);
+    const double tmo = std::max(1.0, ctx->opt("hostcomm_timeout_s", 30.0));
+    hipLaunchKernelGGL(proxy_wait_kernel, dim3(1), dim3(1), 0, stream, p->done_dev + slot, op.seq, p->err_dev,
+                       (long long)(tmo * (double)kProxyTicksPerSecond));
     BK_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -369,7 +369,9 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
         shifts_carried = false;
     };
     int chunk = (int)ctx->opt("gmres_chunk", 4.0);
-    if (nt != 0 || chunk < 2 || !ctx->h_rec_dev || sstep_on) chunk = 1;
+    // (with blocks on, the chunks only take over where the basis has outgrown the block kernels -- beyond 32 vectors: restart = 63
+    // cycles, unpreconditioned solves -- instead of host-synchronised single steps)
+    if (nt != 0 || chunk < 2 || !ctx->h_rec_dev) chunk = 1;
     if (chunk > kRecChunks) chunk = kRecChunks;
     // Speculation cap from the residual history (all quantities are all-reduced, i.e. identical on every rank): with the
     // last reduction factor rho = beta_k / beta_{k-1} the estimate reaches the tolerance after `need` further steps; never
@@ -390,7 +392,8 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     // device Gram matrix of the Gram-corrected step; dev_gram: every column of this cycle was measured on the device so far
     double* d_gram = nullptr;
     bool dev_gram = false, cycle_on_host = false;
-    if (chunk > 1 && B.use_gram) BK_TRY(ws.get((size_t)(kMaxBasis + 1) * (kMaxBasis + 1), &d_gram));
+    bool blocks_done = false;                  // this cycle's basis is past the block kernels' range: the device chunks continue it
+    if (chunk > 1 && B.use_gram && !sstep_on) BK_TRY(ws.get((size_t)(kMaxBasis + 1) * (kMaxBasis + 1), &d_gram));
     // next Hessenberg column (Arnoldi step from V[j]): from the queue of device-computed columns, else computed now
     // The update pass of a block (Q_new = (P - QC) R^-1, k + 2s vector streams) is DEFERRED: the block's Hessenberg columns
     // do not need it.  It runs when the new vectors are needed explicitly -- the next block, a restart's residual -- and is
@@ -406,7 +409,18 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     };
     auto next_column = [&](int j, double* hcol, double* hnext_out) -> int {
         if (!(q_count > 0 && j >= q_first && j < q_first + q_count)) BK_TRY(flush_pending());   // new work starts from explicit vectors
-        if (sstep_on && !cycle_on_host) {
+        if (sstep_on && !cycle_on_host && !blocks_done && chunk > 1 && j + 1 > 32 &&
+            !(q_count > 0 && j >= q_first && j < q_first + q_count)) {
+            // hand the rest of the cycle to the device-resident chunks (two-pass policy: the device has no Gram matrix of this basis, its
+            // defect estimate starts at the tolerance, i.e. on the safe side -- what the host path does in the same situation)
+            blocks_done = true;
+            dev_gram = false;
+            q_count = 0;
+            const double ot = B.orth_tol;
+            BK_HIP(ctx, hipMemcpyAsync(d_coef + kMaxBasis + 2, &ot, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        if (sstep_on && !cycle_on_host && !blocks_done) {
             if (!(q_count > 0 && j >= q_first && j < q_first + q_count)) {
                 int steps = std::min(std::min(blk_cur, shifts.empty() ? kMonomialMax : sstep_max), m - j);
                 const bool capped = steps < blk_cur;
@@ -448,7 +462,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
                 return 0;
             }
         }
-        if (chunk > 1 && !cycle_on_host) {
+        if (chunk > 1 && !cycle_on_host && (!sstep_on || blocks_done)) {
             if (!(q_count > 0 && j >= q_first && j < q_first + q_count)) {
                 int steps = std::min(std::min(ramp, chunk), m - j);
                 if (predict && steps > 1 && beta_now > 0.0) {
@@ -529,6 +543,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
         B.gram_n = 0;                          // ... and its Gram column is measured by the first step
         dev_gram = d_gram != nullptr;
         cycle_on_host = false;
+        blocks_done = false;
         if (chunk > 1) BK_HIP(ctx, hipMemsetAsync(d_coef + kMaxBasis + 2, 0, sizeof(double), ctx->stream));
         q_count = 0;                           // a new cycle: nothing speculative carries over
         pend.active = false;                   // (a deferred update of the finished cycle is void with its basis)
