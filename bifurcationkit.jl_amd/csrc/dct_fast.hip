@@ -58,6 +58,14 @@ struct FftK {
     // sample's own index; inverse -- the stored value is fz_ct * result + fz_cx * fz_v[same index]
     const double* fz_v;
     double fzA, fzB, fzC, fz_cx, fz_ct;
+    // SLAB kernels (z passes of the slab z-solve as forward / inverse HALVES, dct.hip: dct_apply_slab): the forward half stores
+    // y^_k = sym_k f^_k and the values of y = B^-1 f at the four planes next to the slab faces (face_y[p * face_L + line], p = planes
+    // 0, 1, nl-2, nl-1: sums over the spectrum with the local basis phi); the inverse half adds sym_k * sum_p phi_k(p) delta_p(line)
+    // -- the Woodbury correction, applied in the z-spectral domain -- before it transforms back
+    double* face_y;
+    const double* face_d;
+    const double* phi;        // [2][N]: local DCT-II basis at planes 0 and 1 (phi_k(N-1-z) = (-1)^k phi_k(z))
+    unsigned face_L;          // lines of the slab (n0 * n1)
 };
 
 template <int NT>
@@ -351,9 +359,11 @@ __device__ __forceinline__ void lds_barrier() {
 // the dot product v . (M^-1 v) of this tile's lines -- goes to P.dotp[workgroup]; costs no memory traffic.
 // FZ (AX0 only): the pointwise work of the stencil-free preconditioned operator rides in the x passes (ops.h: DctFuse) -- one more
 // 8 B/point read stream in the pass, same tile pipeline.
-template <int NT, int MODE, bool AX0, bool NTM, bool DOT = false, bool FZ = false>   // MODE 0: forward, 1: inverse, 2: forward - symbol - inverse (AX0: 0 / 1 only)
+// SLAB (axis 2 only): 1 = forward half (MODE 0), 2 = inverse half (MODE 1) of the slab z-solve -- see FftK.
+template <int NT, int MODE, bool AX0, bool NTM, bool DOT = false, bool FZ = false, int SLAB = 0>   // MODE 0: forward, 1: inverse, 2: forward - symbol - inverse (AX0: 0 / 1 only)
 __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
     static_assert(!FZ || (AX0 && MODE != 2), "FZ: x passes only");
+    static_assert(SLAB == 0 || (!AX0 && !FZ && !DOT && ((SLAB == 1 && MODE == 0) || (SLAB == 2 && MODE == 1))), "SLAB: z halves only");
     __shared__ double dsum[NT / 64];
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int N = P.N, bits = P.bits, G = N >> 3;
@@ -363,7 +373,8 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
     const int twl = dctc::tw_len(N), ewl = dctc::ew_len(N);
     c2* tw = z + (size_t)npairs * pstride;                    // N/2 FFT twiddles (dct_core.h: twi layout, twl slots)
     c2* ew = tw + twl;                                        // N/2 + 1 post twiddles exp(-i pi k / 2N), k <= N/2 (ewl slots)
-    double* lamk = reinterpret_cast<double*>(ew + ewl + 1);   // MODE 2: eigenvalues along the transform axis
+    double* lamk = reinterpret_cast<double*>(ew + ewl + 1);   // MODE 2 / SLAB: eigenvalues along the transform axis
+    double* phik = lamk + N;                                  // SLAB: [2][N] local basis at planes 0, 1
     const int tid = threadIdx.x;
     const int nfirst = AX0 ? npairs * (G >> 1) : npairs * G;  // work items of the outer stages ...
     const int nmid = npairs * (G >> 1);                       // ... and of the merged middle
@@ -436,6 +447,7 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
     // pfb; (axis >= 1) the 8 samples of item tid in pfa and of item tid + NT in pfb
     c2 pfa[8], pfb[8];
     c2 qfa[FZ ? 8 : 1], qfb[FZ ? 8 : 1];     // FZ: the second stream's values at the same indices (u forward, x inverse)
+    c2 dl[SLAB == 2 ? 4 : 1];                // SLAB 2: the correction's right-hand side at the four face planes, lines a / b of this item
     // (the host launches this kernel only when nfirst <= NT (AX0) / 2 NT, so the two register sets cover the tile)
     const bool act0 = tid < nfirst, act1 = !AX0 && tid + NT < nfirst;
     auto issue = [&](int tile) {
@@ -444,6 +456,14 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
         if (MODE == 1) {                                      // the 8 + 8 spectral pairs of this lane's merged-middle item
             const bool act = tid < nmid;
             const int pr = AX0 ? tid >> hbits : tid & (npairs - 1), t = AX0 ? tid & ((1 << hbits) - 1) : tid >> pbits;
+            if (SLAB == 2) {
+                const size_t fb = (size_t)tile_other(tile) * P.n0 + (size_t)tile_x0(tile) + (size_t)(2 * pr);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double2 d = *reinterpret_cast<const double2*>(P.face_d + (size_t)q * P.face_L + fb);
+                    dl[SLAB == 2 ? q : 0].x = d.x; dl[SLAB == 2 ? q : 0].y = d.y;
+                }
+            }
             const unsigned o = AX0 ? (unsigned)(2 * pr) * lstride : 2u * pr;
             const int ga = t, gb = t == 0 ? (G >> 1) : G - t;
 #pragma unroll
@@ -519,8 +539,10 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
         // form, tables stored before or after the first stage -- costs 20-30 % in every pass (measured): the in-order return
         // puts the short table loads behind 16 HBM loads per lane.
         for (int q = tid; q < twl + ewl; q += NT) tw[q] = reinterpret_cast<const c2*>(P.twid)[q];
-        if (MODE == 2)
+        if (MODE == 2 || SLAB)
             for (int q = tid; q < N; q += NT) lamk[q] = (P.axis == 1 ? P.lam1 : P.lam2)[q];
+        if (SLAB)
+            for (int q = tid; q < 2 * N; q += NT) phik[q] = P.phi[q];
         issue(tile);
         lds_barrier();
         const int x0 = tile_x0(tile), other = tile_other(tile);
@@ -531,7 +553,7 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
         // axes: the per-line constant first, the last-axis eigenvalue per k, then lam2 (y pass of a 3-D array) or an exact
         // + 0.0.  (One merged-middle item per lane: nmid <= NT, host-checked.)
         double ca = 0.0, cb = 0.0, lo2 = 0.0;
-        if (MODE == 2) {
+        if (MODE == 2 || SLAB) {
             const int i0 = x0 + 2 * (tid & (npairs - 1));
             const double l1 = P.axis == 1 ? 0.0 : P.lam1[other];
             lo2 = P.axis == 1 ? (P.lam2 ? P.lam2[other] : 0.0) : 0.0;
@@ -566,11 +588,27 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
         }
         c2 dtot;
         dtot.x = dtot.y = 0.0;
+        c2 fy[4];                                                  // SLAB 1: this item's share of y at the four face planes (lines a / b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fy[q].x = fy[q].y = 0.0;
         if (MODE == 1) {
             if (tid < nmid) {
                 const int pr = AX0 ? tid >> hbits : tid & (npairs - 1), t = AX0 ? tid & ((1 << hbits) - 1) : tid >> pbits;
                 dctc::fused_mid<1, false>(z + (size_t)pr * pstride, N, t, tw, ew, s0, s2,
-                                          [&](int slot, int) { return slot < 8 ? pfa[slot & 7] : pfb[slot & 7]; }, nost, nosym, dtot);
+                                          [&](int slot, int k) {
+                                              c2 v = slot < 8 ? pfa[slot & 7] : pfb[slot & 7];
+                                              if (SLAB == 2) {
+                                                  // a^_k = y^_k + sym_k (phi_k(0) d0 + phi_k(1) d1 + (-1)^k (phi_k(1) d2 + phi_k(0) d3))
+                                                  const double p0 = phik[k], p1 = phik[N + k], lk = lamk[k];
+                                                  const double sa = ca + lk, sb = cb + lk;
+                                                  const double fa = rcp_nr(sa * sa + P.shift, 2), fb_ = rcp_nr(sb * sb + P.shift, 2);
+                                                  const double sg = (k & 1) ? -1.0 : 1.0;
+                                                  constexpr int I1 = SLAB == 2 ? 1 : 0, I2 = SLAB == 2 ? 2 : 0, I3 = SLAB == 2 ? 3 : 0;
+                                                  v.x += fa * (p0 * dl[0].x + p1 * dl[I1].x + sg * (p1 * dl[I2].x + p0 * dl[I3].x));
+                                                  v.y += fb_ * (p0 * dl[0].y + p1 * dl[I1].y + sg * (p1 * dl[I2].y + p0 * dl[I3].y));
+                                              }
+                                              return v;
+                                          }, nost, nosym, dtot);
             }
             if (FZ) {
                 // the values this lane's last stage will be added to, requested now: they travel while the inverse middle stages run
@@ -598,6 +636,18 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
                     c2 r; r.x = rcp_nr(sa * sa + P.shift, 2); r.y = rcp_nr(sb * sb + P.shift, 2); return r;
                 };
                 dctc::fused_mid<2, DOT>(zp, N, t, tw, ew, s0, s2, nold, nost, sym, dtot);
+            } else if (MODE == 0 && SLAB == 1) {
+                dctc::fused_mid<0, false>(zp, N, t, tw, ew, s0, s2, nold, [&](int k, c2 v) {
+                    const double p0 = phik[k], p1 = phik[N + k], lk = lamk[k];
+                    const double sa = ca + lk, sb = cb + lk;
+                    v.x *= rcp_nr(sa * sa + P.shift, 2); v.y *= rcp_nr(sb * sb + P.shift, 2);      // y^_k = sym_k f^_k
+                    const double sg = (k & 1) ? -1.0 : 1.0;
+                    fy[0].x = fma(p0, v.x, fy[0].x); fy[0].y = fma(p0, v.y, fy[0].y);            // y(plane 0)
+                    fy[1].x = fma(p1, v.x, fy[1].x); fy[1].y = fma(p1, v.y, fy[1].y);            // y(plane 1)
+                    fy[2].x = fma(sg * p1, v.x, fy[2].x); fy[2].y = fma(sg * p1, v.y, fy[2].y);  // y(plane N-2)
+                    fy[3].x = fma(sg * p0, v.x, fy[3].x); fy[3].y = fma(sg * p0, v.y, fy[3].y);  // y(plane N-1)
+                    stg(o + (unsigned)k * estride, v);
+                }, nosym, dtot);
             } else if (MODE == 0) {
                 if (AX0) dctc::fused_mid<0, false>(zp, N, t, tw, ew, s0, s2, nold, [&](int k, c2 v) { st1(o + (unsigned)k, v); }, nosym, dtot);
                 else if (P.split == 1) dctc::fused_mid<0, false>(zp, N, t, tw, ew, s0, s2, nold, [&](int k, c2 v) { stg(o + P.kmap[k], v); }, nosym, dtot);
@@ -605,6 +655,29 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
             }
         }
         stamp(3);
+        if (MODE == 0 && SLAB == 1) {
+            // the items of one line pair (same pr, t = 0 .. G/2 - 1) sit npairs lanes apart: their shares are summed through the tile's
+            // LDS area, which is dead once every item has left the merged middle
+            lds_barrier();
+            double* sc = smem;
+            if (tid < nmid) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { sc[(size_t)tid * 8 + 2 * q] = fy[q].x; sc[(size_t)tid * 8 + 2 * q + 1] = fy[q].y; }
+            }
+            lds_barrier();
+            if (tid < npairs) {
+                double acc[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+                for (int t = 0; t < (G >> 1); ++t)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc[q] += sc[(size_t)(tid + npairs * t) * 8 + q];
+                const size_t fb = (size_t)other * P.n0 + (size_t)x0 + (size_t)(2 * tid);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<double2*>(P.face_y + (size_t)q * P.face_L + fb) = make_double2(acc[2 * q], acc[2 * q + 1]);
+            }
+        }
         if (MODE == 0) {
             if (P.trace) { __builtin_amdgcn_s_waitcnt(0); stamp(6); }
             return;
@@ -698,11 +771,25 @@ bool dct_axis_fused_ok(bk_ctx* ctx, int n0, int n1, int n2, int axis, const doub
     return n0 % LT == 0;
 }
 
+// the slab z-solve's half passes: the fused z kernel with ONE merged-middle item per lane (per-lane symbol constants) on a slab whose
+// face buffers are 16-B aligned per line pair
+bool dct_slab_half_ok(bk_ctx* ctx, int n0, int n1, int nl, const double* a, const double* b) {
+    if (!dct_axis_fused_ok(ctx, n0, n1, nl, 2, a, b, 0)) return false;
+    const int LT = choose_lt(nl, 2, n0, (size_t)n1 * nl, ctx->opt("dct_lt_wide", 1.0) != 0.0);
+    return (size_t)(LT / 2) * (nl / 16) <= 256 && (((size_t)n0 * n1) % 2 == 0) && (size_t)n0 * n1 < ((size_t)1 << 32);
+}
+
 int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, const double* twid, const double* in,
                  double* out, const double* lam0, const double* lam1, const double* lam2, double shift,
-                 int fuse_scale, const DctSplit* split, int* dot_blocks, const DctFuse* fz) {
+                 int fuse_scale, const DctSplit* split, int* dot_blocks, const DctFuse* fz, const DctSlabHalf* sh) {
     FftK P;
     P.dotp = nullptr;
+    P.face_y = nullptr; P.face_d = nullptr; P.phi = nullptr; P.face_L = 0;
+    if (sh) {
+        if (!dct_slab_half_ok(ctx, n0, n1, n2, in, out) || axis != 2 || fuse_scale != 0 || split || fz)
+            return set_error(ctx, "dct_axis_fft: the slab half passes need the fused z-axis kernel (dct_slab_half_ok)");
+        P.face_y = sh->face_y; P.face_d = sh->face_d; P.phi = sh->phi; P.face_L = (unsigned)sh->L;
+    }
     P.fz_v = nullptr; P.fzA = 1.0; P.fzB = P.fzC = 0.0; P.fz_cx = 0.0; P.fz_ct = 1.0;
     // the pointwise work this pass is asked to take in: the factor on a forward pass, the axpy on an inverse one
     const bool want_fz = fz && (inverse ? fz->xadd != nullptr : fz->u != nullptr);
@@ -776,7 +863,11 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
                              reinterpret_cast<const void*>(dct_fused_kernel<256, 0, true, false, false, true>),
                              reinterpret_cast<const void*>(dct_fused_kernel<256, 1, true, false, false, true>),
                              reinterpret_cast<const void*>(dct_fused_kernel<256, 0, true, true, false, true>),
-                             reinterpret_cast<const void*>(dct_fused_kernel<256, 1, true, true, false, true>)};
+                             reinterpret_cast<const void*>(dct_fused_kernel<256, 1, true, true, false, true>),
+                             reinterpret_cast<const void*>(dct_fused_kernel<256, 0, false, false, false, false, 1>),
+                             reinterpret_cast<const void*>(dct_fused_kernel<256, 1, false, false, false, false, 2>),
+                             reinterpret_cast<const void*>(dct_fused_kernel<256, 0, false, true, false, false, 1>),
+                             reinterpret_cast<const void*>(dct_fused_kernel<256, 1, false, true, false, false, 2>)};
         for (const void* f : fns) {
             const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             if (e != hipSuccess) attr_err = e;
@@ -794,7 +885,8 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
         P.fast = (ctx->opt("dct_fastio", 1.0) != 0.0 && full_tiles && shapes) ? 1 : 0;
     }
     if (fused_ok && (P.LT == 16 || (axis != 0 && (P.LT == 32 || P.LT == 64 || P.LT == 128)))) {
-        const size_t ldsf = lds + ((size_t)(dctc::ew_len(P.N) + 1) + (P.roundtrip ? P.N / 2 : 0)) * sizeof(c2);
+        const size_t ldsf = lds + ((size_t)(dctc::ew_len(P.N) + 1) + (P.roundtrip ? P.N / 2 : 0)) * sizeof(c2) +
+                            (sh ? (size_t)3 * P.N * sizeof(double) : 0);     // SLAB: eigenvalues + the two basis rows
         const bool trace = ctx->opt("dct_trace", 0.0) != 0.0;
         P.trace = nullptr;
         if (trace) {
@@ -819,7 +911,11 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
         const int mode = P.roundtrip ? 2 : (P.inverse ? 1 : 0);
 #define BK_DCT_LAUNCH(M, A, T) hipLaunchKernelGGL((dct_fused_kernel<256, M, A, T>), dim3(grid), dim3(256), ldsf, ctx->stream, P)
 #define BK_DCT_LAUNCH_FZ(M, T) hipLaunchKernelGGL((dct_fused_kernel<256, M, true, T, false, true>), dim3(grid), dim3(256), ldsf, ctx->stream, P)
-        if (axis == 0 && want_fz) {
+#define BK_DCT_LAUNCH_SLAB(M, T, S) hipLaunchKernelGGL((dct_fused_kernel<256, M, false, T, false, false, S>), dim3(grid), dim3(256), ldsf, ctx->stream, P)
+        if (sh) {
+            if (mode == 1) { if (ntm) BK_DCT_LAUNCH_SLAB(1, true, 2); else BK_DCT_LAUNCH_SLAB(1, false, 2); }
+            else { if (ntm) BK_DCT_LAUNCH_SLAB(0, true, 1); else BK_DCT_LAUNCH_SLAB(0, false, 1); }
+        } else if (axis == 0 && want_fz) {
             if (mode == 1) { if (ntm) BK_DCT_LAUNCH_FZ(1, true); else BK_DCT_LAUNCH_FZ(1, false); }
             else { if (ntm) BK_DCT_LAUNCH_FZ(0, true); else BK_DCT_LAUNCH_FZ(0, false); }
         } else if (axis == 0) {
@@ -835,6 +931,7 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
         else { if (ntm) BK_DCT_LAUNCH(0, false, true); else BK_DCT_LAUNCH(0, false, false); }
 #undef BK_DCT_LAUNCH
 #undef BK_DCT_LAUNCH_FZ
+#undef BK_DCT_LAUNCH_SLAB
         BK_HIP(ctx, hipGetLastError());
         if (trace) {
             // phase durations (wall_clock64 ticks of 10 ns) averaged over the tiles: stamps 0 start, 1 first stage done,

@@ -89,9 +89,20 @@ struct DctSplit {
     const unsigned* kmap;
     unsigned plane;
 };
+// z passes of the slab z-solve as forward / inverse halves (dct_slab.hip, dct.hip: dct_apply_slab): the forward half (inverse = 0)
+// stores y^ = sym .* f^ and the values of y = B^-1 f at the four planes next to the slab faces in face_y[4][L]; the inverse half
+// (inverse = 1) adds the Woodbury correction sym_k sum_p phi_k(p) face_d[p][line] in the z-spectral domain and transforms back.
+struct DctSlabHalf {
+    double* face_y = nullptr;
+    const double* face_d = nullptr;
+    const double* phi = nullptr;      // [2][nl] local DCT-II basis at planes 0, 1
+    size_t L = 0;                     // lines of the slab (n0 * n1)
+};
 int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, const double* twid, const double* in,
                  double* out, const double* symx, const double* symy, const double* symz, double shift, int fuse_scale,
-                 const DctSplit* split = nullptr, int* dot_blocks = nullptr, const DctFuse* fz = nullptr);
+                 const DctSplit* split = nullptr, int* dot_blocks = nullptr, const DctFuse* fz = nullptr,
+                 const DctSlabHalf* sh = nullptr);
+bool dct_slab_half_ok(bk_ctx* ctx, int n0, int n1, int nl, const double* a, const double* b);
 bool dct_axis_fft_supported(int n);
 bool dct_axis_fused_ok(bk_ctx* ctx, int n0, int n1, int n2, int axis, const double* in, const double* out, int fuse_scale);
 

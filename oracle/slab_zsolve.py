@@ -93,3 +93,42 @@ def slab_zsolve(f, c, s, R, a):
 def exact_zsolve(f, c, s, a):
     n = f.shape[0]
     return sfft.idct(sfft.dct(f, type=2, norm="ortho") / ((c + lam_neumann(n, a)) ** 2 + s), type=2, norm="ortho")
+
+
+def slab_zsolve_split(f, c, s, R, a):
+    """The same solve the way round 5's HIP path takes it (dct.hip: dct_apply_slab with dct_slab_split; dct_fast.hip: SLAB 1 / 2):
+    ONE forward local transform, the face values of y = B^-1 f from sums over the spectrum, the capacitance system, and the correction
+    applied in the z-spectral domain inside ONE inverse transform -- two single transforms instead of two round trips."""
+    n = f.shape[0]
+    nl = n // R
+    assert nl * R == n and nl >= 4
+    m = np.arange(nl)
+    sym = 1.0 / ((c + lam_neumann(nl, a)) ** 2 + s)
+    sk = np.where(m == 0, np.sqrt(1.0 / nl), np.sqrt(2.0 / nl))
+    phi = np.stack([sk * np.cos(np.pi * (2 * z + 1) * m / (2.0 * nl)) for z in (0, 1)])       # [2][nl]: planes 0, 1
+    sg = (-1.0) ** m
+    Yh = sfft.dct(f.reshape(R, nl), type=2, norm="ortho", axis=1) * sym                      # forward half: y^ = sym .* f^
+    if R == 1:
+        return sfft.idct(Yh, type=2, norm="ortho", axis=1).reshape(-1)
+    # y at planes (0, 1, nl-2, nl-1) of every slab: phi_k(nl-1-z) = (-1)^k phi_k(z)
+    yf = np.stack([Yh @ phi[0], Yh @ phi[1], (Yh * sg) @ phi[1], (Yh * sg) @ phi[0]], axis=1)          # [R][4]
+    D0, E, Ptop, Pbot = reduced_blocks(c, s, nl, a)
+    g = np.stack([Ptop.T @ yf[i, 2:] + Pbot.T @ yf[i + 1, :2] for i in range(R - 1)])
+    nf = R - 1
+    Dk, gk = [None] * nf, [None] * nf
+    Dk[0], gk[0] = D0, g[0]
+    for i in range(1, nf):
+        W = E.T @ np.linalg.inv(Dk[i - 1])
+        Dk[i] = D0 - W @ E
+        gk[i] = g[i] - W @ gk[i - 1]
+    nu = [None] * nf
+    nu[nf - 1] = np.linalg.solve(Dk[nf - 1], gk[nf - 1])
+    for i in range(nf - 2, -1, -1):
+        nu[i] = np.linalg.solve(Dk[i], gk[i] - E @ nu[i + 1])
+    delta = np.zeros((R, 4))                              # -U nu at the planes (0, 1, nl-2, nl-1) of every slab
+    for i in range(nf):
+        delta[i, 2:] -= Ptop @ nu[i]
+        delta[i + 1, :2] -= Pbot @ nu[i]
+    # inverse half: a^_k = y^_k + sym_k (phi_k(0) d0 + phi_k(1) d1 + (-1)^k (phi_k(1) d2 + phi_k(0) d3))
+    corr = delta[:, 0:1] * phi[0] + delta[:, 1:2] * phi[1] + sg * (delta[:, 2:3] * phi[1] + delta[:, 3:4] * phi[0])
+    return sfft.idct(Yh + sym * corr, type=2, norm="ortho", axis=1).reshape(-1)

@@ -26,8 +26,10 @@ if "slabemu" in what:
         g_ = torch.Generator(device="cuda").manual_seed(0)
         v_ = hip.HipVec(ctx, torch.rand(N_, dtype=torch.float64, device="cuda", generator=g_))
         o_ = v_.similar()
-        for emu in (0, R):
+        # (emu, split): transposed z pass / slab z-solve as two round trips (round 2) / as forward + inverse halves (round 5)
+        for emu, split in ((0, 1), (R, 0), (R, 1)):
             ctx.set_option("dct_slab_emulate", emu)
+            ctx.set_option("dct_slab_split", split)
             pr = hip.SwiftHohenberg(ctx, (n, n, nzl), (math.pi * n / 32, math.pi * n / 32, math.pi * nzl / 32))
             P_ = hip.DCTPreconditioner(pr, 1.0)
             f_ = lambda: ctx.check(ctx.lib.bk_precond_apply(P_.h, C.c_void_p(v_.t.data_ptr()), C.c_void_p(o_.t.data_ptr())))
@@ -39,10 +41,11 @@ if "slabemu" in what:
                 f_()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / 10
-            print(json.dumps(dict(kernel="precond_apply_on_slab", n=n, R=R, nzl=nzl, slab_zsolve=bool(emu), ms=dt * 1e3,
+            print(json.dumps(dict(kernel="precond_apply_on_slab", n=n, R=R, nzl=nzl, slab_zsolve=bool(emu), halves=bool(emu and split), ms=dt * 1e3,
                                   passes=6 if emu else 5, gbs=16.0 * N_ * (6 if emu else 5) / dt / 1e9)), flush=True)
             del P_, pr
         ctx.set_option("dct_slab_emulate", 0)
+        ctx.set_option("dct_slab_split", 1)
         del v_, o_
     sys.exit(0)
 

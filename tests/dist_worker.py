@@ -249,7 +249,10 @@ def slab_checks(ctx, hip, rank, world, tag, only=None):
              # round 5: x extents >= 64 -- the x transform passes run as the fused LDS kernel, so the solvers take the STENCIL-FREE
              # Arnoldi step (Pl^-1 J = -I + Pl^-1 diag(g + s): no halo exchange inside GMRES) -- on the slab z-solve and on ragged slabs
              ((64, 64, 16 * world), (4.0, 4.0, 1.0 * world)),
-             ((64, 32, 4 * world + 2), (4.0, 2.0, 2.5))]
+             ((64, 32, 4 * world + 2), (4.0, 2.0, 2.5)),
+             # 64-plane slabs: the slab z-solve runs as forward / inverse HALVES of the fused z kernel (face values from sums over the
+             # spectrum, Woodbury correction applied in the z-spectral domain; dct.hip: dct_slab_split)
+             ((64, 64, 64 * world), (4.0, 4.0, 4.0 * world))]
     for ci, (dims, ls) in enumerate(cases):
         if only is not None and ci not in only:
             continue
@@ -343,9 +346,9 @@ def slab_checks(ctx, hip, rank, world, tag, only=None):
 # exchange in line; the transposed preconditioner; the two-pass Gram-Schmidt
 VARIANTS = [(("two_lanes", 1),), (("gmres_sstep", 0),), (("gmres_sstep", 0), ("two_lanes", 1)), (("gmres_sstep", 0), ("gmres_chunk", 1)),
             (("halo_overlap", 0),), (("dct_dist_slab", 0),), (("gmres_sstep", 0), ("gmres_gram", 0)),
-            (("gmres_stencil_free", 0), ("jvp_fused_dot_ranks", 0)), (("gmres_stencil_free", 2),)]
+            (("gmres_stencil_free", 0), ("jvp_fused_dot_ranks", 0)), (("gmres_stencil_free", 2),), (("dct_slab_split", 0),)]
 DEFAULTS = {"two_lanes": 0, "gmres_sstep": -1, "gmres_chunk": 4, "halo_overlap": 1, "dct_dist_slab": 1, "gmres_gram": 1,
-            "gmres_stencil_free": 1, "jvp_fused_dot_ranks": 1}
+            "gmres_stencil_free": 1, "jvp_fused_dot_ranks": 1, "dct_slab_split": 1}
 
 
 def main_gpu_many(rank, world):
@@ -361,8 +364,9 @@ def main_gpu_many(rank, world):
         for key, val in var:
             ctx.set_option(key, val)
         sf_var = any(k == "gmres_stencil_free" for k, _ in var)           # (those only matter where the stencil-free step can run)
+        split_var = any(k == "dct_slab_split" for k, _ in var)            # (... and this one where the half passes run)
         slab_checks(ctx, hip, rank, world, f"hostcomm x{world} {var}",
-                    only=(4,) if sf_var else ((0, 3) if var != (("two_lanes", 1),) else None))
+                    only=(6,) if split_var else ((4,) if sf_var else ((0, 3) if var != (("two_lanes", 1),) else (0, 1, 2, 3, 4, 5))))
         for key, _ in var:
             ctx.set_option(key, DEFAULTS[key])
     ctx.close()

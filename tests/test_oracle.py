@@ -440,6 +440,10 @@ def test_slab_zsolve_woodbury_equals_the_global_dct_inverse(n, R):
         f = rng.standard_normal(n)
         x, xe = Z.slab_zsolve(f, c, 1.0, R, a), Z.exact_zsolve(f, c, 1.0, a)
         worst = max(worst, np.abs(x - xe).max() / np.abs(xe).max())
+        # round 5: the same solve as forward / inverse HALVES (face values from sums over the spectrum, correction applied in the
+        # z-spectral domain) -- the form the HIP path takes for slabs of >= 64 planes
+        x2 = Z.slab_zsolve_split(f, c, 1.0, R, a)
+        worst = max(worst, np.abs(x2 - xe).max() / np.abs(xe).max())
     assert worst <= 1e-11, worst
 
 
