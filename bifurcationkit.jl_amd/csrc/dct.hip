@@ -78,8 +78,6 @@ int dense_mfma_pass(bk_ctx* ctx, int n0, int n1, int nb, int axis, int inverse, 
 struct SlabK;
 int slab_faces_gather(bk_ctx* ctx, const SlabK& P, const double* y, double* sbuf);
 int slab_faces_solve(bk_ctx* ctx, const SlabK& P, const double* rbuf, double* out);
-int slab_faces_gather_planes(bk_ctx* ctx, const SlabK& P, const double* yf, double* sbuf);
-int slab_faces_delta(bk_ctx* ctx, const SlabK& P, const double* rbuf, double* df);
 int slab_faces_correct(bk_ctx* ctx, const SlabK& P, const double* rbuf, double* f);
 struct SlabK {                                // kernel argument of dct_slab.hip (same definition there)
     int nx, ny, nl, R, rank;
@@ -606,7 +604,7 @@ static int slab_tables_create(bk_ctx* ctx, DctPlan* p, int nl, bool even, double
                 phi[k] = sk * std::cos(M_PI * (double)k / (2.0 * nl));                 // plane 0
                 phi[nl + k] = sk * std::cos(M_PI * 3.0 * (double)k / (2.0 * nl));      // plane 1
             }
-            const size_t fb = 8 * L;          // [4][L] all-to-all buffer + [4][L] face planes of the half passes (dct_apply_slab), each
+            const size_t fb = 4 * L;
             if (hipMalloc(&p->twid_loc, sizeof(double) * tw.size()) != hipSuccess ||
                 hipMalloc(&p->lam_loc, sizeof(double) * nl) != hipSuccess ||
                 hipMalloc(&p->phi_loc, sizeof(double) * 2 * nl) != hipSuccess ||
@@ -648,23 +646,19 @@ static int dct_apply_slab(bk_ctx* ctx, DctPlan* p, const double* v, double* out,
     double *a = p->t1, *b = p->t2;
     BK_TRY(pass(0, 0, p->twid[0], v, a, 0, nullptr));
     BK_TRY(pass(1, 0, p->twid[1], a, b, 0, nullptr));               // b = f (z-solve right-hand side, spectral in x, y)
-    if (ctx->opt("dct_slab_split", 1.0) != 0.0 && dct_slab_half_ok(ctx, nx, ny, nl, b, a)) {
+    if (ctx->opt("dct_slab_split", 1.0) != 0.0 && dct_slab_half_ok(ctx, nx, ny, nl, b, a) && K.Lr % 2 == 0) {
         // Round 5: the z solve as forward / inverse HALVES.  M^-1 f = B^-1 (f + delta) with delta supported on the four planes next to
         // the faces, and B^-1 = Phi diag(sym) Phi': the forward half leaves y^ = sym .* Phi' f and, from sums over the spectrum, the
         // values of y = B^-1 f at those planes (all the capacitance system needs); the correction sym_k sum_p phi_k(p) delta_p is a
         // pointwise update of y^ inside the inverse half.  Two single transforms instead of two round trips (the same 32 B/point of
-        // traffic through kernels that run at 0.72 instead of 0.45 of peak), and the gather / correct kernels touch [4][L] arrays only.
-        double *yf = p->fsend + 4 * K.L, *df = p->frecv + 4 * K.L;
+        // traffic), and the face gather / correction kernels are gone: the halves write and read the all-to-all buffers themselves.
         DctSlabHalf hf;
-        hf.phi = p->phi_loc; hf.L = K.L; hf.face_y = yf; hf.face_d = df;
+        hf.phi = p->phi_loc; hf.Lr = K.Lr; hf.a = K.a; hf.has_bottom = K.rank > 0; hf.has_top = K.rank < K.R - 1;
+        hf.face_y = p->fsend; hf.face_d = p->frecv;
         {
             ProfScope ps(ctx, "dct_pass", 16.0 * n3);
             BK_TRY(dct_axis_fft(ctx, nx, ny, nl, 2, 0, p->twid_loc, b, a, p->lam[0], p->lam[1], p->lam_loc, p->shift, 0, nullptr, nullptr,
-                                nullptr, &hf));                     // a = y^, yf = y at the face planes
-        }
-        {
-            ProfScope ps(ctx, "blas1", 8.0 * 8.0 * K.L);
-            BK_TRY(slab_faces_gather_planes(ctx, K, yf, p->fsend));
+                                nullptr, &hf));                     // a = y^; fsend = this rank's face data, per line owner
         }
         { ProfScope ps(ctx, "alltoall", 8.0 * 4.0 * K.L);
         BK_TRY(comm_alltoallv(ctx, p->fsend, p->cnt_s.data(), p->dsp_s.data(), p->frecv, p->cnt_s.data(), p->dsp_s.data())); }
@@ -675,13 +669,9 @@ static int dct_apply_slab(bk_ctx* ctx, DctPlan* p, const double* v, double* out,
         { ProfScope ps(ctx, "alltoall", 8.0 * 4.0 * K.L);
         BK_TRY(comm_alltoallv(ctx, p->fsend, p->cnt_s.data(), p->dsp_s.data(), p->frecv, p->cnt_s.data(), p->dsp_s.data())); }
         {
-            ProfScope ps(ctx, "blas1", 8.0 * 8.0 * K.L);
-            BK_TRY(slab_faces_delta(ctx, K, p->frecv, df));
-        }
-        {
             ProfScope ps(ctx, "dct_pass", 16.0 * n3);
             BK_TRY(dct_axis_fft(ctx, nx, ny, nl, 2, 1, p->twid_loc, a, b, p->lam[0], p->lam[1], p->lam_loc, p->shift, 0, nullptr, nullptr,
-                                nullptr, &hf));                     // b = Phi (y^ + sym .* Phi' delta) = M^-1 f
+                                nullptr, &hf));                     // b = Phi (y^ + sym .* Phi' delta) = M^-1 f, delta = -U nu from frecv
         }
         BK_TRY(pass(1, 1, p->twid[1], b, a, 0, nullptr));
         BK_TRY(pass(0, 1, p->twid[0], a, out, 0, nullptr));
@@ -846,7 +836,7 @@ bk_precond* precond_lane_shadow(bk_precond* pl, bk_ctx* lane) {
     q->t1 = q->t2 = q->fsend = q->frecv = nullptr;
     bool ok = ws_get(lane, q->total, &q->t1) == 0 && ws_get(lane, q->total, &q->t2) == 0;
     if (ok && P->plan->fsend) {                // slab z-solve: the face buffers are scratch too (4 doubles per line each)
-        const size_t fb = 8 * (size_t)q->n[0] * (size_t)q->n[1];
+        const size_t fb = 4 * (size_t)q->n[0] * (size_t)q->n[1];
         ok = ws_get(lane, fb, &q->fsend) == 0 && ws_get(lane, fb, &q->frecv) == 0;
     }
     if (!ok) {

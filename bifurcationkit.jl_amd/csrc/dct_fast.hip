@@ -59,13 +59,17 @@ struct FftK {
     const double* fz_v;
     double fzA, fzB, fzC, fz_cx, fz_ct;
     // SLAB kernels (z passes of the slab z-solve as forward / inverse HALVES, dct.hip: dct_apply_slab): the forward half stores
-    // y^_k = sym_k f^_k and the values of y = B^-1 f at the four planes next to the slab faces (face_y[p * face_L + line], p = planes
-    // 0, 1, nl-2, nl-1: sums over the spectrum with the local basis phi); the inverse half adds sym_k * sum_p phi_k(p) delta_p(line)
-    // -- the Woodbury correction, applied in the z-spectral domain -- before it transforms back
+    // y^_k = sym_k f^_k and, from sums over the spectrum with the local basis phi, the values of y = B^-1 f at the four planes next to
+    // the slab faces (planes 0, 1, nl-2, nl-1); the inverse half adds sym_k * sum_p phi_k(p) delta_p(line) -- the Woodbury correction,
+    // applied in the z-spectral domain -- before it transforms back
+    // The face data goes straight into / comes straight from the all-to-all buffers of the capacitance solve ([owner][4][Lr], dct_slab.hip):
+    // the forward half writes (u'y, w'y) of this rank's bottom and top face, the inverse half reads (nu_u, nu_w) of both faces.
     double* face_y;
     const double* face_d;
     const double* phi;        // [2][N]: local DCT-II basis at planes 0 and 1 (phi_k(N-1-z) = (-1)^k phi_k(z))
-    unsigned face_L;          // lines of the slab (n0 * n1)
+    unsigned face_Lr;         // lines per owner
+    double slab_a;            // 1 / h_z^2
+    int slab_hasb, slab_hast; // this rank has a bottom / a top neighbour
 };
 
 template <int NT>
@@ -457,11 +461,14 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
             const bool act = tid < nmid;
             const int pr = AX0 ? tid >> hbits : tid & (npairs - 1), t = AX0 ? tid & ((1 << hbits) - 1) : tid >> pbits;
             if (SLAB == 2) {
-                const size_t fb = (size_t)tile_other(tile) * P.n0 + (size_t)tile_x0(tile) + (size_t)(2 * pr);
+                // nu = (nu_u, nu_w) of the bottom and the top face for this lane's two lines; delta = -U nu on planes 0, 1, nl-2, nl-1 is
+                // formed when the per-line constants are known (below)
+                const size_t line = (size_t)tile_other(tile) * P.n0 + (size_t)tile_x0(tile) + (size_t)(2 * pr);
+                const size_t d = line / P.face_Lr, l = line - d * P.face_Lr;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const double2 d = *reinterpret_cast<const double2*>(P.face_d + (size_t)q * P.face_L + fb);
-                    dl[SLAB == 2 ? q : 0].x = d.x; dl[SLAB == 2 ? q : 0].y = d.y;
+                    const double2 v2 = *reinterpret_cast<const double2*>(P.face_d + (d * 4 + q) * (size_t)P.face_Lr + l);
+                    dl[SLAB == 2 ? q : 0].x = v2.x; dl[SLAB == 2 ? q : 0].y = v2.y;
                 }
             }
             const unsigned o = AX0 ? (unsigned)(2 * pr) * lstride : 2u * pr;
@@ -559,6 +566,17 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
             lo2 = P.axis == 1 ? (P.lam2 ? P.lam2[other] : 0.0) : 0.0;
             ca = 1.0 + P.lam0[i0] + l1;
             cb = 1.0 + P.lam0[i0 + 1] + l1;
+        }
+        if (SLAB == 2) {
+            // delta_0 = (c - a) nu_u^b + nu_w^b, delta_1 = a nu_u^b (bottom face); delta_{nl-2} = -a nu_u^t, delta_{nl-1} = -((c - a) nu_u^t + nu_w^t)
+            constexpr int I1 = SLAB == 2 ? 1 : 0, I2 = SLAB == 2 ? 2 : 0, I3 = SLAB == 2 ? 3 : 0;
+            const double a_ = P.slab_a;
+            const c2 nub_u = dl[0], nub_w = dl[I1], nut_u = dl[I2], nut_w = dl[I3];
+            const double hb = P.slab_hasb ? 1.0 : 0.0, ht = P.slab_hast ? 1.0 : 0.0;
+            dl[0].x = hb * ((ca - a_) * nub_u.x + nub_w.x); dl[0].y = hb * ((cb - a_) * nub_u.y + nub_w.y);
+            dl[I1].x = hb * (a_ * nub_u.x); dl[I1].y = hb * (a_ * nub_u.y);
+            dl[I2].x = -ht * (a_ * nut_u.x); dl[I2].y = -ht * (a_ * nut_u.y);
+            dl[I3].x = -ht * ((ca - a_) * nut_u.x + nut_w.x); dl[I3].y = -ht * ((cb - a_) * nut_u.y + nut_w.y);
         }
         if (MODE != 1) {
             if (AX0) {
@@ -672,10 +690,16 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
                 for (int t = 0; t < (G >> 1); ++t)
 #pragma unroll
                     for (int q = 0; q < 8; ++q) acc[q] += sc[(size_t)(tid + npairs * t) * 8 + q];
-                const size_t fb = (size_t)other * P.n0 + (size_t)x0 + (size_t)(2 * tid);
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<double2*>(P.face_y + (size_t)q * P.face_L + fb) = make_double2(acc[2 * q], acc[2 * q + 1]);
+                // acc = (y0, y1, y_{nl-2}, y_{nl-1}) of lines a / b: the face data of the capacitance system (dct_slab.hip: slab_face_gather),
+                // (u'y, w'y) of the bottom face (this rank is the q side) and of the top face (the p side), into the owner's [4][Lr] block
+                const size_t line = (size_t)other * P.n0 + (size_t)x0 + (size_t)(2 * tid);
+                const size_t d = line / P.face_Lr, l = line - d * P.face_Lr;
+                double* o = P.face_y + d * 4 * (size_t)P.face_Lr + l;
+                const double a_ = P.slab_a, hb = P.slab_hasb ? 1.0 : 0.0, ht = P.slab_hast ? 1.0 : 0.0;
+                *reinterpret_cast<double2*>(o) = make_double2(hb * (-(ca - a_) * acc[0] - a_ * acc[2]), hb * (-(cb - a_) * acc[1] - a_ * acc[3]));
+                *reinterpret_cast<double2*>(o + P.face_Lr) = make_double2(-hb * acc[0], -hb * acc[1]);
+                *reinterpret_cast<double2*>(o + 2 * (size_t)P.face_Lr) = make_double2(ht * (a_ * acc[4] + (ca - a_) * acc[6]), ht * (a_ * acc[5] + (cb - a_) * acc[7]));
+                *reinterpret_cast<double2*>(o + 3 * (size_t)P.face_Lr) = make_double2(ht * acc[6], ht * acc[7]);
             }
         }
         if (MODE == 0) {
@@ -784,11 +808,13 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
                  int fuse_scale, const DctSplit* split, int* dot_blocks, const DctFuse* fz, const DctSlabHalf* sh) {
     FftK P;
     P.dotp = nullptr;
-    P.face_y = nullptr; P.face_d = nullptr; P.phi = nullptr; P.face_L = 0;
+    P.face_y = nullptr; P.face_d = nullptr; P.phi = nullptr; P.face_Lr = 0; P.slab_a = 0.0; P.slab_hasb = P.slab_hast = 0;
     if (sh) {
         if (!dct_slab_half_ok(ctx, n0, n1, n2, in, out) || axis != 2 || fuse_scale != 0 || split || fz)
             return set_error(ctx, "dct_axis_fft: the slab half passes need the fused z-axis kernel (dct_slab_half_ok)");
-        P.face_y = sh->face_y; P.face_d = sh->face_d; P.phi = sh->phi; P.face_L = (unsigned)sh->L;
+        if (sh->Lr % 2 != 0) return set_error(ctx, "dct_axis_fft: slab half passes need an even number of lines per owner");
+        P.face_y = sh->face_y; P.face_d = sh->face_d; P.phi = sh->phi; P.face_Lr = (unsigned)sh->Lr; P.slab_a = sh->a;
+        P.slab_hasb = sh->has_bottom ? 1 : 0; P.slab_hast = sh->has_top ? 1 : 0;
     }
     P.fz_v = nullptr; P.fzA = 1.0; P.fzB = P.fzC = 0.0; P.fz_cx = 0.0; P.fz_ct = 1.0;
     // the pointwise work this pass is asked to take in: the factor on a forward pass, the axpy on an inverse one

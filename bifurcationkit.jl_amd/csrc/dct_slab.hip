@@ -53,45 +53,6 @@ __global__ void __launch_bounds__(256) slab_face_gather(SlabK P, const double* _
     o[3 * P.Lr] = hast ? yt0 : 0.0;
 }
 
-// the same from the four face planes the forward half pass left in yf[4][L] (planes 0, 1, nl-2, nl-1; dct_fast.hip: SLAB 1)
-__global__ void __launch_bounds__(256) slab_face_gather_planes(SlabK P, const double* __restrict__ yf, double* __restrict__ sbuf) {
-    const size_t line = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (line >= P.L) return;
-    const int ix = (int)(line % P.nx), iy = (int)(line / P.nx);
-    const double c = 1.0 + P.lam0[ix] + P.lam1[iy];
-    const double y0 = yf[line], y1 = yf[P.L + line], yt1 = yf[2 * P.L + line], yt0 = yf[3 * P.L + line];
-    const size_t d = line / P.Lr, l = line - d * P.Lr;
-    double* o = sbuf + d * 4 * P.Lr + l;
-    const bool hasb = P.rank > 0, hast = P.rank < P.R - 1;
-    o[0] = hasb ? -(c - P.a) * y0 - P.a * y1 : 0.0;
-    o[P.Lr] = hasb ? -y0 : 0.0;
-    o[2 * P.Lr] = hast ? P.a * yt1 + (c - P.a) * yt0 : 0.0;
-    o[3 * P.Lr] = hast ? yt0 : 0.0;
-}
-
-// delta = -U nu on the four planes next to this rank's faces, as its own [4][L] array (what slab_face_correct adds to f): the
-// inverse half pass applies B^-1 to it in the z-spectral domain (dct_fast.hip: SLAB 2)
-__global__ void __launch_bounds__(256) slab_face_delta(SlabK P, const double* __restrict__ rbuf, double* __restrict__ df) {
-    const size_t line = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (line >= P.L) return;
-    const int ix = (int)(line % P.nx), iy = (int)(line / P.nx);
-    const double c = 1.0 + P.lam0[ix] + P.lam1[iy];
-    const size_t d = line / P.Lr, l = line - d * P.Lr;
-    const double* nu = rbuf + d * 4 * P.Lr + l;
-    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
-    if (P.rank > 0) {                                         // bottom face: planes 0, 1
-        const double nu_u = nu[0], nu_w = nu[P.Lr];
-        d0 = (c - P.a) * nu_u + nu_w;
-        d1 = P.a * nu_u;
-    }
-    if (P.rank < P.R - 1) {                                   // top face: planes nl-2, nl-1
-        const double nu_u = nu[2 * P.Lr], nu_w = nu[3 * P.Lr];
-        d2 = -P.a * nu_u;
-        d3 = -((c - P.a) * nu_u + nu_w);
-    }
-    df[line] = d0; df[P.L + line] = d1; df[2 * P.L + line] = d2; df[3 * P.L + line] = d3;
-}
-
 struct M2 { double a, b, c, d; };      // [[a, b], [c, d]]
 __device__ __forceinline__ M2 inv2(M2 m) {
     const double r = 1.0 / (m.a * m.d - m.b * m.c);
@@ -201,16 +162,6 @@ __global__ void __launch_bounds__(256) slab_face_correct(SlabK P, const double* 
 
 int slab_faces_gather(bk_ctx* ctx, const SlabK& P, const double* y, double* sbuf) {
     hipLaunchKernelGGL(slab_face_gather, dim3((unsigned)((P.L + 255) / 256)), dim3(256), 0, ctx->stream, P, y, sbuf);
-    BK_HIP(ctx, hipGetLastError());
-    return 0;
-}
-int slab_faces_gather_planes(bk_ctx* ctx, const SlabK& P, const double* yf, double* sbuf) {
-    hipLaunchKernelGGL(slab_face_gather_planes, dim3((unsigned)((P.L + 255) / 256)), dim3(256), 0, ctx->stream, P, yf, sbuf);
-    BK_HIP(ctx, hipGetLastError());
-    return 0;
-}
-int slab_faces_delta(bk_ctx* ctx, const SlabK& P, const double* rbuf, double* df) {
-    hipLaunchKernelGGL(slab_face_delta, dim3((unsigned)((P.L + 255) / 256)), dim3(256), 0, ctx->stream, P, rbuf, df);
     BK_HIP(ctx, hipGetLastError());
     return 0;
 }

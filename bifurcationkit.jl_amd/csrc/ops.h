@@ -90,13 +90,17 @@ struct DctSplit {
     unsigned plane;
 };
 // z passes of the slab z-solve as forward / inverse halves (dct_slab.hip, dct.hip: dct_apply_slab): the forward half (inverse = 0)
-// stores y^ = sym .* f^ and the values of y = B^-1 f at the four planes next to the slab faces in face_y[4][L]; the inverse half
-// (inverse = 1) adds the Woodbury correction sym_k sum_p phi_k(p) face_d[p][line] in the z-spectral domain and transforms back.
+// stores y^ = sym .* f^ and writes the face data of the capacitance system -- (u'y, w'y) of this rank's two faces, from the values of
+// y = B^-1 f at the four planes next to them -- into the all-to-all send buffer face_y ([owner][4][Lr]); the inverse half (inverse = 1)
+// reads the solution (nu_u, nu_w) of both faces from the receive buffer face_d, forms delta = -U nu, adds sym_k sum_p phi_k(p) delta_p
+// in the z-spectral domain and transforms back.
 struct DctSlabHalf {
     double* face_y = nullptr;
     const double* face_d = nullptr;
     const double* phi = nullptr;      // [2][nl] local DCT-II basis at planes 0, 1
-    size_t L = 0;                     // lines of the slab (n0 * n1)
+    size_t Lr = 0;                    // lines per owner (even)
+    double a = 0.0;                   // 1 / h_z^2
+    bool has_bottom = false, has_top = false;
 };
 int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, const double* twid, const double* in,
                  double* out, const double* symx, const double* symy, const double* symz, double shift, int fuse_scale,
