@@ -162,6 +162,11 @@ struct bk_op {              // a linear operator on (device vector [+ one host t
     // true: GMRES builds its Krylov space on A itself and applies (alpha0, alpha1) to the Hessenberg matrix whatever the flavor
     // (the space of alpha0 + alpha1 A is the space of A; the iterates are the same) -- for operators whose shift costs a stream
     virtual bool hessenberg_shift() const { return false; }
+    // The shift theta0 of the blocks that have no Ritz values yet ("monomial" blocks p_{i+1} = (A - theta0) p_i): 0 for an ordinary
+    // operator.  An operator that iterates on a rearranged form A = W + theta0 I of the operator W the solve is about (solver.hip:
+    // ShiftPrecOp, T = Pl^-1 J + I) returns theta0, so that its first block is built on powers of W as before the rearrangement --
+    // powers of the compact part T alone collapse onto its few dominant eigenvectors and the block truncates (measured).
+    virtual double monomial_shift() const { return 0.0; }
 };
 
 struct bk_precond {

@@ -14,6 +14,7 @@
 // (re-orthogonalise with a second A/B pair only when beta < eta ||w||).  The Hessenberg matrix, Givens
 // rotations, the (a0, a1) shift and the restart logic stay on the host, as in the packages.
 #include <cmath>
+#include <cstdio>
 #include <thread>
 #include <vector>
 
@@ -353,12 +354,16 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
         for (const auto& e : ev) pts.push_back(e.real());
         std::vector<double> lj;
         std::vector<char> used(pts.size(), 0);
+        // Leja order: the first point is the one farthest from the origin of the operator the solve is about -- for an operator that
+        // iterates on a rearranged form A = W + theta0 I (bk_op::monomial_shift) that origin sits at theta0, so the order (and with it the
+        // blocks' conditioning) is the one the literal operator W would get: the later points only depend on mutual distances
+        const double origin = A->monomial_shift();
         for (int t = 0; t < sstep::kS && t < (int)pts.size(); ++t) {
             int best = -1;
             double bv = -1.0;
             for (size_t i = 0; i < pts.size(); ++i) {
                 if (used[i]) continue;
-                double v = t == 0 ? std::fabs(pts[i]) : 1.0;
+                double v = t == 0 ? std::fabs(pts[i] - origin) : 1.0;
                 for (double q : lj) v *= std::fabs(pts[i] - q);
                 if (v > bv) { bv = v; best = (int)i; }
             }
@@ -436,8 +441,13 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
                 double ratio = 0.0;
                 double theta[sstep::kS] = {0.0, 0.0, 0.0, 0.0};
                 for (int i = 0; i < steps && !shifts.empty(); ++i) theta[i] = shifts[i % shifts.size()];
-                BK_TRY(arnoldi_block(ctx, A, B, j, steps, Hraw.data(), ldh, op_a0, op_a1, &got, &ratio, shifts.empty() ? nullptr : theta,
+                const double mono = shifts.empty() ? A->monomial_shift() : 0.0;      // (blocks without Ritz values: bk_op::monomial_shift)
+                if (mono != 0.0) for (int i = 0; i < steps; ++i) theta[i] = mono;
+                BK_TRY(arnoldi_block(ctx, A, B, j, steps, Hraw.data(), ldh, op_a0, op_a1, &got, &ratio, (shifts.empty() && mono == 0.0) ? nullptr : theta,
                                      ctx->opt("gmres_defer_update", 1.0) != 0.0 ? &pend : nullptr));
+                if (ctx->opt("gmres_block_log", 0.0) != 0.0)
+                    fprintf(stderr, "bk block: solve n=%zu j=%d steps=%d got=%d last_pivot_ratio=%.2e theta=[%.3g %.3g %.3g %.3g] beta=%.3e tol=%.3e\n", n, j, steps,
+                            got, ratio, theta[0], theta[1], theta[2], theta[3], beta_now, tol_now);
                 if (got < steps && shifts_carried) { shifts.clear(); shifts_carried = false; }     // a stale set: back to the monomial block
                 if (got > 0 && !shifts_carried && ((int)shifts.size() < sstep::kS || j + got <= 12)) ritz_shifts(j + got);
                 // diagnostics (bench.py reports them): operator applications issued by blocks / of those void (truncated tails)
@@ -737,6 +747,10 @@ struct ShiftPrecOp : bk_op {
     }
     bool shift_is_free() const override { return Pr ? false : (P ? (fold || tmode) : J->shift_is_free()); }
     bool hessenberg_shift() const override { return tmode; }
+    // T = W + I (order 0), T' = W' + a1 I (order 1): the first block of a solve runs on powers of W (W'), see bk_op::monomial_shift
+    double monomial_shift() const override {
+        return tmode && ctx->opt("gmres_monomial_shift", 1.0) != 0.0 ? (order == 0 ? 1.0 : a1) : 0.0;
+    }
     int apply(const double* x, const double*, double b0, double b1, double* out, double*) override {
         // out = b0 x + b1 * W(x)
         if (tmode) return P->apply_pw(x, pw, b0, b1, out);      // W = T (T'): see above
