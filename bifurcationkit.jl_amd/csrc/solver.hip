@@ -357,7 +357,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
         // Leja order: the first point is the one farthest from the origin of the operator the solve is about -- for an operator that
         // iterates on a rearranged form A = W + theta0 I (bk_op::monomial_shift) that origin sits at theta0, so the order (and with it the
         // blocks' conditioning) is the one the literal operator W would get: the later points only depend on mutual distances
-        const double origin = A->monomial_shift();
+        const double origin = ctx->opt("gmres_leja_origin", 1.0) != 0.0 ? A->monomial_shift() : 0.0;
         for (int t = 0; t < sstep::kS && t < (int)pts.size(); ++t) {
             int best = -1;
             double bv = -1.0;
@@ -385,6 +385,12 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     // stream from HBM a wasted step is a whole operator application; the cache-resident sizes keep the plain ramp
     // (option gmres_predict: 1 = always, 0 = never, default: HBM-sized vectors and RCCL ranks).
     const bool predict = ctx->opt("gmres_predict", (rccl_ranks || sstep_on || n > ((size_t)1 << 20)) ? 1.0 : 0.0) != 0.0;
+    // (the prediction asks for the estimate to reach pmargin x tolerance: option gmres_predict_margin, default 1.  An optimistic prediction
+    // costs a whole extra block -- projection pass, update pass, synchronisation: 4-5 ms at 512^3 -- for the one step it missed, a
+    // pessimistic one at most one operator application past convergence (3.6 ms), and the estimate of a nearly converged solve flattens
+    // out rather than speeds up.  Rounds 3-4 used 2: measured in round 5 on two sizes x two block orderings, 1 wins every pairing
+    // (512^3 headline 98 -> 92 ms; profiles/r5_predict_margin_leja_sweep.txt))
+    const double pmargin = ctx->opt("gmres_predict_margin", 1.0);
     double beta_prev = 0.0, beta_now = 0.0, tol_now = 0.0;
     double* d_coef = nullptr;
     const double* h_rec = ctx->h_rec;          // the records land in pinned, device-mapped host memory: no copy operation
@@ -433,7 +439,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
                 if (predict && steps > 1 && beta_now > 0.0) {
                     const double rho = (beta_prev > 0.0 && beta_now < beta_prev) ? beta_now / beta_prev : 1.0;
                     int need = 1;
-                    for (double b_ = beta_now * rho; b_ > 2.0 * tol_now && need < steps; b_ *= rho) ++need;
+                    for (double b_ = beta_now * rho; b_ > pmargin * tol_now && need < steps; b_ *= rho) ++need;
                     predicted = need < steps;
                     steps = need;
                 }
@@ -478,7 +484,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
                 if (predict && steps > 1 && beta_now > 0.0) {
                     const double rho = (beta_prev > 0.0 && beta_now < beta_prev) ? beta_now / beta_prev : 1.0;
                     int need = 1;
-                    for (double b_ = beta_now * rho; b_ > 2.0 * tol_now && need < steps; b_ *= rho) ++need;
+                    for (double b_ = beta_now * rho; b_ > pmargin * tol_now && need < steps; b_ *= rho) ++need;
                     steps = need;
                 }
                 ramp = std::min(chunk, 2 * ramp);
