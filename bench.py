@@ -560,6 +560,9 @@ def main():
                                    f"Pl = (L1+shift)^-1 (DCT), BorderingBLS",
                        "grid": [n, n, nzz], "unknowns": prob.nglobal, "parallelism": f"z-slabs x{world}",
                        "itlinear_per_step": last["itlineartot"], "residual_after_step": last["residuals"][-1],
+                       # (the count moves between 24 and 26 with the last digits of the cell solutions: from the 8th Arnoldi step on the
+                       # solve fits the rounding noise of its own right-hand side -- compare rounds by this figure)
+                       "ms_per_operator_application": ms / max(last["itlineartot"], 1),
                        "cell": list(CELL), "tiles": list(tiles), "h": [2 * l / c for l, c in zip(CELL_L, CELL)],
                        "precond_shift": args.shift, "state": "z-invariant hexagons (stable), l = 0.1, nu = 1.2",
                        "cell_umax": c0["u"].norminf(),
