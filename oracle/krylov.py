@@ -206,13 +206,15 @@ def gmres_krylovkit(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-
     return x, False, numops, beta
 
 
-def leja_shifts(H, kk, count=4):
-    """Up to ``count`` real parts of the eigenvalues of H[:kk, :kk] in Leja order (largest modulus first, then the point that
-    maximises the product of distances to those already chosen): the Newton shifts of the library's block Arnoldi step."""
+def leja_shifts(H, kk, count=4, origin=0.0):
+    """Up to ``count`` real parts of the eigenvalues of H[:kk, :kk] in Leja order (the point farthest from ``origin`` first, then the
+    point that maximises the product of distances to those already chosen): the Newton shifts of the library's block Arnoldi step.
+    ``origin``: 0 for an ordinary operator; an operator iterated in the rearranged form A = W + theta0 I passes theta0, the origin
+    of W (csrc/solver.hip: ritz_shifts, bk_op::monomial_shift), so that the order is the one W itself would get."""
     pts = list(np.linalg.eigvals(H[:kk, :kk]).real)
     out = []
     while pts and len(out) < count:
-        score = [abs(p) if not out else float(np.prod([abs(p - q) for q in out])) for p in pts]
+        score = [abs(p - origin) if not out else float(np.prod([abs(p - q) for q in out])) for p in pts]
         out.append(pts.pop(int(np.argmax(score))))
     return out
 
@@ -256,7 +258,8 @@ def block_arnoldi_coefficients(G, H, k, u, s, Aq, Gp, pivot_tol=1e-8, theta=None
 
 
 def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, rtol=1e-12, Pl=None, block=4,
-                history=None, basis_out=None, stats=None, newton=True, shifts=None, keep_shifts=False, defer=True):
+                history=None, basis_out=None, stats=None, newton=True, shifts=None, keep_shifts=False, defer=True,
+                mono_shift=0.0, predict_margin=1.0):
     """The library's GMRES for vectors that stream from HBM since round 4, restated (csrc/solver.hip: gmres_core with
     arnoldi_block): KrylovKit's restarted GMRES -- same stopping rules, restart and numops bookkeeping as gmres_krylovkit
     above -- whose Arnoldi steps are taken in BLOCKS of up to ``block``: p_1 = A q_j, .., p_s = A p_{s-1}, then ONE pass of
@@ -267,14 +270,18 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
     cases at hand (``stats['wasted']``); numops counts consumed steps, as the library does.  ``defer``: the update pass of a
     block (Q_new = R^-T (P - C'Q)) waits until the new vectors are needed explicitly -- the next block, a restart's residual
     -- and a solve that ends inside the block folds it into the solution update, x += Q (y_old - C R^-1 y_new) + P (R^-1
-    y_new) (csrc/solver.hip: PendingBlock; ``stats['folded']`` counts those).  Not a reference algorithm: the tests show it
-    reproduces the reference restatement's counts, residual history and solution."""
+    y_new) (csrc/solver.hip: PendingBlock; ``stats['folded']`` counts those).  ``mono_shift`` (round 5): the operator is iterated in
+    the rearranged form A = W + mono_shift I (the stencil-free preconditioned operator T = Pl^-1 J + I); blocks without Ritz values then
+    run on powers of W, p_{i+1} = (A - mono_shift) p_i, and the Leja order of the Newton shifts starts from the point farthest from
+    W's origin -- the blocks are W's blocks.  ``predict_margin``: the speculated block length aims at margin x tolerance (library
+    option gmres_predict_margin, 1 since round 5).  Not a reference algorithm: the tests show it reproduces the reference
+    restatement's counts, residual history and solution."""
     if Pl is not None:
         A_, a0_, a1_ = A, a0, a1
         lin = lambda dx: a1_ * Pl(apply(A_, dx)) + a0_ * dx
         return gmres_block(lin, Pl(np.asarray(b, dtype=float)), 0.0, 1.0, krylovdim=krylovdim, maxiter=maxiter, atol=atol,
                            rtol=rtol, block=block, history=history, basis_out=basis_out, stats=stats, newton=newton,
-                           shifts=shifts, keep_shifts=keep_shifts, defer=defer)
+                           shifts=shifts, keep_shifts=keep_shifts, defer=defer, mono_shift=mono_shift, predict_margin=predict_margin)
     b = np.asarray(b, dtype=float)
     n = b.shape[0]
     x = np.zeros(n)
@@ -323,7 +330,7 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
             if res_prev is not None and sb > 1:
                 rho = res / res_prev if res < res_prev else 1.0
                 need, bb = 1, res * rho
-                while bb > 2.0 * tol and need < sb:
+                while bb > predict_margin * tol and need < sb:
                     bb *= rho
                     need += 1
                 predicted = need < sb
@@ -332,7 +339,7 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
             if not classic:
                 P = np.zeros((sb, n))
                 p = Q[j]
-                theta = [shifts[i % len(shifts)] for i in range(sb)] if shifts else None
+                theta = [shifts[i % len(shifts)] for i in range(sb)] if shifts else ([mono_shift] * sb if mono_shift != 0.0 else None)
                 for i in range(sb):
                     p = apply(A, p) - (theta[i] * p if theta else 0.0)
                     P[i] = p
@@ -356,7 +363,7 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
                     if got < sb and carried:
                         shifts, carried = [], False
                     if newton and not carried and (len(shifts) < 4 or j + got <= 12):
-                        shifts = leja_shifts(H, j + got)
+                        shifts = leja_shifts(H, j + got, origin=mono_shift)
                     if got < sb:
                         blk_cur = got
                     elif not capped and not predicted and blk_cur < block and ratio >= 1e-4:

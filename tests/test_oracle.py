@@ -537,9 +537,14 @@ def test_block_arnoldi_gmres_reproduces_the_reference_restatement():
             xb, okb, nb, _ = krylov.gmres_block(c["A"], rhs, c["a0"], c["a1"], krylovdim=c["krylovdim"], maxiter=60, rtol=c["rtol"],
                                                 atol=1e-14, Pl=c["Pl"], block=block, history=hb, basis_out=basis, stats=st)
             assert okm and okb and nb == nm, (c["krylovdim"], block, nb, nm)
-            # no consumed-then-discarded step, no refused block; a block may be truncated where its vectors lose independence
-            # (its tail applications are void: at most a few per solve, the next blocks are sized accordingly)
-            assert st["wasted"] == 0 and st["refused"] == 0 and max(st["blocks"]) <= block and st["void"] <= 0.05 * nb + 3, st
+            # no refused block; a block may be truncated where its vectors lose independence (its tail applications are void: at most a
+            # few per solve, the next blocks are sized accordingly); with the speculation margin at 1 x tolerance (round 5) a solve may
+            # issue a few applications past convergence (discarded, not counted: numops above is exact) -- none with the margin at 2
+            assert st["wasted"] <= 0.02 * nb + 2 and st["refused"] == 0 and max(st["blocks"]) <= block and st["void"] <= 0.05 * nb + 3, st
+            st2 = {}
+            nb2 = krylov.gmres_block(c["A"], rhs, c["a0"], c["a1"], krylovdim=c["krylovdim"], maxiter=60, rtol=c["rtol"], atol=1e-14,
+                                     Pl=c["Pl"], block=block, stats=st2, predict_margin=2.0)[2]
+            assert nb2 == nm and st2["wasted"] == 0, (block, nb2, nm, st2["wasted"])
             k = min(len(hm), len(hb))
             assert np.allclose(hb[:k], hm[:k], rtol=1e-3, atol=1e-13 * hm[0])
             assert np.abs(xb - xm).max() <= 1e-11 * np.abs(xm).max()
@@ -613,6 +618,23 @@ def test_stencil_free_form_of_the_preconditioned_operator_is_the_same_krylov_pro
             assert np.abs(x1 - x0).max() <= 1e-8 * np.abs(x0).max()
             k = min(len(h0), len(h1), 12)
             assert np.allclose(h0[:k], h1[:k], rtol=1e-6, atol=0.0), (h0[:k], h1[:k])
+        # ... and the library's BLOCK Arnoldi process on T is, block for block, the one on the literal operator W = Pl^-1 J when the
+        # shift-less first block runs on powers of W (mono_shift) and the Leja order of the Newton shifts is taken from W's origin
+        hw, ht, sw, st = [], [], {}, {}
+        xw, okw, nw, _ = krylov.gmres_block(J, rhs, 0.0, 1.0, krylovdim=30, maxiter=200, rtol=1e-10, atol=0.0, Pl=Po, history=hw, stats=sw)
+        xt, okt, nt_, _ = krylov.gmres_block(T, Po(rhs), -1.0, 1.0, krylovdim=30, maxiter=200, rtol=1e-10, atol=0.0, history=ht, stats=st,
+                                             mono_shift=1.0)
+        nk = krylov.gmres_krylovkit(J, rhs, 0.0, 1.0, krylovdim=30, maxiter=200, rtol=1e-10, atol=0.0, Pl=Po)[2]
+        assert okw and okt and nt_ == nk, (s, nw, nt_, nk)              # the stencil-free blocks reproduce MGS2's count for both shifts
+        if s == 1.0:                                                    # (well conditioned: the two block runs agree block for block)
+            assert nw == nt_ and sw["blocks"] == st["blocks"] and sw["void"] == st["void"], (s, nw, nt_, sw["blocks"], st["blocks"])
+            assert np.allclose(sorted(sw["shifts"]), sorted(np.asarray(st["shifts"]) - 1.0), rtol=0, atol=1e-6)
+            assert np.allclose(hw[:10], ht[:10], rtol=1e-6)
+        else:
+            # s = 0 (Pl = L1, ill conditioned on this grid): the literal form loses a few digits to the cancellation in W v = -v + T v
+            # and needs a restart (36 applications), the stencil-free form does not (30, MGS2's count)
+            assert nw >= nt_, (nw, nt_)
+        assert np.abs(xw - xt).max() <= 1e-7 * np.abs(xw).max()
         a0, a1 = -0.4, 1.1
         T1 = lambda v: Po((a0 + a1 * s + a1 * g) * v)
         xa, oka, ita = krylov.gmres_iterativesolvers(J, rhs, a0, a1, restart=30, maxiter=400, reltol=1e-10, Pl=Po)
