@@ -164,8 +164,9 @@ struct bk_op {              // a linear operator on (device vector [+ one host t
     virtual bool hessenberg_shift() const { return false; }
     // The shift theta0 of the blocks that have no Ritz values yet ("monomial" blocks p_{i+1} = (A - theta0) p_i): 0 for an ordinary
     // operator.  An operator that iterates on a rearranged form A = W + theta0 I of the operator W the solve is about (solver.hip:
-    // ShiftPrecOp, T = Pl^-1 J + I) returns theta0, so that its first block is built on powers of W as before the rearrangement --
-    // powers of the compact part T alone collapse onto its few dominant eigenvectors and the block truncates (measured).
+    // ShiftPrecOp, T = Pl^-1 J + I) returns theta0: its first block then is the literal operator's first block, and the Leja order of
+    // the later Newton shifts is taken from W's origin (solver.hip: ritz_shifts) -- the order relative to T's origin truncated a block
+    // per solve on running branches (measured; powers of T themselves are the better-conditioned first block: DESIGN 10).
     virtual double monomial_shift() const { return 0.0; }
 };
 
