@@ -1,5 +1,7 @@
 #!/bin/bash
-# GPU-box runs of round 4, one script, parts selected by name:   bash scripts/gpu_evidence.sh <part> [<part> ...]
+# GPU-box runs (rounds 4-5), one script, parts selected by name:   bash scripts/gpu_evidence.sh <part> [<part> ...]   (TAG=r5 ...)
+# (the box shows 256 logical CPUs under a 16-CPU cgroup quota: anything OpenMP must be pinned to the quota -- scripts/cpu_diag.sh,
+#  bench.available_cpus(); the full-size parity tests and bench.py's CPU baseline do that themselves)
 #   leads     start-offset / LDS-layout sweep of the hot kernels (both layouts), then bench.py with the winning options
 #   tests     pytest -m gpu + smoke   (6 min serial; `-n 3 --dist loadfile` was tried: ~5 min, tests/test_gpu_parity.py keeps one worker busy)
 #   newtests  only the tests added this round (TESTS_K = pytest -k expression)
