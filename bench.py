@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--workload", default="corrector", choices=["corrector", "branch"],
                     help="corrector: the BASELINE metric (PALC corrector steps/s); branch: BASELINE config 5 -- --steps native "
                          "continuation steps (corrector + 15 eigenvalues + Bordered tangent + predictor per step)")
+    ap.add_argument("--block-log", action="store_true", help="after the timed region, repeat the step once with the block log on and "
+                                                             "report every Arnoldi block (config.block_log)")
+    ap.add_argument("--no-fixed", action="store_true", help="skip the fixed_input record (the step from the committed cell states)")
     ap.add_argument("--no-steady", action="store_true", help="skip the steady-state record (corrector of a running branch)")
     ap.add_argument("--nev", type=int, default=15)
     ap.add_argument("--eig-tol", type=float, default=1e-8)
@@ -425,6 +428,55 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- fixed input (VERDICT r5 Next 7): the SAME step from the committed cell solutions tests/golden/bench_cell_states.npz
+    # (CPU oracle, generated once: scripts/gen_bench_cell_states.py) -- its operator-application count does not depend on the last
+    # digits of this build's own cell Newton solves, so two builds can be compared by it
+    fixed = None
+    fx = os.path.join(ROOT, "tests", "golden", "bench_cell_states.npz")
+    if os.path.exists(fx) and not args.no_fixed and args.shift == 1.0:
+        import numpy as np
+        d = np.load(fx)
+        if tuple(int(v) for v in d["cell"]) == CELL:
+            dev = ctx.torch_device
+            tl_ = lambda a: hip.HipVec(ctx, tile_cell(torch.from_numpy(np.ascontiguousarray(a)).to(dev), tiles, prob.slab, dev), prob.nglobal)
+            fz0, fz1 = B(tl_(d["u0"]), float(d["p0"])), B(tl_(d["u1"]), float(d["p1"]))
+            ftau = fz1.copy().add_(fz0, -1.0)
+            fn_ = math.sqrt(ftau.u.inner(ftau.u) / prob.nglobal * theta + ftau.p * ftau.p * (1 - theta))
+            ftau.scale_(math.copysign(1.0, ds) / fn_)
+            fpred = fz0.copy().add_(ftau, ds)
+            fstep = lambda: hip.newton_palc_native(prob, fz0, ftau, fpred, ds, theta, bls, tol=0.0, max_iterations=1,
+                                                   p_min=-0.1, p_max=0.15, norm_inf=True)
+            for _ in range(min(args.warmup, 2)):
+                fl = fstep()
+            barrier()
+            tf0 = time.perf_counter()
+            nf = max(1, min(args.steps, 10))
+            for _ in range(nf):
+                fl = fstep()
+            barrier()
+            fms = (time.perf_counter() - tf0) / nf * 1e3
+            fixed = {"what": "the same corrector pass started from the committed cell solutions tests/golden/bench_cell_states.npz "
+                             "(CPU oracle, scripts/gen_bench_cell_states.py) instead of this build's own cell Newton solves",
+                     "steps": nf, "ms_per_step": fms, "steps_per_s": 1e3 / fms, "itlinear": fl["itlineartot"],
+                     "ms_per_operator_application": fms / max(fl["itlineartot"], 1), "residuals": fl["residuals"], "p": fl["u"].p}
+            del fz0, fz1, ftau, fpred
+
+    # ---- block log: the timed step once more with the library's block log on (bk_solver_block_log): per Arnoldi block the steps
+    # issued / accepted, the last pivot ratio (conditioning margin against the truncation threshold 1e-8) and the Newton shifts
+    block_log = None
+    if args.block_log:
+        ctx.set_option("gmres_block_log", 1)
+        ctx.solver_block_log()
+        bl = one_step()
+        recs = ctx.solver_block_log()
+        ctx.set_option("gmres_block_log", 0)
+        clean = lambda r: {k_: (None if isinstance(v_, float) and v_ != v_ else v_) for k_, v_ in r.items()}
+        first = [r for r in recs if r["j"] == 0]
+        block_log = {"itlinear": bl["itlineartot"], "blocks": [clean(r) for r in recs],
+                     "first_block_last_pivot_ratio": [r["last_pivot_ratio"] for r in first],
+                     "min_last_pivot_ratio": min((r["last_pivot_ratio"] for r in recs if r["got"] > 0), default=None),
+                     "truncated_blocks": sum(1 for r in recs if r["got"] < r["steps"])}
+
     trace_rec = None
     if args.trace:
         ctx.set_option("solver_trace", 1)
@@ -546,6 +598,8 @@ def main():
                         "speculated_past_convergence": ctx.get_option("gmres_block_unconsumed")}
     except Exception:  # noqa: BLE001
         gmres_blocks = None
+    fd_opt = [float(kv.split("=")[1]) for kv in args.opt if kv.startswith("fd_dparam=")]
+    dfdp = "literal" if (fd_opt and fd_opt[-1] == 0.0) else "routed"
     sf_opt = [float(kv.split("=")[1]) for kv in args.opt if kv.startswith("gmres_stencil_free=")]
     stencil_free = bool((sf_opt[-1] if sf_opt else 1.0) != 0.0) and P is not None and args.linsolver == "gmres"
     if rank == 0:
@@ -564,7 +618,14 @@ def main():
                        # solve fits the rounding noise of its own right-hand side -- compare rounds by this figure)
                        "ms_per_operator_application": ms / max(last["itlineartot"], 1),
                        "cell": list(CELL), "tiles": list(tiles), "h": [2 * l / c for l, c in zip(CELL_L, CELL)],
-                       "precond_shift": args.shift, "state": "z-invariant hexagons (stable), l = 0.1, nu = 1.2",
+                       "precond_shift": args.shift,
+                       "precond_pairing": ("Pl = cholesky(L1), examples/SH3d.jl:88-93" if args.shift == 0.0 else
+                                           "Pl = lu(L1 + I), examples/SH2d-fronts.jl:121" if args.shift == 1.0 else "Pl = L1 + shift I"),
+                       # which dF/dp the corrector's right-hand side uses (src/continuation/Palc.jl:239-240): "routed" = the
+                       # cancellation-free one-pass quotient bk_residual_dparam (what the Julia binding's dispatch installs),
+                       # "literal" = (F(x, p + eps) - F(x, p)) / eps from two residual evaluations (--opt fd_dparam=0)
+                       "dfdp": dfdp,
+                       "state": "z-invariant hexagons (stable), l = 0.1, nu = 1.2",
                        "cell_umax": c0["u"].norminf(),
                        "cell_newton": {"converged": c0["converged"], "itnewton": c0["itnewton"],
                                        "residual": c0["residuals"][-1]},
@@ -575,7 +636,7 @@ def main():
                        "cell_corrector": {"converged": cfull["converged"], "itnewton": cfull["itnewton"],
                                           "itlinear": cfull["itlineartot"], "residuals": cfull["residuals"],
                                           "p": cfull["u"].p},
-                       "two_lanes": two_lanes, "gmres_blocks": gmres_blocks, "trace": trace_rec,
+                       "two_lanes": two_lanes, "gmres_blocks": gmres_blocks, "block_log": block_log, "trace": trace_rec,
                        "arnoldi_operator": ("stencil-free: Pl^-1 J = -I + Pl^-1 diag(g(u) + shift) for Pl = L1 + shift I (exact; "
                                             "src/LinearSolver.jl:270-277 `_linmap` rearranged) -- the pointwise factor rides in the "
                                             "x-forward transform pass, -I is a Hessenberg shift, the stencil kernel runs only in the "
@@ -584,7 +645,7 @@ def main():
                        "jvp_calls_per_step": (kernels["jvp"]["calls"] / max(args.steps, 1)) if "jvp" in kernels else 0,
                        "setup_seconds": t_setup, "sh_kernel": args.sh_kernel, "linsolver": args.linsolver,
                        "preconditioner": "none" if P is None else "dct"},
-            "roofline": roofline, "inner_loop": inner, "steady_state": steady, "kernels": kernels, "comm": comm_rec,
+            "roofline": roofline, "inner_loop": inner, "fixed_input": fixed, "steady_state": steady, "kernels": kernels, "comm": comm_rec,
         }
         cb = None
         if world == 1 and args.cpu_sample > 0:

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # BKHIP_LIB: an explicit library file (A/B builds of the same sources, e.g. `make layout0`); default = the in-tree build
 LIB_PATH = os.environ.get("BKHIP_LIB") or os.path.join(_HERE, "lib", "libbkhip.so")
 
-BK_ABI_VERSION = 5          # include/bkhip.h: layout version of the option structs mirrored below
+BK_ABI_VERSION = 6          # include/bkhip.h: layout version of the option structs mirrored below
 BK_UNIQUE_ID_BYTES = 128
 BK_MAX_PARAMS = 8
 BK_MAX_NEWTON_ITER = 64
@@ -116,6 +116,7 @@ SIGNATURES = {
     "bk_prof_reset": (I, [VP]),
     "bk_prof_get": (I, [VP, C.c_char_p, c_double_p, C.POINTER(C.c_longlong), c_double_p]),
     "bk_solver_history": (I, [VP, c_double_p, SZ, C.POINTER(SZ), I]),
+    "bk_solver_block_log": (I, [VP, c_double_p, SZ, C.POINTER(SZ), I]),
     "bk_malloc": (I, [VP, SZ, C.POINTER(VP)]),
     "bk_free": (I, [VP, VP]),
     "bk_upload": (I, [VP, VP, c_double_p, SZ]),

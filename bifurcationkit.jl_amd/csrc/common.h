@@ -86,6 +86,28 @@ struct bk_ctx {
     // one entry per Krylov iteration (the solver's own residual estimate); a negative entry -(k+1) opens solve k
     std::vector<double> hist;
     int hist_solves = 0;
+    // block log of the GMRES solves (option "gmres_block_log" != 0; bk_solver_block_log): kBlockLogRec doubles per Arnoldi block --
+    // solve number, first column j, steps issued, steps accepted, last pivot ratio, theta[0..3] (NaN: slot unused), residual
+    // estimate and tolerance when the block was issued
+    static constexpr int kBlockLogRec = 11;
+    std::vector<double> block_log;
+    int block_log_solves = 0;
+    // diagnostics counters of the GMRES solves (plain fields: the solver loop never looks a counter up by name); read through
+    // bk_ctx_get_option under the names in diag_get, reset by bk_ctx_set_option(name, 0)
+    struct Diag {
+        double block_steps = 0.0, block_truncated = 0.0, block_unconsumed = 0.0;    // operator applications issued in blocks / void tails / speculated past convergence
+        double last_orth_defect = 0.0, last_orth_estimate = 0.0;                   // option orth_probe
+        double check_mismatch = 0.0;                                               // explicit residual checks that contradicted the Arnoldi estimate (stencil-free form)
+    } diag;
+    double* diag_slot(const std::string& key) {
+        if (key == "gmres_block_steps") return &diag.block_steps;
+        if (key == "gmres_block_truncated") return &diag.block_truncated;
+        if (key == "gmres_block_unconsumed") return &diag.block_unconsumed;
+        if (key == "gmres_last_orth_defect") return &diag.last_orth_defect;
+        if (key == "gmres_last_orth_estimate") return &diag.last_orth_estimate;
+        if (key == "gmres_check_mismatch") return &diag.check_mismatch;
+        return nullptr;
+    }
     std::vector<double> newton_shifts; // option gmres_newton_carry: Leja-ordered Ritz values of the last GMRES solve (solver.hip)
     int gmres_last_steps = 1 << 20;   // Arnoldi steps of the previous GMRES solve (speculation ramp of the device-resident chunks)
     const double* eig_x0 = nullptr;   // one-shot start vector of the next eigensolve (bk_eig_set_start_vector)

@@ -553,6 +553,19 @@ void ctx_lane_merge(bk_ctx* ctx, bk_ctx* lane) {
             e.ms += kv.second.ms; e.calls += kv.second.calls; e.bytes += kv.second.bytes;
         }
     lane->prof_entries.clear();
+    ctx->diag.block_steps += lane->diag.block_steps; ctx->diag.block_truncated += lane->diag.block_truncated;
+    ctx->diag.block_unconsumed += lane->diag.block_unconsumed; ctx->diag.check_mismatch += lane->diag.check_mismatch;
+    lane->diag = bk_ctx::Diag();
+    if (!lane->block_log.empty()) {
+        for (size_t i = 0; i < lane->block_log.size(); ++i) {
+            double v = lane->block_log[i];
+            if (i % bk_ctx::kBlockLogRec == 0) v += ctx->block_log_solves;      // the lane numbered its solves from 1
+            ctx->block_log.push_back(v);
+        }
+        ctx->block_log_solves += lane->block_log_solves;
+        lane->block_log.clear();
+        lane->block_log_solves = 0;
+    }
     if (!lane->hist.empty()) {
         // the lane numbered its solves from 1: renumber them behind the context's own
         for (double v : lane->hist) {
@@ -732,12 +745,14 @@ int bk_ctx_set_lane_comm(bk_ctx* ctx, bk_allreduce_fn allreduce, bk_sendrecv_fn 
 
 int bk_ctx_set_option(bk_ctx* ctx, const char* key, double value) {
     if (!ctx || !key) return -1;
+    if (double* d = ctx->diag_slot(key)) { *d = value; return 0; }
     ctx->opts[key] = value;
     return 0;
 }
 
 int bk_ctx_get_option(bk_ctx* ctx, const char* key, double* value) {
     if (!ctx || !key || !value) return -1;
+    if (const double* d = ctx->diag_slot(key)) { *value = *d; return 0; }
     auto it = ctx->opts.find(key);
     if (it == ctx->opts.end()) return set_error(ctx, "unknown option %s", key);
     *value = it->second;
@@ -764,6 +779,15 @@ int bk_solver_history(bk_ctx* ctx, double* buf, size_t cap, size_t* n, int reset
     if (buf)
         for (size_t i = 0; i < ctx->hist.size() && i < cap; ++i) buf[i] = ctx->hist[i];
     if (reset) { ctx->hist.clear(); ctx->hist_solves = 0; }
+    return 0;
+}
+
+int bk_solver_block_log(bk_ctx* ctx, double* buf, size_t cap, size_t* n, int reset) {
+    if (!ctx) return -1;
+    if (n) *n = ctx->block_log.size();
+    if (buf)
+        for (size_t i = 0; i < ctx->block_log.size() && i < cap; ++i) buf[i] = ctx->block_log[i];
+    if (reset) { ctx->block_log.clear(); ctx->block_log_solves = 0; }
     return 0;
 }
 

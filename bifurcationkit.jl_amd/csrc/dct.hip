@@ -808,6 +808,7 @@ struct ShDctPrecond : bk_precond {
         return dct_axis_fused_ok(ctx, plan->n[0], plan->n[1], nzl, 0, x, plan->t1, 0) &&
                dct_axis_fused_ok(ctx, plan->n[0], plan->n[1], nzl, 0, plan->t2, const_cast<double*>(out), 0);
     }
+    bool pw_plan_ok() const override { return plan && plan->t1 && plan->t2 && pw_fused_ok(plan->t1, plan->t1, plan->t2); }
     int apply_pw(const double* x, const DctFuse& d, double cx, double ct, double* out) override {
         if (!pw_fused_ok(x, d.u, out) || ctx->opt("dct_fuse_pw", 1.0) == 0.0) return bk_precond::apply_pw(x, d, cx, ct, out);
         DctFuse f = d;
@@ -847,6 +848,7 @@ bk_precond* precond_lane_shadow(bk_precond* pl, bk_ctx* lane) {
     ShDctPrecond* S = new ShDctPrecond();
     S->ctx = lane; S->n = P->n; S->plan = q; S->shadow = true;
     S->has_grid = P->has_grid; S->grid = P->grid; S->grid_lo = P->grid_lo; S->grid_hi = P->grid_hi;
+    S->pw_agreed = P->pw_agreed;
     return S;
 }
 

@@ -547,5 +547,99 @@ BK_HD void fused_mid(c2* zp, int N, int t, const c2* tw, const c2* ew, double s0
     for (int q = 0; q < 8; ++q) zp[swz(gb + q * G)] = vb[q];
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Lane-pair split of the round-trip merged middle (round 6; dct_fused_kernel with 512 lanes per tile).  The item t of fused_mid
+// <2, DOT> is shared by TWO adjacent lanes: h = 0 owns the top group ga = t, h = 1 the group gb = N/8 - t (t = 0: the self-paired
+// groups 0 and N/16) -- 8 complex values per lane instead of 16, which is what lets the kernel run 4 waves per SIMD inside 128
+// VGPRs.  Every spectral index k meets N-k in the pair (va[q], vb[7-q]): after the top DIT stage the lanes swap their upper halves
+// v[4..7] (one DPP move per register on the device), lane 0 then holds (va[0..3], vb[4..7]) = the pairs k = ga + qG, q < 4, lane 1
+// (va[4..7], vb[0..3]) = the pairs q >= 4 (k > N/2: the table holds k <= N/2 only); they swap back and each runs the top inverse
+// stage of its own group.  Same arithmetic per value as fused_mid -- the host replay (tests/cpp/dct_core_check.cpp) compares the
+// two bit for bit.  Three phases with the exchanges between them:
+//   mid_half_fwd    LDS -> top DIT stage of the lane's group
+//   [p[i] <- partner's v[4 + i]]
+//   mid_half_pairs  post -> symbol -> pre on the lane's four (k, N-k) pairs (t = 0: on its own self-paired group, p untouched)
+//   [r[i] <- partner's p[i];  t != 0: v[4 + i] = r[i]]
+//   mid_half_inv    top inverse DIF stage -> LDS
+BK_HD int mid_half_group(int N, int t, int h) { const int G = N >> 3; return h == 0 ? t : (t == 0 ? (G >> 1) : G - t); }
+
+BK_HD void mid_half_fwd(const c2* zp, int N, int t, int h, const c2* tw, c2* v) {
+    const int G = N >> 3, g = mid_half_group(N, t, h);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = zp[swz(g + q * G)];
+    c2 w[7];
+    r8_twiddles(w, g, 0, tw);
+    r8_fwd_regs(v, w);
+}
+
+// one (k, N-k) pair, round trip, `upper` (k > N/2) a run-time flag: the arithmetic of mid_pair<2, UPPER, DOT>
+template <bool DOT, class Sym>
+BK_HD void mid_pair_rt(c2& x, c2& y, int k, int N, bool upper, const c2* ew, double hs2, double f2, Sym&& sym, c2& pacc) {
+    const c2 t = ew[twi(upper ? N - k : k)];
+    c2 e, en;
+    e.x = upper ? -t.y : t.x; e.y = upper ? -t.x : t.y;
+    en.x = upper ? t.x : -t.y; en.y = upper ? t.y : -t.x;
+    const double c = hs2 * f2;
+    c2 X = post_one(x, y, e, 1.0), Y = post_one(y, x, en, 1.0);
+    c2 f = sym(k);
+    if (DOT) { pacc.x = fma(X.x * X.x, f.x, pacc.x); pacc.y = fma(X.y * X.y, f.y, pacc.y); }
+    X.x *= f.x * c; X.y *= f.y * c;
+    f = sym(N - k);
+    if (DOT) { pacc.x = fma(Y.x * Y.x, f.x, pacc.x); pacc.y = fma(Y.y * Y.y, f.y, pacc.y); }
+    Y.x *= f.x * c; Y.y *= f.y * c;
+    x = pre_one(X, Y, e, 1.0, 1.0); y = pre_one(Y, X, en, 1.0, 1.0);
+}
+
+template <bool DOT, class Sym>
+BK_HD void mid_half_pairs(c2* v, c2* p, int N, int t, int h, const c2* ew, double s0, double s2, Sym&& sym, c2& dacc) {
+    const int G = N >> 3;
+    const double rN = 1.0 / N, f2 = rN / s2, f0 = rN / s0, hs2 = 0.5 * s2;
+    c2 pacc, sacc;
+    pacc.x = pacc.y = sacc.x = sacc.y = 0.0;
+    if (t == 0) {
+        if (h == 0) {
+            mid_single<2, DOT>(v[0], 0, ew, 0.5 * s0, f0, 0.0, sym, sacc);
+            mid_single<2, DOT>(v[4], N >> 1, ew, hs2, f2, f2, sym, sacc);
+#pragma unroll
+            for (int q = 1; q < 4; ++q) mid_pair<2, false, DOT>(v[q], v[8 - q], q * G, N, ew, hs2, f2, sym, pacc);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mid_pair<2, false, DOT>(v[q], v[7 - q], (G >> 1) + q * G, N, ew, hs2, f2, sym, pacc);
+        }
+    } else {
+        // h = 0: (va[i], vb[7 - i]) = (v[i], p[3 - i]);  h = 1: (va[4 + i], vb[3 - i]) = (p[i], v[3 - i]).  The lanes of a pair run in
+        // lockstep: every choice between them is a select on VALUES (never on addresses -- the register arrays must stay registers)
+        const bool up = h != 0;
+        c2 X[4], Y[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const c2 vi = v[i], pi = p[i];
+            X[i].x = up ? pi.x : vi.x; X[i].y = up ? pi.y : vi.y;
+            Y[3 - i].x = up ? vi.x : pi.x; Y[3 - i].y = up ? vi.y : pi.y;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mid_pair_rt<DOT>(X[i], Y[i], t + (up ? 4 + i : i) * G, N, up, ew, hs2, f2, sym, pacc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const c2 xi = X[i], yi = Y[3 - i];
+            v[i].x = up ? yi.x : xi.x; v[i].y = up ? yi.y : xi.y;
+            p[i].x = up ? xi.x : yi.x; p[i].y = up ? xi.y : yi.y;
+        }
+    }
+    if (DOT) {
+        dacc.x += fma(hs2 * hs2, pacc.x, sacc.x);
+        dacc.y += fma(hs2 * hs2, pacc.y, sacc.y);
+    }
+}
+
+BK_HD void mid_half_inv(c2* zp, int N, int t, int h, const c2* tw, c2* v) {
+    const int G = N >> 3, g = mid_half_group(N, t, h);
+    c2 w[7];
+    r8_twiddles(w, g, 0, tw);
+    r8_inv_regs(v, w);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) zp[swz(g + q * G)] = v[q];
+}
+
 }  // namespace dctc
 }  // namespace bk

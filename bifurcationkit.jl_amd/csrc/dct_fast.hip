@@ -364,8 +364,23 @@ __device__ __forceinline__ void lds_barrier() {
 // FZ (AX0 only): the pointwise work of the stencil-free preconditioned operator rides in the x passes (ops.h: DctFuse) -- one more
 // 8 B/point read stream in the pass, same tile pipeline.
 // SLAB (axis 2 only): 1 = forward half (MODE 0), 2 = inverse half (MODE 1) of the slab z-solve -- see FftK.
+// value of the neighbouring lane (lane ^ 1): two DPP moves (quad_perm [1, 0, 3, 2]), no LDS traffic
+__device__ __forceinline__ double lane_xor1(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ c2 lane_xor1(c2 v) { c2 r; r.x = lane_xor1(v.x); r.y = lane_xor1(v.y); return r; }
+
+// NT = 512 (round 6, the z round trip only): one first- / last-stage item per lane and the merged middle split over lane PAIRS
+// (dct_core.h: mid_half_*), 8 complex values per lane instead of 16 -- the tile's phases are latency-bound (one wave per SIMD and
+// tile with 256 lanes: 38 % of the wave cycles issue, profiles/r5_sq_stall_breakdown.txt), so the same two tiles per CU now bring 4
+// waves per SIMD inside 128 VGPRs.  (Round 3's 512-lane instantiation of the unsplit kernel spilled 264 B per lane and ran 2x slower.)
 template <int NT, int MODE, bool AX0, bool NTM, bool DOT = false, bool FZ = false, int SLAB = 0>   // MODE 0: forward, 1: inverse, 2: forward - symbol - inverse (AX0: 0 / 1 only)
-__global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
+__global__ void __launch_bounds__(NT, NT == 512 ? 4 : 2) dct_fused_kernel(FftK P) {
+    constexpr bool SPLIT = NT == 512;
+    static_assert(!SPLIT || (MODE == 2 && !AX0 && !FZ && SLAB == 0), "512 lanes: the z / y round trip only");
     static_assert(!FZ || (AX0 && MODE != 2), "FZ: x passes only");
     static_assert(SLAB == 0 || (!AX0 && !FZ && !DOT && ((SLAB == 1 && MODE == 0) || (SLAB == 2 && MODE == 1))), "SLAB: z halves only");
     __shared__ double dsum[NT / 64];
@@ -449,11 +464,11 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
 
     // first-stage samples held in registers: (AX0) the 8 + 8 sample pairs of this lane's item, line a in pfa / line b in
     // pfb; (axis >= 1) the 8 samples of item tid in pfa and of item tid + NT in pfb
-    c2 pfa[8], pfb[8];
+    c2 pfa[8], pfb[SPLIT ? 1 : 8];
     c2 qfa[FZ ? 8 : 1], qfb[FZ ? 8 : 1];     // FZ: the second stream's values at the same indices (u forward, x inverse)
     c2 dl[SLAB == 2 ? 4 : 1];                // SLAB 2: the correction's right-hand side at the four face planes, lines a / b of this item
     // (the host launches this kernel only when nfirst <= NT (AX0) / 2 NT, so the two register sets cover the tile)
-    const bool act0 = tid < nfirst, act1 = !AX0 && tid + NT < nfirst;
+    const bool act0 = tid < nfirst, act1 = !AX0 && !SPLIT && tid + NT < nfirst;
     auto issue = [&](int tile) {
         // every lane requests unconditionally (idle lanes re-read element 0 of the tile)
         const double* g = tile_in(tile);
@@ -517,7 +532,7 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 pfa[r] = ldfrom(g, act0 ? o + (unsigned)dctc::first_sample(g0, r, N) * estride : 0u);
-                pfb[r] = ldfrom(g, act1 ? o + (unsigned)dctc::first_sample(g1, r, N) * estride : 0u);
+                if (!SPLIT) pfb[SPLIT ? 0 : r] = ldfrom(g, act1 ? o + (unsigned)dctc::first_sample(g1, r, N) * estride : 0u);
             }
         }
     };
@@ -561,7 +576,7 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
         // + 0.0.  (One merged-middle item per lane: nmid <= NT, host-checked.)
         double ca = 0.0, cb = 0.0, lo2 = 0.0;
         if (MODE == 2 || SLAB) {
-            const int i0 = x0 + 2 * (tid & (npairs - 1));
+            const int i0 = x0 + 2 * ((SPLIT ? tid >> 1 : tid) & (npairs - 1));      // (SPLIT: lanes 2w, 2w + 1 share the item w)
             const double l1 = P.axis == 1 ? 0.0 : P.lam1[other];
             lo2 = P.axis == 1 ? (P.lam2 ? P.lam2[other] : 0.0) : 0.0;
             ca = 1.0 + P.lam0[i0] + l1;
@@ -593,7 +608,7 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
             } else {
                 c2* zp = z + (size_t)(tid & (npairs - 1)) * pstride;
                 if (act0) dctc::fused_first(zp, N, bits, tid >> pbits, [&](int r, int) { return pfa[r]; });
-                if (act1) dctc::fused_first(zp, N, bits, (tid + NT) >> pbits, [&](int r, int) { return pfb[r]; });
+                if (!SPLIT && act1) dctc::fused_first(zp, N, bits, (tid + NT) >> pbits, [&](int r, int) { return pfb[SPLIT ? 0 : r]; });
             }
             lds_barrier();
             stamp(1);
@@ -642,6 +657,27 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
                     qfb[2 * r + 1] = ld16(xrow + lstride + m * (gq + G * r));
                 }
             }
+        } else if (SPLIT) {
+            // lane pair (2w, 2w + 1) = item w (host-checked: 2 nmid == NT, every lane is active -- the DPP exchanges need no mask)
+            const int w = tid >> 1, h = tid & 1;
+            const int pr = w & (npairs - 1), t = w >> pbits;
+            c2* zp = z + (size_t)pr * pstride;
+            auto sym = [&](int k) {
+                const double lk = lamk[k];
+                const double sa = ca + lk + lo2, sb = cb + lk + lo2;
+                c2 r; r.x = rcp_nr(sa * sa + P.shift, 2); r.y = rcp_nr(sb * sb + P.shift, 2); return r;
+            };
+            c2 v[8], p[4];
+            dctc::mid_half_fwd(zp, N, t, h, tw, v);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) p[i] = lane_xor1(v[4 + i]);
+            dctc::mid_half_pairs<DOT>(v, p, N, t, h, ew, s0, s2, sym, dtot);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const c2 r = lane_xor1(p[i]);
+                if (t != 0) v[4 + i] = r;
+            }
+            dctc::mid_half_inv(zp, N, t, h, tw, v);
         } else
         for (int w = tid; w < nmid; w += NT) {
             const int pr = AX0 ? w >> hbits : w & (npairs - 1), t = AX0 ? w & ((1 << hbits) - 1) : w >> pbits;
@@ -749,6 +785,9 @@ __global__ void __launch_bounds__(NT, 2) dct_fused_kernel(FftK P) {
     }
     if (P.trace) { __builtin_amdgcn_s_waitcnt(0); stamp(6); }
 }
+
+// lanes per tile of the round-trip pass (option dct_rt_lanes): 512 = lane-pair split of the merged middle
+constexpr double kRoundTripLanesDefault = 512.0;
 
 inline int choose_lt(int N, int axis, int n0, size_t rows, bool wide = false) {
     // 16 lines per tile (axis >= 1: one 128-B segment per line element), fewer only if the tile would not fit a
@@ -884,6 +923,10 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
                              reinterpret_cast<const void*>(dct_fused_kernel<256, 2, false, true>),
                              reinterpret_cast<const void*>(dct_fused_kernel<256, 2, false, false, true>),
                              reinterpret_cast<const void*>(dct_fused_kernel<256, 2, false, true, true>),
+                             reinterpret_cast<const void*>(dct_fused_kernel<512, 2, false, false>),
+                             reinterpret_cast<const void*>(dct_fused_kernel<512, 2, false, true>),
+                             reinterpret_cast<const void*>(dct_fused_kernel<512, 2, false, false, true>),
+                             reinterpret_cast<const void*>(dct_fused_kernel<512, 2, false, true, true>),
                              reinterpret_cast<const void*>(dct_fused_kernel<256, 0, true, true>),
                              reinterpret_cast<const void*>(dct_fused_kernel<256, 1, true, true>),
                              reinterpret_cast<const void*>(dct_fused_kernel<256, 0, true, false, false, true>),
@@ -935,6 +978,10 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
         P.xmap = (grid % 8 == 0 && ((int)ctx->opt("dct_xcd_map", 3.0) >> axis & 1)) ? 1 : 0;   // bit per axis; default x, y
         const bool ntm = P.nt_load && P.nt_store;
         const int mode = P.roundtrip ? 2 : (P.inverse ? 1 : 0);
+        // the round trip with 512 lanes per tile and the merged middle split over lane pairs (option dct_rt_lanes: 512 / 256):
+        // tiles of exactly 512 first-stage items = 256 merged-middle items
+        const bool split512 = mode == 2 && axis != 0 && (size_t)(P.LT / 2) * (P.N / 8) == 512 &&
+                              ctx->opt("dct_rt_lanes", kRoundTripLanesDefault) == 512.0;
 #define BK_DCT_LAUNCH(M, A, T) hipLaunchKernelGGL((dct_fused_kernel<256, M, A, T>), dim3(grid), dim3(256), ldsf, ctx->stream, P)
 #define BK_DCT_LAUNCH_FZ(M, T) hipLaunchKernelGGL((dct_fused_kernel<256, M, true, T, false, true>), dim3(grid), dim3(256), ldsf, ctx->stream, P)
 #define BK_DCT_LAUNCH_SLAB(M, T, S) hipLaunchKernelGGL((dct_fused_kernel<256, M, false, T, false, false, S>), dim3(grid), dim3(256), ldsf, ctx->stream, P)
@@ -949,9 +996,17 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
             else { if (ntm) BK_DCT_LAUNCH(0, true, true); else BK_DCT_LAUNCH(0, true, false); }
         } else if (mode == 2 && dot_blocks && (size_t)grid <= kPartialDoubles && ctx->opt("dct_fused_dot", 1.0) != 0.0) {
             P.dotp = ctx->d_partials;
-            if (ntm) hipLaunchKernelGGL((dct_fused_kernel<256, 2, false, true, true>), dim3(grid), dim3(256), ldsf, ctx->stream, P);
-            else hipLaunchKernelGGL((dct_fused_kernel<256, 2, false, false, true>), dim3(grid), dim3(256), ldsf, ctx->stream, P);
+            if (split512) {
+                if (ntm) hipLaunchKernelGGL((dct_fused_kernel<512, 2, false, true, true>), dim3(grid), dim3(512), ldsf, ctx->stream, P);
+                else hipLaunchKernelGGL((dct_fused_kernel<512, 2, false, false, true>), dim3(grid), dim3(512), ldsf, ctx->stream, P);
+            } else {
+                if (ntm) hipLaunchKernelGGL((dct_fused_kernel<256, 2, false, true, true>), dim3(grid), dim3(256), ldsf, ctx->stream, P);
+                else hipLaunchKernelGGL((dct_fused_kernel<256, 2, false, false, true>), dim3(grid), dim3(256), ldsf, ctx->stream, P);
+            }
             *dot_blocks = (int)grid;
+        } else if (mode == 2 && split512) {
+            if (ntm) hipLaunchKernelGGL((dct_fused_kernel<512, 2, false, true>), dim3(grid), dim3(512), ldsf, ctx->stream, P);
+            else hipLaunchKernelGGL((dct_fused_kernel<512, 2, false, false>), dim3(grid), dim3(512), ldsf, ctx->stream, P);
         } else if (mode == 2) { if (ntm) BK_DCT_LAUNCH(2, false, true); else BK_DCT_LAUNCH(2, false, false); }
         else if (mode == 1) { if (ntm) BK_DCT_LAUNCH(1, false, true); else BK_DCT_LAUNCH(1, false, false); }
         else { if (ntm) BK_DCT_LAUNCH(0, false, true); else BK_DCT_LAUNCH(0, false, false); }

@@ -168,6 +168,10 @@ struct bk_op {              // a linear operator on (device vector [+ one host t
     // the later Newton shifts is taken from W's origin (solver.hip: ritz_shifts) -- the order relative to T's origin truncated a block
     // per solve on running branches (measured; powers of T themselves are the better-conditioned first block: DESIGN 10).
     virtual double monomial_shift() const { return 0.0; }
+    // The offset theta0 of a rearranged operator A = W + theta0 I itself, whatever the first block does (option gmres_monomial_shift
+    // only gates monomial_shift): the origin of the Leja order (option gmres_leja_origin), so that the two options can be set
+    // independently
+    virtual double rearranged_origin() const { return 0.0; }
 };
 
 struct bk_precond {
@@ -184,6 +188,13 @@ struct bk_precond {
     // Default: a pointwise pass, apply, an axpby; the spectral preconditioner fuses both into its first / last transform pass.
     virtual int apply_pw(const double* x, const bk::DctFuse& d, double cx, double ct, double* out);
     virtual bool pw_fused_ok(const double* x, const double* u, const double* out) const { return false; }
+    // the same for this rank's part of the plan alone (shape of the x passes, library-owned scratch; no caller pointer looked at) ...
+    virtual bool pw_plan_ok() const { return false; }
+    // ... and what the ranks agreed on, once per preconditioner (solver.hip: ShiftPrecOp::init_fold; -1: not asked yet).  The FORM of
+    // the operator inside GMRES -- stencil-free or the halo-exchanging chain -- follows this rank-invariant flag only; a rank whose
+    // caller vectors are not 16-byte aligned runs the same form with a separate pointwise pass (apply_pw's default), i.e. the same
+    // sequence of collectives.
+    int pw_agreed = -1;
 };
 
 namespace bk {

@@ -92,7 +92,20 @@ int bk_problem::jvp_axpy_dot(const double* v, const double* u, const double* par
     a.v = v; a.u = u; a.out = out;
     a.halo_lo = ranks ? halo_lo : nullptr; a.halo_hi = ranks ? halo_hi : nullptr;
     a.addv = r; a.addc = r ? c : 0.0;
-    if (!sh_fused_dot_ok(ctx, a)) return 0;
+    if (ranks) {
+        // The decision must not differ between ranks (the fused path exchanges the halo on ctx->stream, the other one on the
+        // communication stream): it is taken from GLOBAL quantities only -- the options and the two slab heights a z-partition of
+        // d.n[2] planes over nranks ranks can produce -- never from this rank's own height or pointers.  A vector that is
+        // not 16-byte aligned (nothing the library hands out) is an error here instead of a silent change of path.
+        ShArgs g = a;
+        g.addv = nullptr;
+        g.nz = d.n[2] / ctx->nranks;
+        const bool ok_lo = sh_fused_dot_ok(ctx, g);
+        g.nz = (d.n[2] + ctx->nranks - 1) / ctx->nranks;
+        if (!ok_lo || !sh_fused_dot_ok(ctx, g)) return 0;
+        if (r && ((uintptr_t)r & 15)) return set_error(ctx, "jvp_axpy_dot: on ranks the vectors must be 16-byte aligned");
+    }
+    if (!sh_fused_dot_ok(ctx, a)) return ranks ? set_error(ctx, "jvp_axpy_dot: slab height outside the partition's two heights") : 0;
     if (ranks) {
         ProfScope ps(ctx, "halo", 32.0 * plane * 2);
         BK_TRY(halo_exchange(ctx, ctx->stream, v, plane, a.nz, 2, halo_lo, halo_hi));

@@ -26,6 +26,10 @@ namespace bk {
 
 namespace {
 
+// First block of a solve on a rearranged operator A = W + theta0 I (ShiftPrecOp, stencil-free form): 0 = powers of A itself,
+// 1 = powers of the literal operator W (see gmres_core: first block).  Option gmres_monomial_shift.
+constexpr double kMonomialShiftDefault = 0.0;
+
 inline size_t round_up(size_t n, size_t m) { return (n + m - 1) / m * m; }
 
 struct Basis {                 // (m+1) device vectors + host tails (nt scalars per vector: the border block)
@@ -342,6 +346,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     // (A structural first-block shift -- the accumulation point a0 - a1 of the spectrum of a0 + a1 Pl^-1 J, i.e. blocks built on
     // powers of the smoothing operator Pl^-1 (s I + diag g) -- looked good at 128 x 64 x 64 (pivot ratios 2e-1 .. 2e-5) and
     // truncated the first block of every solve at 512^3: measured, 122.9 vs 116.6 ms per step, removed.)
+    const bool leja_origin_on = ctx->opt("gmres_leja_origin", 1.0) != 0.0;
     auto ritz_shifts = [&](int kk) {              // Leja-ordered real parts of the eigenvalues of Hraw[0:kk, 0:kk]
         if (!use_shifts || kk < 2) return;
         dense::Mat Hm(kk, kk);
@@ -357,7 +362,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
         // Leja order: the first point is the one farthest from the origin of the operator the solve is about -- for an operator that
         // iterates on a rearranged form A = W + theta0 I (bk_op::monomial_shift) that origin sits at theta0, so the order (and with it the
         // blocks' conditioning) is the one the literal operator W would get: the later points only depend on mutual distances
-        const double origin = ctx->opt("gmres_leja_origin", 1.0) != 0.0 ? A->monomial_shift() : 0.0;
+        const double origin = leja_origin_on ? A->rearranged_origin() : 0.0;
         for (int t = 0; t < sstep::kS && t < (int)pts.size(); ++t) {
             int best = -1;
             double bv = -1.0;
@@ -391,6 +396,11 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     // out rather than speeds up.  Rounds 3-4 used 2: measured in round 5 on two sizes x two block orderings, 1 wins every pairing
     // (512^3 headline 98 -> 92 ms; profiles/r5_predict_margin_leja_sweep.txt))
     const double pmargin = ctx->opt("gmres_predict_margin", 1.0);
+    // (options read once per solve: nothing inside the block loop looks anything up by name)
+    const bool block_log = ctx->opt("gmres_block_log", 0.0) != 0.0;
+    const bool defer_update = ctx->opt("gmres_defer_update", 1.0) != 0.0;
+    const bool orth_probe = ctx->opt("orth_probe", 0.0) != 0.0;
+    if (block_log) ctx->block_log_solves += 1;
     double beta_prev = 0.0, beta_now = 0.0, tol_now = 0.0;
     double* d_coef = nullptr;
     const double* h_rec = ctx->h_rec;          // the records land in pinned, device-mapped host memory: no copy operation
@@ -449,18 +459,24 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
                 for (int i = 0; i < steps && !shifts.empty(); ++i) theta[i] = shifts[i % shifts.size()];
                 const double mono = shifts.empty() ? A->monomial_shift() : 0.0;      // (blocks without Ritz values: bk_op::monomial_shift)
                 if (mono != 0.0) for (int i = 0; i < steps; ++i) theta[i] = mono;
-                BK_TRY(arnoldi_block(ctx, A, B, j, steps, Hraw.data(), ldh, op_a0, op_a1, &got, &ratio, (shifts.empty() && mono == 0.0) ? nullptr : theta,
-                                     ctx->opt("gmres_defer_update", 1.0) != 0.0 ? &pend : nullptr));
-                if (ctx->opt("gmres_block_log", 0.0) != 0.0)
-                    fprintf(stderr, "bk block: solve n=%zu j=%d steps=%d got=%d last_pivot_ratio=%.2e theta=[%.3g %.3g %.3g %.3g] beta=%.3e tol=%.3e\n", n, j, steps,
-                            got, ratio, theta[0], theta[1], theta[2], theta[3], beta_now, tol_now);
+                const bool shifted = !(shifts.empty() && mono == 0.0);
+                BK_TRY(arnoldi_block(ctx, A, B, j, steps, Hraw.data(), ldh, op_a0, op_a1, &got, &ratio, shifted ? theta : nullptr,
+                                     defer_update ? &pend : nullptr));
+                if (block_log) {
+                    // one record per block (bk_solver_block_log; common.h: kBlockLogRec); theta slots the block did not use are NaN
+                    const double rec[bk_ctx::kBlockLogRec] = {(double)ctx->block_log_solves, (double)j, (double)steps, (double)got, ratio,
+                                                              shifted && steps > 0 ? theta[0] : NAN, shifted && steps > 1 ? theta[1] : NAN,
+                                                              shifted && steps > 2 ? theta[2] : NAN, shifted && steps > 3 ? theta[3] : NAN,
+                                                              beta_now, tol_now};
+                    ctx->block_log.insert(ctx->block_log.end(), rec, rec + bk_ctx::kBlockLogRec);
+                }
                 if (got < steps && shifts_carried) { shifts.clear(); shifts_carried = false; }     // a stale set: back to the monomial block
                 if (got > 0 && !shifts_carried && ((int)shifts.size() < sstep::kS || j + got <= 12)) ritz_shifts(j + got);
                 // diagnostics (bench.py reports them): operator applications issued by blocks / of those void (truncated tails)
                 // ("truncated": tails of blocks cut at a small pivot; "unconsumed", counted at the end of the solve: accepted steps the
                 // host never needed because the solve converged earlier in the block -- speculation past convergence)
-                ctx->opts["gmres_block_steps"] = ctx->opt("gmres_block_steps", 0.0) + steps;
-                ctx->opts["gmres_block_truncated"] = ctx->opt("gmres_block_truncated", 0.0) + (steps - got);
+                ctx->diag.block_steps += steps;
+                ctx->diag.block_truncated += steps - got;
                 blk_accepted += got;
                 if (got > 0) {
                     q_first = j; q_count = got;
@@ -604,7 +620,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
             BK_TRY(next_column(k, h.data(), &hnext));
             numops += 1;
         }
-        if (ctx->opt("orth_probe", 0.0) != 0.0 && nt == 0) {
+        if (orth_probe && nt == 0) {
             BK_TRY(flush_pending());
             // diagnostics (tests): the MEASURED orthogonality defect max |V'V - I| of this cycle's basis V[0..k] next to the
             // running estimate the single-pass policy steers by -- options gmres_last_orth_defect / gmres_last_orth_estimate
@@ -620,8 +636,8 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
                 BK_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 est = std::max(est, B.dlt);
             }
-            ctx->opts["gmres_last_orth_defect"] = std::max(worst, numiter > 1 ? ctx->opt("gmres_last_orth_defect", 0.0) : 0.0);
-            ctx->opts["gmres_last_orth_estimate"] = est;
+            ctx->diag.last_orth_defect = std::max(worst, numiter > 1 ? ctx->diag.last_orth_defect : 0.0);
+            ctx->diag.last_orth_estimate = est;
         }
         // solve R yk = y[0..k) and update x += V[0..k) yk
         std::vector<double> yk(k);
@@ -674,7 +690,24 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
                 BK_TRY(start_cycle());
             }
         } else {
-            if (beta <= tol) { res->converged = 1; break; }
+            if (beta <= tol) {
+                if (!A->hessenberg_shift()) { res->converged = 1; break; }
+                // The cycle ran on an algebraically rearranged operator (ShiftPrecOp, stencil-free form): before the solve returns
+                // `converged` on the Arnoldi estimate alone, the residual is evaluated once through the ORIGINAL chain (stencil kernel,
+                // plain preconditioner), as the KrylovKit flavor does after every converged cycle -- a mismatch between the stencil's L1
+                // and the spectral one cannot pass silently in any flavor.  Within 1.5 x the tolerance the estimate stands
+                // (and is what the solve reports, as IterativeSolvers / Krylov.jl do); beyond it the solve continues from the true residual.
+                double bt_ = 0.0;
+                BK_TRY(A->apply_check(x, nullptr, alpha0, alpha1, w, nullptr));
+                BK_TRY(v_diff_nrm2(ctx, n, b, w, &bt_));
+                if (bt_ <= 1.5 * tol) { res->converged = 1; break; }
+                ctx->diag.check_mismatch += 1.0;
+                if (stop || iters >= o.maxiter) { beta = bt_; break; }
+                BK_TRY(v_axpbyz(ctx, n, 1.0, b, -1.0, w, r));
+                beta = bt_;
+                BK_TRY(start_cycle());
+                continue;
+            }
             if (stop || iters >= o.maxiter) break;
             double wt[BK_MAX_BORDER] = {0.0};
             BK_TRY(A->apply_check(x, nt ? xtail : nullptr, alpha0, alpha1, w, wt));
@@ -687,7 +720,7 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     }
     res->niter = kk ? numops : iters;
     res->resnorm = beta;
-    if (sstep_on) ctx->opts["gmres_block_unconsumed"] = ctx->opt("gmres_block_unconsumed", 0.0) + (blk_accepted - blk_consumed);
+    if (sstep_on) ctx->diag.block_unconsumed += blk_accepted - blk_consumed;
     ctx->gmres_last_steps = iters;
     if (carry && !shifts.empty()) ctx->newton_shifts = shifts;
     if (xt) for (int q = 0; q < nt; ++q) xt[q] = xtail[q];
@@ -729,34 +762,45 @@ struct ShiftPrecOp : bk_op {
     bool tmode = false;
     DctFuse pw;
     double t_alpha0 = 0.0, t_alpha1 = 1.0;
-    void init_fold() {
+    int init_fold() {
         const bool same = P && J->sh_problem() && P->is_l1_plus_shift(J->sh_problem(), &pl_shift);
         fold = same && order == 0 && ctx->opt("gmres_fold_shift", 1.0) != 0.0;
         // 1 (default): where the x passes run as the fused LDS kernel; 2: everywhere (separate pointwise pass: tests); 0: off
         const double sf = ctx->opt("gmres_stencil_free", 1.0);
         const double* u = nullptr;
         double l = 0.0, nu = 0.0;
-        tmode = same && !Pr && sf != 0.0 && J->sh_state(&u, &l, &nu) && (sf == 2.0 || P->pw_fused_ok(u, u, u));
-        if (ctx->nranks > 1 && same && !Pr && sf == 1.0) {
-            // every rank must take the same form (the chain exchanges halos inside GMRES, the stencil-free form does not): the
-            // local test looks at this rank's slab and buffers, so agree on it
-            double no = tmode ? 0.0 : 1.0;
-            if (comm_allreduce_host(ctx, &no, 1, 1) != 0) no = 1.0;
-            tmode = no == 0.0;
+        tmode = same && !Pr && sf != 0.0 && J->sh_state(&u, &l, &nu);
+        if (tmode && sf != 2.0) {
+            if (ctx->nranks > 1) {
+                // every rank must take the same form (the chain exchanges halos inside GMRES, the stencil-free form does not).  The
+                // inputs of the decision are static -- the shape of this rank's part of the plan -- so the ranks agree ONCE per
+                // preconditioner and every later solve reads the cached flag; a failed all-reduce is this solve's error, never a silent
+                // fall-back to the other form
+                if (P->pw_agreed < 0) {
+                    double no = P->pw_plan_ok() ? 0.0 : 1.0;
+                    BK_TRY(comm_allreduce_host(ctx, &no, 1, 1));
+                    P->pw_agreed = no == 0.0 ? 1 : 0;
+                }
+                tmode = P->pw_agreed == 1;
+            } else {
+                tmode = P->pw_fused_ok(u, u, u);
+            }
         }
-        if (!tmode) return;
+        mono_first = ctx->opt("gmres_monomial_shift", kMonomialShiftDefault) != 0.0;
+        if (!tmode) return 0;
         // g(u) = l + 2 nu u - 3 u^2 (examples/SH3d.jl:50-53); factor = c0 + cg g = A + u (B + C u)
         const double cg = order == 0 ? 1.0 : a1, c0 = order == 0 ? pl_shift : a0 + a1 * pl_shift;
         pw.u = u; pw.A = c0 + cg * l; pw.B = 2.0 * nu * cg; pw.C = -3.0 * cg;
         t_alpha0 = order == 0 ? a0 - a1 : -a1;
         t_alpha1 = order == 0 ? a1 : 1.0;
+        return 0;
     }
     bool shift_is_free() const override { return Pr ? false : (P ? (fold || tmode) : J->shift_is_free()); }
     bool hessenberg_shift() const override { return tmode; }
     // T = W + I (order 0), T' = W' + a1 I (order 1): the first block of a solve runs on powers of W (W'), see bk_op::monomial_shift
-    double monomial_shift() const override {
-        return tmode && ctx->opt("gmres_monomial_shift", 1.0) != 0.0 ? (order == 0 ? 1.0 : a1) : 0.0;
-    }
+    double rearranged_origin() const override { return tmode ? (order == 0 ? 1.0 : a1) : 0.0; }
+    double monomial_shift() const override { return mono_first ? rearranged_origin() : 0.0; }
+    bool mono_first = false;      // option gmres_monomial_shift, read once per solve (init_fold)
     int apply(const double* x, const double*, double b0, double b1, double* out, double*) override {
         // out = b0 x + b1 * W(x)
         if (tmode) return P->apply_pw(x, pw, b0, b1, out);      // W = T (T'): see above
@@ -952,7 +996,7 @@ int linsolve(bk_ctx* ctx, bk_op* J, const double* rhs, double* x, double a0, dou
     W.ctx = ctx; W.n = J->n; W.ntail = 0;
     W.J = J; W.P = pl; W.a0 = a0; W.a1 = a1; W.order = kk ? 0 : 1; W.tmp = nullptr;
     W.Pr = kk ? nullptr : o.pr;
-    W.init_fold();
+    BK_TRY(W.init_fold());
     const double* b = rhs;
     if (pl || W.Pr) BK_TRY(ws.get(J->n, &W.tmp));
     if (W.Pr) BK_TRY(ws.get(J->n, &W.tmp2));
@@ -1085,7 +1129,7 @@ int bk_precond_op_apply(bk_ctx* ctx, bk_precond* pl, bk_op* J, const double* x, 
     ShiftPrecOp W;
     W.ctx = ctx; W.n = J->n; W.ntail = 0;
     W.J = J; W.P = pl; W.a0 = a0; W.a1 = a1; W.order = 0; W.tmp = nullptr;
-    W.init_fold();
+    BK_TRY(W.init_fold());
     BK_TRY(ws.get(J->n, &W.tmp));
     if (stencil_free) *stencil_free = W.tmode ? 1 : 0;
     // tmode: W.apply(b0, b1) = b0 x + b1 T x and a0 + a1 Pl^-1 J = (a0 - a1) + a1 T; else the chain a0 x + a1 Pl^-1 (J x)

@@ -118,6 +118,25 @@ class Context:
         self.check(self.lib.bk_prof_get(self.h, name.encode(), C.byref(ms), C.byref(calls), C.byref(nbytes)))
         return dict(ms=ms.value, calls=calls.value, bytes=nbytes.value)
 
+    BLOCK_LOG_FIELDS = ("solve", "j", "steps", "got", "last_pivot_ratio", "theta0", "theta1", "theta2", "theta3", "beta", "tol")
+
+    def solver_block_log(self, reset=True):
+        """Block log of the GMRES solves since the last reset (needs ``set_option("gmres_block_log", 1)``): one dict per Arnoldi
+        block -- solve number, first column ``j``, steps issued / accepted (``got``), last pivot ratio, the Newton shifts
+        (NaN: unused), residual estimate ``beta`` and tolerance when the block was issued (include/bkhip.h: bk_solver_block_log)."""
+        n = C.c_size_t()
+        self.check(self.lib.bk_solver_block_log(self.h, None, 0, C.byref(n), 0))
+        buf = (C.c_double * max(n.value, 1))()
+        self.check(self.lib.bk_solver_block_log(self.h, buf, n.value, C.byref(n), 1 if reset else 0))
+        k = len(self.BLOCK_LOG_FIELDS)
+        recs = []
+        for i in range(0, n.value - n.value % k, k):
+            r = dict(zip(self.BLOCK_LOG_FIELDS, buf[i:i + k]))
+            for f in ("solve", "j", "steps", "got"):
+                r[f] = int(r[f])
+            recs.append(r)
+        return recs
+
     def solver_history(self, reset=True):
         """Residual histories of the linear solves since the last reset (needs ``set_option("solver_trace", 1)``):
         a list with one list per solve, [initial residual, estimate after iteration 1, ...]."""

@@ -42,7 +42,7 @@ int bk_version(void);
 /* Layout version of the option structs below (bk_gmres_opts, bk_bordering_opts, bk_eig_opts, ...).  A binding compares it with
  * the BK_ABI_VERSION it was written against before its first call: the structs carry no size field, and a client built against
  * an older header would hand over shorter ones.                                                                  */
-#define BK_ABI_VERSION 5
+#define BK_ABI_VERSION 6
 int bk_abi_version(void);
 /* Create a single-GPU context on `device`; `stream` is the hipStream_t all work is enqueued on
  * (NULL = the default stream, which orders the library with the caller's own default-stream work). */
@@ -102,6 +102,13 @@ int bk_prof_get(bk_ctx* ctx, const char* name, double* total_ms, long long* call
  * available; reset != 0 clears the log.  The reference's counterpart is the `verbose` / `log = true` switch of the
  * Krylov packages (src/LinearSolver.jl:169,202,244).                                                              */
 int bk_solver_history(bk_ctx* ctx, double* buf, size_t cap, size_t* n, int reset);
+/* Block log of the GMRES solves (ABI 6; option "gmres_block_log" != 0): one record of 11 doubles per Arnoldi block -- solve number
+ * (from 1, since the last reset), first Hessenberg column j of the block, operator applications issued, steps the host algebra
+ * accepted (fewer: the block was truncated at a small pivot), last pivot ratio of the block's Cholesky factor (the conditioning
+ * margin against the truncation threshold 1e-8), the block's Newton shifts theta[0..3] (NaN: slot unused), residual estimate and
+ * tolerance when the block was issued.  Same calling convention as bk_solver_history.  The library never writes to stderr.
+ * Reference counterpart: `verbose` of the Krylov packages (src/LinearSolver.jl:169,202,244).                              */
+int bk_solver_block_log(bk_ctx* ctx, double* buf, size_t cap, size_t* n, int reset);
 
 /* ------------------------------------------------------------------ memory ----------------- */
 

@@ -44,7 +44,7 @@ struct EigOpts
     sigma::Cdouble; krylovdim::Cint; maxiter::Cint; tol::Cdouble; hermitian::Cint; seed::Culonglong
 end
 
-const BK_ABI_VERSION = Cint(5)     # include/bkhip.h
+const BK_ABI_VERSION = Cint(6)     # include/bkhip.h
 const BK_MAX_NEWTON_ITER = 64
 struct NewtonOpts            # bk_newton_opts
     tol::Cdouble; max_iterations::Cint; norm_inf::Cint; linesearch::Cint; alpha::Cdouble; alpha_min::Cdouble

@@ -170,6 +170,19 @@ class CGL2d:
         return self.J(u, **p) @ du
 
 
+def dct_symbol(dims, ls, shift=0.0):
+    """Eigenvalues ``(1 + lam_x + lam_y + lam_z)^2 + shift`` of ``L1 + shift I`` in the DCT basis, array axes (z, y, x).
+    ``1 / min`` is the 2-norm of ``Pl^-1``: with ``Pl = cholesky(L1)`` (examples/SH3d.jl:88, shift 0) the modes next to the critical
+    circle |k| = 1 of Swift-Hohenberg leave eigenvalues of order (h^2/12)^2 -- tests scale their rounding floors with it."""
+    dims = tuple(int(d) for d in dims)
+    lam = []
+    for n, l in zip(dims, ls):
+        h = 2.0 * l / n
+        lam.append(-(4.0 / h**2) * np.sin(np.pi * np.arange(n) / (2.0 * n)) ** 2)
+    grids = np.meshgrid(*lam[::-1], indexing="ij")
+    return (1.0 + sum(grids)) ** 2 + shift
+
+
 def dct_preconditioner(dims, ls, shift=0.0, workers=1):
     """Exact ``(L1 + shift I)^-1`` for the Neumann-ghost ``L1 = (I + Lap)^2`` through the orthonormal DCT-II
     (the 1-D operator of SH3d.jl:21-32 has eigenvectors cos(pi k (j+1/2)/N), eigenvalues -(4/h^2) sin^2(pi k/2N)).
@@ -177,14 +190,9 @@ def dct_preconditioner(dims, ls, shift=0.0, workers=1):
     no longer fits; mathematically the same operator.  Returns a callable v -> Pl \\ v on flat x-fastest vectors."""
     import scipy.fft as sfft
     dims = tuple(int(d) for d in dims)
-    lam = []
-    for n, l in zip(dims, ls):
-        h = 2.0 * l / n
-        lam.append(-(4.0 / h**2) * np.sin(np.pi * np.arange(n) / (2.0 * n)) ** 2)
     # array axes are (z, y, x) for a C-ordered reshape of an x-fastest vector
     shape = dims[::-1]
-    grids = np.meshgrid(*lam[::-1], indexing="ij")
-    sym = (1.0 + sum(grids)) ** 2 + shift
+    sym = dct_symbol(dims, ls, shift)
 
     def apply(v):
         a = np.asarray(v, dtype=float).reshape(shape)

@@ -90,6 +90,9 @@ def generate(path):
     out = dict(generator="oracle", versions=dict(note="oracle-generated schema exercise, NOT reference output"))
     out["sh3d_22"] = sh_case((22, 22, 22), (np.pi,) * 3, 0.1, 1.2, 4)
     out["sh2d_151x100"] = sh_case((151, 100), (8 * np.pi, 4 * np.pi / np.sqrt(3)), -0.1, 1.3, 3)
+    # (round 6: a grid on which the library's default Arnoldi step is the stencil-free one; the 64^3 case of julia/gen_fixtures.jl needs a
+    # sparse factorisation of a 262 144-unknown 25-point operator and is left to the real generator -- its consumers skip)
+    out["sh2d_128x64"] = sh_case((128, 64), (12.5, 6.0), -0.1, 1.3, 2)
     out["cgl_41x21"] = cgl_case()
     json.dump(out, open(path, "w"), indent=1)
 

@@ -73,3 +73,20 @@ def test_fused_roundtrip_spectral_dot_is_the_physical_dot(exe, N):
     za, zb = idct(sa * dct(a)), idct(sb * dct(b))
     assert np.abs(o[:N, 0] - za).max() < 1e-13 and np.abs(o[:N, 1] - zb).max() < 1e-13
     assert abs(o[N, 0] - a @ za) < 1e-13 * abs(a @ za) * N and abs(o[N, 1] - b @ zb) < 1e-13 * abs(b @ zb) * N
+
+
+@pytest.mark.parametrize("N", [64, 128, 256, 512, 1024])
+def test_lane_pair_split_of_the_merged_middle_is_bitwise_the_unsplit_round_trip(exe, N):
+    """Round 6 (dct_core.h: mid_half_fwd / mid_half_pairs / mid_half_inv): the merged middle of the z round trip shared by two
+    lanes -- each owns one top group, the upper halves are exchanged around the (k, N - k) pairing -- performs the SAME arithmetic
+    per value as fused_mid<2>: the replay is bitwise equal (modes 11 vs 6), and the spectral dot of the split (mode 12) agrees with
+    the unsplit one (mode 10) to the rounding of a differently ordered sum."""
+    rng = np.random.default_rng(3 * N)
+    a, b = rng.standard_normal(N), rng.standard_normal(N)
+    body = " ".join(map(repr, a.tolist())) + "\n" + " ".join(map(repr, b.tolist()))
+    run = lambda mode: np.array(list(map(float, subprocess.run([exe], input=f"{mode} {N}\n" + body, capture_output=True, text=True,
+                                                                check=True).stdout.split())))
+    o6, o11, o10, o12 = run(6), run(11), run(10), run(12)
+    assert np.array_equal(o6, o11)
+    assert np.array_equal(o10[:2 * N], o12[:2 * N])
+    assert np.abs(o10[2 * N:] - o12[2 * N:]).max() <= 1e-14 * np.abs(o10[2 * N:]).max()

@@ -19,11 +19,12 @@ def test_consumers_run_end_to_end_on_a_schema_file(tmp_path):
     # the keys julia/gen_fixtures.jl writes per Swift-Hohenberg case
     want = {"dims", "ls", "l", "nu", "F_u0", "dF_u0_probe1", "newton", "gmres", "gmres_shift", "bordering", "matrixfree",
             "shift_invert", "branch", "minres", "cg"}
-    assert want <= set(d["sh3d_22"]) and want <= set(d["sh2d_151x100"])
+    assert want <= set(d["sh3d_22"]) and want <= set(d["sh2d_151x100"]) and want <= set(d["sh2d_128x64"])
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_reference_fixtures.py"), "-q", "-m",
                         "not gpu", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "3 passed" in r.stdout and "skipped" not in r.stdout, r.stdout[-500:]
+    # (sh3d_64 is the one case the schema file does not hold: its two consumers skip)
+    assert "4 passed, 1 skipped" in r.stdout, r.stdout[-500:]
     # and the real file is still absent / untouched: nothing oracle-generated may sit in tests/golden/
     real = os.path.join(ROOT, "tests", "golden", "julia_fixtures.json")
     if os.path.exists(real):

@@ -107,14 +107,18 @@ def test_fullsize_preconditioner_roundtrip(ctx, big):
     assert again.add_(v, -1.0).norminf() <= 1e-9 * v.norminf()
 
 
-def test_fullsize_tiled_corrector_matches_cpu_oracle_cell(ctx, big):
+@pytest.mark.parametrize("shift", [1.0, 0.0])
+def test_fullsize_tiled_corrector_matches_cpu_oracle_cell(ctx, big, shift):
     """bench.py's workload: the hexagon cell solution (CPU oracle) reflected to 8 x 16 x 16 cells is an exact discrete
-    solution at 512^3, and the 512^3 corrector reproduces the oracle's one-cell corrector."""
+    solution at 512^3, and the 512^3 corrector reproduces the oracle's one-cell corrector -- with Pl = lu(L1 + I)
+    (examples/SH2d-fronts.jl:121) and with the reference SH3d example's own Pl = cholesky(L1) (examples/SH3d.jl:88-93, shift 0:
+    |Pl^-1| ~ 1e5 on the modes next to the critical circle, of which the tiled domain holds a dense band the symmetric right-hand
+    sides do not excite -- rounding does, at eps |Pl^-1|)."""
     import torch
     import bench
     from bk_amd import hip
     from oracle import bordered, krylov, operators, palc
-    ds, theta, shift = -0.001, 0.5, 1.0
+    ds, theta = -0.001, 0.5
     tiles = bench.tiles_for(big.dims[0])
     # CPU oracle on the one cell
     shc = operators.SwiftHohenberg(bench.CELL, bench.CELL_L)
@@ -150,6 +154,10 @@ def test_fullsize_tiled_corrector_matches_cpu_oracle_cell(ctx, big):
     ls = hip.GMRESKrylovKit(dim=30, rtol=1e-9, atol=1e-12, maxiter=150, Pl=P)
     sg = hip.newton_palc_native(big, Z0, T, ZP, ds, theta, hip.BorderingBLS(ls, check_precision=False), tol=1e-9,
                                 max_iterations=15, p_min=-0.1, p_max=0.15, norm_inf=True)
+    import time
+    _phase("tiled_corrector", time.time(), n=big.dims[0], shift=shift, gpu=dict(converged=sg["converged"], itnewton=sg["itnewton"],
+           itlinear=sg["itlineartot"], residuals=sg["residuals"], p=sg["u"].p), cell_oracle=dict(itnewton=so["itnewton"],
+           itlinear=so["itlineartot"], residuals=so["residuals"], p=so["p"]))
     assert sg["converged"] and sg["itnewton"] == so["itnewton"]
     r0 = so["residuals"][0]
     # same predictor => same residual up to the rounding of ONE stencil evaluation.  The predictor residual is O(ds^2) ~
@@ -291,40 +299,82 @@ def _scratch_dir(tmp_path, need_gib):
     return str(tmp_path)
 
 
-# (dims, amplitude): white noise of amplitude +-1 makes the Jacobian -L1 + l + 2 nu u - 3 u^2 safely definite (mean of the
-# pointwise term 0.1 - 3 * 4 / 12 = -0.9; GMRES(30) needs ~11 iterations on both sides); amplitude 0.4 leaves it BARELY definite
-# (mean 0.1 - 0.16 = -0.06): 38 / 48 operator applications on the CPU side, i.e. both solves of the bordered system restart.
-# Smaller amplitudes leave it indefinite and GMRES(30) stagnates -- in the CPU restatement as well.
-GENERIC = [((256, 128, 128), 1.0), ((100, 90, 66), 1.0), ((256, 256, 256), 1.0), ((256, 256, 256), 0.4)]
+# (dims, amplitude, shift, base).  base "noise": white noise of amplitude +-1 makes the Jacobian -L1 + l + 2 nu u - 3 u^2 safely
+# definite (mean of the pointwise term 0.1 - 3 * 4 / 12 = -0.9; GMRES(30) needs ~11 iterations on both sides); amplitude 0.4 leaves it
+# BARELY definite (mean 0.1 - 0.16 = -0.06): 38 / 48 operator applications on the CPU side, i.e. both solves of the bordered system
+# restart.  Smaller amplitudes leave it indefinite and GMRES(30) stagnates -- in the CPU restatement as well.
+# Shift 0 = the reference SH3d example's own pairing Pl = cholesky(L1) (examples/SH3d.jl:88-93).  On white noise that pairing
+# degenerates with the domain size -- the right-hand side excites the whole near-null band of L1 next to the critical circle,
+# |Pl^-1| ~ 1e5: cpu_ref needs 84 + 73 applications at 64^3, 682 + 566 at 128 x 128 x 64, 2863 + 1462 at 256 x 128 x 128 (round 6,
+# measured here) -- so its cases are: base "hex" = the bench's Newton-converged hexagon cell tiled by even reflections, plus white
+# noise of the given amplitude (no symmetry left; 262 + 144 applications on the CPU side at 128 x 64 x 64, i.e. ~14 restart cycles),
+# and amplitude 0 = the bench's own state at config 4's size (the second point is the tiled second cell solution).
+GENERIC = [((256, 128, 128), 1.0, 1.0, "noise"), ((100, 90, 66), 1.0, 1.0, "noise"), ((256, 256, 256), 1.0, 1.0, "noise"),
+           ((256, 256, 256), 0.4, 1.0, "noise"), ((128, 64, 64), 0.02, 0.0, "hex"), ((256, 256, 256), 0.0, 0.0, "hex"),
+           ((256, 256, 256), 0.0, 1.0, "hex")]
 
 
-@pytest.mark.parametrize("dims,amp", GENERIC)
-def test_generic_state_against_the_cpp_restatement(ctx, dims, amp, tmp_path):
-    """VERDICT r3 Weak 1 / Next 3, r4 Next 1(a): parity on a GENERIC state -- white noise, no symmetry, nothing the
+def _hex_cell_points(ds):
+    """The bench's two Newton-converged hexagon cell solutions from the CPU oracle (cached per session)."""
+    import bench
+    from oracle import krylov, operators, palc
+    if "cell" not in _CPU_REF:
+        shc = operators.SwiftHohenberg(bench.CELL, bench.CELL_L)
+        Plc = operators.dct_preconditioner(bench.CELL, bench.CELL_L, 1.0)
+        ols = lambda J, r, a0=0.0, a1=1.0: krylov.gmres_krylovkit(J, r, a0, a1, krylovdim=30, maxiter=150, rtol=1e-9, atol=1e-12, Pl=Plc)[:3]
+        pc = palc.Problem(lambda x, p: shc.F(x, p, 1.2), lambda x, p: (lambda dx: shc.dF(x, p, 1.2, dx)))
+        c0 = palc.newton(pc, bench.hex_guess_np(), 0.1, ols, tol=1e-10, max_iterations=40, normN=palc.norminf)
+        c1 = palc.newton(pc, c0["u"], 0.1 + ds / 150.0, ols, tol=1e-10, max_iterations=20, normN=palc.norminf)
+        assert c0["converged"] and c1["converged"]
+        _CPU_REF["cell"] = (c0["u"], c1["u"])
+    return _CPU_REF["cell"]
+
+
+@pytest.mark.parametrize("dims,amp,shift,base", GENERIC)
+def test_generic_state_against_the_cpp_restatement(ctx, dims, amp, shift, base, tmp_path):
+    """VERDICT r3 Weak 1 / Next 3, r4 Next 1(a), r5 Next 1(a): parity on a GENERIC state -- white noise, no symmetry, nothing the
     even-reflection tiling could hide -- against oracle/cpu_ref.cpp, the C++/OpenMP restatement of the reference's own CSR
     formulation (assembled L1 = A*A, SpMV, MGS2 GMRES(30), BEC; pinned to the NumPy oracle by tests/test_oracle.py).  Compared
     directly, vector by vector: the residual F at the secant predictor, the Jacobian-vector product J tau, the iterate of the
     preconditioned GMRES solve J x1 = F (and its true residual through the HIP operator), then one whole newton_palc iteration
     (residual history, corrected parameter, operator applications per solve).  Mirrors test/linear_solvers/test_linear.jl:
     106-169 in spirit (every solver == J \\ rhs): at BASELINE config 4's own size, 256^3 = 16.8 M unknowns, on a definite state
-    and on a barely definite one whose two solves RESTART (>= 35 operator applications each on both sides); at 4.2 M unknowns; and
-    at 0.6 M unknowns with extents that are no powers of two (dense fp64-MFMA transform passes)."""
+    and on a barely definite one whose two solves RESTART (>= 35 operator applications each on both sides); at 4.2 M unknowns; at
+    0.6 M unknowns with extents that are no powers of two (dense fp64-MFMA transform passes); and with the reference SH3d example's
+    own preconditioner Pl = cholesky(L1) (shift 0) on noisy hexagons (a dozen restart cycles) and on the bench's state at 256^3.
+    Every comparison is evaluated and logged (gpurun_out/fullsize_phases.jsonl) before any is asserted."""
     import json
     import shutil
     import subprocess
     import torch
+    import bench
     from bk_amd import hip
     import time
     t_ = time.time()
     exe, env = _build_cpu_ref(tmp_path)
     t_ = _phase("build", t_, dims=dims, amp=amp, omp=env["OMP_NUM_THREADS"])
     N = dims[0] * dims[1] * dims[2]
-    ls_ = tuple(math.pi * d / 32 for d in dims)                       # h = pi / 16 on every axis, the bench's spacing
-    rng = np.random.default_rng(dims[0] + dims[2])
-    u0 = 2.0 * amp * (rng.random(N) - 0.5)
-    u1 = u0 + 1e-3 * (rng.random(N) - 0.5)
-    p0, ds, theta, shift = 0.1, -0.001, 0.5, 1.0
+    p0, ds, theta = 0.1, -0.001, 0.5
     p1 = p0 + ds / 150.0
+    rng = np.random.default_rng(dims[0] + dims[2])
+    if base == "noise":
+        ls_ = tuple(math.pi * d / 32 for d in dims)                       # h = pi / 16 on every axis, the bench's spacing
+        u0 = 2.0 * amp * (rng.random(N) - 0.5)
+        u1 = u0 + 1e-3 * (rng.random(N) - 0.5)
+    else:
+        tiles = tuple(d // c for d, c in zip(dims, bench.CELL))
+        ls_ = tuple(l * t for l, t in zip(bench.CELL_L, tiles))
+        cx, cy, cz = bench.CELL
+        idx = [np.concatenate([np.arange(nc) if c % 2 == 0 else np.arange(nc)[::-1] for c in range(T_)]) for nc, T_ in zip(bench.CELL, tiles)]
+        tile = lambda v: np.ascontiguousarray(v.reshape(cz, cy, cx)[np.ix_(idx[2], idx[1], idx[0])]).reshape(-1)
+        c0, c1 = _hex_cell_points(ds)
+        u0 = tile(c0)
+        if amp > 0.0:
+            u0 += 2.0 * amp * (rng.random(N) - 0.5)
+            u1 = u0 + 1e-3 * (rng.random(N) - 0.5)
+        else:
+            u1 = tile(c1)
+    hs = [2.0 * l / d for l, d in zip(ls_, dims)]
     work = _scratch_dir(tmp_path, 8 * 8 * N / 2 ** 30)
     try:
         f0, f1, pre = os.path.join(work, "u0.bin"), os.path.join(work, "u1.bin"), os.path.join(work, "d_")
@@ -337,11 +387,11 @@ def test_generic_state_against_the_cpp_restatement(ctx, dims, amp, tmp_path):
         except subprocess.TimeoutExpired:
             pytest.skip(f"the CPU restatement did not finish {dims} within {_CPU_LIMIT} s on this host ({env['OMP_NUM_THREADS']} threads)")
         ref = json.loads(r.stdout.strip().splitlines()[-1])
-        t_ = _phase("cpu_ref", t_, dims=dims, amp=amp, step_s=ref["seconds_per_step"], setup_s=ref["setup_seconds"], threads=ref["threads"],
-                    itlinear=ref["itlinear_each"])
+        t_ = _phase("cpu_ref", t_, dims=dims, amp=amp, shift=shift, base=base, step_s=ref["seconds_per_step"], setup_s=ref["setup_seconds"],
+                    threads=ref["threads"], itlinear=ref["itlinear_each"])
         load = lambda tag: np.fromfile(pre + tag + ".bin")
-        restart = amp < 0.9
-        if restart:
+        restart = max(ref["itlinear_each"]) > 31
+        if base == "noise" and amp < 0.9:
             assert min(ref["itlinear_each"]) >= 35, ref["itlinear_each"]      # the case exists to exercise restarts
         prob = hip.SwiftHohenberg(ctx, dims, ls_, l=0.1, nu=1.2)
         B = hip.BorderedArray
@@ -351,26 +401,28 @@ def test_generic_state_against_the_cpp_restatement(ctx, dims, amp, tmp_path):
         nrm = math.sqrt(T.u.inner(T.u) / N * theta + T.p * T.p * (1 - theta))
         T.scale_(math.copysign(1.0, ds) / nrm)
         ZP = Z0.copy().add_(T, ds)
-        assert abs(T.p - ref["tau_p"]) <= 1e-12 * abs(ref["tau_p"]) and abs(ZP.p - ref["p_pred"]) <= 1e-15
+        chk = {}
+        chk["tau_p"] = (abs(T.p - ref["tau_p"]), 1e-12 * abs(ref["tau_p"]))
+        chk["p_pred"] = (abs(ZP.p - ref["p_pred"]), 1e-15)
         xp = load("xp")
         xpmax = np.abs(xp).max()
-        assert np.abs(ZP.u.numpy() - xp).max() <= 1e-15 * xpmax
+        chk["predictor"] = (np.abs(ZP.u.numpy() - xp).max(), 1e-15 * xpmax)
         del xp
         # F at the predictor and J tau: one stencil evaluation each; bound = the rounding of a cancelling 25-term sum
-        h = math.pi / 16
-        l1_inf = (1.0 + 12.0 / h ** 2) ** 2
+        l1_inf = (1.0 + sum(4.0 / h_ ** 2 for h_ in hs)) ** 2
         floor = 8 * np.finfo(float).eps * l1_inf
         res = prob.residual(ZP.u, ZP.p)
         rref = load("res")
-        assert np.abs(res.numpy() - rref).max() <= floor * xpmax, np.abs(res.numpy() - rref).max()
-        assert abs(res.norminf() - ref["residuals"][0]) <= 1e-12 * ref["residuals"][0]
+        chk["residual"] = (np.abs(res.numpy() - rref).max(), floor * xpmax)
+        # (on the exact tiled state the predictor residual is O(ds^2) ~ 5.6e-6, i.e. its inf-norm itself sits at the absolute floor)
+        chk["residual_inf"] = (abs(res.norminf() - ref["residuals"][0]), 1e-12 * ref["residuals"][0] + (floor * xpmax if amp == 0.0 else 0.0))
         del rref
         J = prob.jacobian(ZP.u, ZP.p)
         # (the two sides normalise the tangent with differently ordered sums: tau agrees to a few eps RELATIVE, and |J tau| is
         # |L1|_inf ~ 1e5 times |tau| on white noise -- so that scale difference is removed exactly before the floor applies)
         jt = J(T.u).numpy() * (ref["tau_p"] / T.p)
         jref = load("jtau")
-        assert np.abs(jt - jref).max() <= floor * np.abs(T.u.numpy()).max(), np.abs(jt - jref).max()
+        chk["J_tau"] = (np.abs(jt - jref).max(), floor * np.abs(T.u.numpy()).max())
         del jt, jref
         # J x1 = F, GMRES(30) rtol 1e-9 on the preconditioned residual, both sides; the iterates differ by the solver tolerance
         # (times the conditioning of the preconditioned operator: ~1 on the definite state, ~20 on the barely definite one)
@@ -378,13 +430,20 @@ def test_generic_state_against_the_cpp_restatement(ctx, dims, amp, tmp_path):
         ls = hip.GMRESKrylovKit(dim=30, rtol=1e-9, atol=1e-12, maxiter=150, Pl=P)
         x1, ok, it = ls(J, res)
         x1ref = load("x1")
-        assert ok and abs(it - ref["itlinear_each"][0]) <= 2, (it, ref["itlinear_each"])
+        itref = ref["itlinear_each"][0]
+        chk["solve_converged"] = (0.0 if ok else 1.0, 0.0)
+        # (counts: +-2 per solve, a few per cent over a dozen restart cycles)
+        chk["solve_count"] = (abs(it - itref), max(2, itref // 12))
         xtol = 1e-6 if restart else 1e-7
-        assert np.abs(x1.numpy() - x1ref).max() <= xtol * np.abs(x1ref).max(), np.abs(x1.numpy() - x1ref).max() / np.abs(x1ref).max()
+        if shift == 0.0:
+            # Pl = L1: the solves control |Pl^-1 r| <= 1e-9 |Pl^-1 b|, the iterate's error is that times the conditioning of Pl^-1 J --
+            # whose spectrum now spans |Pl^-1| -- and the white-noise component of the right-hand side is amplified the same way
+            xtol = 1e-5 if amp > 0.0 else 1e-6
+        chk["solve_iterate_rel"] = (np.abs(x1.numpy() - x1ref).max() / np.abs(x1ref).max(), xtol)
         del x1ref
         # the TRUE residual, through the stencil kernel and the plain preconditioner (the solver itself iterates stencil-free)
         rr = P.ldiv(J(x1).add_(res, -1.0))
-        assert rr.norm() <= 2e-9 * P.ldiv(res).norm()
+        chk["true_residual_rel"] = (rr.norm() / P.ldiv(res).norm(), 2e-9)
         del rr, x1
         # one newton_palc iteration with the reference's literal finite-difference dF/dp, as cpu_ref forms it
         ctx.set_option("fd_dparam", 0)
@@ -393,17 +452,22 @@ def test_generic_state_against_the_cpp_restatement(ctx, dims, amp, tmp_path):
                                         max_iterations=1, p_min=-10.0, p_max=10.0, norm_inf=True)
         finally:
             ctx.set_option("fd_dparam", 1)
-        assert abs(sg["residuals"][0] - ref["residuals"][0]) <= 1e-12 * ref["residuals"][0]
-        assert abs(sg["residuals"][1] - ref["residuals"][1]) <= 1e-6 * ref["residuals"][0], (sg["residuals"], ref["residuals"])
+        chk["step_residual_0"] = (abs(sg["residuals"][0] - ref["residuals"][0]), chk["residual_inf"][1])
+        chk["step_residual_1"] = (abs(sg["residuals"][1] - ref["residuals"][1]), 1e-6 * ref["residuals"][0] + (2 * floor * xpmax if amp == 0.0 else 0.0))
         dl = abs(ref["p"] - ref["p_pred"])
-        assert abs(sg["u"].p - ref["p"]) <= (1e-5 if restart else 1e-6) * max(dl, 1e-12) + 1e-12, (sg["u"].p, ref["p"], dl)
-        assert abs(sg["itlineartot"] - ref["itlinear"]) <= 4, (sg["itlineartot"], ref["itlinear"])
+        chk["step_p"] = (abs(sg["u"].p - ref["p"]), (1e-5 if restart else 1e-6) * max(dl, 1e-12) + 1e-12)
+        chk["step_count"] = (abs(sg["itlineartot"] - ref["itlinear"]), max(4, ref["itlinear"] // 12))
         # the corrected state carries dl * J^-1 dF/dp, and the literal quotient (F(x, p + eps) - F(x, p)) / eps carries the rounding
         # noise of F divided by eps = 1.5e-8: ~4 eps_mach |F|_inf / eps = 4e-3 absolute on this white-noise state (|F|_inf = 7e4), a
         # different realisation on each side -- hence 1e-4 relative here, where the solves above agree to 1e-7
         xref = load("x")
-        assert np.abs(sg["u"].u.numpy() - xref).max() <= (1e-3 if restart else 1e-4) * np.abs(xref).max()
-        _phase("gpu_side", t_, dims=dims, amp=amp, itlinear_gpu=sg["itlineartot"])
+        chk["step_state_rel"] = (np.abs(sg["u"].u.numpy() - xref).max() / np.abs(xref).max(), 1e-3 if restart else 1e-4)
+        del xref
+        chk = {k: (float(a_), float(b_)) for k, (a_, b_) in chk.items()}
+        _phase("gpu_side", t_, dims=dims, amp=amp, shift=shift, base=base, itlinear_gpu=sg["itlineartot"], itlinear_cpu=ref["itlinear"],
+               checks={k: {"value": a_, "bound": b_} for k, (a_, b_) in chk.items()})
+        bad = {k: v for k, v in chk.items() if not v[0] <= v[1]}
+        assert not bad, bad
     finally:
         if work != str(tmp_path):
             shutil.rmtree(work, ignore_errors=True)

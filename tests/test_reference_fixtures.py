@@ -61,7 +61,9 @@ def sh_guess(dims, ls):
     return np.ascontiguousarray(s.reshape(-1, order="F"))
 
 
-SH_CASES = ["sh3d_22", "sh2d_151x100"]
+# (sh3d_64 / sh2d_128x64, round 6: grids on which the library's default Arnoldi step is the stencil-free one, with the reference
+# example's own Pl = cholesky(L1); a case the fixture file does not hold is skipped)
+SH_CASES = ["sh3d_22", "sh2d_151x100", "sh3d_64", "sh2d_128x64"]
 
 
 # ------------------------------------------------------------------------------------------------ oracle vs reference (CPU)
@@ -69,6 +71,8 @@ SH_CASES = ["sh3d_22", "sh2d_151x100"]
 def test_oracle_swift_hohenberg_matches_reference(fx, name):
     import scipy.sparse.linalg as spla
     from oracle import bordered, krylov, operators, palc
+    if name not in fx:
+        pytest.skip(f"{name}: not in this fixture file (julia/gen_fixtures.jl emits it from round 6 on)")
     c = fx[name]
     dims, ls, l, nu = tuple(c["dims"]), tuple(c["ls"]), c["l"], c["nu"]
     sh = operators.SwiftHohenberg(dims, ls)
@@ -142,6 +146,8 @@ def test_oracle_cgl_matches_reference(fx):
 def test_hip_swift_hohenberg_matches_reference(fx, ctx, name):
     from bk_amd import continuation as Cn
     from bk_amd import hip
+    if name not in fx:
+        pytest.skip(f"{name}: not in this fixture file (julia/gen_fixtures.jl emits it from round 6 on)")
     c = fx[name]
     dims, ls, l, nu = tuple(c["dims"]), tuple(c["ls"]), c["l"], c["nu"]
     prob = hip.SwiftHohenberg(ctx, dims, ls, l=l, nu=nu)
