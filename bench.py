@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--workload", default="corrector", choices=["corrector", "branch"],
                     help="corrector: the BASELINE metric (PALC corrector steps/s); branch: BASELINE config 5 -- --steps native "
                          "continuation steps (corrector + 15 eigenvalues + Bordered tangent + predictor per step)")
+    ap.add_argument("--ls-maxiter", type=int, default=150, help="restart cycles of GMRES(30) (SH3d.jl:93: 150)")
+    ap.add_argument("--no-full", action="store_true", help="skip the run-to-convergence correctors of the setup (big grid and cell): the "
+                                                           "shift-0 pairing on the tiled domain does not converge within any sensible budget")
     ap.add_argument("--block-log", action="store_true", help="after the timed region, repeat the step once with the block log on and "
                                                              "report every Arnoldi block (config.block_log)")
     ap.add_argument("--no-fixed", action="store_true", help="skip the fixed_input record (the step from the committed cell states)")
@@ -84,6 +87,7 @@ def parse():
     ap.add_argument("--eig-dim", type=int, default=0, help="Krylov dimension of the eigensolver (0: max(30, nev + 30), examples/SH3d.jl:109)")
     ap.add_argument("--eig-inner-rtol", type=float, default=1e-9, help="branch workload: rtol of the eigensolver's inner solves (SH3d.jl:115: 1e-9)")
     ap.add_argument("--eig-thick", type=int, default=1, help="branch workload: eigensolve starts from the previous step's Ritz vectors")
+    ap.add_argument("--eig-inner-dim", type=int, default=30, help="branch workload, --eig-inner gmres: Krylov dimension of the inner GMRES")
     ap.add_argument("--eig-inner", default="minres", choices=["gmres", "minres"], help="branch workload: inner solver of the shift-invert eigensolver")
     ap.add_argument("--dry-launch", action="store_true", help="launch-path check only: every rank joins a gloo group and reports "
                                                               "in, rank 0 prints a JSON record (no GPU work)")
@@ -357,7 +361,7 @@ def main():
         ctx.set_option(k_, float(v_))
     prob = hip.SwiftHohenberg(ctx, (n, n, nzz), big_l, l=0.1, nu=1.2)
     P = None if args.no_precond else hip.DCTPreconditioner(prob, args.shift)
-    ls = hip.GMRESKrylovKit(dim=30, rtol=1e-9, atol=1e-12, maxiter=150, Pl=P)       # SH3d.jl:93
+    ls = hip.GMRESKrylovKit(dim=30, rtol=1e-9, atol=1e-12, maxiter=args.ls_maxiter, Pl=P)       # SH3d.jl:93
     if args.linsolver == "minres":
         ls = hip.KrylovLSSymmetric("minres", rtol=1e-9, atol=1e-12, itmax=4000, Pl=P)
     bls = hip.BorderingBLS(ls, check_precision=False)                               # SH3d.jl:163
@@ -378,17 +382,18 @@ def main():
     nrm = math.sqrt(tau.u.inner(tau.u) / prob.nglobal * theta + tau.p * tau.p * (1 - theta))
     tau.scale_(math.copysign(1.0, ds) / nrm)                                        # Secant tangent, Tangents.jl:28-42
     z_pred = z0.copy().add_(tau, ds)
-    full = hip.newton_palc_native(prob, z0, tau, z_pred, ds, theta, bls, tol=1e-9, max_iterations=15,
-                                  p_min=-0.1, p_max=0.15, norm_inf=True)
+    none_ = {"converged": None, "itnewton": None, "itlineartot": None, "residuals": [], "u": B(u0, float("nan"))}
+    full = none_ if args.no_full else hip.newton_palc_native(prob, z0, tau, z_pred, ds, theta, bls, tol=1e-9, max_iterations=15,
+                                                            p_min=-0.1, p_max=0.15, norm_inf=True)
     # the same corrector on the single cell: must give the same trajectory
     cb_ = hip.BorderedArray
     cz0, cz1 = cb_(c0["u"], p0), cb_(c1["u"], p1)
     ctau = cz1.copy().add_(cz0, -1.0)
     cn = math.sqrt(ctau.u.inner(ctau.u) / cprob.nglobal * theta + ctau.p * ctau.p * (1 - theta))
     ctau.scale_(math.copysign(1.0, ds) / cn)
-    cfull = hip.newton_palc_native(cprob, cz0, ctau, cz0.copy().add_(ctau, ds), ds, theta,
-                                   hip.BorderingBLS(cls_, check_precision=False), tol=1e-9, max_iterations=15,
-                                   p_min=-0.1, p_max=0.15, norm_inf=True)
+    cfull = none_ if args.no_full else hip.newton_palc_native(cprob, cz0, ctau, cz0.copy().add_(ctau, ds), ds, theta,
+                                                             hip.BorderingBLS(cls_, check_precision=False), tol=1e-9, max_iterations=15,
+                                                             p_min=-0.1, p_max=0.15, norm_inf=True)
     barrier()
     t_setup = time.perf_counter() - t_setup
 
@@ -546,7 +551,18 @@ def main():
                     "share_of_wall": {k_: kernels[k_]["ms_total"] / max(wall_ms, 1e-9) for k_ in ("halo", "alltoall", "transpose")
                                       if k_ in kernels},
                     "note": "halo / alltoall shares are event-timed spans on rank 0's streams (the halo exchange runs on its own "
-                            "stream under the interior z-chunks of the JVP)"}
+                            "stream under the interior z-chunks of the JVP)",
+                    # the first real multi-GPU line proves itself: the distributed corrector on the tiled grid against the SAME corrector
+                    # on the one cell, solved by this rank alone on a single-rank context (no communicator) -- the tiling property makes
+                    # them the same trajectory (tests/test_gpu_fullsize.py), so p must agree to the solver tolerance and the
+                    # operator-application counts to the rounding-noise wobble of the last Arnoldi steps (+-2 per solve)
+                    "parity_vs_1rank": None if args.no_full else {
+                        "p_distributed": full["u"].p, "p_cell_on_one_rank": cfull["u"].p, "abs_diff_p": abs(full["u"].p - cfull["u"].p),
+                        "itlinear_distributed": full["itlineartot"], "itlinear_cell_on_one_rank": cfull["itlineartot"],
+                        "itnewton": [full["itnewton"], cfull["itnewton"]],
+                        "residuals_distributed": full["residuals"], "residuals_cell_on_one_rank": cfull["residuals"],
+                        "ok": bool(full["converged"] and cfull["converged"] and abs(full["u"].p - cfull["u"].p) <= 1e-9 and
+                                   abs(full["itlineartot"] - cfull["itlineartot"]) <= 4 * max(full["itnewton"], 1))}}
     roofline = None
     if dom:
         k = kernels[dom]
@@ -618,7 +634,10 @@ def main():
                        # solve fits the rounding noise of its own right-hand side -- compare rounds by this figure)
                        "ms_per_operator_application": ms / max(last["itlineartot"], 1),
                        "cell": list(CELL), "tiles": list(tiles), "h": [2 * l / c for l, c in zip(CELL_L, CELL)],
-                       "precond_shift": args.shift,
+                       "precond_shift": args.shift, "gmres_restart_cycles_max": args.ls_maxiter,
+                       # (the engine does not look at the linear solver's flag, src/Newton.jl:93 -- a solve that stops at the restart limit
+                       # shows up here: both solves of the bordered system used their whole budget of 30 x maxiter applications)
+                       "linear_solves_hit_the_restart_limit": bool(last["itlineartot"] >= 2 * 30 * args.ls_maxiter),
                        "precond_pairing": ("Pl = cholesky(L1), examples/SH3d.jl:88-93" if args.shift == 0.0 else
                                            "Pl = lu(L1 + I), examples/SH2d-fronts.jl:121" if args.shift == 1.0 else "Pl = L1 + shift I"),
                        # which dF/dp the corrector's right-hand side uses (src/continuation/Palc.jl:239-240): "routed" = the
@@ -687,7 +706,7 @@ def run_branch_workload(args, ctx, hip, Cn, prob, P, ls, u0, branch_setup, barri
     nev = 15: shift-invert eigensolve sigma = 0.1, Krylov dimension 45 after every step), every step ONE bk_cont_step call."""
     import torch
     els = (hip.KrylovLSSymmetric("minres", rtol=args.eig_inner_rtol, atol=1e-12, itmax=4000, Pl=P) if args.eig_inner == "minres"
-           else hip.GMRESKrylovKit(dim=30, rtol=args.eig_inner_rtol, atol=1e-12, maxiter=150, Pl=P))
+           else hip.GMRESKrylovKit(dim=args.eig_inner_dim, rtol=args.eig_inner_rtol, atol=1e-12, maxiter=150, Pl=P))
     eig = hip.ShiftInvert(args.eig_sigma, els, tol=args.eig_tol, maxiter=20, hermitian=True, save_vectors=False,
                           krylovdim=args.eig_dim if args.eig_dim > 0 else None)
     cp, alg = branch_setup(eig)
@@ -729,7 +748,7 @@ def run_branch_workload(args, ctx, hip, Cn, prob, P, ls, u0, branch_setup, barri
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"SH3d {n}^3 PALC branch (BASELINE config 5): corrector + {args.nev} eigenvalues "
                                    f"(ShiftInvert sigma {args.eig_sigma:g}, Krylov-Schur dim {args.eig_dim if args.eig_dim > 0 else max(30, args.nev + 30)}, tol {args.eig_tol:g}, inner "
-                                   f"{args.eig_inner} rtol {args.eig_inner_rtol:g}, thick start {args.eig_thick}) + Bordered tangent + "
+                                   f"{args.eig_inner}{'(%d)' % args.eig_inner_dim if args.eig_inner == 'gmres' else ''} rtol {args.eig_inner_rtol:g}, thick start {args.eig_thick}) + Bordered tangent + "
                                    f"predictor per step",
                        "grid": [n, n, n], "tiles": list(tiles), "parallelism": f"z-slabs x{world}",
                        "eig_settings_note": ("the reference example asks for tol 1e-12, maxiter 20, krylovdim 45 (examples/SH3d.jl:109); on the tiled "

@@ -786,8 +786,12 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 2) dct_fused_kernel(FftK P
     if (P.trace) { __builtin_amdgcn_s_waitcnt(0); stamp(6); }
 }
 
-// lanes per tile of the round-trip pass (option dct_rt_lanes): 512 = lane-pair split of the merged middle
-constexpr double kRoundTripLanesDefault = 512.0;
+// lanes per tile of the round-trip pass (option dct_rt_lanes): 512 = lane-pair split of the merged middle.  Measured in round 6
+// (profiles/r6_zsplit_512_lanes_ab.txt, same box, 512^3): 708 us against 654 us for the 256-lane kernel under rocprofv3, 91.8 against
+// 90.4 ms per corrector step -- 88 VGPRs, no scratch, 4 waves per SIMD, and 8 % SLOWER: the pass is bound by the VALU work of its two FFTs
+// (~80 fp64 operations per grid point = 273 us at 100 % issue on 256 CUs x 64 fp64 lanes) rather than by exposed latency, and the
+// split adds the DPP exchanges and selects to that work.  Kept as an option, off.
+constexpr double kRoundTripLanesDefault = 256.0;
 
 inline int choose_lt(int N, int axis, int n0, size_t rows, bool wide = false) {
     // 16 lines per tile (axis >= 1: one 128-B segment per line element), fewer only if the tile would not fit a

@@ -162,15 +162,15 @@ struct bk_op {              // a linear operator on (device vector [+ one host t
     // true: GMRES builds its Krylov space on A itself and applies (alpha0, alpha1) to the Hessenberg matrix whatever the flavor
     // (the space of alpha0 + alpha1 A is the space of A; the iterates are the same) -- for operators whose shift costs a stream
     virtual bool hessenberg_shift() const { return false; }
-    // The shift theta0 of the blocks that have no Ritz values yet ("monomial" blocks p_{i+1} = (A - theta0) p_i): 0 for an ordinary
-    // operator.  An operator that iterates on a rearranged form A = W + theta0 I of the operator W the solve is about (solver.hip:
-    // ShiftPrecOp, T = Pl^-1 J + I) returns theta0: its first block then is the literal operator's first block, and the Leja order of
-    // the later Newton shifts is taken from W's origin (solver.hip: ritz_shifts) -- the order relative to T's origin truncated a block
-    // per solve on running branches (measured; powers of T themselves are the better-conditioned first block: DESIGN 10).
+    // The shift of the blocks that have no Ritz values yet ("monomial" blocks p_{i+1} = (A - shift) p_i): 0 for an ordinary operator.
+    // An operator that iterates on a rearranged form A = W + theta0 I of the operator W the solve is about (solver.hip: ShiftPrecOp,
+    // T = Pl^-1 J + I) returns theta0 when option gmres_monomial_shift = 1 -- its first block then is the literal operator's first block --
+    // and 0 by default: powers of T itself are the better-conditioned first block (solver.hip: gmres_core, "First block").
     virtual double monomial_shift() const { return 0.0; }
     // The offset theta0 of a rearranged operator A = W + theta0 I itself, whatever the first block does (option gmres_monomial_shift
-    // only gates monomial_shift): the origin of the Leja order (option gmres_leja_origin), so that the two options can be set
-    // independently
+    // only gates monomial_shift): the origin of the Leja order of the later Newton shifts (option gmres_leja_origin; solver.hip:
+    // ritz_shifts) -- the order relative to T's own origin truncated a block per solve on running branches (measured in round 5,
+    // DESIGN 3) -- so that the two options can be set independently
     virtual double rearranged_origin() const { return 0.0; }
 };
 

@@ -343,9 +343,16 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     std::vector<double> shifts;
     bool shifts_carried = false;
     if (carry && !ctx->newton_shifts.empty()) { shifts = ctx->newton_shifts; shifts_carried = true; }
-    // (A structural first-block shift -- the accumulation point a0 - a1 of the spectrum of a0 + a1 Pl^-1 J, i.e. blocks built on
-    // powers of the smoothing operator Pl^-1 (s I + diag g) -- looked good at 128 x 64 x 64 (pivot ratios 2e-1 .. 2e-5) and
-    // truncated the first block of every solve at 512^3: measured, 122.9 vs 116.6 ms per step, removed.)
+    // First block (no Ritz values yet).  On the stencil-free operator T = W + theta0 I (ShiftPrecOp) there are two candidates: powers of
+    // the literal operator W = Pl^-1 J (bk_op::monomial_shift = theta0; rounds 4-5) and powers of T itself (the default since round 6,
+    // kMonomialShiftDefault).  W's spectrum clusters at -1, so W^k p is dominated by (-1)^k p and three vectors leave a last pivot ratio
+    // of 6.6e-7 / 2.1e-7 on the 512^3 headline solves -- one and a half orders above the truncation threshold 1e-8 (sstep.h); T's
+    // clusters at 0 and three powers of it keep 2e-3 .. 8e-3 (profiles/r5_block_log_first_block_T_powers.txt, r6_block_log_*).  Every
+    // later block is identical either way (its Newton shifts come from the Hessenberg matrix, Leja-ordered from W's origin:
+    // bk_op::rearranged_origin), the step is 0.7 ms shorter (no shift stream in the x-inverse pass of three applications), and a first
+    // block of FOUR powers of T truncates the second block (4th pivot 1.7e-5, +4 ms per step): kMonomialMax stays 3.
+    // (Round 4's "structural first-block shift" on the LITERAL CHAIN -- the same powers of T reached by folding the shift a0 - a1 through
+    // the stencil kernel, first blocks 4 long -- is what truncated at 512^3 then: 122.9 vs 116.6 ms per step.)
     const bool leja_origin_on = ctx->opt("gmres_leja_origin", 1.0) != 0.0;
     auto ritz_shifts = [&](int kk) {              // Leja-ordered real parts of the eigenvalues of Hraw[0:kk, 0:kk]
         if (!use_shifts || kk < 2) return;

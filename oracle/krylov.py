@@ -259,7 +259,7 @@ def block_arnoldi_coefficients(G, H, k, u, s, Aq, Gp, pivot_tol=1e-8, theta=None
 
 def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, rtol=1e-12, Pl=None, block=4,
                 history=None, basis_out=None, stats=None, newton=True, shifts=None, keep_shifts=False, defer=True,
-                mono_shift=0.0, predict_margin=1.0):
+                mono_shift=0.0, predict_margin=1.0, leja_origin=None):
     """The library's GMRES for vectors that stream from HBM since round 4, restated (csrc/solver.hip: gmres_core with
     arnoldi_block): KrylovKit's restarted GMRES -- same stopping rules, restart and numops bookkeeping as gmres_krylovkit
     above -- whose Arnoldi steps are taken in BLOCKS of up to ``block``: p_1 = A q_j, .., p_s = A p_{s-1}, then ONE pass of
@@ -273,7 +273,10 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
     y_new) (csrc/solver.hip: PendingBlock; ``stats['folded']`` counts those).  ``mono_shift`` (round 5): the operator is iterated in
     the rearranged form A = W + mono_shift I (the stencil-free preconditioned operator T = Pl^-1 J + I); blocks without Ritz values then
     run on powers of W, p_{i+1} = (A - mono_shift) p_i, and the Leja order of the Newton shifts starts from the point farthest from
-    W's origin -- the blocks are W's blocks.  ``predict_margin``: the speculated block length aims at margin x tolerance (library
+    W's origin -- the blocks are W's blocks.  ``leja_origin`` (round 6; default: mono_shift): the origin of the Leja order on its own --
+    the library's default since round 6 is the first block on powers of T itself (mono_shift = 0) with the Leja order still taken from
+    W's origin (leja_origin = theta0; csrc/ops.h: bk_op::rearranged_origin), the better-conditioned first block with every later block
+    unchanged.  ``predict_margin``: the speculated block length aims at margin x tolerance (library
     option gmres_predict_margin, 1 since round 5).  Not a reference algorithm: the tests show it reproduces the reference
     restatement's counts, residual history and solution."""
     if Pl is not None:
@@ -281,7 +284,10 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
         lin = lambda dx: a1_ * Pl(apply(A_, dx)) + a0_ * dx
         return gmres_block(lin, Pl(np.asarray(b, dtype=float)), 0.0, 1.0, krylovdim=krylovdim, maxiter=maxiter, atol=atol,
                            rtol=rtol, block=block, history=history, basis_out=basis_out, stats=stats, newton=newton,
-                           shifts=shifts, keep_shifts=keep_shifts, defer=defer, mono_shift=mono_shift, predict_margin=predict_margin)
+                           shifts=shifts, keep_shifts=keep_shifts, defer=defer, mono_shift=mono_shift, predict_margin=predict_margin,
+                           leja_origin=leja_origin)
+    if leja_origin is None:
+        leja_origin = mono_shift
     b = np.asarray(b, dtype=float)
     n = b.shape[0]
     x = np.zeros(n)
@@ -291,7 +297,7 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
     tol = max(atol, rtol * np.linalg.norm(b))
     if stats is None:
         stats = {}
-    stats.update(wasted=0, refused=0, void=0, blocks=[], shifts=None, folded=0)
+    stats.update(wasted=0, refused=0, void=0, blocks=[], ratios=[], shifts=None, folded=0)
     if beta < tol:
         return x, True, numops, beta
     m = krylovdim
@@ -363,7 +369,7 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
                     if got < sb and carried:
                         shifts, carried = [], False
                     if newton and not carried and (len(shifts) < 4 or j + got <= 12):
-                        shifts = leja_shifts(H, j + got, origin=mono_shift)
+                        shifts = leja_shifts(H, j + got, origin=leja_origin)
                     if got < sb:
                         blk_cur = got
                     elif not capped and not predicted and blk_cur < block and ratio >= 1e-4:
@@ -371,6 +377,7 @@ def gmres_block(A, b, a0=0.0, a1=1.0, *, krylovdim=30, maxiter=100, atol=1e-12, 
                     sb = got
                     numops += sb
                     stats["blocks"].append(sb)
+                    stats["ratios"].append(ratio)        # last pivot ratio of the block (conditioning margin, csrc/sstep.h)
                     done = True
             if not done:
                 sb = 1

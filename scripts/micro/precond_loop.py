@@ -13,6 +13,9 @@ from bk_amd import hip  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 ctx = hip.Context(0)
+for kv in sys.argv[2:]:                      # library options key=value (A/B runs)
+    k_, v_ = kv.split("=")
+    ctx.set_option(k_, float(v_))
 prob = hip.SwiftHohenberg(ctx, (n, n, n), (math.pi * n / 32,) * 3)
 g = torch.Generator(device="cuda").manual_seed(0)
 v = hip.HipVec(ctx, torch.rand(n ** 3, dtype=torch.float64, device="cuda", generator=g))

@@ -107,13 +107,15 @@ def test_fullsize_preconditioner_roundtrip(ctx, big):
     assert again.add_(v, -1.0).norminf() <= 1e-9 * v.norminf()
 
 
-@pytest.mark.parametrize("shift", [1.0, 0.0])
+@pytest.mark.parametrize("shift", [1.0])
 def test_fullsize_tiled_corrector_matches_cpu_oracle_cell(ctx, big, shift):
     """bench.py's workload: the hexagon cell solution (CPU oracle) reflected to 8 x 16 x 16 cells is an exact discrete
-    solution at 512^3, and the 512^3 corrector reproduces the oracle's one-cell corrector -- with Pl = lu(L1 + I)
-    (examples/SH2d-fronts.jl:121) and with the reference SH3d example's own Pl = cholesky(L1) (examples/SH3d.jl:88-93, shift 0:
-    |Pl^-1| ~ 1e5 on the modes next to the critical circle, of which the tiled domain holds a dense band the symmetric right-hand
-    sides do not excite -- rounding does, at eps |Pl^-1|)."""
+    solution at 512^3, and the 512^3 corrector reproduces the oracle's one-cell corrector, with Pl = lu(L1 + I)
+    (examples/SH2d-fronts.jl:121).  (The reference SH3d example's own Pl = cholesky(L1), shift 0, does NOT survive the tiling: the
+    tiled domain holds a dense band of modes next to the critical circle |k| = 1 on which L1 is numerically singular, rounding
+    excites them, and restarted GMRES(30) needs 17 / 28 / 76 / 909 applications for the first solve on 1 / 4 / 8 / 32 cells in the CPU
+    restatement (oracle/cpu_ref.cpp, measured in round 6) and stagnates above rtol = 1e-9 at 256^3 on both sides -- that pairing is
+    compared with the CPU restatement on 8 and 32 cells in test_generic_state_against_the_cpp_restatement.)"""
     import torch
     import bench
     from bk_amd import hip
@@ -308,10 +310,13 @@ def _scratch_dir(tmp_path, need_gib):
 # |Pl^-1| ~ 1e5: cpu_ref needs 84 + 73 applications at 64^3, 682 + 566 at 128 x 128 x 64, 2863 + 1462 at 256 x 128 x 128 (round 6,
 # measured here) -- so its cases are: base "hex" = the bench's Newton-converged hexagon cell tiled by even reflections, plus white
 # noise of the given amplitude (no symmetry left; 262 + 144 applications on the CPU side at 128 x 64 x 64, i.e. ~14 restart cycles),
-# and amplitude 0 = the bench's own state at config 4's size (the second point is the tiled second cell solution).
+# and amplitude 0 = the bench's own (exactly tiled) state, the second point being the tiled second cell solution: on 8 cells
+# (76 + 20 applications in the CPU restatement) and on 32 cells (909 + 32: thirty restart cycles -- the near-null band of L1 grows with
+# the tiling and rounding excites it; at config 4's size, 256^3 = 256 cells, neither side reaches rtol 1e-9 any more, which is why the
+# shift-1 pairing of examples/SH2d-fronts.jl:121 is what the 256^3 / 512^3 runs use); with shift 1 that state is compared at 256^3.
 GENERIC = [((256, 128, 128), 1.0, 1.0, "noise"), ((100, 90, 66), 1.0, 1.0, "noise"), ((256, 256, 256), 1.0, 1.0, "noise"),
-           ((256, 256, 256), 0.4, 1.0, "noise"), ((128, 64, 64), 0.02, 0.0, "hex"), ((256, 256, 256), 0.0, 0.0, "hex"),
-           ((256, 256, 256), 0.0, 1.0, "hex")]
+           ((256, 256, 256), 0.4, 1.0, "noise"), ((128, 64, 64), 0.02, 0.0, "hex"), ((128, 64, 64), 0.0, 0.0, "hex"),
+           ((128, 128, 128), 0.0, 0.0, "hex"), ((256, 256, 256), 0.0, 1.0, "hex")]
 
 
 def _hex_cell_points(ds):
@@ -433,12 +438,24 @@ def test_generic_state_against_the_cpp_restatement(ctx, dims, amp, shift, base, 
         itref = ref["itlinear_each"][0]
         chk["solve_converged"] = (0.0 if ok else 1.0, 0.0)
         # (counts: +-2 per solve, a few per cent over a dozen restart cycles)
-        chk["solve_count"] = (abs(it - itref), max(2, itref // 12))
+        tiled = base == "hex" and amp == 0.0
         xtol = 1e-6 if restart else 1e-7
+        if tiled:
+            # the exactly tiled state: the right-hand side is the O(ds^2) predictor residual, 5.6e-6, evaluated by two stencil
+            # implementations that differ at the absolute floor ~1e-10 -- 2e-5 of it -- and the solves reproduce that difference
+            xtol = 1e-5
         if shift == 0.0:
             # Pl = L1: the solves control |Pl^-1 r| <= 1e-9 |Pl^-1 b|, the iterate's error is that times the conditioning of Pl^-1 J --
-            # whose spectrum now spans |Pl^-1| -- and the white-noise component of the right-hand side is amplified the same way
-            xtol = 1e-5 if amp > 0.0 else 1e-6
+            # whose spectrum now spans |Pl^-1| = 1 / min symbol (5e5 on these grids) -- measured 8e-8 (noisy hexagons) .. 6e-5 (tiled)
+            from oracle import operators
+            xtol = max(1e-5, 1e-9 / operators.dct_symbol(dims, ls_, 0.0).min()) if tiled else 1e-5
+        if shift == 0.0 and tiled:
+            # On the tiled state with shift 0 the count itself is ill-conditioned (it is decided by how rounding excites the near-null
+            # band): the CPU restatement, which forms w = -v + T v literally, needs 78 + 20 / 1116 + 32 applications on 8 / 32 cells,
+            # the HIP path (stencil-free form) 60 / 789 in total -- fewer, never more
+            chk["solve_count"] = (float(not (itref // 3 <= it <= itref + max(4, itref // 10))), 0.0)
+        else:
+            chk["solve_count"] = (abs(it - itref), max(2, itref // 12))
         chk["solve_iterate_rel"] = (np.abs(x1.numpy() - x1ref).max() / np.abs(x1ref).max(), xtol)
         del x1ref
         # the TRUE residual, through the stencil kernel and the plain preconditioner (the solver itself iterates stencil-free)
@@ -453,15 +470,22 @@ def test_generic_state_against_the_cpp_restatement(ctx, dims, amp, shift, base, 
         finally:
             ctx.set_option("fd_dparam", 1)
         chk["step_residual_0"] = (abs(sg["residuals"][0] - ref["residuals"][0]), chk["residual_inf"][1])
-        chk["step_residual_1"] = (abs(sg["residuals"][1] - ref["residuals"][1]), 1e-6 * ref["residuals"][0] + (2 * floor * xpmax if amp == 0.0 else 0.0))
+        # (shift 0: the solves control |Pl^-1 r| only; an error dx of the corrected state shows up in F as L1 dx, i.e. amplified by |L1|_inf)
+        chk["step_residual_1"] = (abs(sg["residuals"][1] - ref["residuals"][1]),
+                                  1e-6 * ref["residuals"][0] + (2 * floor * xpmax if amp == 0.0 else 0.0) +
+                                  ((1e-5 * l1_inf * xpmax if amp > 0.0 else 1e-7) if shift == 0.0 else 0.0))
         dl = abs(ref["p"] - ref["p_pred"])
-        chk["step_p"] = (abs(sg["u"].p - ref["p"]), (1e-5 if restart else 1e-6) * max(dl, 1e-12) + 1e-12)
-        chk["step_count"] = (abs(sg["itlineartot"] - ref["itlinear"]), max(4, ref["itlinear"] // 12))
+        # (tiled state: dl = O(ds^2 / |tau|) ~ 1e-6 itself; the tiled-corrector test's own bound on p, 1e-9 absolute, applies)
+        chk["step_p"] = (abs(sg["u"].p - ref["p"]), (1e-5 if restart else 1e-6) * max(dl, 1e-12) + (1e-9 if tiled else 1e-12))
+        if shift == 0.0 and tiled:
+            chk["step_count"] = (float(not (ref["itlinear"] // 3 <= sg["itlineartot"] <= ref["itlinear"] + max(8, ref["itlinear"] // 10))), 0.0)
+        else:
+            chk["step_count"] = (abs(sg["itlineartot"] - ref["itlinear"]), max(4, ref["itlinear"] // 12))
         # the corrected state carries dl * J^-1 dF/dp, and the literal quotient (F(x, p + eps) - F(x, p)) / eps carries the rounding
         # noise of F divided by eps = 1.5e-8: ~4 eps_mach |F|_inf / eps = 4e-3 absolute on this white-noise state (|F|_inf = 7e4), a
         # different realisation on each side -- hence 1e-4 relative here, where the solves above agree to 1e-7
         xref = load("x")
-        chk["step_state_rel"] = (np.abs(sg["u"].u.numpy() - xref).max() / np.abs(xref).max(), 1e-3 if restart else 1e-4)
+        chk["step_state_rel"] = (np.abs(sg["u"].u.numpy() - xref).max() / np.abs(xref).max(), max(1e-3 if restart else 1e-4, 10 * xtol if shift == 0.0 else 0.0))
         del xref
         chk = {k: (float(a_), float(b_)) for k, (a_, b_) in chk.items()}
         _phase("gpu_side", t_, dims=dims, amp=amp, shift=shift, base=base, itlinear_gpu=sg["itlineartot"], itlinear_cpu=ref["itlinear"],
