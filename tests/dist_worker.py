@@ -346,9 +346,10 @@ def slab_checks(ctx, hip, rank, world, tag, only=None):
 # exchange in line; the transposed preconditioner; the two-pass Gram-Schmidt
 VARIANTS = [(("two_lanes", 1),), (("gmres_sstep", 0),), (("gmres_sstep", 0), ("two_lanes", 1)), (("gmres_sstep", 0), ("gmres_chunk", 1)),
             (("halo_overlap", 0),), (("dct_dist_slab", 0),), (("gmres_sstep", 0), ("gmres_gram", 0)),
-            (("gmres_stencil_free", 0), ("jvp_fused_dot_ranks", 0)), (("gmres_stencil_free", 2),), (("dct_slab_split", 0),)]
+            (("gmres_stencil_free", 0), ("jvp_fused_dot_ranks", 0)), (("gmres_stencil_free", 2),), (("dct_slab_split", 0),),
+            (("gmres_monomial_shift", 1),)]       # (round 6: the round-5 first block -- powers of the literal operator -- as a variant)
 DEFAULTS = {"two_lanes": 0, "gmres_sstep": -1, "gmres_chunk": 4, "halo_overlap": 1, "dct_dist_slab": 1, "gmres_gram": 1,
-            "gmres_stencil_free": 1, "jvp_fused_dot_ranks": 1, "dct_slab_split": 1}
+            "gmres_stencil_free": 1, "jvp_fused_dot_ranks": 1, "dct_slab_split": 1, "gmres_monomial_shift": 0}
 
 
 def main_gpu_many(rank, world):
@@ -363,7 +364,7 @@ def main_gpu_many(rank, world):
     for var in VARIANTS if world == 4 else VARIANTS[:1]:
         for key, val in var:
             ctx.set_option(key, val)
-        sf_var = any(k == "gmres_stencil_free" for k, _ in var)           # (those only matter where the stencil-free step can run)
+        sf_var = any(k in ("gmres_stencil_free", "gmres_monomial_shift") for k, _ in var)   # (those only matter where the stencil-free step can run)
         split_var = any(k == "dct_slab_split" for k, _ in var)            # (... and this one where the half passes run)
         slab_checks(ctx, hip, rank, world, f"hostcomm x{world} {var}",
                     only=(6,) if split_var else ((4,) if sf_var else ((0, 3) if var != (("two_lanes", 1),) else (0, 1, 2, 3, 4, 5))))

@@ -231,3 +231,49 @@ def test_stencil_free_forced_on_a_dense_transform_grid(ctx):
     # (a random right-hand side on the unshifted Jacobian: 5-7 restart cycles per solve, counts a few per cent apart)
     assert all(abs(a - b) <= max(1, a // 20) for a, b in zip(it0, it2)), (it0, it2)
     assert abs(dl2 - dl0) <= 1e-8 * max(1.0, abs(dl0)) and np.abs(x2 - x0).max() <= 1e-8 * np.abs(x0).max()
+
+
+def test_block_log_first_block_conditioning_floor(ctx):
+    """VERDICT r5 Next 1(c) / 8: the block log comes through the C ABI (bk_solver_block_log, ABI 6 -- the library no longer prints), and
+    the FIRST block of every stencil-free solve -- powers of T = Pl^-1 diag(g + s) since round 6 (solver.hip: kMonomialShiftDefault) --
+    keeps a last pivot ratio far above the truncation threshold 1e-8 of csrc/sstep.h: asserted >= 1e-4 on the bench's own cell problem
+    (64 x 32 x 32, h = 0.196, the hexagon state; measured 8e-3 / 3e-3, the same figures as at 512^3 -- the tiled problem's spectrum),
+    against 7e-7 for the powers of the literal operator W = T - I (option gmres_monomial_shift = 1), which the same run shows.  No block
+    of the default run is truncated, and both runs need the same number of operator applications."""
+    import math
+    import bench
+    hip = _hip()
+    d = np.load(bench.os.path.join(bench.ROOT, "tests", "golden", "bench_cell_states.npz"))
+    prob = hip.SwiftHohenberg(ctx, bench.CELL, bench.CELL_L, l=0.1, nu=1.2)
+    B = hip.BorderedArray
+    z0, z1 = B(prob.vec(d["u0"]), float(d["p0"])), B(prob.vec(d["u1"]), float(d["p1"]))
+    ds, theta = -0.001, 0.5
+    tau = z1.copy().add_(z0, -1.0)
+    tau.scale_(math.copysign(1.0, ds) / math.sqrt(tau.u.inner(tau.u) / prob.nglobal * theta + tau.p * tau.p * (1 - theta)))
+    zp = z0.copy().add_(tau, ds)
+    P = hip.DCTPreconditioner(prob, 1.0)
+    ls = hip.GMRESKrylovKit(dim=30, rtol=1e-9, atol=1e-12, maxiter=150, Pl=P)
+    bls = hip.BorderingBLS(ls, check_precision=False)
+    out = {}
+    try:
+        for mono in (0, 1):
+            ctx.set_option("gmres_monomial_shift", mono)
+            ctx.set_option("gmres_block_log", 1)
+            ctx.solver_block_log()
+            s = hip.newton_palc_native(prob, z0, tau, zp, ds, theta, bls, tol=0.0, max_iterations=1, p_min=-0.1, p_max=0.15, norm_inf=True)
+            out[mono] = (s["itlineartot"], ctx.solver_block_log())
+    finally:
+        ctx.set_option("gmres_block_log", 0)
+        ctx.set_option("gmres_monomial_shift", 0)
+    (it_t, log_t), (it_w, log_w) = out[0], out[1]
+    assert {r["solve"] for r in log_t} == {1, 2} and all(set(r) == set(hip.Context.BLOCK_LOG_FIELDS) for r in log_t)
+    first_t = [r for r in log_t if r["j"] == 0]
+    first_w = [r for r in log_w if r["j"] == 0]
+    _probe("block_log", first_T=[r["last_pivot_ratio"] for r in first_t], first_W=[r["last_pivot_ratio"] for r in first_w],
+           itlinear=(it_t, it_w), min_ratio_T=min(r["last_pivot_ratio"] for r in log_t), blocks_T=[(r["j"], r["steps"], r["got"]) for r in log_t])
+    assert len(first_t) == 2 and all(r["steps"] == 3 and r["got"] == 3 for r in first_t)
+    assert all(r["last_pivot_ratio"] >= 1e-4 for r in first_t), first_t
+    assert all(r["got"] == r["steps"] for r in log_t), log_t                    # nothing truncated
+    assert all(math.isnan(r["theta0"]) for r in first_t)                        # powers of T: no shift in the first block
+    assert all(r["theta0"] == 1.0 for r in first_w) and max(r["last_pivot_ratio"] for r in first_w) < 1e-4, first_w
+    assert abs(it_t - it_w) <= 1, (it_t, it_w)
