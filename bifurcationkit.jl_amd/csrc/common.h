@@ -206,6 +206,8 @@ int v_diff_nrm2(bk_ctx* ctx, size_t n, const double* x, const double* y, double*
 int v_axpy_dot(bk_ctx* ctx, size_t n, double c, const double* r, double* y, const double* z, double* out);
 int v_minres_update(bk_ctx* ctx, size_t n, double cz, const double* z, double c1, const double* w1, double c2, const double* w2,
                     double* w, double phi, double* x);
+int v_minres_update2(bk_ctx* ctx, size_t n, double cza, const double* za, double c1a, double c2a, double czb, const double* zb, double c1b,
+                     double c2b, const double* m2, const double* m1, double* wa, double* wb, double phia, double phib, double* x);
 int v_nrminf(bk_ctx* ctx, size_t n, const double* x, double* out);
 // out[i] = <V_i, w> for i < k, out[k] = <w, w>;  V_i = V + i*ldv
 int v_multidot(bk_ctx* ctx, size_t n, const double* V, size_t ldv, int k, const double* w, double* out);

@@ -1100,6 +1100,56 @@ int v_minres_update(bk_ctx* ctx, size_t n, double cz, const double* z, double c1
     return 0;
 }
 
+// Two consecutive MINRES direction / solution updates in ONE pass (round 6): with (m2, m1) = (w_{k-2}, w_{k-1}),
+//   wa = cza za + c1a m2 + c2a m1,   wb = czb zb + c1b m1 + c2b wa,   x <- (x + phia wa) + phib wb
+// -- the arithmetic of two v_minres_update calls, element for element, in 8 array streams instead of 12.  wb may alias m2 (an element is
+// read before it is written by its own lane); wa must not alias any input.
+template <bool NTH>
+__global__ void __launch_bounds__(kThreads) minres_update2_kernel(size_t n2, double cza, const double* __restrict__ za, double c1a, double c2a,
+                                                                  double czb, const double* __restrict__ zb, double c1b, double c2b,
+                                                                  const double* m2, const double* __restrict__ m1, double* __restrict__ wa,
+                                                                  double* wb, double phia, double phib, double* __restrict__ x) {
+    stream_loop<2>(n2, [&](auto uc, size_t i0, size_t st) {
+        constexpr int UU = decltype(uc)::value;
+        double2 av[UU], bv[UU], p2[UU], p1[UU], xv[UU];
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+            av[u] = ld2<NTH>(za, i0 + u * st);
+            bv[u] = ld2<NTH>(zb, i0 + u * st);
+            p2[u] = ld2<NTH>(m2, i0 + u * st);
+            p1[u] = ld2<NTH>(m1, i0 + u * st);
+            xv[u] = ld2<NTH>(x, i0 + u * st);
+        }
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+            double2 a_, b_;
+            a_.x = fma(c2a, p1[u].x, fma(c1a, p2[u].x, cza * av[u].x));
+            a_.y = fma(c2a, p1[u].y, fma(c1a, p2[u].y, cza * av[u].y));
+            b_.x = fma(c2b, a_.x, fma(c1b, p1[u].x, czb * bv[u].x));
+            b_.y = fma(c2b, a_.y, fma(c1b, p1[u].y, czb * bv[u].y));
+            xv[u].x = fma(phib, b_.x, fma(phia, a_.x, xv[u].x));
+            xv[u].y = fma(phib, b_.y, fma(phia, a_.y, xv[u].y));
+            if (NTH) { st2nt(wa, i0 + u * st, a_); st2nt(wb, i0 + u * st, b_); st2nt(x, i0 + u * st, xv[u]); }
+            else {
+                reinterpret_cast<double2*>(wa)[i0 + u * st] = a_; reinterpret_cast<double2*>(wb)[i0 + u * st] = b_;
+                reinterpret_cast<double2*>(x)[i0 + u * st] = xv[u];
+            }
+        }
+    });
+}
+
+// 0: done; 1: this shape is not covered (odd length / unaligned buffers) -- the caller takes two v_minres_update calls
+int v_minres_update2(bk_ctx* ctx, size_t n, double cza, const double* za, double c1a, double c2a, double czb, const double* zb, double c1b,
+                     double c2b, const double* m2, const double* m1, double* wa, double* wb, double phia, double phib, double* x) {
+    if ((n & 1) || !(aligned16(za) && aligned16(zb) && aligned16(m2) && aligned16(m1) && aligned16(wa) && aligned16(wb) && aligned16(x))) return 1;
+    const int grid = grid_for(n, 2, 4096);
+    ProfScope ps(ctx, "blas1", 8.0 * n * 8);
+    if (nt_hint(ctx, n)) hipLaunchKernelGGL((minres_update2_kernel<true>), dim3(grid), dim3(kThreads), 0, ctx->stream, n >> 1, cza, za, c1a, c2a, czb, zb, c1b, c2b, m2, m1, wa, wb, phia, phib, x);
+    else hipLaunchKernelGGL((minres_update2_kernel<false>), dim3(grid), dim3(kThreads), 0, ctx->stream, n >> 1, cza, za, c1a, c2a, czb, zb, c1b, c2b, m2, m1, wa, wb, phia, phib, x);
+    BK_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
 int v_nrminf(bk_ctx* ctx, size_t n, const double* x, double* out) {
     const int grid = grid_for(n, 1, kRedBlocks);
     {

@@ -695,6 +695,39 @@ def test_fused_minres_passes_reproduce_the_separate_ones(ctx, dims):
         assert oko and abs(it1 - ito) <= max(2, ito // 4) and np.abs(x1 - xo).max() <= 1e-6 * np.abs(xo).max()
 
 
+@pytest.mark.parametrize("dims", [(64, 64, 64), (128, 64), (70, 34, 20)])
+def test_minres_pair_update_is_bitwise_the_single_updates(ctx, dims):
+    """Round 6 (option minres_pair_update, default on; csrc/solver.hip: minres_core, csrc/vecops.hip: v_minres_update2): the MINRES
+    direction / solution update taken two iterations at a time -- 8 array streams instead of 2 x 6 -- performs the arithmetic of the
+    two single updates element for element: the same iteration count, residual history and BITWISE the same solution, for solves that
+    end on an even count, on an odd count (the pending update is flushed alone) and at the iteration limit."""
+    hip = _hip()
+    ls3 = (np.pi, 2.5, 2.0)[:len(dims)]
+    sh, prob, rng, u = _sh_setup(ctx, dims, ls3, seed=sum(dims) + 1)
+    J = prob.jacobian(prob.vec(u), 0.1)
+    rhs = prob.vec(rng.standard_normal(sh.N))
+    P = hip.DCTPreconditioner(prob, 1.0)
+    seen = set()
+    try:
+        for kw in (dict(atol=1e-13, rtol=1e-10), dict(atol=1e-13, rtol=1e-7), dict(atol=1e-13, rtol=1e-9), dict(atol=0.0, rtol=1e-15, itmax=7),
+                   dict(atol=0.0, rtol=1e-15, itmax=8)):
+            out = {}
+            for pair in (0, 1):
+                ctx.set_option("minres_pair_update", pair)
+                ctx.set_option("solver_trace", 1)
+                ctx.solver_history(reset=True)
+                x, ok, it = hip.KrylovLSSymmetric("minres", Pl=P, **kw)(J, rhs, -0.1, 1.0)
+                out[pair] = (x.numpy(), ok, it, ctx.solver_history(reset=True)[0])
+            (x0, ok0, it0, h0), (x1, ok1, it1, h1) = out[0], out[1]
+            assert ok0 == ok1 and it0 == it1 and h0 == h1, (kw, it0, it1)
+            assert np.array_equal(x0, x1), (kw, np.abs(x0 - x1).max())
+            seen.add(it1 % 2)
+        assert seen == {0, 1}                                  # both parities of the final count were exercised
+    finally:
+        ctx.set_option("minres_pair_update", 1)
+        ctx.set_option("solver_trace", 0)
+
+
 # --------------------------------------------------------------------------------------------- bordered solvers
 @pytest.mark.parametrize("shift", [None, 0.3])
 @pytest.mark.parametrize("xi", [(1.0, 1.0), (0.4, 0.6)])
