@@ -114,7 +114,7 @@ def test_fullsize_tiled_corrector_matches_cpu_oracle_cell(ctx, big, shift):
     (examples/SH2d-fronts.jl:121).  (The reference SH3d example's own Pl = cholesky(L1), shift 0, does NOT survive the tiling: the
     tiled domain holds a dense band of modes next to the critical circle |k| = 1 on which L1 is numerically singular, rounding
     excites them, and restarted GMRES(30) needs 17 / 28 / 76 / 909 applications for the first solve on 1 / 4 / 8 / 32 cells in the CPU
-    restatement (oracle/cpu_ref.cpp, measured in round 6) and stagnates above rtol = 1e-9 at 256^3 on both sides -- that pairing is
+    restatement (oracle/cpu_ref.cpp, measured in round 6), and on the GPU at 256^3 it stagnates above rtol = 1e-9 -- that pairing is
     compared with the CPU restatement on 8 and 32 cells in test_generic_state_against_the_cpp_restatement.)"""
     import torch
     import bench
@@ -312,7 +312,7 @@ def _scratch_dir(tmp_path, need_gib):
 # noise of the given amplitude (no symmetry left; 262 + 144 applications on the CPU side at 128 x 64 x 64, i.e. ~14 restart cycles),
 # and amplitude 0 = the bench's own (exactly tiled) state, the second point being the tiled second cell solution: on 8 cells
 # (76 + 20 applications in the CPU restatement) and on 32 cells (909 + 32: thirty restart cycles -- the near-null band of L1 grows with
-# the tiling and rounding excites it; at config 4's size, 256^3 = 256 cells, neither side reaches rtol 1e-9 any more, which is why the
+# the tiling and rounding excites it; at config 4's size, 256^3 = 256 cells, the HIP solve stagnates above rtol 1e-9, which is why the
 # shift-1 pairing of examples/SH2d-fronts.jl:121 is what the 256^3 / 512^3 runs use); with shift 1 that state is compared at 256^3.
 GENERIC = [((256, 128, 128), 1.0, 1.0, "noise"), ((100, 90, 66), 1.0, 1.0, "noise"), ((256, 256, 256), 1.0, 1.0, "noise"),
            ((256, 256, 256), 0.4, 1.0, "noise"), ((128, 64, 64), 0.02, 0.0, "hex"), ((128, 64, 64), 0.0, 0.0, "hex"),
