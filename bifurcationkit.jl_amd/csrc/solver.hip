@@ -346,11 +346,12 @@ int gmres_core(bk_ctx* ctx, bk_op* A, const double* b, const double* bt, double*
     // First block (no Ritz values yet).  On the stencil-free operator T = W + theta0 I (ShiftPrecOp) there are two candidates: powers of
     // the literal operator W = Pl^-1 J (bk_op::monomial_shift = theta0; rounds 4-5) and powers of T itself (the default since round 6,
     // kMonomialShiftDefault).  W's spectrum clusters at -1, so W^k p is dominated by (-1)^k p and three vectors leave a last pivot ratio
-    // of 6.6e-7 / 2.1e-7 on the 512^3 headline solves -- one and a half orders above the truncation threshold 1e-8 (sstep.h); T's
-    // clusters at 0 and three powers of it keep 2e-3 .. 8e-3 (profiles/r5_block_log_first_block_T_powers.txt, r6_block_log_*).  Every
-    // later block is identical either way (its Newton shifts come from the Hessenberg matrix, Leja-ordered from W's origin:
-    // bk_op::rearranged_origin), the step is 0.7 ms shorter (no shift stream in the x-inverse pass of three applications), and a first
-    // block of FOUR powers of T truncates the second block (4th pivot 1.7e-5, +4 ms per step): kMonomialMax stays 3.
+    // of 6.6e-7 / 6.9e-7 on the 512^3 headline solves -- one and a half orders above the truncation threshold 1e-8 (sstep.h); T's
+    // clusters at 0 and three powers of it keep 8.1e-3 / 2.6e-3 (profiles/r6_first_block_ab_512.txt; round 5's experiment:
+    // r5_block_log_first_block_T_powers.txt).  Every later block is identical either way (its Newton shifts come from the Hessenberg
+    // matrix, Leja-ordered from W's origin: bk_op::rearranged_origin), the step is 2.4 % shorter on identical inputs (no shift stream in
+    // the x-inverse pass of three applications per solve), and a first block of FOUR powers of T truncates the second block (4th pivot
+    // 1.7e-5, +4 ms per step): kMonomialMax stays 3.
     // (Round 4's "structural first-block shift" on the LITERAL CHAIN -- the same powers of T reached by folding the shift a0 - a1 through
     // the stencil kernel, first blocks 4 long -- is what truncated at 512^3 then: 122.9 vs 116.6 ms per step.)
     const bool leja_origin_on = ctx->opt("gmres_leja_origin", 1.0) != 0.0;
@@ -957,7 +958,9 @@ static int minres_core(bk_ctx* ctx, bk_op* J, const double* b, double* x, double
             // rotated anything: w = w_{k-2}, w2 = w_{k-3}, w1 = spare.  Pending:  w_{k-1} = pa_cz vh + pa_c1 w2 + pa_c2 w;  this
             // iteration:  w_k = cz y + c1 w + c2 w_{k-1}.
             double* m2 = w2;  double* m1 = w;  double* wa = w1;  double* wb = w2;      // wb overwrites w_{k-3} (element-wise safe)
-            if (v_minres_update2(ctx, n, pa_cz, vh, pa_c1, pa_c2, cz, y, c1, c2, m2, m1, wa, wb, pa_phi, phi, x) != 0) {
+            const int st2 = v_minres_update2(ctx, n, pa_cz, vh, pa_c1, pa_c2, cz, y, c1, c2, m2, m1, wa, wb, pa_phi, phi, x);
+            if (st2 < 0) return st2;                   // a launch error; 1 = shape not covered: the two single updates
+            if (st2 > 0) {
                 BK_TRY(v_minres_update(ctx, n, pa_cz, vh, pa_c1, m2, pa_c2, m1, wa, pa_phi, x));
                 BK_TRY(v_minres_update(ctx, n, cz, y, c1, m1, c2, wa, wb, phi, x));
             }
