@@ -31,9 +31,17 @@ def _run(mode, world=2, timeout=300):
         try:
             o, _ = p.communicate(timeout=timeout)
         except subprocess.TimeoutExpired:
+            # a rank that hangs must leave its last words in the report: kill every rank, collect what each of them printed
             for q in procs:
                 q.kill()
-            raise
+            tails = []
+            for r, q in enumerate(procs):
+                try:
+                    t, _ = q.communicate(timeout=20)
+                except Exception:  # noqa: BLE001
+                    t = ""
+                tails.append(f"--- rank {r} (last output) ---\n{(t or '')[-1500:]}")
+            pytest.fail(f"{mode} x{world}: no result within {timeout} s\n" + "\n".join(tails))
         outs.append(o)
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
