@@ -472,8 +472,9 @@ int dct_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out, int* dot_bl
     int cur = 0;
     auto axis_pass = [&](int a, int inverse, const double* in, double* o, int fuse) -> int {
         // the fused pointwise work (DctFuse) rides in the first pass (input side: in == v) and the last one (output side: o == out)
-        const DctFuse* f = (fz && a == 0 && ((!inverse && in == v && fz->u) || (inverse && o == out && fz->xadd))) ? fz : nullptr;
-        ProfScope ps(ctx, "dct_pass", (f ? 24.0 : 16.0) * p->total);   // one read + one write of the array per axis pass (+ the fused stream)
+        const DctFuse* f = (fz && a == 0 && ((!inverse && in == v && (fz->u || fz->add)) || (inverse && o == out && fz->xadd))) ? fz : nullptr;
+        // one read + one write of the array per axis pass (+ the fused stream; + the stored sum of the pre-axpy form)
+        ProfScope ps(ctx, "dct_pass", (f ? (!inverse && fz->add ? 32.0 : 24.0) : 16.0) * p->total);
         if (use_fft && p->twid[a]) {
             return dct_axis_fft(ctx, n0, n1, n2, a, inverse, p->twid[a], in, o, p->lam[0], p->lam[1],
                                 p->ndim == 3 ? p->lam[2] : nullptr, p->shift, fuse, nullptr, fuse == 2 ? dot_blocks : nullptr, f);
@@ -817,6 +818,19 @@ struct ShDctPrecond : bk_precond {
         if (cx != 0.0) { f.xadd = x; f.cx = cx; f.ct = ct; }
         BK_TRY(plan->dist ? dct_apply_dist(ctx, plan, x, out, &f) : dct_apply(ctx, plan, x, out, nullptr, &f));
         return scale_after ? v_scale(ctx, n, ct, out) : 0;
+    }
+    int apply_dot_pre_axpy(double* y, double c, const double* r, double* out, double* dot) override {
+        if (plan->kind >= 1 || plan->dist || plan->ndim < 2 || ctx->nranks != 1 || ctx->opt("minres_fuse_axpy", 1.0) == 0.0 ||
+            ctx->opt("dct_roundtrip", 1.0) == 0.0 || (((uintptr_t)r) & 15) || !pw_fused_ok(y, y, out))
+            return bk_precond::apply_dot_pre_axpy(y, c, r, out, dot);
+        DctFuse f;
+        f.add = r; f.cadd = c; f.store = y;
+        int nb = 0;
+        BK_TRY(dct_apply(ctx, plan, y, out, &nb, &f));
+        if (nb == 0) return v_dot(ctx, n, y, out, dot);       // the merged middle did not run as the fused kernel
+        BK_TRY(reduce_finish(ctx, nb, 1, 0));
+        *dot = ctx->h_red[0];
+        return 0;
     }
     int apply_dot(const double* v, double* out, double* dot) override {
         if (plan->kind >= 1 || plan->dist || plan->ndim < 2 || ctx->nranks != 1) return bk_precond::apply_dot(v, out, dot);

@@ -58,6 +58,7 @@ struct FftK {
     // sample's own index; inverse -- the stored value is fz_ct * result + fz_cx * fz_v[same index]
     const double* fz_v;
     double fzA, fzB, fzC, fz_cx, fz_ct;
+    double* fz_store;         // FZS (forward): the sample + fz_cx * fz_v[same index] is what gets transformed, and it is stored here
     // SLAB kernels (z passes of the slab z-solve as forward / inverse HALVES, dct.hip: dct_apply_slab): the forward half stores
     // y^_k = sym_k f^_k and, from sums over the spectrum with the local basis phi, the values of y = B^-1 f at the four planes next to
     // the slab faces (planes 0, 1, nl-2, nl-1); the inverse half adds sym_k * sum_p phi_k(p) delta_p(line) -- the Woodbury correction,
@@ -377,9 +378,13 @@ __device__ __forceinline__ c2 lane_xor1(c2 v) { c2 r; r.x = lane_xor1(v.x); r.y 
 // (dct_core.h: mid_half_*), 8 complex values per lane instead of 16 -- the tile's phases are latency-bound (one wave per SIMD and
 // tile with 256 lanes: 38 % of the wave cycles issue, profiles/r5_sq_stall_breakdown.txt), so the same two tiles per CU now bring 4
 // waves per SIMD inside 128 VGPRs.  (Round 3's 512-lane instantiation of the unsplit kernel spilled 264 B per lane and ran 2x slower.)
-template <int NT, int MODE, bool AX0, bool NTM, bool DOT = false, bool FZ = false, int SLAB = 0>   // MODE 0: forward, 1: inverse, 2: forward - symbol - inverse (AX0: 0 / 1 only)
+// FZS (round 6, with FZ, MODE 0): the second stream is ADDED -- sample + fz_cx * fz_v -- instead of entering a pointwise factor, and the
+// sum is stored to fz_store (the MINRES recurrence's y <- y + c r riding in the preconditioner's first pass: DctFuse::add).  A separate
+// instantiation: the kernels of the corrector's hot path are compiled exactly as before.
+template <int NT, int MODE, bool AX0, bool NTM, bool DOT = false, bool FZ = false, int SLAB = 0, bool FZS = false>   // MODE 0: forward, 1: inverse, 2: forward - symbol - inverse (AX0: 0 / 1 only)
 __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 2) dct_fused_kernel(FftK P) {
     constexpr bool SPLIT = NT == 512;
+    static_assert(!FZS || (FZ && MODE == 0), "FZS: the x-forward pass only");
     static_assert(!SPLIT || (MODE == 2 && !AX0 && !FZ && SLAB == 0), "512 lanes: the z / y round trip only");
     static_assert(!FZ || (AX0 && MODE != 2), "FZ: x passes only");
     static_assert(SLAB == 0 || (!AX0 && !FZ && !DOT && ((SLAB == 1 && MODE == 0) || (SLAB == 2 && MODE == 1))), "SLAB: z halves only");
@@ -597,9 +602,18 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 2) dct_fused_kernel(FftK P
             if (AX0) {
                 if (act0)
                     dctc::fused_first2(z + (size_t)(tid >> hbits) * pstride, N, bits, tid & ((1 << hbits) - 1),
-                                       [&](int s, int, double& ea, double& oa, double& eb, double& ob) {
+                                       [&](int s, int j, double& ea, double& oa, double& eb, double& ob) {
                                            ea = pfa[s].x; oa = pfa[s].y; eb = pfb[s].x; ob = pfb[s].y;
-                                           if (FZ) {
+                                           if (FZS) {
+                                               // sample + c * r, product and sum rounded separately (as v_axpbyz forms them: this file
+                                               // compiles with contraction on), stored back before it enters the transform
+                                               const int t = FZ ? s : 0;
+                                               ea = __dadd_rn(__dmul_rn(P.fz_cx, qfa[t].x), ea); oa = __dadd_rn(__dmul_rn(P.fz_cx, qfa[t].y), oa);
+                                               eb = __dadd_rn(__dmul_rn(P.fz_cx, qfb[t].x), eb); ob = __dadd_rn(__dmul_rn(P.fz_cx, qfb[t].y), ob);
+                                               double* srow = P.fz_store + tile_base(tile) + (size_t)(2 * (tid >> hbits)) * lstride;
+                                               st16(srow + 2 * j, ea, oa);
+                                               st16(srow + lstride + 2 * j, eb, ob);
+                                           } else if (FZ) {
                                                const int t = FZ ? s : 0;
                                                auto d = [&](double u) { return P.fzA + u * (P.fzB + P.fzC * u); };
                                                ea *= d(qfa[t].x); oa *= d(qfa[t].y); eb *= d(qfb[t].x); ob *= d(qfb[t].y);
@@ -859,14 +873,17 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
         P.face_y = sh->face_y; P.face_d = sh->face_d; P.phi = sh->phi; P.face_Lr = (unsigned)sh->Lr; P.slab_a = sh->a;
         P.slab_hasb = sh->has_bottom ? 1 : 0; P.slab_hast = sh->has_top ? 1 : 0;
     }
-    P.fz_v = nullptr; P.fzA = 1.0; P.fzB = P.fzC = 0.0; P.fz_cx = 0.0; P.fz_ct = 1.0;
-    // the pointwise work this pass is asked to take in: the factor on a forward pass, the axpy on an inverse one
-    const bool want_fz = fz && (inverse ? fz->xadd != nullptr : fz->u != nullptr);
+    P.fz_v = nullptr; P.fzA = 1.0; P.fzB = P.fzC = 0.0; P.fz_cx = 0.0; P.fz_ct = 1.0; P.fz_store = nullptr;
+    // the pointwise work this pass is asked to take in: the factor (or the pre-axpy) on a forward pass, the axpy on an inverse one
+    const bool want_fzs = fz && !inverse && fz->add != nullptr;
+    const bool want_fz = fz && (inverse ? fz->xadd != nullptr : (fz->u != nullptr || want_fzs));
     if (want_fz) {
         if (axis != 0 || fuse_scale != 0 || split || !dct_axis_fused_ok(ctx, n0, n1, n2, 0, in, out, 0) ||
-            (((uintptr_t)(inverse ? fz->xadd : fz->u)) & 15) != 0)
+            (((uintptr_t)(inverse ? fz->xadd : (want_fzs ? fz->add : fz->u))) & 15) != 0 ||
+            (want_fzs && (fz->u != nullptr || fz->store == nullptr || (((uintptr_t)fz->store) & 15) != 0)))
             return set_error(ctx, "dct_axis_fft: fused pointwise work needs the fused x-axis kernel (pw_fused_ok)");
         if (inverse) { P.fz_v = fz->xadd; P.fz_cx = fz->cx; P.fz_ct = fz->ct; }
+        else if (want_fzs) { P.fz_v = fz->add; P.fz_cx = fz->cadd; P.fz_store = fz->store; }
         else { P.fz_v = fz->u; P.fzA = fz->A; P.fzB = fz->B; P.fzC = fz->C; }
     }
     if (dot_blocks) *dot_blocks = 0;
@@ -937,6 +954,8 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
                              reinterpret_cast<const void*>(dct_fused_kernel<256, 1, true, false, false, true>),
                              reinterpret_cast<const void*>(dct_fused_kernel<256, 0, true, true, false, true>),
                              reinterpret_cast<const void*>(dct_fused_kernel<256, 1, true, true, false, true>),
+                             reinterpret_cast<const void*>(dct_fused_kernel<256, 0, true, false, false, true, 0, true>),
+                             reinterpret_cast<const void*>(dct_fused_kernel<256, 0, true, true, false, true, 0, true>),
                              reinterpret_cast<const void*>(dct_fused_kernel<256, 0, false, false, false, false, 1>),
                              reinterpret_cast<const void*>(dct_fused_kernel<256, 1, false, false, false, false, 2>),
                              reinterpret_cast<const void*>(dct_fused_kernel<256, 0, false, true, false, false, 1>),
@@ -992,6 +1011,9 @@ int dct_axis_fft(bk_ctx* ctx, int n0, int n1, int n2, int axis, int inverse, con
         if (sh) {
             if (mode == 1) { if (ntm) BK_DCT_LAUNCH_SLAB(1, true, 2); else BK_DCT_LAUNCH_SLAB(1, false, 2); }
             else { if (ntm) BK_DCT_LAUNCH_SLAB(0, true, 1); else BK_DCT_LAUNCH_SLAB(0, false, 1); }
+        } else if (axis == 0 && want_fzs) {
+            if (ntm) hipLaunchKernelGGL((dct_fused_kernel<256, 0, true, true, false, true, 0, true>), dim3(grid), dim3(256), ldsf, ctx->stream, P);
+            else hipLaunchKernelGGL((dct_fused_kernel<256, 0, true, false, false, true, 0, true>), dim3(grid), dim3(256), ldsf, ctx->stream, P);
         } else if (axis == 0 && want_fz) {
             if (mode == 1) { if (ntm) BK_DCT_LAUNCH_FZ(1, true); else BK_DCT_LAUNCH_FZ(1, false); }
             else { if (ntm) BK_DCT_LAUNCH_FZ(0, true); else BK_DCT_LAUNCH_FZ(0, false); }

@@ -80,6 +80,11 @@ struct DctFuse {
     double A = 1.0, B = 0.0, C = 0.0;
     const double* xadd = nullptr;
     double cx = 0.0, ct = 1.0;
+    // round 6 (MINRES: bk_precond::apply_dot_pre_axpy): the x-forward pass transforms in[i] + cadd * add[i] and stores that combined
+    // vector to store[i] (may be the input array itself) -- the pass y <- y + c r of the Lanczos recurrence rides in the transform
+    const double* add = nullptr;
+    double cadd = 0.0;
+    double* store = nullptr;
 };
 int dct_apply(bk_ctx* ctx, DctPlan* p, const double* v, double* out, int* dot_blocks = nullptr, const DctFuse* fz = nullptr);
 // axis pass of the LDS FFT kernels (dct_fast.hip).  fuse_scale 0: plain, 1: forward + inverse symbol, 2: forward,
@@ -182,6 +187,10 @@ struct bk_precond {
     // out = Pl \ v and *dot = v . out (out must not alias v).  Default: apply, then a dot pass; the spectral
     // preconditioner takes the dot from the spectrum (Parseval) inside its merged middle pass.
     virtual int apply_dot(const double* v, double* out, double* dot);
+    // y <- y + c r, then out = Pl \ y and *dot = y . out (out must not alias y or r).  Default: the axpy pass, then apply_dot; the
+    // spectral preconditioner lets the axpy ride in its x-forward transform pass (4 array streams instead of 3 + 2), the same values
+    // bit for bit (the sum is formed without contraction, as v_axpbyz forms it).
+    virtual int apply_dot_pre_axpy(double* y, double c, const double* r, double* out, double* dot);
     // true if this preconditioner is the exact inverse of L1 + *shift I of the problem `prob` (the spectral preconditioner)
     virtual bool is_l1_plus_shift(const bk_problem* prob, double* shift) const { return false; }
     // out = cx x + ct Pl \ (d .* x), d_i = A + u_i (B + C u_i)   (out must not alias x unless pw_fused_ok)

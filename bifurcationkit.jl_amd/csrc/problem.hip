@@ -167,6 +167,11 @@ int bk_op::apply_axpy_dot(const double* x, double a0, double a1, double c, const
     return v_axpy_dot(ctx, n, c, r, out, x, dot);
 }
 
+int bk_precond::apply_dot_pre_axpy(double* y, double c, const double* r, double* out, double* dot) {
+    BK_TRY(v_axpby(ctx, n, c, r, 1.0, y));
+    return apply_dot(y, out, dot);
+}
+
 int bk_precond::apply_pw(const double* x, const bk::DctFuse& d, double cx, double ct, double* out) {
     // the separate passes: t = d .* x ; t = Pl \ t ; out = cx x + ct t
     if (cx == 0.0) {

@@ -922,7 +922,10 @@ static int minres_core(bk_ctx* ctx, bk_op* J, const double* b, double* x, double
             else BK_TRY(J->bk_op::apply_axpy_dot(z, a0 / beta, a1 / beta, c, r, y, &zy));
         }
         const double alfa = zy / beta;
-        BK_TRY(v_axpby(ctx, n, -alfa / beta, r2, 1.0, y));
+        // y -= (alfa / beta) r2, then z = M^-1 y and b2 = y . z: with the spectral preconditioner the axpy rides in its x-forward
+        // transform pass (bk_precond::apply_dot_pre_axpy, round 6: one array stream and one launch fewer per iteration, the same values)
+        const double cy = -alfa / beta;
+        const double* r2_old = r2;
         // direction / solution update need v = z / beta of THIS iteration: do it before z is overwritten
         const double oldeps = epsln;
         const double delta = cs * dbar + sn * alfa;
@@ -931,7 +934,8 @@ static int minres_core(bk_ctx* ctx, bk_op* J, const double* b, double* x, double
         // the rotation needs the NEXT beta = sqrt(r2 . M^-1 r2): keep v's vector alive in `y` (free now) meanwhile
         { double* tmp = y; y = z; z = tmp; }                                         // y holds the old z (v * beta), z is free
         double b2;
-        BK_TRY(prec_dot(r2, z, &b2));
+        if (pl && fused) BK_TRY(pl->apply_dot_pre_axpy(r2, cy, r2_old, z, &b2));
+        else { BK_TRY(v_axpby(ctx, n, cy, r2_old, 1.0, r2)); BK_TRY(prec_dot(r2, z, &b2)); }
         const double vbeta = beta;                                                   // scale of the vector kept in y
         oldb = beta;
         if (b2 < 0.0) return set_error(ctx, "minres: the preconditioner is not positive definite");
@@ -1009,9 +1013,10 @@ static int cg_core(bk_ctx* ctx, bk_op* J, const double* b, double* x, double a0,
         if (!(pAp > 0.0)) break;                                                     // not positive definite along p
         const double alpha = gamma / pAp;
         BK_TRY(v_axpby(ctx, n, alpha, p, 1.0, x));
-        BK_TRY(v_axpby(ctx, n, -alpha, Ap, 1.0, r));
+        // r -= alpha Ap, z = M^-1 r, gnext = r . z: the axpy rides in the spectral preconditioner's x-forward pass where it can (as in MINRES)
         double gnext;
-        BK_TRY(prec_dot(r, z, &gnext));
+        if (pl && fused) BK_TRY(pl->apply_dot_pre_axpy(r, -alpha, Ap, z, &gnext));
+        else { BK_TRY(v_axpby(ctx, n, -alpha, Ap, 1.0, r)); BK_TRY(prec_dot(r, z, &gnext)); }
         rnorm = std::sqrt(std::max(gnext, 0.0));
         BK_TRY(v_axpby(ctx, n, 1.0, z, gnext / gamma, p));                           // p = z + beta p
         gamma = gnext;

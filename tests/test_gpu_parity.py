@@ -699,8 +699,11 @@ def test_fused_minres_passes_reproduce_the_separate_ones(ctx, dims):
 def test_minres_pair_update_is_bitwise_the_single_updates(ctx, dims):
     """Round 6 (option minres_pair_update, default on; csrc/solver.hip: minres_core, csrc/vecops.hip: v_minres_update2): the MINRES
     direction / solution update taken two iterations at a time -- 8 array streams instead of 2 x 6 -- performs the arithmetic of the
-    two single updates element for element: the same iteration count, residual history and BITWISE the same solution, for solves that
-    end on an even count, on an odd count (the pending update is flushed alone) and at the iteration limit."""
+    two single updates element for element; and option minres_fuse_axpy (default on; bk_precond::apply_dot_pre_axpy, csrc/dct_fast.hip:
+    the FZS instantiation of the x-forward pass) lets the recurrence's y <- y - (alfa / beta) r2 ride in the preconditioner's first
+    transform pass, product and sum rounded separately as the separate pass rounds them: the same iteration count, residual history
+    and BITWISE the same solution in all four combinations, for solves that end on an even count, on an odd count (the pending update
+    is flushed alone) and at the iteration limit (on 70 x 34 x 20 the transforms are dense and the fused pass does not apply)."""
     hip = _hip()
     ls3 = (np.pi, 2.5, 2.0)[:len(dims)]
     sh, prob, rng, u = _sh_setup(ctx, dims, ls3, seed=sum(dims) + 1)
@@ -712,19 +715,23 @@ def test_minres_pair_update_is_bitwise_the_single_updates(ctx, dims):
         for kw in (dict(atol=1e-13, rtol=1e-10), dict(atol=1e-13, rtol=1e-7), dict(atol=1e-13, rtol=1e-9), dict(atol=0.0, rtol=1e-15, itmax=7),
                    dict(atol=0.0, rtol=1e-15, itmax=8)):
             out = {}
-            for pair in (0, 1):
+            for pair, fuse in ((0, 0), (1, 0), (0, 1), (1, 1)):
                 ctx.set_option("minres_pair_update", pair)
+                ctx.set_option("minres_fuse_axpy", fuse)
                 ctx.set_option("solver_trace", 1)
                 ctx.solver_history(reset=True)
                 x, ok, it = hip.KrylovLSSymmetric("minres", Pl=P, **kw)(J, rhs, -0.1, 1.0)
-                out[pair] = (x.numpy(), ok, it, ctx.solver_history(reset=True)[0])
-            (x0, ok0, it0, h0), (x1, ok1, it1, h1) = out[0], out[1]
-            assert ok0 == ok1 and it0 == it1 and h0 == h1, (kw, it0, it1)
-            assert np.array_equal(x0, x1), (kw, np.abs(x0 - x1).max())
-            seen.add(it1 % 2)
+                out[pair, fuse] = (x.numpy(), ok, it, ctx.solver_history(reset=True)[0])
+            x0, ok0, it0, h0 = out[0, 0]
+            for key in ((1, 0), (0, 1), (1, 1)):
+                x1, ok1, it1, h1 = out[key]
+                assert ok0 == ok1 and it0 == it1 and h0 == h1, (kw, key, it0, it1)
+                assert np.array_equal(x0, x1), (kw, key, np.abs(x0 - x1).max())
+            seen.add(it0 % 2)
         assert seen == {0, 1}                                  # both parities of the final count were exercised
     finally:
         ctx.set_option("minres_pair_update", 1)
+        ctx.set_option("minres_fuse_axpy", 1)
         ctx.set_option("solver_trace", 0)
 
 
