@@ -18,7 +18,7 @@ def _free_port():
     return p
 
 
-def _run(mode, world=2, timeout=300):
+def _run(mode, world=2, timeout=int(os.environ.get("BK_DIST_TIMEOUT", "300"))):
     port = _free_port()
     procs = []
     for r in range(world):
@@ -40,7 +40,7 @@ def _run(mode, world=2, timeout=300):
                     t, _ = q.communicate(timeout=20)
                 except Exception:  # noqa: BLE001
                     t = ""
-                tails.append(f"--- rank {r} (last output) ---\n{(t or '')[-1500:]}")
+                tails.append(f"--- rank {r} (last output) ---\n{(t or '')[-2500:]}")
             pytest.fail(f"{mode} x{world}: no result within {timeout} s\n" + "\n".join(tails))
         outs.append(o)
     for r, (p, o) in enumerate(zip(procs, outs)):
