@@ -64,8 +64,9 @@ def test_two_ranks_share_one_gpu_host_communicator():
 def test_ragged_and_thin_slabs_host_communicator(world):
     """3 and 4 ranks on one GPU: z extents that do not divide evenly, slabs of 2-3 planes (every z-chunk is a face chunk).  The
     host-staged communicator enqueues its collectives in the stream (proxy thread) since round 4: the ranks run the RCCL ranks'
-    code path -- block Arnoldi / device-resident chunks with in-stream all-reduces, halo exchange on the second stream, two
-    lanes with their own communicator -- with the defaults and with every variant switched (tests/dist_worker.py: VARIANTS)."""
+    code path -- block Arnoldi / device-resident chunks with in-stream all-reduces, halo exchange on the second stream -- with the
+    defaults and with every variant switched (tests/dist_worker.py: VARIANTS; two lanes on ranks left the automatic list in round 6:
+    an intermittent cross-lane wait cycle, see there)."""
     _run("gpu_many", world)
 
 
