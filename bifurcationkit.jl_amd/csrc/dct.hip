@@ -820,7 +820,8 @@ struct ShDctPrecond : bk_precond {
         return scale_after ? v_scale(ctx, n, ct, out) : 0;
     }
     int apply_dot_pre_axpy(double* y, double c, const double* r, double* out, double* dot) override {
-        if (plan->kind >= 1 || plan->dist || plan->ndim < 2 || ctx->nranks != 1 || ctx->opt("minres_fuse_axpy", 1.0) == 0.0 ||
+        // (plan->slab_ok: the cost model's slab emulation routes through dct_apply_slab, which only knows the stencil-free operator's fusions)
+        if (plan->kind >= 1 || plan->dist || plan->slab_ok || plan->ndim < 2 || ctx->nranks != 1 || ctx->opt("minres_fuse_axpy", 1.0) == 0.0 ||
             ctx->opt("dct_roundtrip", 1.0) == 0.0 || (((uintptr_t)r) & 15) || !pw_fused_ok(y, y, out))
             return bk_precond::apply_dot_pre_axpy(y, c, r, out, dot);
         DctFuse f;
