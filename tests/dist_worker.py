@@ -365,6 +365,8 @@ def main_gpu_many(rank, world):
     ranks of a multi-GPU node execute -- defaults first, then the same option variants as main_rccl."""
     from bk_amd import hip
     ctx = hip.Context(0, hostcomm.comm_tuple())
+    if os.environ.get("BK_TEST_LANE_PRIORITY") is not None:          # (hand-run A/B of the two-lane hazard: 0 = round 5's default-priority lane streams)
+        ctx.set_option("lane_priority", float(os.environ["BK_TEST_LANE_PRIORITY"]))
     slab_checks(ctx, hip, rank, world, f"hostcomm x{world}")
     # (every collective is a Python / gloo round trip here: the variants run on the power-of-two world only, on the ragged
     # grid and on the slab-z-solve grid; the other worlds run the first variant)
