@@ -54,11 +54,6 @@ struct bk_ctx {
     bk::CommKind comm = bk::COMM_NONE;
     ncclComm_t nccl = nullptr;
     hipStream_t comm_stream = nullptr;   // halo exchange runs here, overlapped with the interior z-chunks of the JVP
-    // Streams of the SECOND LANE are created at the highest stream priority (context.hip: ctx_lane; 0 = default priority): the runtime
-    // keeps a separate pool of hardware queues per priority level, so the lane's streams never share a hardware queue with the
-    // context's own (default-priority) streams -- the sharing is what lets the device-side waits of two lanes' collectives form a cycle
-    // across ranks (profiles/r6_dist_two_lane_hang.txt).  A mitigation, not a proof: queue assignment is the runtime's business.
-    int stream_priority = 0;
     hipEvent_t ev_ready = nullptr, ev_halo = nullptr;
     void* blas = nullptr;          // rocblas_handle, created on first use by the dense transform passes (dct.hip)
     bk_allreduce_fn h_allreduce = nullptr;

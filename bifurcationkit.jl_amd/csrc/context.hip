@@ -503,17 +503,11 @@ bk_ctx* ctx_lane(bk_ctx* ctx) {
         return ctx->lane2;
     }
     hipStream_t st = nullptr;
-    int prio_least = 0, prio_greatest = 0;
-    if (hipSetDevice(ctx->device) != hipSuccess) { set_error(ctx, "second lane: hipSetDevice failed"); return nullptr; }
-    // (option lane_priority, default 1: the lane's streams at the highest priority = their own pool of hardware queues, common.h)
-    const bool hp = ctx->opt("lane_priority", 1.0) != 0.0 && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess &&
-                    prio_greatest != prio_least;
-    if ((hp ? hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio_greatest) : hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) {
+    if (hipSetDevice(ctx->device) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
         set_error(ctx, "second lane: stream creation failed");
         return nullptr;
     }
     bk_ctx* l = new bk_ctx();
-    l->stream_priority = hp ? prio_greatest : 0;
     // (every failure path below frees the lane, its stream included, through bk_ctx_destroy)
     const int si = ctx_init_common(l, ctx->device, st);
     l->stream = st;

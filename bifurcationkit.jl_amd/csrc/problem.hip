@@ -26,8 +26,7 @@ int bk_problem::apply(int mode, const double* v, const double* u, const double* 
             const bool overlap = ctx->opt("halo_overlap", 1.0) != 0.0;
             if (overlap) {
                 if (!ctx->comm_stream) {
-                    if (ctx->stream_priority != 0) BK_HIP(ctx, hipStreamCreateWithPriority(&ctx->comm_stream, hipStreamNonBlocking, ctx->stream_priority));
-                    else BK_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+                    BK_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
                     BK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
                     BK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_halo, hipEventDisableTiming));
                 }
