@@ -1072,11 +1072,10 @@ int linsolve(bk_ctx* ctx, bk_op* J, const double* rhs, double* x, double a0, dou
 int linsolve2(bk_ctx* ctx, bk_op* J, const double* rhs1, double* x1, const double* rhs2, double* x2, double a0, double a1,
               const bk_gmres_opts& o, bk_precond* pl, GmresResult* r1, GmresResult* r2) {
     PdeJacobian* PJ = dynamic_cast<PdeJacobian*>(J);
-    // ranks: opt-in (two_lanes = 1) and hazardous -- both lanes enqueue collectives that wait ON THE DEVICE (flag kernels of the
-    // host-staged communicator, RCCL's kernels), the runtime multiplexes a process's streams onto a few hardware queues, and when the
-    // lanes' streams share a queue in one order on one rank and in the other on a peer the waits form a cycle: observed 1 time in 10 with
-    // three ranks sharing a GPU (profiles/r6_dist_two_lane_hang.txt).  Safe only with per-lane hardware queues.  The decision itself
-    // only looks at options, the communicator and the GLOBAL problem, so every rank takes the same one
+    // ranks: opt-in (two_lanes = 1) and NOT safe yet -- with two lanes every rank drives two independent sequences of blocking
+    // collectives (two host threads, two communicators, collectives that wait on the device), and repeated runs on ranks sharing a GPU
+    // hang now and then: 1 / 4 / 2 in 24 with two / three / four ranks, cause not established (profiles/r6_dist_two_lane_hang.txt; one
+    // lane never hung).  The decision itself only looks at options, the communicator and the GLOBAL problem, so every rank takes the same one
     const bool want = ctx->opt("two_lanes", (ctx->nranks == 1 && J->n <= ((size_t)1 << 24)) ? 1.0 : 0.0) != 0.0;
     bk_ctx* lane = (want && PJ && J->ntail == 0 && !o.pr) ? ctx_lane(ctx) : nullptr;     // (a right preconditioner lives on ctx)
     bk_precond* pl2 = nullptr;

@@ -344,12 +344,12 @@ def slab_checks(ctx, hip, rank, world, tag, only=None):
 # reduce_finish, halo exchange on the second stream under the interior z-chunks, slab z-solve): two lanes; single Arnoldi steps as
 # device-resident chunks (all-reduce enqueued between the kernels, one host synchronisation per chunk) and host-driven; the halo
 # exchange in line; the transposed preconditioner; the two-pass Gram-Schmidt
-# Two lanes on ranks (("two_lanes", 1) alone and with gmres_sstep = 0) left this list in round 6: repeated on the GPU box, the 3-rank run
-# of that variant hung 1 time in 10 (3 of 30, twice; profiles/r6_dist_two_lane_hang.txt) -- one rank reports "a collective timed out on
-# the device", its peers wait.  Each rank then drives TWO independent sequences of blocking collectives (two host threads, two
-# communicators, collectives that wait on the device); the suspected mechanism is a wait cycle between the lanes across ranks, but it
-# is NOT established: giving the lane's streams their own priority level (hardware-queue pool) did not change the rate.  The option
-# stays opt-in on ranks and is exercised by hand only:  BK_TEST_RANK_LANES=1 python tests/dist_worker.py gpu_many  (DESIGN section 8).
+# Two lanes on ranks (("two_lanes", 1) alone and with gmres_sstep = 0) left this list in round 6: repeated on the GPU box, a run of that
+# variant's checks hung 1 time in 24 with two ranks, 4 in 24 with three, 2 in 24 with four (profiles/r6_dist_two_lane_hang.txt) -- every rank
+# waits, or one reports "a collective timed out on the device" and its peers wait.  Each rank then drives TWO independent sequences of
+# blocking collectives (two host threads, two communicators, collectives that wait on the device); the cause is NOT established (not the
+# number of processes on the one GPU, not the lanes' streams sharing a priority level).  One lane never hung.  The option stays opt-in on
+# ranks and is exercised by hand only:  BK_TEST_RANK_LANES=1 [BK_TEST_RANK_LANES_ONLY=1] python tests/dist_worker.py gpu_many  (DESIGN 8).
 _LANES = [(("two_lanes", 1),), (("gmres_sstep", 0), ("two_lanes", 1))] if os.environ.get("BK_TEST_RANK_LANES") == "1" else []
 VARIANTS = _LANES if os.environ.get("BK_TEST_RANK_LANES_ONLY") == "1" else _LANES + [(("gmres_sstep", 0),), (("gmres_sstep", 0), ("gmres_chunk", 1)),
             (("halo_overlap", 0),), (("dct_dist_slab", 0),), (("gmres_sstep", 0), ("gmres_gram", 0)),
