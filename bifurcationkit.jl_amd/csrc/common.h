@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <set>
 #include <string>
 #include <utility>
 #include <vector>
@@ -115,6 +116,10 @@ struct bk_ctx {
     // reduction buffers, workspace pool, profile -- on which the second of two independent linear solves runs concurrently
     // with the first (solver.hip: linsolve2).  Created on first use, destroyed with the context.
     bk_ctx* lane2 = nullptr;
+    // Two lanes on RANKS (solver.hip: linsolve2): the (global problem size, Krylov dimension) pairs whose two solves have already run
+    // once one after the other on their lanes, so that every pool -- workspace buffers, the proxy's staging buffers, streams, events,
+    // kernel attributes -- holds what a concurrent pair of solves asks for.  Cleared whenever an option changes (bk_ctx_set_option).
+    std::set<std::pair<size_t, int>> lanes_warm;
 
     double opt(const char* key, double dflt) const {
         auto it = opts.find(key);

@@ -747,6 +747,7 @@ int bk_ctx_set_option(bk_ctx* ctx, const char* key, double value) {
     if (!ctx || !key) return -1;
     if (double* d = ctx->diag_slot(key)) { *d = value; return 0; }
     ctx->opts[key] = value;
+    ctx->lanes_warm.clear();                 // (another option set may ask the pools for other buffers: linsolve2 warms them again)
     return 0;
 }
 

@@ -1121,13 +1121,33 @@ int linsolve2(bk_ctx* ctx, bk_op* J, const double* rhs1, double* x1, const doubl
         delete pl2;
         return set_error(ctx, "linsolve2: lane hand-over failed");
     }
+    // RANKS: no runtime call that synchronises the whole device may run inside a lane while the other lane can sit in a collective --
+    // hipFree / hipHostFree (the proxy's staging buffers growing, a workspace pool miss) wait for EVERY stream of the process, the
+    // other lane's collective among them, and two ranks that do so in different lanes at the same moment wait for each other for
+    // ever (the suspected cause of the intermittent two-lane hang of round 6, profiles/r6_dist_two_lane_hang.txt).  So the FIRST
+    // pair of solves of a (global size, Krylov dimension) runs one solve after the other, each on its own lane: every pool of both
+    // lanes then holds what the concurrent pairs that follow ask for.  Same arithmetic either way (the lanes reproduce sequential calls).
+    const bk_problem_desc& gd = PJ->prob->desc;
+    const std::pair<size_t, int> wkey{(size_t)gd.n[0] * (size_t)std::max(gd.n[1], 1) * (size_t)std::max(gd.n[2], 1), o.dim};
+    const bool cold = ctx->nranks > 1 && ctx->lanes_warm.count(wkey) == 0;
+    int s1 = 0;
+    if (cold) {
+        s1 = linsolve(ctx, J, rhs1, x1, a0, a1, o, pl, r1);
+        if (s1 == 0 && hipStreamSynchronize(ctx->stream) != hipSuccess) s1 = set_error(ctx, "linsolve2: synchronisation failed");
+        if (s1 == 0) {
+            s2 = linsolve(lane, &J2, rhs2, x2, a0, a1, o, pl2, r2);
+            if (hipStreamSynchronize(lane->stream) != hipSuccess && s2 == 0) s2 = set_error(lane, "linsolve2: lane synchronisation failed");
+        }
+        if (s1 == 0 && s2 == 0) ctx->lanes_warm.insert(wkey);
+    } else {
     std::thread th([&]() {
         (void)hipSetDevice(lane->device);
         s2 = linsolve(lane, &J2, rhs2, x2, a0, a1, o, pl2, r2);
         if (hipStreamSynchronize(lane->stream) != hipSuccess && s2 == 0) s2 = set_error(lane, "linsolve2: lane synchronisation failed");
     });
-    const int s1 = linsolve(ctx, J, rhs1, x1, a0, a1, o, pl, r1);
+    s1 = linsolve(ctx, J, rhs1, x1, a0, a1, o, pl, r1);
     th.join();
+    }
     (void)hipEventDestroy(ev);
     delete pl2;
     ctx_lane_merge(ctx, lane);
